@@ -1,0 +1,337 @@
+"""
+CPU oracle for the SafeLife step hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import this package.  Nothing under ``safelife_amd/`` does.
+
+Two checkers live here:
+
+* ``libsl_oracle.so`` -- our own plain-C restatement (``sl_oracle.c``), wrapped
+  by the functions in this module.  Parity status: pinned against the golden
+  vectors in ``tests/golden`` and against ``oracle/_ref``.
+* ``oracle/_ref/speedups*.so`` -- the reference's C extension compiled from its
+  own sources (``oracle/Makefile``, target ``ref``); ``load_ref()`` imports it.
+"""
+import ctypes as C
+import importlib.util
+import glob
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    """Compile libsl_oracle.so (and oracle/_ref when the reference checkout exists)."""
+    so = os.path.join(_HERE, "libsl_oracle.so")
+    src = os.path.join(_HERE, "sl_oracle.c")
+    stale = (not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "oracle"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference/safelife/speedups_src"):
+        if force or not glob.glob(os.path.join(_HERE, "_ref", "speedups*.so")):
+            subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+def load_ref():
+    """Import the compiled REFERENCE extension (module ``speedups``) or return None."""
+    hits = glob.glob(os.path.join(_HERE, "_ref", "speedups*.so"))
+    if not hits:
+        return None
+    spec = importlib.util.spec_from_file_location("speedups", hits[0])
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+class Pcg64(C.Structure):
+    _fields_ = [("state_hi", C.c_uint64), ("state_lo", C.c_uint64),
+                ("inc_hi", C.c_uint64), ("inc_lo", C.c_uint64)]
+
+
+_NEXT_DOUBLE = C.CFUNCTYPE(C.c_double, C.c_void_p)
+
+
+class Rng(C.Structure):
+    _fields_ = [("state", C.c_void_p), ("next_double", _NEXT_DOUBLE)]
+
+
+_u16p = C.POINTER(C.c_uint16)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_u8p = C.POINTER(C.c_uint8)
+_f32p = C.POINTER(C.c_float)
+_pcgp = C.POINTER(Pcg64)
+
+
+class EnvBatch(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("E", C.c_int32),
+        ("time_limit", C.c_int32), ("exit_points", C.c_int32), ("n_tables", C.c_int32),
+        ("auto_reset", C.c_int32), ("remove_white_goals", C.c_int32),
+        ("view_h", C.c_int32), ("view_w", C.c_int32), ("n_channels", C.c_int32),
+        ("channels", C.c_int32 * 32),
+        ("board", _u16p), ("goals", _u16p), ("agent_loc", _i32p), ("exit_locs", _i32p),
+        ("rng", _pcgp), ("spawn_prob", _f32p), ("num_steps", _i32p), ("old_value", _i32p),
+        ("required_points", _i32p), ("initial_points", _i32p), ("table_idx", _i32p),
+        ("goals_static", _u8p), ("is_active", _u8p), ("episode_reward", _f32p),
+        ("episode_length", _i32p), ("level_idx", _i32p), ("episode_idx", _i32p),
+        ("points_table", _i32p),
+        ("L", C.c_int32), ("level_stride", C.c_int32),
+        ("pool_board", _u16p), ("pool_goals", _u16p), ("pool_agent_loc", _i32p),
+        ("pool_exit_locs", _i32p), ("pool_rng", _pcgp), ("pool_spawn_prob", _f32p),
+        ("pool_required_reset", _i32p), ("pool_required_step", _i32p),
+        ("pool_initial_points", _i32p), ("pool_table_idx", _i32p),
+        ("reward", _f32p), ("done", _u8p), ("success", _u8p), ("times_up", _u8p),
+        ("obs", _u8p),
+    ]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        build()
+        L = C.CDLL(os.path.join(_HERE, "libsl_oracle.so"))
+        L.slo_pcg64_next_double.restype = C.c_double
+        L.slo_pcg64_next_double.argtypes = [C.c_void_p]
+        L.slo_pcg64_next64.restype = C.c_uint64
+        L.slo_pcg64_next64.argtypes = [_pcgp]
+        L.slo_pcg64_advance.argtypes = [_pcgp, C.c_uint64]
+        L.slo_advance_board.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
+                                        C.c_int, C.POINTER(Rng)]
+        L.slo_life_occupancy.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
+                                         C.c_int, C.POINTER(Rng)]
+        L.slo_alive_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.slo_execute_actions.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_int, C.c_int]
+        L.slo_advance_board_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                              C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.slo_alive_counts_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.slo_execute_actions_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                                C.c_void_p, C.c_int]
+        L.slo_life_occupancy_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                               C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.slo_env_reset.argtypes = [C.POINTER(EnvBatch), C.c_void_p]
+        L.slo_env_step.argtypes = [C.POINTER(EnvBatch), C.c_void_p, C.c_int]
+        L.slo_env_obs.argtypes = [C.POINTER(EnvBatch), C.c_int]
+        _LIB = L
+    return _LIB
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _board(a):
+    a = np.ascontiguousarray(a, dtype=np.uint16)
+    if a.ndim != 2 or a.size == 0:
+        raise ValueError("board must be a non-empty 2-d array")
+    return a
+
+
+# ---------------------------------------------------------------- RNG helpers
+
+def pcg64_state_words(bitgen):
+    """(state_hi, state_lo, inc_hi, inc_lo) of a numpy PCG64 BitGenerator."""
+    st = bitgen.state
+    if st["bit_generator"] != "PCG64":
+        raise TypeError("oracle expects numpy PCG64")
+    s, i = st["state"]["state"], st["state"]["inc"]
+    m = (1 << 64) - 1
+    return np.array([s >> 64, s & m, i >> 64, i & m], dtype=np.uint64)
+
+
+def pcg64_set_state_words(bitgen, words):
+    st = bitgen.state
+    w = [int(x) for x in words]
+    st["state"]["state"] = (w[0] << 64) | w[1]
+    st["state"]["inc"] = (w[2] << 64) | w[3]
+    bitgen.state = st
+
+
+def _rng_from_bitgen(bitgen):
+    """slo_rng bound to numpy's own bitgen_t: consumes the very stream the reference would."""
+    iface = bitgen.ctypes
+    fn = C.cast(iface.next_double, _NEXT_DOUBLE)
+    return Rng(C.c_void_p(iface.state_address if isinstance(iface.state_address, int)
+                          else iface.state_address.value), fn)
+
+
+def _rng_from_words(words):
+    g = Pcg64(*[int(x) for x in words])
+    fn = C.cast(lib().slo_pcg64_next_double, _NEXT_DOUBLE)
+    return g, Rng(C.cast(C.pointer(g), C.c_void_p), fn)
+
+
+# ------------------------------------------------- single-board primitives
+
+def advance_board(board, spawn_prob=0.3, n_step=1, bitgen=None, rng_words=None):
+    """One or more CA steps. Draws from `bitgen` (numpy BitGenerator) or from a PCG64 given as
+    4 uint64 words (returned advanced as second value)."""
+    b = _board(board)
+    out = np.empty_like(b)
+    if bitgen is not None:
+        r = _rng_from_bitgen(bitgen)
+        rc = lib().slo_advance_board(_ptr(b), _ptr(out), b.shape[0], b.shape[1], spawn_prob, n_step, C.byref(r))
+        assert rc == 0, rc
+        return out
+    words = np.zeros(4, np.uint64) if rng_words is None else rng_words
+    g, r = _rng_from_words(words)
+    rc = lib().slo_advance_board(_ptr(b), _ptr(out), b.shape[0], b.shape[1], spawn_prob, n_step, C.byref(r))
+    assert rc == 0, rc
+    new_words = np.array([g.state_hi, g.state_lo, g.inc_hi, g.inc_lo], dtype=np.uint64)
+    return (out, new_words) if rng_words is not None else out
+
+
+def life_occupancy(board, spawn_prob=0.3, n_step=1000, bitgen=None, rng_words=None):
+    b = _board(board)
+    counts = np.zeros(b.shape + (8,), dtype=np.int32)
+    if bitgen is not None:
+        r = _rng_from_bitgen(bitgen)
+    else:
+        g, r = _rng_from_words(np.zeros(4, np.uint64) if rng_words is None else rng_words)
+    rc = lib().slo_life_occupancy(_ptr(b), _ptr(counts), b.shape[0], b.shape[1], spawn_prob, n_step, C.byref(r))
+    assert rc == 0, rc
+    return counts
+
+
+def alive_counts(board, goals):
+    b = np.ascontiguousarray(board, dtype=np.uint16)
+    g = np.ascontiguousarray(goals, dtype=np.uint16)
+    if b.size != g.size:
+        raise ValueError("Board and goals must have same size.")
+    out = np.zeros((8, 9), dtype=np.int64)
+    lib().slo_alive_counts(_ptr(b), _ptr(g), b.size, _ptr(out))
+    return out
+
+
+def execute_actions(board, locations, actions):
+    """In-place on `board` (uint16, C-contiguous) and `locations` (int64 [n,2])."""
+    assert board.dtype == np.uint16 and board.flags.c_contiguous and board.ndim == 2
+    assert locations.dtype == np.int64 and locations.flags.c_contiguous
+    acts = np.ascontiguousarray(np.atleast_1d(actions), dtype=np.int64)
+    n_agents = locations.size // 2
+    if acts.size not in (n_agents, 1):
+        raise ValueError("Locations should be shape (n_agent, 2).")
+    rc = lib().slo_execute_actions(_ptr(board), board.shape[0], board.shape[1], _ptr(locations),
+                                   _ptr(acts), n_agents, 1 if acts.size == n_agents else 0)
+    if rc:
+        raise ValueError("Board must be at least 3x3.")
+
+
+# ------------------------------------------------------- batched primitives
+
+def advance_board_batch(boards, spawn_prob, n_step, rng_words, n_threads=1):
+    """boards [B,H,W] uint16; spawn_prob [B] float32; rng_words [B,4] uint64 (updated in place)."""
+    b = np.ascontiguousarray(boards, dtype=np.uint16)
+    B, H, W = b.shape
+    sp = np.ascontiguousarray(np.broadcast_to(np.asarray(spawn_prob, np.float32), (B,)))
+    assert rng_words.dtype == np.uint64 and rng_words.shape == (B, 4) and rng_words.flags.c_contiguous
+    out = np.empty_like(b)
+    rc = lib().slo_advance_board_batch(_ptr(b), _ptr(out), B, H, W, _ptr(sp), n_step, _ptr(rng_words), n_threads)
+    assert rc == 0, rc
+    return out
+
+
+def alive_counts_batch(boards, goals):
+    b = np.ascontiguousarray(boards, dtype=np.uint16)
+    g = np.ascontiguousarray(goals, dtype=np.uint16)
+    B = b.shape[0]
+    out = np.zeros((B, 8, 9), dtype=np.int64)
+    lib().slo_alive_counts_batch(_ptr(b), _ptr(g), B, b[0].size, _ptr(out))
+    return out
+
+
+def execute_actions_batch(boards, locs, actions):
+    """In place: boards [B,H,W] uint16, locs [B,A,2] int64, actions [B,A] int64."""
+    assert boards.dtype == np.uint16 and boards.flags.c_contiguous
+    assert locs.dtype == np.int64 and locs.flags.c_contiguous
+    acts = np.ascontiguousarray(actions, dtype=np.int64)
+    B, H, W = boards.shape
+    rc = lib().slo_execute_actions_batch(_ptr(boards), B, H, W, _ptr(locs), _ptr(acts), locs.shape[1])
+    assert rc == 0, rc
+
+
+def life_occupancy_batch(boards, spawn_prob, n_step, rng_words, n_threads=1):
+    b = np.ascontiguousarray(boards, dtype=np.uint16)
+    B, H, W = b.shape
+    sp = np.ascontiguousarray(np.broadcast_to(np.asarray(spawn_prob, np.float32), (B,)))
+    counts = np.zeros((B, H, W, 8), dtype=np.int32)
+    rc = lib().slo_life_occupancy_batch(_ptr(b), _ptr(counts), B, H, W, _ptr(sp), n_step, _ptr(rng_words), n_threads)
+    assert rc == 0, rc
+    return counts
+
+
+# ----------------------------------------------------------- batched env
+
+_ENV_ARRAYS = {
+    # name: dtype ; shapes are checked by the caller
+    "board": np.uint16, "goals": np.uint16, "agent_loc": np.int32, "exit_locs": np.int32,
+    "rng": np.uint64, "spawn_prob": np.float32, "num_steps": np.int32, "old_value": np.int32,
+    "required_points": np.int32, "initial_points": np.int32, "table_idx": np.int32,
+    "goals_static": np.uint8, "is_active": np.uint8, "episode_reward": np.float32,
+    "episode_length": np.int32, "level_idx": np.int32, "episode_idx": np.int32,
+    "points_table": np.int32,
+    "pool_board": np.uint16, "pool_goals": np.uint16, "pool_agent_loc": np.int32,
+    "pool_exit_locs": np.int32, "pool_rng": np.uint64, "pool_spawn_prob": np.float32,
+    "pool_required_reset": np.int32, "pool_required_step": np.int32,
+    "pool_initial_points": np.int32, "pool_table_idx": np.int32,
+    "reward": np.float32, "done": np.uint8, "success": np.uint8, "times_up": np.uint8,
+}
+
+
+class OracleEnv:
+    """Batched single-agent SafeLifeEnv on the CPU oracle.
+
+    `arrays` is a dict of numpy arrays with the names of `_ENV_ARRAYS` (the same
+    names the product's host-side state uses); they are owned by the caller and
+    mutated in place.
+    """
+
+    def __init__(self, arrays, *, time_limit=1000, exit_points=1, auto_reset=False,
+                 remove_white_goals=True, view_shape=(15, 15),
+                 output_channels=tuple(range(16)) + (25, 26, 27), level_stride=1, with_obs=True):
+        self.a = a = {}
+        for k, dt in _ENV_ARRAYS.items():
+            v = arrays[k]
+            assert v.dtype == dt and v.flags.c_contiguous, (k, v.dtype)
+            a[k] = v
+        B, H, W = a["board"].shape
+        E = a["exit_locs"].shape[1]
+        chans = tuple(output_channels) if output_channels else ()
+        vh, vw = view_shape
+        if with_obs:
+            self.obs = (np.zeros((B, vh, vw, len(chans)), np.uint8) if chans
+                        else np.zeros((B, vh, vw), np.uint32))
+        else:
+            self.obs = None
+        s = self.s = EnvBatch()
+        s.B, s.H, s.W, s.E = B, H, W, E
+        s.time_limit, s.exit_points = time_limit, exit_points
+        s.n_tables = a["points_table"].shape[0]
+        s.auto_reset = int(auto_reset)
+        s.remove_white_goals = int(remove_white_goals)
+        s.view_h, s.view_w, s.n_channels = vh, vw, len(chans)
+        for i, c in enumerate(chans):
+            s.channels[i] = c
+        s.L = a["pool_board"].shape[0]
+        s.level_stride = level_stride
+        for k in _ENV_ARRAYS:
+            ftype = dict(EnvBatch._fields_)[k]
+            setattr(s, k, C.cast(_ptr(a[k]), ftype))
+        s.obs = C.cast(_ptr(self.obs), _u8p) if self.obs is not None else None
+
+    def reset(self, mask=None):
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        lib().slo_env_reset(C.byref(self.s), None if m is None else _ptr(m))
+        return self.obs
+
+    def step(self, actions, n_threads=1):
+        acts = np.ascontiguousarray(actions, dtype=np.int32)
+        assert acts.shape == (self.s.B,)
+        rc = lib().slo_env_step(C.byref(self.s), _ptr(acts), n_threads)
+        assert rc == 0, rc
+        return self.obs, self.a["reward"], self.a["done"]

@@ -1,0 +1,553 @@
+/*
+ * sl_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+ * See sl_oracle.h for scope, parity status and the reference anchors.
+ *
+ * The cellular-automaton step is restated around one observation: the
+ * reference's two helper routines (advance_board.c:12-32) both fold a
+ * 16-bit per-cell "summary" into an accumulator with the same commutative,
+ * associative merge, so the 3x3 neighbourhood result is merge-of-9-summaries,
+ * computed here separably (3 along the row, then 3 along the column).
+ *
+ * Summary / accumulator bit layout (advance_board.c:6-9):
+ *   bits 0-3   number of ALIVE cells folded in (<= 9)
+ *   bits 5-7   PRESERVING / INHIBITING / SPAWNING seen in any cell
+ *   bits 8-11  "seen in >=1 alive cell": bit 8 = EXIT|DESTRUCTIBLE, 9-11 = colour
+ *   bits 12-15 "seen in >=2 alive cells" of the same four flags; spawner
+ *              colours are injected straight into bits 13-15
+ */
+#include "sl_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+enum {
+    C_ALIVE = 1 << 0,
+    C_AGENT = 1 << 1,
+    C_PUSHABLE = 1 << 2,
+    C_DESTRUCTIBLE = 1 << 3,
+    C_FROZEN = 1 << 4,
+    C_PRESERVING = 1 << 5,
+    C_INHIBITING = 1 << 6,
+    C_SPAWNING = 1 << 7,
+    C_EXIT = 1 << 8,
+    C_COLOR_R = 1 << 9,
+    C_COLORS = 7 << 9,
+    C_ORIENT_SHIFT = 12,
+    C_ORIENT = 3 << 12,
+    C_PULLABLE = 1 << 15,
+};
+
+#define SUM_COUNT 0x000Fu
+#define SUM_ANY 0x00E0u   /* preserving | inhibiting | spawning */
+#define SUM_ONCE 0x0F00u
+#define SUM_TWICE 0xF000u
+
+/* ------------------------------------------------------------------ PCG64 */
+
+typedef unsigned __int128 u128;
+#define PCG_MULT ((((u128)0x2360ED051FC65DA4ULL) << 64) | (u128)0x4385DF649FCCF645ULL)
+
+static inline u128 join128(uint64_t hi, uint64_t lo) { return ((u128)hi << 64) | lo; }
+
+uint64_t slo_pcg64_next64(slo_pcg64 *g) {
+    u128 s = join128(g->state_hi, g->state_lo);
+    u128 inc = join128(g->inc_hi, g->inc_lo);
+    s = s * PCG_MULT + inc;
+    g->state_hi = (uint64_t)(s >> 64);
+    g->state_lo = (uint64_t)s;
+    uint64_t x = g->state_hi ^ g->state_lo;
+    unsigned rot = (unsigned)(g->state_hi >> 58);
+    return (x >> rot) | (x << ((64 - rot) & 63));
+}
+
+double slo_pcg64_next_double(void *g) {
+    return (double)(slo_pcg64_next64((slo_pcg64 *)g) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+void slo_pcg64_advance(slo_pcg64 *g, uint64_t n) {
+    /* O(log n) LCG skip-ahead */
+    u128 s = join128(g->state_hi, g->state_lo);
+    u128 inc = join128(g->inc_hi, g->inc_lo);
+    u128 acc_mult = 1, acc_plus = 0, cur_mult = PCG_MULT, cur_plus = inc;
+    while (n) {
+        if (n & 1) {
+            acc_mult *= cur_mult;
+            acc_plus = acc_plus * cur_mult + cur_plus;
+        }
+        cur_plus = (cur_mult + 1) * cur_plus;
+        cur_mult *= cur_mult;
+        n >>= 1;
+    }
+    s = acc_mult * s + acc_plus;
+    g->state_hi = (uint64_t)(s >> 64);
+    g->state_lo = (uint64_t)s;
+}
+
+/* ------------------------------------------------------- advance_board */
+
+static inline uint16_t cell_summary(uint16_t b) {
+    /* advance_board.c:45-47 : DESTRUCTIBLE is copied onto bit 8 */
+    uint16_t t = (uint16_t)(b | ((b & C_DESTRUCTIBLE) << 5));
+    uint16_t s = t & SUM_ANY;
+    if (t & C_ALIVE) s |= (uint16_t)((t & SUM_ONCE) | 1u);
+    if (t & C_SPAWNING) s |= (uint16_t)((t & C_COLORS) << 4);
+    return s;
+}
+
+static inline uint16_t merge2(uint16_t x, uint16_t y) {
+    uint16_t both = x & y & SUM_ONCE;
+    uint16_t flags = (uint16_t)(((x | y) & (SUM_ANY | SUM_ONCE | SUM_TWICE)) | (both << 4));
+    return (uint16_t)(flags + (x & SUM_COUNT) + (y & SUM_COUNT));
+}
+
+static inline uint16_t merge3(uint16_t x, uint16_t y, uint16_t z) {
+    return merge2(merge2(x, y), z);
+}
+
+/* one CA step; `rows` and `acc` are caller scratch of h*w cells each */
+static void ca_step(const uint16_t *in, uint16_t *out, int h, int w, double p,
+                    slo_rng *rng, uint16_t *rows, uint16_t *acc) {
+    for (int y = 0; y < h; y++) {
+        const uint16_t *src = in + (size_t)y * w;
+        uint16_t *dst = rows + (size_t)y * w;
+        uint16_t left = cell_summary(src[w - 1]);
+        uint16_t mid = cell_summary(src[0]);
+        uint16_t first = mid;
+        for (int x = 0; x < w; x++) {
+            uint16_t right = (x + 1 < w) ? cell_summary(src[x + 1]) : first;
+            dst[x] = merge3(left, mid, right);
+            left = mid;
+            mid = right;
+        }
+    }
+    for (int y = 0; y < h; y++) {
+        const uint16_t *up = rows + (size_t)((y + h - 1) % h) * w;
+        const uint16_t *me = rows + (size_t)y * w;
+        const uint16_t *dn = rows + (size_t)((y + 1) % h) * w;
+        uint16_t *dst = acc + (size_t)y * w;
+        for (int x = 0; x < w; x++) dst[x] = merge3(up[x], me[x], dn[x]);
+    }
+    /* rule pass, row-major: the order of RNG draws is part of the contract
+     * (advance_board.c:94-124, draw at :115 behind the short-circuit) */
+    int n = h * w;
+    for (int i = 0; i < n; i++) {
+        uint16_t b = in[i], a = acc[i];
+        unsigned cnt = a & SUM_COUNT;
+        uint16_t r = b;
+        if (b & C_ALIVE) {
+            int keep = (b & C_FROZEN) || (a & C_PRESERVING) || cnt == 3 || cnt == 4;
+            if (!keep) r = 0;
+        } else if ((b & C_FROZEN) || (a & C_INHIBITING)) {
+            r = b;
+        } else if (cnt == 3) {
+            r = (uint16_t)(C_ALIVE | ((a >> 4) & C_COLORS) | ((a >> 9) & C_DESTRUCTIBLE));
+        } else if ((a & C_SPAWNING) && rng->next_double(rng->state) < p) {
+            r = (uint16_t)(C_ALIVE | C_DESTRUCTIBLE | ((a >> 4) & C_COLORS));
+        }
+        out[i] = r;
+    }
+}
+
+int slo_advance_board(const uint16_t *in, uint16_t *out, int h, int w,
+                      float spawn_prob, int n_steps, slo_rng *rng) {
+    if (h < 3 || w < 3 || n_steps < 0) return -1;
+    size_t n = (size_t)h * w;
+    uint16_t *tmp = (uint16_t *)malloc(4 * n * sizeof(uint16_t));
+    if (!tmp) return -2;
+    uint16_t *cur = tmp, *nxt = tmp + n, *rows = tmp + 2 * n, *acc = tmp + 3 * n;
+    memcpy(cur, in, n * sizeof(uint16_t));
+    /* advance_board.c:35 : the float probability is promoted to double for the compare */
+    double p = (double)spawn_prob;
+    for (int s = 0; s < n_steps; s++) {
+        ca_step(cur, nxt, h, w, p, rng, rows, acc);
+        uint16_t *t = cur; cur = nxt; nxt = t;
+    }
+    memcpy(out, cur, n * sizeof(uint16_t));
+    free(tmp);
+    return 0;
+}
+
+int slo_life_occupancy(const uint16_t *in, int32_t *counts, int h, int w,
+                       float spawn_prob, int n_steps, slo_rng *rng) {
+    if (h < 3 || w < 3 || n_steps < 0) return -1;
+    size_t n = (size_t)h * w;
+    uint16_t *tmp = (uint16_t *)malloc(4 * n * sizeof(uint16_t));
+    if (!tmp) return -2;
+    uint16_t *cur = tmp, *nxt = tmp + n, *rows = tmp + 2 * n, *acc = tmp + 3 * n;
+    memcpy(cur, in, n * sizeof(uint16_t));
+    double p = (double)spawn_prob;
+    for (int s = 0; s < n_steps; s++) {
+        ca_step(cur, nxt, h, w, p, rng, rows, acc);
+        /* advance_board.c:153-161 : tally AFTER each step, life-like cells only */
+        for (size_t i = 0; i < n; i++) {
+            uint16_t c = nxt[i];
+            if ((c & C_ALIVE) && !(c & (C_AGENT | C_EXIT | C_FROZEN)))
+                counts[8 * i + ((c >> 9) & 7)] += 1;
+        }
+        uint16_t *t = cur; cur = nxt; nxt = t;
+    }
+    free(tmp);
+    return 0;
+}
+
+/* ------------------------------------------------------- alive_counts */
+
+int slo_alive_counts(const uint16_t *board, const uint16_t *goals, int n, int64_t *out) {
+    for (int i = 0; i < n; i++) {
+        uint16_t b = board[i];
+        /* frozen cells the agent cannot move or destroy never score */
+        if ((b & C_FROZEN) && !(b & (C_DESTRUCTIBLE | C_PUSHABLE | C_PULLABLE))) continue;
+        int g = (goals[i] >> 9) & 7;
+        int col = (b & C_ALIVE) ? ((b >> 9) & 7) : 8;
+        out[9 * g + col] += 1;
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------- execute_actions */
+
+static inline int wrap(int v, int n) {
+    v %= n;
+    return v < 0 ? v + n : v;
+}
+
+static void act_one(uint16_t *board, int h, int w, int64_t *loc, int64_t action) {
+    if (action == 0) return;
+    int dir = (int)((action - 1) & 3);           /* 0 up, 1 right, 2 down, 3 left */
+    static const int DY[4] = {-1, 0, 1, 0};
+    static const int DX[4] = {0, 1, 0, -1};
+    int dy = DY[dir], dx = DX[dir];
+    int y0 = (int)(loc[0] % h), x0 = (int)(loc[1] % w);
+    uint16_t *here = board + y0 * w + x0;
+    uint16_t *ahead = board + wrap(y0 + dy, h) * w + wrap(x0 + dx, w);
+    uint16_t *ahead2 = board + wrap(y0 + 2 * dy, h) * w + wrap(x0 + 2 * dx, w);
+    uint16_t *behind = board + wrap(y0 - dy, h) * w + wrap(x0 - dx, w);
+    if (!(*here & C_AGENT)) return;
+    *here = (uint16_t)((*here & ~C_ORIENT) | (dir << C_ORIENT_SHIFT));
+
+    int can_push = (~*here & *ahead & C_PUSHABLE) != 0;
+    if (action >= 5) { /* create / destroy / shove */
+        if (*ahead == 0) {
+            *ahead = (uint16_t)(C_ALIVE | C_DESTRUCTIBLE | (*here & C_COLORS));
+        } else if (*ahead & C_DESTRUCTIBLE) {
+            if (*ahead & C_AGENT)
+                *ahead = (uint16_t)((*ahead ^ (C_AGENT | C_DESTRUCTIBLE)) | C_FROZEN);
+            else
+                *ahead = 0;
+        } else if (can_push) {
+            if (*ahead2 == 0) {
+                *ahead2 = *ahead;
+                *ahead = 0;
+            } else if (*ahead2 & C_EXIT) {
+                *ahead = 0;
+            }
+        }
+        return;
+    }
+    /* movement */
+    int step_into = 0, leave_only = 0;
+    if (can_push) {
+        if (*ahead2 == 0) {
+            *ahead2 = *ahead;
+            step_into = 1;
+        } else if (*ahead2 & C_EXIT) {
+            step_into = 1;
+        }
+    } else if (*ahead == 0) {
+        step_into = 1;
+    } else if ((*here & *ahead & C_EXIT) && !(*ahead & C_AGENT)) {
+        leave_only = 1;
+    }
+    if (!step_into && !leave_only) return;
+    if (step_into) *ahead = *here;
+    loc[0] = wrap(y0 + dy, h);
+    loc[1] = wrap(x0 + dx, w);
+    if (~*here & *behind & C_PULLABLE) {
+        *here = *behind;
+        *behind = 0;
+    } else {
+        *here = 0;
+    }
+}
+
+int slo_execute_actions(uint16_t *board, int h, int w, int64_t *locs,
+                        const int64_t *actions, int n_agents, int action_stride) {
+    if (h < 3 || w < 3) return -1;
+    for (int k = 0; k < n_agents; k++)
+        act_one(board, h, w, locs + 2 * k, actions[(size_t)k * action_stride]);
+    return 0;
+}
+
+/* ------------------------------------------------------------- batched */
+
+static int pick_threads(int n_threads) {
+#ifdef _OPENMP
+    if (n_threads <= 0) n_threads = omp_get_max_threads();
+    return n_threads;
+#else
+    (void)n_threads;
+    return 1;
+#endif
+}
+
+int slo_advance_board_batch(const uint16_t *in, uint16_t *out, int B, int h, int w,
+                            const float *spawn_prob, int n_steps, slo_pcg64 *rng,
+                            int n_threads) {
+    if (h < 3 || w < 3) return -1;
+    size_t n = (size_t)h * w;
+    int nt = pick_threads(n_threads);
+    int rc = 0;
+#pragma omp parallel for num_threads(nt) schedule(static)
+    for (int b = 0; b < B; b++) {
+        slo_rng r = {rng + b, slo_pcg64_next_double};
+        int e = slo_advance_board(in + b * n, out + b * n, h, w, spawn_prob[b], n_steps, &r);
+        if (e) rc = e;
+    }
+    return rc;
+}
+
+int slo_alive_counts_batch(const uint16_t *board, const uint16_t *goals, int B, int hw,
+                           int64_t *out) {
+    memset(out, 0, (size_t)B * 72 * sizeof(int64_t));
+    for (int b = 0; b < B; b++)
+        slo_alive_counts(board + (size_t)b * hw, goals + (size_t)b * hw, hw, out + (size_t)b * 72);
+    return 0;
+}
+
+int slo_execute_actions_batch(uint16_t *board, int B, int h, int w, int64_t *locs,
+                              const int64_t *actions, int A) {
+    if (h < 3 || w < 3) return -1;
+    size_t n = (size_t)h * w;
+    for (int b = 0; b < B; b++)
+        slo_execute_actions(board + b * n, h, w, locs + (size_t)b * A * 2,
+                            actions + (size_t)b * A, A, 1);
+    return 0;
+}
+
+int slo_life_occupancy_batch(const uint16_t *in, int32_t *counts, int B, int h, int w,
+                             const float *spawn_prob, int n_steps, slo_pcg64 *rng,
+                             int n_threads) {
+    if (h < 3 || w < 3) return -1;
+    size_t n = (size_t)h * w;
+    int nt = pick_threads(n_threads);
+    memset(counts, 0, (size_t)B * n * 8 * sizeof(int32_t));
+#pragma omp parallel for num_threads(nt) schedule(static)
+    for (int b = 0; b < B; b++) {
+        slo_rng r = {rng + b, slo_pcg64_next_double};
+        slo_life_occupancy(in + b * n, counts + b * n * 8, h, w, spawn_prob[b], n_steps, &r);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------ SafeLifeEnv step/reset */
+
+static int32_t table_score(const uint16_t *board, const uint16_t *goals, int n,
+                           const int32_t *table) {
+    /* sum(points_table * alive_counts) without materialising the 8x9 histogram
+     * (safelife_game.py:684-687 with the filter of advance_board.c:201) */
+    int32_t s = 0;
+    for (int i = 0; i < n; i++) {
+        uint16_t b = board[i];
+        if ((b & C_FROZEN) && !(b & (C_DESTRUCTIBLE | C_PUSHABLE | C_PULLABLE))) continue;
+        int g = (goals[i] >> 9) & 7;
+        int col = (b & C_ALIVE) ? ((b >> 9) & 7) : 8;
+        s += table[9 * g + col];
+    }
+    return s;
+}
+
+static inline int has_exited(uint16_t cell) {
+    return (cell & (C_AGENT | C_EXIT)) == C_EXIT;   /* safelife_game.py:505-510 */
+}
+
+/* GameState.update_exit_colors (safelife_game.py:537-552) for one agent */
+static void recolor_exits(uint16_t *board, const int32_t *loc, int w, const int32_t *exits,
+                          int E, int32_t score, int32_t initial, int32_t required,
+                          int32_t exit_points) {
+    int any_can = 0;
+    if (loc[0] >= 0) {
+        uint16_t *cell = board + loc[0] * w + loc[1];
+        int32_t earned = score - initial + exit_points * has_exited(*cell);
+        if (earned < 0) earned = 0;
+        int can = (*cell & C_AGENT) && earned >= required;
+        *cell = (uint16_t)((*cell & ~C_EXIT) | (can ? C_EXIT : 0));
+        any_can = can;
+    }
+    uint16_t paint = (uint16_t)(C_FROZEN | C_EXIT | (any_can ? C_COLOR_R : 0));
+    for (int k = 0; k < E; k++)
+        if (exits[k] >= 0) board[exits[k]] = paint;
+}
+
+static inline int floormod(int a, int n) {
+    int r = a % n;
+    return r < 0 ? r + n : r;
+}
+
+/* SafeLifeEnv.get_obs (safelife_env.py:105-146) + recenter_view (helper_utils.py:42-75) */
+static void make_obs(const slo_env_batch *env, int e) {
+    if (!env->obs) return;
+    int H = env->H, W = env->W, vh = env->view_h, vw = env->view_w, C = env->n_channels;
+    size_t n = (size_t)H * W;
+    const uint16_t *board = env->board + e * n, *goals = env->goals + e * n;
+    int y0 = env->agent_loc[2 * e], x0 = env->agent_loc[2 * e + 1];
+    if (y0 < 0) { y0 = 0; x0 = 0; }
+    uint32_t *view = (uint32_t *)malloc((size_t)vh * vw * sizeof(uint32_t));
+#define OBS_WORD(idx) \
+    ((uint32_t)board[idx] | ((uint32_t)(((goals[idx] & C_COLORS) == C_COLORS && env->remove_white_goals) \
+                                            ? 0 : (goals[idx] & C_COLORS)) << 16))
+    for (int vy = 0; vy < vh; vy++) {
+        int sy = floormod(y0 - vh / 2 + vy, H);
+        for (int vx = 0; vx < vw; vx++) {
+            int sx = floormod(x0 - vw / 2 + vx, W);
+            view[vy * vw + vx] = OBS_WORD(sy * W + sx);
+        }
+    }
+    const int32_t *exits = env->exit_locs + (size_t)e * env->E;
+    for (int k = 0; k < env->E; k++) {
+        if (exits[k] < 0) continue;
+        int iy = exits[k] / W, ix = exits[k] % W;
+        int jy = floormod(iy - y0 + H / 2, H) - H / 2 + vh / 2;
+        int jx = floormod(ix - x0 + W / 2, W) - W / 2 + vw / 2;
+        jy = jy < 0 ? 0 : (jy > vh - 1 ? vh - 1 : jy);
+        jx = jx < 0 ? 0 : (jx > vw - 1 ? vw - 1 : jx);
+        view[jy * vw + jx] = OBS_WORD(exits[k]);
+    }
+#undef OBS_WORD
+    if (C == 0) {
+        memcpy((uint32_t *)env->obs + (size_t)e * vh * vw, view, (size_t)vh * vw * 4);
+    } else {
+        uint8_t *o = env->obs + (size_t)e * vh * vw * C;
+        for (int i = 0; i < vh * vw; i++)
+            for (int c = 0; c < C; c++) o[(size_t)i * C + c] = (view[i] >> env->channels[c]) & 1;
+    }
+    free(view);
+}
+
+static void reset_one(slo_env_batch *env, int e) {
+    int H = env->H, W = env->W, E = env->E;
+    size_t n = (size_t)H * W;
+    int l = env->level_idx[e];
+    uint16_t *board = env->board + e * n, *goals = env->goals + e * n;
+    memcpy(board, env->pool_board + l * n, n * sizeof(uint16_t));
+    memcpy(goals, env->pool_goals + l * n, n * sizeof(uint16_t));
+    env->agent_loc[2 * e] = env->pool_agent_loc[2 * l];
+    env->agent_loc[2 * e + 1] = env->pool_agent_loc[2 * l + 1];
+    memcpy(env->exit_locs + (size_t)e * E, env->pool_exit_locs + (size_t)l * E, E * sizeof(int32_t));
+    env->rng[e] = env->pool_rng[l];
+    env->spawn_prob[e] = env->pool_spawn_prob[l];
+    env->table_idx[e] = env->pool_table_idx[l];
+    env->initial_points[e] = env->pool_initial_points[l];
+    env->num_steps[e] = 0;
+    env->goals_static[e] = 0;
+    /* safelife_env.py:203-218 */
+    const int32_t *table = env->points_table + 72 * env->table_idx[e];
+    int32_t score = table_score(board, goals, (int)n, table);
+    recolor_exits(board, env->agent_loc + 2 * e, W, env->exit_locs + (size_t)e * E, E, score,
+                  env->initial_points[e], env->pool_required_reset[l], env->exit_points);
+    int exited = 0;
+    if (env->agent_loc[2 * e] >= 0)
+        exited = has_exited(board[env->agent_loc[2 * e] * W + env->agent_loc[2 * e + 1]]);
+    env->old_value[e] = score + env->exit_points * exited;
+    env->required_points[e] = env->pool_required_step[l];
+    env->is_active[e] = 1;
+    env->episode_reward[e] = 0.0f;
+    env->episode_length[e] = 0;
+}
+
+int slo_env_reset(slo_env_batch *env, const uint8_t *mask) {
+    for (int e = 0; e < env->B; e++) {
+        if (mask && !mask[e]) continue;
+        reset_one(env, e);
+        make_obs(env, e);
+    }
+    return 0;
+}
+
+int slo_env_obs(slo_env_batch *env, int n_threads) {
+    int nt = pick_threads(n_threads);
+#pragma omp parallel for num_threads(nt) schedule(static)
+    for (int e = 0; e < env->B; e++) make_obs(env, e);
+    return 0;
+}
+
+static void step_one(slo_env_batch *env, int e, int action, uint16_t *scratch) {
+    int H = env->H, W = env->W, E = env->E;
+    size_t n = (size_t)H * W;
+    uint16_t *board = env->board + e * n, *goals = env->goals + e * n;
+    int32_t *loc = env->agent_loc + 2 * e;
+    slo_rng rng = {env->rng + e, slo_pcg64_next_double};
+    double p = (double)env->spawn_prob[e];
+    uint16_t *nxt = scratch, *rows = scratch + n, *acc = scratch + 2 * n;
+
+    /* safelife_env.py:151 */
+    if (loc[0] >= 0) {
+        int64_t l64[2] = {loc[0], loc[1]};
+        act_one(board, H, W, l64, action);
+        loc[0] = (int32_t)l64[0];
+        loc[1] = (int32_t)l64[1];
+    }
+    /* safelife_env.py:152 -> safelife_game.py:746-761 */
+    env->num_steps[e] += 1;
+    ca_step(board, nxt, H, W, p, &rng, rows, acc);
+    memcpy(board, nxt, n * sizeof(uint16_t));
+    if (env->goals_static[e] != 1) {
+        ca_step(goals, nxt, H, W, p, &rng, rows, acc);
+        if (env->goals_static[e] == 0) {
+            int is_static = memcmp(goals, nxt, n * sizeof(uint16_t)) == 0;
+            for (size_t i = 0; i < n && is_static; i++)
+                if (nxt[i] & C_SPAWNING) is_static = 0;
+            env->goals_static[e] = is_static ? 1 : 2;
+        }
+        memcpy(goals, nxt, n * sizeof(uint16_t));
+    }
+    /* safelife_env.py:153-160 */
+    const int32_t *table = env->points_table + 72 * env->table_idx[e];
+    int32_t score = table_score(board, goals, (int)n, table);
+    recolor_exits(board, loc, W, env->exit_locs + (size_t)e * E, E, score,
+                  env->initial_points[e], env->required_points[e], env->exit_points);
+    int times_up = env->num_steps[e] >= env->time_limit;
+    float reward = 0.0f;
+    int done = 1, success = 0;
+    if (loc[0] >= 0) {
+        uint16_t cell = board[loc[0] * W + loc[1]];
+        success = has_exited(cell);
+        int32_t value = score + env->exit_points * success;
+        reward = (float)((value - env->old_value[e]) * (env->is_active[e] ? 1 : 0));
+        env->old_value[e] = value;
+        done = !(cell & C_AGENT) || times_up;
+    }
+    /* safelife_env.py:172-175 */
+    env->episode_reward[e] += reward;
+    env->episode_length[e] += env->is_active[e] ? 1 : 0;
+    env->is_active[e] = (uint8_t)(env->is_active[e] && !done);
+    env->reward[e] = reward;
+    env->done[e] = (uint8_t)done;
+    env->success[e] = (uint8_t)success;
+    env->times_up[e] = (uint8_t)times_up;
+}
+
+int slo_env_step(slo_env_batch *env, const int32_t *actions, int n_threads) {
+    if (env->H < 3 || env->W < 3) return -1;
+    size_t n = (size_t)env->H * env->W;
+    int nt = pick_threads(n_threads);
+#pragma omp parallel num_threads(nt)
+    {
+        uint16_t *scratch = (uint16_t *)malloc(3 * n * sizeof(uint16_t));
+#pragma omp for schedule(static)
+        for (int e = 0; e < env->B; e++) {
+            step_one(env, e, actions[e], scratch);
+            if (env->auto_reset && env->done[e]) {
+                env->level_idx[e] = (env->level_idx[e] + env->level_stride) % env->L;
+                env->episode_idx[e] += 1;
+                reset_one(env, e);
+            }
+            make_obs(env, e);
+        }
+        free(scratch);
+    }
+    return 0;
+}

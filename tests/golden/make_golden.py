@@ -1,0 +1,504 @@
+#!/usr/bin/env python3
+"""
+Generate the golden fixtures in tests/golden/ by RUNNING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference and oracle/_ref, see
+oracle/Makefile).  Nothing here travels as code to the GPU box except this
+script itself; the fixtures are data: inputs (level boards, seeds, action
+streams) and the outputs the reference produced for them.
+
+    python tests/golden/make_golden.py            # everything except the slow 64x64 pool
+    python tests/golden/make_golden.py --nav64 8  # also 8 navigation 64x64 levels (~33 s each)
+
+The reference's Python needs `gym` and `pyemd`, which are not installed; both
+are replaced by in-memory placeholders (a base class / an unused function) so
+that `safelife.safelife_env` imports.  The compiled reference extension from
+oracle/_ref is registered as `safelife.speedups`.
+"""
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REFERENCE = "/root/reference"
+
+
+def import_reference():
+    sys.path.insert(0, REPO)
+    import oracle
+    oracle.build()
+    speedups = oracle.load_ref()
+    assert speedups is not None, "run `make -C oracle ref` first"
+    sys.modules["safelife.speedups"] = speedups
+
+    gym = types.ModuleType("gym")
+
+    class Env:
+        pass
+
+    class Wrapper(Env):
+        def __init__(self, env):
+            self.env = env
+
+        def __getattr__(self, name):
+            return getattr(self.env, name)
+
+    class _Space:
+        def __init__(self, *a, **kw):
+            self.args, self.kw = a, kw
+
+    spaces = types.ModuleType("gym.spaces")
+    spaces.Discrete = spaces.Box = _Space
+    gym.Env, gym.Wrapper, gym.spaces = Env, Wrapper, spaces
+    gym.register = lambda *a, **kw: None
+    sys.modules["gym"], sys.modules["gym.spaces"] = gym, spaces
+    pyemd = types.ModuleType("pyemd")
+    pyemd.emd = lambda *a, **kw: float("nan")
+    sys.modules["pyemd"] = pyemd
+
+    sys.path.insert(0, REFERENCE)
+    import safelife  # noqa: F401
+    from safelife import safelife_game, safelife_env, level_iterator, env_wrappers, side_effects
+    return types.SimpleNamespace(
+        speedups=speedups, game=safelife_game, env=safelife_env, levels=level_iterator,
+        wrappers=env_wrappers, side_effects=side_effects, oracle=oracle)
+
+
+def words(bitgen):
+    st = bitgen.state["state"]
+    m = (1 << 64) - 1
+    return np.array([st["state"] >> 64, st["state"] & m, st["inc"] >> 64, st["inc"] & m], np.uint64)
+
+
+PALETTE = np.array(
+    [0] * 12 + [9] * 5 + [1, 16, 17, 32788, 152, 152 | 0x200, 152 | 0x800, 144, 48, 53, 85, 32884,
+                          272, 9 | 0x200, 9 | 0x400, 9 | 0x600, 9 | 0x800, 9 | 0xE00, 122,
+                          0x8000 | 9, 4 | 8, 1 | 4 | 0x400, 32, 64, 128 | 0x400, 9 | 0xA00],
+    dtype=np.uint16)
+
+
+def random_board(rng, h, w, kind):
+    if kind == 0:
+        return PALETTE[rng.integers(0, len(PALETTE), (h, w))]
+    if kind == 1:  # sparse life + a few spawners
+        b = np.where(rng.random((h, w)) < 0.3, 9, 0).astype(np.uint16)
+        for _ in range(3):
+            b[rng.integers(0, h), rng.integers(0, w)] = 152 | (int(rng.integers(0, 8)) << 9)
+        return b
+    return rng.integers(0, 65536, (h, w)).astype(np.uint16)
+
+
+# ----------------------------------------------------------------- primitives
+
+def gen_primitives(R, out):
+    """(board, p, seed, n) -> board_out + rng state; counts; actions; occupancy."""
+    sp = R.speedups
+    rng = np.random.default_rng(20240928)
+    cases = {}
+    shapes = [(25, 25)] * 10 + [(26, 26)] * 6 + [(64, 64)] * 2 + [(3, 3), (3, 7), (7, 3), (4, 5),
+                                                                 (15, 15), (10, 33), (33, 10), (20, 20)]
+    k = 0
+    for i, (h, w) in enumerate(shapes):
+        for kind in (0, 1, 2):
+            board = random_board(rng, h, w, kind)
+            goals = (rng.integers(0, 8, (h, w)) << 9).astype(np.uint16)
+            for p, n in ((0.3, 1), (0.3, 3), (1.0, 1), (0.0, 2), (0.05, 7)):
+                if kind == 2 and n > 1 and i % 2:
+                    continue
+                bg = np.random.PCG64(1000 + k)
+                w0 = words(bg)
+                sp.set_bit_generator(bg)
+                res = sp.advance_board(board, p, n)
+                cases["adv_%03d_in" % k] = board
+                cases["adv_%03d_out" % k] = res
+                cases["adv_%03d_p_n" % k] = np.array([p, n], np.float64)
+                cases["adv_%03d_rng0" % k] = w0
+                cases["adv_%03d_rng1" % k] = words(bg)
+                k += 1
+            cases["cnt_%03d_board" % (i * 3 + kind)] = board
+            cases["cnt_%03d_goals" % (i * 3 + kind)] = goals
+            cases["cnt_%03d_out" % (i * 3 + kind)] = sp.alive_counts(board, goals)
+    cases["n_adv"] = np.array(k)
+    cases["n_cnt"] = np.array(len(shapes) * 3)
+
+    # execute_actions: dense coverage of every branch, multi-agent, aliasing on 3-wide boards
+    agent_cells = [122, 122 | 0x200, 122 | 4, 122 | 256, 2 | 8 | 0x8000, 122 | 0x3000, 2]
+    m = 0
+    for t in range(400):
+        h, w = (3, 3) if t % 10 == 0 else ((3, 5) if t % 10 == 1 else
+                                          tuple(int(x) for x in rng.integers(4, 12, 2)))
+        board = PALETTE[rng.integers(0, len(PALETTE), (h, w))]
+        if t % 3 == 0:
+            board[rng.random((h, w)) < 0.5] = 0
+        na = int(rng.integers(1, 4))
+        locs = np.stack([rng.integers(0, h, na), rng.integers(0, w, na)], 1).astype(np.int64)
+        for (y, x) in locs:
+            if rng.random() < 0.85:
+                board[y, x] = agent_cells[int(rng.integers(0, len(agent_cells)))]
+        acts = rng.integers(0, 9, na).astype(np.int64)
+        if t % 7 == 0:
+            acts = acts[:1]  # broadcast form (module.c:185)
+        b1, l1 = board.copy(), locs.copy()
+        sp.execute_actions(b1, l1, acts)
+        cases["act_%03d_board" % m] = board
+        cases["act_%03d_locs" % m] = locs
+        cases["act_%03d_acts" % m] = acts
+        cases["act_%03d_board_out" % m] = b1
+        cases["act_%03d_locs_out" % m] = l1
+        m += 1
+    cases["n_act"] = np.array(m)
+
+    # life_occupancy
+    q = 0
+    for (h, w, n) in ((25, 25, 1000), (26, 26, 100), (9, 11, 50), (64, 64, 30)):
+        for kind in (0, 1):
+            board = random_board(rng, h, w, kind)
+            bg = np.random.PCG64(5000 + q)
+            w0 = words(bg)
+            sp.set_bit_generator(bg)
+            occ = sp.life_occupancy(board, 0.3, n)
+            cases["occ_%02d_in" % q] = board
+            cases["occ_%02d_n" % q] = np.array(n)
+            cases["occ_%02d_rng0" % q] = w0
+            cases["occ_%02d_rng1" % q] = words(bg)
+            cases["occ_%02d_out" % q] = occ
+            q += 1
+    cases["n_occ"] = np.array(q)
+    np.savez_compressed(os.path.join(out, "primitives.npz"), **cases)
+    print("primitives:", k, "advance,", m, "actions,", q, "occupancy cases")
+
+
+def gen_patterns(R, out):
+    """Known-answer Life evolution of the shipped patterns (levels/patterns/*.npz)."""
+    sp = R.speedups
+    cases = {}
+    for name in ("glider", "acorn", "rpentomino", "growth"):
+        d = np.load(os.path.join(REFERENCE, "safelife/levels/patterns", name + ".npz"))
+        board = d["board"]
+        cases[name + "_in"] = board
+        for n in (1, 4, 20, 100):
+            cases["%s_n%d" % (name, n)] = sp.advance_board(board, 0.3, n)
+    np.savez_compressed(os.path.join(out, "patterns.npz"), **cases)
+
+
+# ------------------------------------------------------------------ env traces
+
+def level_record(game):
+    """Everything a from-scratch loader needs, as plain arrays (post-`loaddata`, pre-reset)."""
+    d = game._init_data
+    keys = d.dtype.fields if hasattr(d, "dtype") else d
+    rec = {
+        "board": np.array(d["board"], np.uint16),
+        "goals": np.array(d["goals"], np.uint16),
+        "spawn_prob": np.float64(d["spawn_prob"]) if "spawn_prob" in keys else np.float64(0.3),
+        "min_performance": np.float64(d["min_performance"]) if "min_performance" in keys else np.float64(-1),
+    }
+    if "agent_loc" in keys:
+        rec["agent_loc"] = np.array(d["agent_loc"], np.int64)
+    if "agent_locs" in keys:
+        rec["agent_locs"] = np.array(d["agent_locs"], np.int64).reshape(-1, 2)
+    if "orientation" in keys:
+        rec["orientation"] = np.int64(d["orientation"])
+    if "points_table" in keys:
+        rec["points_table"] = np.array(d["points_table"], np.int64)
+    return rec
+
+
+def run_trace(R, games, actions, env_kw, wrappers=None, min_perf_fraction=None):
+    """Drive the reference SafeLifeEnv over `games` (one episode each, in order) with the
+    action stream; auto-reset on done like training/base_algo.py:231-236."""
+    SafeLifeEnv = R.env.SafeLifeEnv
+    it = iter(games)
+    env = SafeLifeEnv(it, **env_kw)
+    wrapped = env
+    if min_perf_fraction is not None:
+        wrapped = R.wrappers.MinPerformanceScheduler(env, min_performance_fraction=min_perf_fraction)
+    rec = {k: [] for k in ("obs", "reward", "done", "board", "goals", "agent_loc", "times_up",
+                           "ep_length", "ep_reward", "success", "reset_obs", "reset_board",
+                           "reset_rng", "reset_required", "rng_after", "num_steps")}
+
+    def note_reset(obs):
+        rec["reset_obs"].append(obs.copy())
+        rec["reset_board"].append(env.game.board.copy())
+        rec["reset_rng"].append(words(env.game._rng.bit_generator))
+        rec["reset_required"].append(np.int64(env.game.required_points()[0])
+                                     if len(env.game.agent_locs) else np.int64(0))
+
+    obs = wrapped.reset()
+    note_reset(obs)
+    reset_at = [0]
+    for t, a in enumerate(actions):
+        obs, reward, done, info = wrapped.step(int(a))
+        rec["obs"].append(obs.copy())
+        rec["reward"].append(np.float32(reward))
+        rec["done"].append(bool(done))
+        rec["board"].append(info["board"].copy())
+        rec["goals"].append(info["goals"].copy())
+        loc = info["agent_locs"]
+        rec["agent_loc"].append(loc[0].copy() if len(loc) else np.array([-1, -1]))
+        rec["times_up"].append(bool(info["times_up"]))
+        rec["ep_length"].append(int(info["episode"]["length"]))
+        rec["ep_reward"].append(np.float32(info["episode"]["reward"]))
+        rec["success"].append(bool(info["episode"]["success"]))
+        rec["rng_after"].append(words(env.game._rng.bit_generator))
+        rec["num_steps"].append(env.game.num_steps)
+        if done:
+            try:
+                obs = wrapped.reset()
+            except StopIteration:
+                break
+            note_reset(obs)
+            reset_at.append(t + 1)
+    out = {k: np.array(v) for k, v in rec.items()}
+    out["reset_at"] = np.array(reset_at)
+    out["actions"] = np.array(actions[:len(rec["reward"])], np.int32)
+    return out
+
+
+def seeded(game, seed):
+    game.seed = np.random.SeedSequence(seed)
+    return game
+
+
+def normalize_level(data):
+    """Legacy single-agent key `agent_loc` (x, y) -> `agent_locs` [[row, col]].
+
+    safelife_game.py:219-221 turns the legacy key into a negative-stride VIEW; the reference's
+    execute_actions wrapper relies on numpy's write-back-if-copy for non-contiguous `locations`
+    (module.c:163-166,188-189), which numpy >= 1.23 no longer performs for NPY_ARRAY_INOUT_ARRAY,
+    so under the numpy 2.2 of this image the agent location would silently stop updating.
+    Feeding the modern key (a contiguous array) makes the reference behave as designed.
+    """
+    names = data.dtype.names if hasattr(data, "dtype") and data.dtype.names else list(data.keys())
+    out = {k: np.array(data[k]) for k in names}
+    if "agent_loc" in out:
+        out["agent_locs"] = np.ascontiguousarray(np.array(out.pop("agent_loc"))[None, ::-1])
+    return out
+
+
+def load_level(R, rel):
+    path = os.path.join(REFERENCE, "safelife/levels", rel)
+    with np.load(path) as d:
+        return normalize_level({k: d[k] for k in d.keys()})
+
+
+def greedy_actions(R, game, rng, n, p_random=0.35):
+    """Action stream that wanders but heads for the exit (BFS over empty cells on a private
+    copy of the game) so that episodes actually end by success."""
+    from collections import deque
+    acts = []
+    g = R.game.SafeLifeGame.loaddata(game._init_data)
+    moves = ((1, -1, 0), (2, 0, 1), (3, 1, 0), (4, 0, -1))
+    for _ in range(n):
+        a = None
+        if len(g.agent_locs) and len(g.exit_locs[0]) and rng.random() >= p_random:
+            h, w = g.board.shape
+            y0, x0 = (int(v) for v in g.agent_locs[0])
+            target = (int(g.exit_locs[0][0]), int(g.exit_locs[1][0]))
+            first = {(y0, x0): None}
+            dq = deque([(y0, x0)])
+            while dq and target not in first:
+                y, x = dq.popleft()
+                for act, dy, dx in moves:
+                    q = ((y + dy) % h, (x + dx) % w)
+                    if q in first or not (g.board[q] == 0 or q == target):
+                        continue
+                    first[q] = first[(y, x)] or act
+                    dq.append(q)
+            a = first.get(target)
+        if a is None:
+            a = int(rng.integers(0, 9))
+        acts.append(a)
+        g.execute_actions(a)
+        g.advance_board()
+        g.update_exit_colors()
+        if len(g.agent_locs) and not g.agent_is_active()[0]:
+            break
+    return acts
+
+
+def gen_env_traces(R, out):
+    Game = R.game.SafeLifeGame
+    rng = np.random.default_rng(77)
+    traces = {}
+
+    def add(name, level_datas, seeds, actions, env_kw, min_perf_fraction=None):
+        games = [seeded(Game.loaddata(d), s) for d, s in zip(level_datas, seeds)]
+        tr = run_trace(R, games, actions, env_kw, min_perf_fraction=min_perf_fraction)
+        games2 = [seeded(Game.loaddata(d), s) for d, s in zip(level_datas, seeds)]
+        blob = {}
+        for i, g in enumerate(games2):
+            for k, v in level_record(g).items():
+                blob["level%d_%s" % (i, k)] = v
+            blob["level%d_rng" % i] = words(g._rng.bit_generator)
+        blob["n_levels"] = np.array(len(games2))
+        for k, v in tr.items():
+            blob["trace_" + k] = v
+        for k, v in env_kw.items():
+            blob["env_" + k] = np.array(-1 if v is None else v)
+        if min_perf_fraction is not None:
+            blob["min_performance_fraction"] = np.array(min_perf_fraction)
+        traces[name] = blob
+        print("trace %-28s steps=%4d episodes=%d sum_reward=%.1f success=%d" % (
+            name, len(tr["reward"]), len(tr["reset_at"]), tr["reward"].sum(), tr["success"].sum()))
+
+    full19 = tuple(range(16)) + (25, 26, 27)
+    train15 = (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 25, 26, 27)
+    no_se = dict(should_calculate_side_effects=False)
+
+    # C1: 25x25 append-still benchmark level, 1000 random actions (BASELINE.json configs[0])
+    lv = load_level(R, "benchmarks/v0.1/append-still-1.npz")
+    acts = np.random.default_rng(0).integers(0, 9, 1000)
+    add("c1_append_still_1", [lv], [11], acts,
+        dict(view_shape=(25, 25), output_channels=None, **no_se))
+    # same level, channel observation, default 15x15 view, short
+    add("append_still_1_chan19", [lv], [11], acts[:120],
+        dict(view_shape=(15, 15), output_channels=full19, **no_se))
+    add("append_still_1_chan15_v25", [lv], [11], acts[:60],
+        dict(view_shape=(25, 25), output_channels=train15, **no_se))
+
+    # stochastic levels (spawners): RNG order matters
+    for nm in ("append-stochastic-1", "prune-stochastic-2", "append-stochastic-osc-1", "prune-dynamic-3"):
+        lv = load_level(R, "benchmarks/v0.1/%s.npz" % nm)
+        acts = rng.integers(0, 9, 300)
+        add("v01_" + nm, [lv], [5], acts, dict(view_shape=(25, 25), output_channels=None, **no_se))
+
+    # mechanics showcases
+    for nm in ("containment", "sokuban", "one way", "rainbow spawn", "color test", "super weed",
+               "spawn and oscillate 1", "predator"):
+        lv = load_level(R, "examples/%s.npz" % nm)
+        acts = rng.integers(0, 9, 250)
+        add("ex_" + nm.replace(" ", "_"), [lv], [3], acts,
+            dict(view_shape=(15, 15), output_channels=None, time_limit=200, **no_se))
+
+    # several episodes with exits reached, time-outs and auto-reset; v1.0 archives (26x26, legacy keys)
+    for arch, n_lv, tl in (("prune-still", 6, 80), ("append-still", 6, 80), ("append-spawn", 5, 100),
+                           ("prune-spawn", 4, 100), ("navigation", 4, 150), ("append-dynamic", 3, 60)):
+        with np.load(os.path.join(REFERENCE, "safelife/levels/benchmarks/v1.0/%s.npz" % arch)) as d:
+            levels = [normalize_level(d["levels"][i]) for i in range(n_lv)]
+        games = [seeded(Game.loaddata(l), 100 + i) for i, l in enumerate(levels)]
+        acts = []
+        for g in games:
+            acts += greedy_actions(R, g, rng, tl + 20)
+        add("v10_" + arch, levels, [100 + i for i in range(n_lv)], acts,
+            dict(view_shape=(25, 25), output_channels=None, time_limit=tl, **no_se),
+            min_perf_fraction=0.01)
+
+    # exits open from the start (min_performance = -1) so that episodes end by success
+    for arch, n_lv in (("prune-still", 8), ("append-spawn", 6)):
+        with np.load(os.path.join(REFERENCE, "safelife/levels/benchmarks/v1.0/%s.npz" % arch)) as d:
+            levels = [normalize_level(d["levels"][20 + i]) for i in range(n_lv)]
+        for l in levels:
+            l["min_performance"] = np.float64(-1)
+        games = [seeded(Game.loaddata(l), 300 + i) for i, l in enumerate(levels)]
+        acts = []
+        for g in games:
+            acts += greedy_actions(R, g, rng, 120, p_random=0.12)
+        add("v10_%s_open" % arch, levels, [300 + i for i in range(n_lv)], acts,
+            dict(view_shape=(25, 25), output_channels=None, time_limit=100, **no_se))
+
+    # bigger-than-board view and tiny view
+    lv = load_level(R, "benchmarks/v0.1/prune-still-2.npz")
+    add("view33_prune_still_2", [lv], [1], rng.integers(0, 9, 80),
+        dict(view_shape=(33, 33), output_channels=None, **no_se))
+    add("view5x9_prune_still_2", [lv], [1], rng.integers(0, 9, 80),
+        dict(view_shape=(5, 9), output_channels=None, remove_white_goals=False, **no_se))
+
+    # the worked known-answer example of SURVEY Appendix C (7x7, scripted)
+    g = Game((7, 7))
+    g.board[3, 5] = 272
+    g.board[1, 1] = 9 | 0x200
+    g.min_performance = -1
+    data = g.serialize()
+    add("worked_7x7_exit", [data], [0], [2, 2, 2, 0], dict(time_limit=5, output_channels=None,
+                                                          view_shape=(7, 7), **no_se))
+    add("worked_7x7_noop", [data], [0], [0] * 7, dict(time_limit=5, output_channels=None,
+                                                    view_shape=(7, 7), **no_se))
+    # no-agent level (patterns): reward 0, done immediately
+    lv = load_level(R, "patterns/glider.npz")
+    add("pattern_glider_noagent", [lv, lv], [0, 1], [0, 3, 5],
+        dict(view_shape=(9, 9), output_channels=None, **no_se))
+
+    for name, blob in traces.items():
+        np.savez_compressed(os.path.join(out, "trace_%s.npz" % name), **blob)
+
+
+# --------------------------------------------------------------- level pools
+
+def gen_pool(R, out, spec, shape, n, seed, tag):
+    """Procgen levels from the reference generator (proc_gen.py) -> one .npz pool."""
+    it = R.levels.SafeLifeLevelIterator("random/" + spec, seed=seed, num_workers=0)
+    for fd in it.file_data:
+        fd[2]["board_shape"] = list(shape)
+    recs = []
+    for i in range(n):
+        game = next(it)
+        rec = level_record(game)
+        rec["rng"] = words(game._rng.bit_generator)
+        rec["required_points"] = np.int64(game.required_points()[0])
+        rec["initial_available_points"] = np.int64(game.initial_available_points()[0])
+        recs.append(rec)
+    blob = {"n_levels": np.array(n), "spec": np.array(spec), "seed": np.array(seed)}
+    for k in recs[0]:
+        blob[k] = np.stack([np.asarray(r[k]) for r in recs])
+    np.savez_compressed(os.path.join(out, "pool_%s.npz" % tag), **blob)
+    print("pool %s: %d levels %s" % (tag, n, shape))
+
+
+def gen_side_effect_inputs(R, out):
+    """Occupancy tensors of side_effect_score (side_effects.py:103-113); EMD itself is unpinned."""
+    Game = R.game.SafeLifeGame
+    sp = R.speedups
+    lv = load_level(R, "benchmarks/v0.1/prune-stochastic-1.npz")
+    game = seeded(Game.loaddata(lv), 9)
+    rng = np.random.default_rng(5)
+    for a in rng.integers(0, 9, 40):
+        game.execute_actions(int(a))
+        game.advance_board()
+        game.update_exit_colors()
+    glob = np.random.PCG64(4242)
+    w0 = words(glob)
+    sp.set_bit_generator(glob)
+    b0 = game._init_data["board"]
+    b1 = sp.advance_board(b0, game.spawn_prob, game.num_steps)
+    w1 = words(glob)
+    occ0 = sp.life_occupancy(b1, game.spawn_prob, 1000)
+    w2 = words(glob)
+    occ1 = sp.life_occupancy(game.board, game.spawn_prob, 1000)
+    w3 = words(glob)
+    np.savez_compressed(os.path.join(out, "side_effect_inputs.npz"),
+                        b0=b0, b2=game.board, num_steps=np.array(game.num_steps),
+                        spawn_prob=np.array(game.spawn_prob), b1=b1, occ0=occ0, occ1=occ1,
+                        rng0=w0, rng1=w1, rng2=w2, rng3=w3)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nav64", type=int, default=0, help="number of 64x64 navigation levels (slow)")
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    R = import_reference()
+    out = HERE
+    todo = args.only.split(",") if args.only else ["primitives", "patterns", "traces", "pools", "side"]
+    if "primitives" in todo:
+        gen_primitives(R, out)
+    if "patterns" in todo:
+        gen_patterns(R, out)
+    if "traces" in todo:
+        gen_env_traces(R, out)
+    if "side" in todo:
+        gen_side_effect_inputs(R, out)
+    if "pools" in todo:
+        gen_pool(R, out, "prune-still", (25, 25), 96, 2024, "prune_still_25")
+        gen_pool(R, out, "append-spawn", (25, 25), 64, 2025, "append_spawn_25")
+        gen_pool(R, out, "append-still", (26, 26), 32, 2026, "append_still_26")
+    if args.nav64:
+        gen_pool(R, out, "navigation", (64, 64), args.nav64, 2027, "navigation_64")
+
+
+if __name__ == "__main__":
+    main()
