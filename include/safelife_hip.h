@@ -1,0 +1,161 @@
+/*
+ * safelife_hip.h -- C-ABI of libsafelife_hip.so: the MI355X (gfx950) implementation of the
+ * SafeLife per-step hot path.  This is the drop-in boundary: every entry point replaces one
+ * prototype of the reference's native layer (safelife/speedups_src/advance_board.h:3-16) or one
+ * method of its Python step surface, batched over B independent boards.
+ *
+ * Conventions (all entry points)
+ *   - Plain pointers and sizes only; no torch / Python types.  Every array pointer is a DEVICE
+ *     pointer (HBM) unless the parameter is documented as "host".  The library allocates nothing
+ *     per call and retains no pointer; the caller owns every buffer.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls only enqueue work.
+ *   - Return value: 0 on success, negative on failure (SL_E_*); slhip_last_error() gives a
+ *     thread-local message.  The Python shim turns SL_E_SHAPE into the reference's ValueError text.
+ *   - Boards are C-contiguous uint16 [B,H,W], the cell bit layout of constants.h:4-33
+ *     (== safelife_game.py:75-123).  3 <= H, W; H*W <= SL_MAX_CELLS.
+ *   - Random numbers: one numpy-compatible PCG64 (XSL-RR 128/64) stream per board replaces the
+ *     reference's process-global bit generator (random.c:21-22,76-83).  Draws are consumed exactly
+ *     as advance_board.c:115 consumes them (eligible cells only, row-major), so a board stepped
+ *     here with the state of numpy generator G equals the reference stepped under G, and the
+ *     state written back equals G's state afterwards.
+ */
+#ifndef SAFELIFE_HIP_H
+#define SAFELIFE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SL_ABI_VERSION 1
+#define SL_MAX_CELLS 16384        /* H*W limit of one board */
+#define SL_MAX_CHANNELS 32
+
+enum sl_status {
+    SL_OK = 0,
+    SL_E_SHAPE = -1,      /* bad board shape / sizes (module.c:32-35,112-114,170-179) */
+    SL_E_ARG = -2,        /* null pointer or inconsistent argument */
+    SL_E_HIP = -3,        /* HIP runtime error, see slhip_last_error() */
+    SL_E_UNSUPPORTED = -4
+};
+
+/* numpy.random.PCG64 state as four 64-bit words (state = hi:lo, inc = hi:lo). */
+typedef struct sl_pcg64 {
+    uint64_t state_hi, state_lo, inc_hi, inc_lo;
+} sl_pcg64;
+
+int slhip_abi_version(void);
+const char *slhip_last_error(void);
+/* Number of HIP devices visible, or a negative sl_status. */
+int slhip_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Batched primitives == the five prototypes of advance_board.h, one launch for B boards.
+ * ------------------------------------------------------------------------------------------ */
+
+/* advance_board_nstep (advance_board.h:6-7; Python advance_board(board, spawn_prob, n_step),
+ * module.c:20-49).  out may alias in.  spawn_prob: [B] float (the reference parses a C float,
+ * module.c:26, and compares the draw against it promoted to double, advance_board.c:35,115).
+ * rng: [B], read and written back advanced by the number of draws consumed. */
+int slhip_advance_board(const uint16_t *in, uint16_t *out, int B, int H, int W,
+                        const float *spawn_prob, int n_steps, sl_pcg64 *rng, void *stream);
+
+/* life_occupancy (advance_board.h:9-10, module.c:52-81).  counts: int32 [B,H,W,8], overwritten
+ * (the reference accumulates into a zeroed array): per cell and colour, the number of steps
+ * 1..n_steps after which the cell is ALIVE and not AGENT|EXIT|FROZEN (advance_board.c:153-161). */
+int slhip_life_occupancy(const uint16_t *in, int32_t *counts, int B, int H, int W,
+                         const float *spawn_prob, int n_steps, sl_pcg64 *rng, void *stream);
+
+/* alive_counts (advance_board.h:12, module.c:99-132).  out: int64 [B,8,9], overwritten.
+ * HW = cells per board (any shape, flat, as the reference). */
+int slhip_alive_counts(const uint16_t *board, const uint16_t *goals, int B, int HW,
+                       int64_t *out, void *stream);
+
+/* execute_actions (advance_board.h:14-16, module.c:155-202).  board and locs are updated in
+ * place; locs: int64 [B,A,2] as (row, col); actions: int64, element (b,k) at
+ * actions[b*action_batch_stride + k*action_stride] (action_stride 0 broadcasts one action to all
+ * agents of a board, module.c:185).  Agents of one board act in index order. */
+int slhip_execute_actions(uint16_t *board, int B, int H, int W, int64_t *locs,
+                          const int64_t *actions, int A, int action_stride,
+                          int action_batch_stride, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused single-agent SafeLifeEnv.step()/reset() over B device-resident environments
+ * (safelife_env.py:148-218 with the game glue of safelife_game.py:505-552,657-719,746-761 and
+ * the observation of safelife_env.py:105-146 / helper_utils.py:42-75).
+ * The struct lives on the HOST; every pointer inside is a device pointer.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct sl_env_batch {
+    int32_t B, H, W, E;          /* envs; board dims; exit slots per env (>= 1) */
+    int32_t time_limit;          /* SafeLifeEnv.time_limit (safelife_env.py:65) */
+    int32_t exit_points;         /* GameState.points_on_level_exit (safelife_game.py:156) */
+    int32_t n_tables;
+    int32_t auto_reset;          /* !=0: an env whose episode ends reloads its next pool level */
+    int32_t remove_white_goals;  /* safelife_env.py:66,125-126 */
+    int32_t view_h, view_w;      /* SafeLifeEnv.view_shape */
+    int32_t n_channels;          /* len(output_channels); 0 => raw uint32 view */
+    int32_t channels[SL_MAX_CHANNELS];
+    /* per-env state */
+    uint16_t *board;             /* [B,H,W] */
+    uint16_t *goals;             /* [B,H,W] */
+    int32_t *agent_loc;          /* [B,2] (row, col); row < 0 => level without agent */
+    int32_t *exit_locs;          /* [B,E] flat cell index of GameState.exit_locs, -1 = unused */
+    sl_pcg64 *rng;               /* [B] SafeLifeGame._rng */
+    float *spawn_prob;           /* [B] */
+    int32_t *num_steps;          /* [B] */
+    int32_t *old_value;          /* [B] SafeLifeEnv._old_game_value */
+    int32_t *required_points;    /* [B] GameWithGoals.required_points() */
+    int32_t *initial_points;     /* [B] sum(points_table * initial_counts) */
+    int32_t *table_idx;          /* [B] row of points_table used by this env */
+    uint8_t *goals_static;       /* [B] SafeLifeGame._static_goals: 0 None, 1 True, 2 False */
+    uint8_t *is_active;          /* [B] SafeLifeEnv._is_active */
+    float *episode_reward;       /* [B] */
+    int32_t *episode_length;     /* [B] */
+    int32_t *level_idx;          /* [B] pool level currently loaded */
+    int32_t *episode_idx;        /* [B] episodes finished by this env */
+    const int32_t *points_table; /* [n_tables,8,9] (safelife_game.py:595-605) */
+    /* level pool: the device-resident counterpart of SafeLifeLevelIterator */
+    int32_t L;
+    int32_t level_stride;        /* next level of an env = (level_idx + level_stride) % L */
+    const uint16_t *pool_board;  /* [L,H,W] as loaded (before update_exit_colors) */
+    const uint16_t *pool_goals;  /* [L,H,W] */
+    const int32_t *pool_agent_loc;      /* [L,2] */
+    const int32_t *pool_exit_locs;      /* [L,E] */
+    const sl_pcg64 *pool_rng;           /* [L] */
+    const float *pool_spawn_prob;       /* [L] */
+    const int32_t *pool_required_reset; /* [L] required_points during reset() */
+    const int32_t *pool_required_step;  /* [L] required_points for the steps that follow
+                                           (differs under MinPerformanceScheduler, env_wrappers.py:142-145) */
+    const int32_t *pool_initial_points; /* [L] */
+    const int32_t *pool_table_idx;      /* [L] */
+    /* per-step outputs */
+    float *reward;               /* [B] np.float32 reward of safelife_env.py:157,172 */
+    uint8_t *done;               /* [B] */
+    uint8_t *success;            /* [B] info['episode']['success'] */
+    uint8_t *times_up;           /* [B] info['times_up'] */
+    float *info_episode_reward;  /* [B] info['episode']['reward'] (value before any auto-reset) */
+    int32_t *info_episode_length;/* [B] info['episode']['length'] */
+    uint8_t *obs;                /* [B,vh,vw,C] uint8, or uint32 [B,vh,vw] if n_channels == 0; NULL = skip */
+} sl_env_batch;
+
+/* SafeLifeEnv.reset() for the envs with mask[e] != 0 (mask NULL = all): loads pool level
+ * level_idx[e] into slot e and writes its first observation. */
+int slhip_env_reset(const sl_env_batch *env, const uint8_t *mask, void *stream);
+
+/* One SafeLifeEnv.step() for every env.  actions: int32 [B] in 0..8. */
+int slhip_env_step(const sl_env_batch *env, const int32_t *actions, void *stream);
+
+/* T consecutive steps in ONE launch (boards stay on chip between steps).  actions: int32 [T,B].
+ * reward_t / done_t: optional [T,B] per-step outputs (NULL = only the last step's outputs in
+ * env->reward/done are kept).  Observations are produced for the final state only. */
+int slhip_env_rollout(const sl_env_batch *env, const int32_t *actions, int T,
+                      float *reward_t, uint8_t *done_t, void *stream);
+
+/* SafeLifeEnv.get_obs() for the current state. */
+int slhip_env_obs(const sl_env_batch *env, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAFELIFE_HIP_H */

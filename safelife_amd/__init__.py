@@ -1,0 +1,24 @@
+"""
+safelife_amd -- the SafeLife per-step hot path on AMD Instinct MI355X (gfx950).
+
+This package accelerates exactly one path of the reference (PartnershipOnAI/safelife): the
+cellular-automaton step of ``safelife/speedups_src`` and the integer glue of
+``SafeLifeEnv.step()/reset()`` around it.  Layout:
+
+* ``speedups``    functions with the reference's ``safelife.speedups`` signatures, on the GPU
+* ``vector_env``  ``SafeLifeVectorEnv``: B device-resident envs, one fused launch per step
+* ``game`` / ``env``  ``SafeLifeGame`` / ``SafeLifeEnv`` look-alikes (one env at a time) built on
+  ``speedups`` so reference-style wrappers and training loops run unchanged
+* ``levels``      ``.npz`` level loader and the device level pool
+* ``sharding``    one process per GPU: env partition + reward/done gather over RCCL
+* ``csrc/``       hand-written HIP kernels and the C-ABI (include/safelife_hip.h)
+
+Importing the package needs neither torch nor a GPU; calling any compute entry point without
+``libsafelife_hip.so`` or without a HIP device raises (there is no CPU fallback).
+"""
+from .cell_types import CellTypes, DEFAULT_POINTS_TABLE  # noqa: F401
+
+__version__ = "0.1.0"
+
+__all__ = ["CellTypes", "DEFAULT_POINTS_TABLE", "speedups", "levels", "vector_env", "game", "env",
+           "sharding"]

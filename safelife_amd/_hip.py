@@ -1,0 +1,129 @@
+"""
+ctypes binding of ``libsafelife_hip.so`` (the C-ABI of include/safelife_hip.h).
+
+This is the only way the package reaches the GPU kernels.  There is no CPU
+fallback: if the library is missing, or no HIP device is visible when a compute
+entry point is called, an exception is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsafelife_hip.so")
+
+SL_MAX_CELLS = 16384
+SL_MAX_CHANNELS = 32
+SL_E_SHAPE, SL_E_ARG, SL_E_HIP, SL_E_UNSUPPORTED = -1, -2, -3, -4
+
+#: every symbol include/safelife_hip.h declares
+EXPORTS = (
+    "slhip_abi_version", "slhip_last_error", "slhip_device_count",
+    "slhip_advance_board", "slhip_life_occupancy", "slhip_alive_counts", "slhip_execute_actions",
+    "slhip_env_reset", "slhip_env_step", "slhip_env_rollout", "slhip_env_obs",
+)
+
+
+class SafeLifeHipError(RuntimeError):
+    pass
+
+
+class Pcg64(C.Structure):
+    _fields_ = [("state_hi", C.c_uint64), ("state_lo", C.c_uint64),
+                ("inc_hi", C.c_uint64), ("inc_lo", C.c_uint64)]
+
+
+_p = C.c_void_p
+
+#: (field name, is-pointer) in the exact order of `struct sl_env_batch`
+ENV_SCALARS_HEAD = ("B", "H", "W", "E", "time_limit", "exit_points", "n_tables", "auto_reset",
+                    "remove_white_goals", "view_h", "view_w", "n_channels")
+ENV_STATE_PTRS = ("board", "goals", "agent_loc", "exit_locs", "rng", "spawn_prob", "num_steps",
+                  "old_value", "required_points", "initial_points", "table_idx", "goals_static",
+                  "is_active", "episode_reward", "episode_length", "level_idx", "episode_idx",
+                  "points_table")
+ENV_POOL_PTRS = ("pool_board", "pool_goals", "pool_agent_loc", "pool_exit_locs", "pool_rng",
+                 "pool_spawn_prob", "pool_required_reset", "pool_required_step",
+                 "pool_initial_points", "pool_table_idx")
+ENV_OUT_PTRS = ("reward", "done", "success", "times_up", "info_episode_reward",
+                "info_episode_length", "obs")
+
+
+class EnvBatch(C.Structure):
+    _fields_ = (
+        [(n, C.c_int32) for n in ENV_SCALARS_HEAD]
+        + [("channels", C.c_int32 * SL_MAX_CHANNELS)]
+        + [(n, _p) for n in ENV_STATE_PTRS]
+        + [("L", C.c_int32), ("level_stride", C.c_int32)]
+        + [(n, _p) for n in ENV_POOL_PTRS]
+        + [(n, _p) for n in ENV_OUT_PTRS]
+    )
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SafeLifeHipError(
+                "safelife_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.slhip_abi_version.restype = C.c_int
+        L.slhip_last_error.restype = C.c_char_p
+        L.slhip_device_count.restype = C.c_int
+        L.slhip_advance_board.argtypes = [_p, _p, C.c_int, C.c_int, C.c_int, _p, C.c_int, _p, _p]
+        L.slhip_life_occupancy.argtypes = [_p, _p, C.c_int, C.c_int, C.c_int, _p, C.c_int, _p, _p]
+        L.slhip_alive_counts.argtypes = [_p, _p, C.c_int, C.c_int, _p, _p]
+        L.slhip_execute_actions.argtypes = [_p, C.c_int, C.c_int, C.c_int, _p, _p, C.c_int, C.c_int,
+                                            C.c_int, _p]
+        L.slhip_env_reset.argtypes = [C.POINTER(EnvBatch), _p, _p]
+        L.slhip_env_step.argtypes = [C.POINTER(EnvBatch), _p, _p]
+        L.slhip_env_rollout.argtypes = [C.POINTER(EnvBatch), _p, C.c_int, _p, _p, _p]
+        L.slhip_env_obs.argtypes = [C.POINTER(EnvBatch), _p]
+        for name in EXPORTS:
+            getattr(L, name)  # AttributeError here means the .so is stale
+        _lib = L
+    return _lib
+
+
+def check(rc, shape_message=None):
+    """Translate a status code into the exception the reference's wrapper would raise."""
+    if rc == 0:
+        return
+    msg = (lib().slhip_last_error() or b"").decode()
+    if rc == SL_E_SHAPE:
+        raise ValueError(shape_message or msg)
+    if rc == SL_E_ARG:
+        raise ValueError(msg)
+    raise SafeLifeHipError("libsafelife_hip: %s (status %d)" % (msg, rc))
+
+
+_device = None
+
+
+def device():
+    """The torch device this process computes on (cuda:LOCAL_RANK).  Raises without a GPU."""
+    global _device
+    if _device is None:
+        import torch
+        if not torch.cuda.is_available():
+            raise SafeLifeHipError(
+                "safelife_amd needs a HIP device (torch.cuda.is_available() is False); "
+                "there is no CPU fallback.")
+        idx = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
+        torch.cuda.set_device(idx)
+        _device = torch.device("cuda", idx)
+    return _device
+
+
+def current_stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())

@@ -1,0 +1,187 @@
+// sl_abi.hip -- the extern "C" boundary declared in include/safelife_hip.h: argument validation,
+// the per-device PCG64 jump table, and dispatch to the gfx950 kernels.
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "sl_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+
+int hip_fail(hipError_t err, const char *what) {
+    return fail(SL_E_HIP, std::string(what) + ": " + hipGetErrorString(err));
+}
+
+// ---- PCG64 jump table: entry k maps a state k LCG steps ahead (mult_k * s + plus_k * inc) -----
+constexpr int kMaxDevices = 64;
+std::mutex g_jump_mutex;
+sl::Jump *g_jump[kMaxDevices] = {nullptr};
+
+typedef unsigned __int128 u128;
+
+int jump_table(const sl::Jump **out) {
+    int dev = 0;
+    hipError_t err = hipGetDevice(&dev);
+    if (err != hipSuccess) return hip_fail(err, "hipGetDevice");
+    if (dev < 0 || dev >= kMaxDevices) return fail(SL_E_UNSUPPORTED, "device index out of range");
+    std::lock_guard<std::mutex> lock(g_jump_mutex);
+    if (!g_jump[dev]) {
+        const u128 mult = (((u128)0x2360ED051FC65DA4ull) << 64) | (u128)0x4385DF649FCCF645ull;
+        std::vector<sl::Jump> host(SL_MAX_CELLS + 1);
+        u128 m = 1, p = 0;   // k = 0: identity
+        for (int k = 0; k <= SL_MAX_CELLS; ++k) {
+            host[k].mult_hi = (uint64_t)(m >> 64);
+            host[k].mult_lo = (uint64_t)m;
+            host[k].plus_hi = (uint64_t)(p >> 64);
+            host[k].plus_lo = (uint64_t)p;
+            p = p * mult + 1;   // plus_{k+1} = sum_{i<=k} mult^i
+            m = m * mult;
+        }
+        sl::Jump *d = nullptr;
+        err = hipMalloc(&d, host.size() * sizeof(sl::Jump));
+        if (err != hipSuccess) return hip_fail(err, "hipMalloc(jump table)");
+        err = hipMemcpy(d, host.data(), host.size() * sizeof(sl::Jump), hipMemcpyHostToDevice);
+        if (err != hipSuccess) {
+            (void)hipFree(d);
+            return hip_fail(err, "hipMemcpy(jump table)");
+        }
+        g_jump[dev] = d;
+    }
+    *out = g_jump[dev];
+    return SL_OK;
+}
+
+int check_board_shape(int B, int H, int W) {
+    if (B < 0) return fail(SL_E_ARG, "negative batch size");
+    if (H < 3 || W < 3) return fail(SL_E_SHAPE, "Board must be at least 3x3.");
+    if ((long long)H * W > SL_MAX_CELLS) return fail(SL_E_SHAPE, "board larger than SL_MAX_CELLS cells");
+    return SL_OK;
+}
+
+int check_env(const sl_env_batch *env) {
+    if (!env) return fail(SL_E_ARG, "null env");
+    int rc = check_board_shape(env->B, env->H, env->W);
+    if (rc) return rc;
+    if (env->E < 1) return fail(SL_E_ARG, "E must be >= 1");
+    if (env->n_channels < 0 || env->n_channels > SL_MAX_CHANNELS) return fail(SL_E_ARG, "bad n_channels");
+    if (env->view_h < 1 || env->view_w < 1) return fail(SL_E_ARG, "bad view shape");
+    if (env->L < 1 || env->n_tables < 1) return fail(SL_E_ARG, "empty level pool or points table");
+    const void *need[] = {env->board, env->goals, env->agent_loc, env->exit_locs, env->rng, env->spawn_prob,
+                          env->num_steps, env->old_value, env->required_points, env->initial_points,
+                          env->table_idx, env->goals_static, env->is_active, env->episode_reward,
+                          env->episode_length, env->level_idx, env->episode_idx, env->points_table,
+                          env->pool_board, env->pool_goals, env->pool_agent_loc, env->pool_exit_locs,
+                          env->pool_rng, env->pool_spawn_prob, env->pool_required_reset,
+                          env->pool_required_step, env->pool_initial_points, env->pool_table_idx,
+                          env->reward, env->done, env->success, env->times_up};
+    for (const void *p : need)
+        if (!p) return fail(SL_E_ARG, "null pointer in sl_env_batch");
+    return SL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int slhip_abi_version(void) { return SL_ABI_VERSION; }
+
+const char *slhip_last_error(void) { return g_last_error.c_str(); }
+
+int slhip_device_count(void) {
+    int n = 0;
+    hipError_t err = hipGetDeviceCount(&n);
+    if (err != hipSuccess) return hip_fail(err, "hipGetDeviceCount");
+    return n;
+}
+
+int slhip_advance_board(const uint16_t *in, uint16_t *out, int B, int H, int W, const float *spawn_prob,
+                        int n_steps, sl_pcg64 *rng, void *stream) {
+    int rc = check_board_shape(B, H, W);
+    if (rc) return rc;
+    if (!in || !out || !spawn_prob || !rng) return fail(SL_E_ARG, "null pointer");
+    if (n_steps < 0) return fail(SL_E_ARG, "negative n_steps");
+    if (B == 0) return SL_OK;
+    const sl::Jump *jump;
+    if ((rc = jump_table(&jump))) return rc;
+    hipError_t err = sl::launch_advance_generic(in, out, B, H, W, spawn_prob, n_steps, rng, jump, nullptr,
+                                                (hipStream_t)stream);
+    return err == hipSuccess ? SL_OK : hip_fail(err, "advance_board launch");
+}
+
+int slhip_life_occupancy(const uint16_t *in, int32_t *counts, int B, int H, int W, const float *spawn_prob,
+                         int n_steps, sl_pcg64 *rng, void *stream) {
+    int rc = check_board_shape(B, H, W);
+    if (rc) return rc;
+    if (!in || !counts || !spawn_prob || !rng) return fail(SL_E_ARG, "null pointer");
+    if (n_steps < 0) return fail(SL_E_ARG, "negative n_steps");
+    if (B == 0) return SL_OK;
+    const sl::Jump *jump;
+    if ((rc = jump_table(&jump))) return rc;
+    hipError_t err = sl::launch_advance_generic(in, nullptr, B, H, W, spawn_prob, n_steps, rng, jump, counts,
+                                                (hipStream_t)stream);
+    return err == hipSuccess ? SL_OK : hip_fail(err, "life_occupancy launch");
+}
+
+int slhip_alive_counts(const uint16_t *board, const uint16_t *goals, int B, int HW, int64_t *out,
+                       void *stream) {
+    if (B < 0 || HW < 0) return fail(SL_E_ARG, "negative size");
+    if (!board || !goals || !out) return fail(SL_E_ARG, "null pointer");
+    if (B == 0) return SL_OK;
+    hipError_t err = sl::launch_alive_counts(board, goals, B, HW, out, (hipStream_t)stream);
+    return err == hipSuccess ? SL_OK : hip_fail(err, "alive_counts launch");
+}
+
+int slhip_execute_actions(uint16_t *board, int B, int H, int W, int64_t *locs, const int64_t *actions,
+                          int A, int action_stride, int action_batch_stride, void *stream) {
+    int rc = check_board_shape(B, H, W);
+    if (rc) return rc;
+    if (A < 0) return fail(SL_E_ARG, "negative agent count");
+    if (!board || (A > 0 && (!locs || !actions))) return fail(SL_E_ARG, "null pointer");
+    if (B == 0 || A == 0) return SL_OK;
+    hipError_t err = sl::launch_execute_actions(board, B, H, W, locs, actions, A, action_stride,
+                                                action_batch_stride, (hipStream_t)stream);
+    return err == hipSuccess ? SL_OK : hip_fail(err, "execute_actions launch");
+}
+
+int slhip_env_reset(const sl_env_batch *env, const uint8_t *mask, void *stream) {
+    int rc = check_env(env);
+    if (rc) return rc;
+    if (env->B == 0) return SL_OK;
+    hipError_t err = sl::launch_env_reset_generic(*env, mask, (hipStream_t)stream);
+    return err == hipSuccess ? SL_OK : hip_fail(err, "env_reset launch");
+}
+
+int slhip_env_rollout(const sl_env_batch *env, const int32_t *actions, int T, float *reward_t,
+                      uint8_t *done_t, void *stream) {
+    int rc = check_env(env);
+    if (rc) return rc;
+    if (!actions) return fail(SL_E_ARG, "null actions");
+    if (T < 0) return fail(SL_E_ARG, "negative T");
+    if (env->B == 0 || T == 0) return SL_OK;
+    const sl::Jump *jump;
+    if ((rc = jump_table(&jump))) return rc;
+    hipError_t err = sl::launch_env_rollout_generic(*env, actions, T, reward_t, done_t, jump,
+                                                    (hipStream_t)stream);
+    return err == hipSuccess ? SL_OK : hip_fail(err, "env_step launch");
+}
+
+int slhip_env_step(const sl_env_batch *env, const int32_t *actions, void *stream) {
+    return slhip_env_rollout(env, actions, 1, nullptr, nullptr, stream);
+}
+
+int slhip_env_obs(const sl_env_batch *env, void *stream) {
+    int rc = check_env(env);
+    if (rc) return rc;
+    if (env->B == 0) return SL_OK;
+    hipError_t err = sl::launch_env_obs_generic(*env, (hipStream_t)stream);
+    return err == hipSuccess ? SL_OK : hip_fail(err, "env_obs launch");
+}
+
+}  // extern "C"

@@ -1,0 +1,139 @@
+// sl_device.h -- device-side building blocks shared by the gfx950 kernels.
+//
+// Cell bit layout: reference safelife/speedups_src/constants.h:4-33.
+// Neighbourhood algebra: the reference folds neighbours with two helper routines
+// (advance_board.c:12-32); both are the same commutative/associative merge of 16-bit
+// "summaries", which is what lets the kernels reduce the 3x3 block in any order and in SWAR form.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/safelife_hip.h"
+
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+namespace sl {
+
+enum : u32 {
+    ALIVE = 1u << 0,
+    AGENT = 1u << 1,
+    PUSHABLE = 1u << 2,
+    DESTRUCTIBLE = 1u << 3,
+    FROZEN = 1u << 4,
+    PRESERVING = 1u << 5,
+    INHIBITING = 1u << 6,
+    SPAWNING = 1u << 7,
+    EXIT = 1u << 8,
+    COLOR_R = 1u << 9,
+    COLORS = 7u << 9,
+    ORIENT_SHIFT = 12,
+    ORIENT_MASK = 3u << 12,
+    PULLABLE = 1u << 15,
+    MOVABLE_OR_DESTRUCTIBLE = DESTRUCTIBLE | PUSHABLE | PULLABLE,
+};
+
+// summary / accumulator fields (advance_board.c:6-9)
+enum : u32 {
+    S_COUNT = 0x000Fu,  // alive cells folded in
+    S_ANY = 0x00E0u,    // preserving | inhibiting | spawning seen anywhere
+    S_ONCE = 0x0F00u,   // bit8 (exit|destructible) + colours seen in >= 1 alive cell
+    S_TWICE = 0xF000u,  // ... in >= 2 alive cells (spawner colours land here directly)
+};
+
+// ---- scalar (one cell per lane) forms, used by the generic kernels -------------------------
+
+__device__ __forceinline__ u32 cell_summary(u32 b) {
+    u32 t = b | ((b & DESTRUCTIBLE) << 5);          // advance_board.c:45-47
+    u32 s = t & S_ANY;
+    if (t & ALIVE) s |= (t & S_ONCE) | 1u;
+    if (t & SPAWNING) s |= (t & COLORS) << 4;       // advance_board.c:19
+    return s;
+}
+
+__device__ __forceinline__ u32 merge2(u32 x, u32 y) {
+    u32 both = x & y & S_ONCE;
+    return (((x | y) & (S_ANY | S_ONCE | S_TWICE)) | (both << 4)) + (x & S_COUNT) + (y & S_COUNT);
+}
+
+__device__ __forceinline__ u32 merge3(u32 x, u32 y, u32 z) { return merge2(merge2(x, y), z); }
+
+// Deterministic part of the rule (advance_board.c:94-124).  Returns the new cell; sets
+// `eligible` when the outcome depends on a random draw (dead, not frozen, not inhibited,
+// count != 3, spawner in the 3x3 block) -- the draw itself is made by the caller in row-major
+// order.  For an eligible cell the returned value is the old cell.
+__device__ __forceinline__ u32 apply_rule(u32 b, u32 acc, bool &eligible) {
+    u32 cnt = acc & S_COUNT;
+    eligible = false;
+    if (b & ALIVE) {
+        bool keep = (b & FROZEN) || (acc & PRESERVING) || cnt == 3 || cnt == 4;
+        return keep ? b : 0u;
+    }
+    if ((b & FROZEN) || (acc & INHIBITING)) return b;
+    if (cnt == 3) return ALIVE | ((acc >> 4) & COLORS) | ((acc >> 9) & DESTRUCTIBLE);
+    eligible = (acc & SPAWNING) != 0;
+    return b;
+}
+
+__device__ __forceinline__ u32 spawned_cell(u32 acc) {
+    return ALIVE | DESTRUCTIBLE | ((acc >> 4) & COLORS);   // advance_board.c:117-118
+}
+
+// Score bin of a cell for sum(points_table * alive_counts): -1 when the cell is excluded by the
+// filter of advance_board.c:201, else 9*goal_colour + (alive ? cell_colour : 8).
+__device__ __forceinline__ int score_bin(u32 b, u32 g) {
+    if ((b & FROZEN) && !(b & MOVABLE_OR_DESTRUCTIBLE)) return -1;
+    int gc = (g >> 9) & 7;
+    int col = (b & ALIVE) ? ((b >> 9) & 7) : 8;
+    return 9 * gc + col;
+}
+
+__device__ __forceinline__ bool has_exited(u32 cell) { return (cell & (AGENT | EXIT)) == EXIT; }
+
+// ---- PCG64 (numpy) ---------------------------------------------------------------------------
+
+struct U128 {
+    u64 hi, lo;
+};
+
+__device__ __forceinline__ U128 mul128(U128 a, U128 b) {
+    U128 r;
+    r.lo = a.lo * b.lo;
+    r.hi = __umul64hi(a.lo, b.lo) + a.hi * b.lo + a.lo * b.hi;
+    return r;
+}
+
+__device__ __forceinline__ U128 add128(U128 a, U128 b) {
+    U128 r;
+    r.lo = a.lo + b.lo;
+    r.hi = a.hi + b.hi + (r.lo < a.lo ? 1u : 0u);
+    return r;
+}
+
+// Jump table entry k: state after k LCG steps = mult * state + plus * inc  (mod 2^128).
+struct Jump {
+    u64 mult_hi, mult_lo, plus_hi, plus_lo;
+};
+
+__device__ __forceinline__ U128 pcg_jump(const Jump *__restrict__ table, int k, U128 state, U128 inc) {
+    Jump j = table[k];
+    U128 m = {j.mult_hi, j.mult_lo}, p = {j.plus_hi, j.plus_lo};
+    return add128(mul128(m, state), mul128(p, inc));
+}
+
+__device__ __forceinline__ U128 pcg_step(U128 state, U128 inc) {
+    const U128 mult = {0x2360ED051FC65DA4ull, 0x4385DF649FCCF645ull};
+    return add128(mul128(mult, state), inc);
+}
+
+// numpy's next_double on an ALREADY STEPPED state: XSL-RR output, top 53 bits.
+__device__ __forceinline__ double pcg_output_double(U128 s) {
+    u64 x = s.hi ^ s.lo;
+    unsigned rot = (unsigned)(s.hi >> 58);
+    u64 o = (x >> rot) | (x << ((64u - rot) & 63u));
+    return (double)(o >> 11) * (1.0 / 9007199254740992.0);
+}
+
+}  // namespace sl

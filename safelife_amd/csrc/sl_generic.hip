@@ -1,0 +1,567 @@
+// sl_generic.hip -- size-generic gfx950 kernels: one 256-thread workgroup per board, the board
+// staged in LDS, one cell per lane per pass.  Correct for every 3 <= H, W with H*W <= SL_MAX_CELLS;
+// this is the path for board shapes the row-per-lane kernels (sl_rowlane.hip) do not cover, and
+// the implementation of the non-fused primitives (alive_counts, execute_actions, life_occupancy).
+//
+// Reference behaviour restated here:
+//   advance_board        safelife/speedups_src/advance_board.c:34-149
+//   life_occupancy       safelife/speedups_src/advance_board.c:153-189
+//   alive_counts         safelife/speedups_src/advance_board.c:192-207
+//   execute_actions      safelife/speedups_src/advance_board.c:217-300
+//   SafeLifeEnv.step     safelife/safelife_env.py:148-201 (+ safelife_game.py:505-552,684-719,746-761)
+//   SafeLifeEnv.reset    safelife/safelife_env.py:203-218
+//   SafeLifeEnv.get_obs  safelife/safelife_env.py:105-146, helper_utils.py:42-75
+#include "sl_device.h"
+#include "sl_kernels.h"
+
+namespace sl {
+
+constexpr int GB = 256;          // threads per workgroup
+constexpr int GW = GB / 64;      // waves per workgroup
+
+__device__ __forceinline__ int row_of(int i, int W, float inv_w) {
+    int y = (int)(((float)i + 0.5f) * inv_w);
+    if (y * W > i) --y;
+    if ((y + 1) * W <= i) ++y;
+    return y;
+}
+
+__device__ __forceinline__ int pos_mod(int a, int n) {
+    int r = a % n;
+    return r < 0 ? r + n : r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One CA step of the board held in LDS `cur` into LDS `nxt` (`rows` is scratch), all GB threads.
+// rng: LDS {state_hi, state_lo, inc_hi, inc_lo}; advanced by the number of draws.
+// Ends with every write to nxt/rng visible to the whole workgroup.
+// ---------------------------------------------------------------------------------------------
+__device__ void ca_step_block(const u16 *cur, u16 *rows, u16 *nxt, int H, int W, float inv_w,
+                              double p, u64 *rng, const Jump *__restrict__ jump, int *wave_tot) {
+    const int HW = H * W;
+    const int tid = threadIdx.x;
+
+    for (int i = tid; i < HW; i += GB) {
+        int y = row_of(i, W, inv_w), x = i - y * W;
+        const u16 *r = cur + y * W;
+        int xl = x ? x - 1 : W - 1, xr = (x + 1 < W) ? x + 1 : 0;
+        rows[i] = (u16)merge3(cell_summary(r[xl]), cell_summary(r[x]), cell_summary(r[xr]));
+    }
+    __syncthreads();
+
+    u64 mask = 0;
+    int it = 0;
+    for (int i = tid; i < HW; i += GB, ++it) {
+        int up = i - W, dn = i + W;
+        if (up < 0) up += HW;
+        if (dn >= HW) dn -= HW;
+        u32 acc = merge3(rows[up], rows[i], rows[dn]);
+        bool el;
+        u32 r = apply_rule(cur[i], acc, el);
+        nxt[i] = (u16)(el ? acc : r);          // eligible cells park their accumulator in nxt
+        mask |= (u64)el << it;
+    }
+    if (!__syncthreads_or(mask != 0)) return;
+
+    // Random draws in row-major order (advance_board.c:115): exclusive prefix count of the
+    // eligibility flags, then a table jump of the board's PCG64 stream per eligible cell.
+    U128 st = {rng[0], rng[1]}, inc = {rng[2], rng[3]};
+    const int lane = tid & 63, wave = tid >> 6;
+    int base = 0;
+    it = 0;
+    for (int i0 = 0; i0 < HW; i0 += GB, ++it) {
+        bool el = (mask >> it) & 1;
+        u64 bal = __ballot(el);
+        int lane_pref = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[wave] = __popcll(bal);
+        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < GW; ++w) {
+            int t = wave_tot[w];
+            woff += (w < wave) ? t : 0;
+            tot += t;
+        }
+        if (el) {
+            int i = i0 + tid;
+            U128 s = pcg_jump(jump, base + woff + lane_pref + 1, st, inc);
+            u32 acc = nxt[i];
+            nxt[i] = (pcg_output_double(s) < p) ? (u16)spawned_cell(acc) : cur[i];
+        }
+        base += tot;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        U128 s = pcg_jump(jump, base, st, inc);
+        rng[0] = s.hi;
+        rng[1] = s.lo;
+    }
+    __syncthreads();
+}
+
+struct GenericLds {
+    u64 *rng;        // [4]
+    int *wave_tot;   // [GW]
+    int *ivar;       // [16] misc workgroup-shared ints
+    u16 *buf[4];
+};
+
+__device__ __forceinline__ GenericLds carve(unsigned char *smem, int HW, int nbuf) {
+    GenericLds l;
+    l.rng = (u64 *)smem;
+    l.wave_tot = (int *)(smem + 32);
+    l.ivar = (int *)(smem + 64);
+    int hwp = (HW + 7) & ~7;
+    u16 *b = (u16 *)(smem + 128);
+    for (int k = 0; k < 4; ++k) l.buf[k] = (k < nbuf) ? b + (size_t)k * hwp : nullptr;
+    return l;
+}
+
+size_t generic_lds_bytes(int HW, int nbuf) { return 128 + (size_t)nbuf * ((HW + 7) & ~7) * sizeof(u16); }
+
+// ------------------------------------------------------------------ advance_board / occupancy
+
+__global__ __launch_bounds__(GB) void k_advance_generic(const u16 *__restrict__ in, u16 *__restrict__ out,
+                                                        int H, int W, const float *__restrict__ spawn_prob,
+                                                        int n_steps, sl_pcg64 *rng,
+                                                        const Jump *__restrict__ jump,
+                                                        int32_t *__restrict__ occupancy) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int HW = H * W, b = blockIdx.x, tid = threadIdx.x;
+    GenericLds l = carve(smem, HW, 3);
+    const u16 *src = in + (size_t)b * HW;
+    for (int i = tid; i < HW; i += GB) l.buf[0][i] = src[i];
+    if (tid < 4) l.rng[tid] = ((const u64 *)(rng + b))[tid];
+    __syncthreads();
+    const float inv_w = 1.0f / (float)W;
+    const double p = (double)spawn_prob[b];
+    u16 *cur = l.buf[0], *nxt = l.buf[2];
+    int32_t *occ = occupancy ? occupancy + (size_t)b * HW * 8 : nullptr;
+    if (occ)
+        for (int i = tid; i < HW * 8; i += GB) occ[i] = 0;
+    for (int s = 0; s < n_steps; ++s) {
+        ca_step_block(cur, l.buf[1], nxt, H, W, inv_w, p, l.rng, jump, l.wave_tot);
+        if (occ) {
+            // each cell is owned by one thread for the whole launch: plain read-modify-write
+            for (int i = tid; i < HW; i += GB) {
+                u32 c = nxt[i];
+                if ((c & ALIVE) && !(c & (AGENT | EXIT | FROZEN))) occ[8 * i + ((c >> 9) & 7)] += 1;
+            }
+        }
+        u16 *t = cur;
+        cur = nxt;
+        nxt = t;
+    }
+    if (out) {
+        u16 *dst = out + (size_t)b * HW;
+        for (int i = tid; i < HW; i += GB) dst[i] = cur[i];
+    }
+    if (tid < 4) ((u64 *)(rng + b))[tid] = l.rng[tid];
+}
+
+// ------------------------------------------------------------------------------ alive_counts
+
+__global__ __launch_bounds__(GB) void k_alive_counts(const u16 *__restrict__ board,
+                                                     const u16 *__restrict__ goals, int HW,
+                                                     int64_t *__restrict__ out) {
+    __shared__ int hist[72];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid < 72) hist[tid] = 0;
+    __syncthreads();
+    const u16 *bd = board + (size_t)b * HW, *gl = goals + (size_t)b * HW;
+    for (int i = tid; i < HW; i += GB) {
+        int bin = score_bin(bd[i], gl[i]);
+        if (bin >= 0) atomicAdd(&hist[bin], 1);
+    }
+    __syncthreads();
+    if (tid < 72) out[(size_t)b * 72 + tid] = hist[tid];
+}
+
+// --------------------------------------------------------------------------- execute_actions
+
+// One agent's action on a board reachable through `board` (LDS or global).  loc = (row, col).
+template <typename LocT>
+__device__ void act_one(u16 *board, int H, int W, LocT *loc, int action) {
+    if (action == 0) return;
+    const int dir = (action - 1) & 3;                 // 0 up, 1 right, 2 down, 3 left
+    const int dy = (dir & 1) ? 0 : dir - 1;
+    const int dx = (dir & 1) ? 2 - dir : 0;
+    const int y0 = (int)(loc[0] % H), x0 = (int)(loc[1] % W);
+    u16 *here = board + y0 * W + x0;
+    if (!(*here & AGENT)) return;
+    u16 *ahead = board + pos_mod(y0 + dy, H) * W + pos_mod(x0 + dx, W);
+    u16 *ahead2 = board + pos_mod(y0 + 2 * dy, H) * W + pos_mod(x0 + 2 * dx, W);
+    u16 *behind = board + pos_mod(y0 - dy, H) * W + pos_mod(x0 - dx, W);
+    *here = (u16)((*here & ~ORIENT_MASK) | (dir << ORIENT_SHIFT));
+    const bool can_push = (~*here & *ahead & PUSHABLE) != 0;
+    if (action >= 5) {
+        if (*ahead == 0) {
+            *ahead = (u16)(ALIVE | DESTRUCTIBLE | (*here & COLORS));
+        } else if (*ahead & DESTRUCTIBLE) {
+            *ahead = (*ahead & AGENT) ? (u16)((*ahead ^ (AGENT | DESTRUCTIBLE)) | FROZEN) : (u16)0;
+        } else if (can_push) {
+            if (*ahead2 == 0) {
+                *ahead2 = *ahead;
+                *ahead = 0;
+            } else if (*ahead2 & EXIT) {
+                *ahead = 0;
+            }
+        }
+        return;
+    }
+    bool step_into = false, leave_only = false;
+    if (can_push) {
+        if (*ahead2 == 0) {
+            *ahead2 = *ahead;
+            step_into = true;
+        } else if (*ahead2 & EXIT) {
+            step_into = true;
+        }
+    } else if (*ahead == 0) {
+        step_into = true;
+    } else if ((*here & *ahead & EXIT) && !(*ahead & AGENT)) {
+        leave_only = true;
+    }
+    if (!step_into && !leave_only) return;
+    if (step_into) *ahead = *here;
+    loc[0] = (LocT)pos_mod(y0 + dy, H);
+    loc[1] = (LocT)pos_mod(x0 + dx, W);
+    if (~*here & *behind & PULLABLE) {
+        *here = *behind;
+        *behind = 0;
+    } else {
+        *here = 0;
+    }
+}
+
+__global__ void k_execute_actions(u16 *board, int B, int H, int W, int64_t *locs,
+                                  const int64_t *__restrict__ actions, int A, int action_stride,
+                                  int action_batch_stride) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    u16 *bd = board + (size_t)b * H * W;
+    for (int k = 0; k < A; ++k) {
+        int a = (int)actions[(size_t)b * action_batch_stride + (size_t)k * action_stride];
+        act_one<int64_t>(bd, H, W, locs + ((size_t)b * A + k) * 2, a);
+    }
+}
+
+// ------------------------------------------------------------------------------ env helpers
+
+__device__ __forceinline__ u32 obs_word(u32 b, u32 g, int remove_white) {
+    u32 gc = g & COLORS;
+    if (remove_white && gc == COLORS) gc = 0;
+    return b | (gc << 16);
+}
+
+// Sum over the workgroup of an int held by every thread; result broadcast to all threads.
+__device__ int block_sum(int v, int *wave_tot) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int s = 0;
+#pragma unroll
+    for (int w = 0; w < GW; ++w) s += wave_tot[w];
+    return s;
+}
+
+// sum(points_table * alive_counts) of the board in LDS against goals (LDS or global).
+__device__ int board_score(const u16 *board, const u16 *goals, int HW,
+                           const int32_t *__restrict__ table, int *wave_tot) {
+    int s = 0;
+    for (int i = threadIdx.x; i < HW; i += GB) {
+        int bin = score_bin(board[i], goals[i]);
+        if (bin >= 0) s += table[bin];
+    }
+    return block_sum(s, wave_tot);
+}
+
+// GameState.update_exit_colors (safelife_game.py:537-552), single agent, by thread 0.
+__device__ void recolor_exits(u16 *board, int W, int ly, int lx, const int32_t *exits, int E,
+                              int score, int initial, int required, int exit_points) {
+    bool any_can = false;
+    if (ly >= 0) {
+        u16 *cell = board + ly * W + lx;
+        int earned = score - initial + exit_points * (has_exited(*cell) ? 1 : 0);
+        if (earned < 0) earned = 0;
+        bool can = (*cell & AGENT) && earned >= required;
+        *cell = (u16)((*cell & ~EXIT) | (can ? EXIT : 0u));
+        any_can = can;
+    }
+    u16 paint = (u16)(FROZEN | EXIT | (any_can ? COLOR_R : 0u));
+    for (int k = 0; k < E; ++k) {
+        int ex = exits[k];
+        if (ex >= 0) board[ex] = paint;
+    }
+}
+
+// SafeLifeEnv.get_obs for env e from the board in LDS; goals through `goals` (LDS or global).
+__device__ void write_obs(const sl_env_batch &env, int e, const u16 *board, const u16 *goals,
+                          int ly, int lx, const int32_t *exits) {
+    if (!env.obs) return;
+    const int H = env.H, W = env.W, vh = env.view_h, vw = env.view_w, C = env.n_channels;
+    const int y0 = ly >= 0 ? ly : 0, x0 = ly >= 0 ? lx : 0;
+    const int nv = vh * vw;
+    const float inv_vw = 1.0f / (float)vw;
+    const float inv_w = 1.0f / (float)W;
+    for (int v = threadIdx.x; v < nv; v += GB) {
+        int vy = row_of(v, vw, inv_vw), vx = v - vy * vw;
+        int sy = pos_mod(y0 - vh / 2 + vy, H), sx = pos_mod(x0 - vw / 2 + vx, W);
+        int s = sy * W + sx;
+        u32 word = obs_word(board[s], goals[s], env.remove_white_goals);
+        // exits that fall outside the view are painted on its perimeter (helper_utils.py:64-74);
+        // later exits overwrite earlier ones, as numpy's fancy assignment does
+        for (int k = 0; k < env.E; ++k) {
+            int ex = exits[k];
+            if (ex < 0) continue;
+            int iy = row_of(ex, W, inv_w), ix = ex - iy * W;
+            int jy = pos_mod(iy - y0 + H / 2, H) - H / 2 + vh / 2;
+            int jx = pos_mod(ix - x0 + W / 2, W) - W / 2 + vw / 2;
+            jy = min(max(jy, 0), vh - 1);
+            jx = min(max(jx, 0), vw - 1);
+            if (jy == vy && jx == vx) word = obs_word(board[ex], goals[ex], env.remove_white_goals);
+        }
+        if (C == 0) {
+            ((u32 *)env.obs)[(size_t)e * nv + v] = word;
+        } else {
+            uint8_t *o = env.obs + ((size_t)e * nv + v) * C;
+            for (int c = 0; c < C; ++c) o[c] = (word >> env.channels[c]) & 1u;
+        }
+    }
+}
+
+// SafeLifeEnv.reset() body for env e: pool level -> LDS board (`brd`) and global per-env state.
+// ivar[0..1] receives the agent location.  All threads participate.
+__device__ void reset_block(const sl_env_batch &env, int e, u16 *brd, int *ivar, int *wave_tot) {
+    const int HW = env.H * env.W, tid = threadIdx.x, E = env.E;
+    const int l = env.level_idx[e];
+    const u16 *pb = env.pool_board + (size_t)l * HW, *pg = env.pool_goals + (size_t)l * HW;
+    u16 *gdst = env.goals + (size_t)e * HW;
+    for (int i = tid; i < HW; i += GB) {
+        brd[i] = pb[i];
+        gdst[i] = pg[i];
+    }
+    for (int k = tid; k < E; k += GB) env.exit_locs[(size_t)e * E + k] = env.pool_exit_locs[(size_t)l * E + k];
+    if (tid == 0) {
+        ivar[0] = env.pool_agent_loc[2 * l];
+        ivar[1] = env.pool_agent_loc[2 * l + 1];
+        env.rng[e] = env.pool_rng[l];
+        env.spawn_prob[e] = env.pool_spawn_prob[l];
+        env.table_idx[e] = env.pool_table_idx[l];
+        env.initial_points[e] = env.pool_initial_points[l];
+        env.required_points[e] = env.pool_required_step[l];
+        env.num_steps[e] = 0;
+        env.goals_static[e] = 0;
+        env.is_active[e] = 1;
+        env.episode_reward[e] = 0.0f;
+        env.episode_length[e] = 0;
+    }
+    __syncthreads();
+    const int32_t *table = env.points_table + 72 * env.pool_table_idx[l];
+    int score = board_score(brd, pg, HW, table, wave_tot);
+    if (tid == 0) {
+        recolor_exits(brd, env.W, ivar[0], ivar[1], env.pool_exit_locs + (size_t)l * E, E, score,
+                      env.pool_initial_points[l], env.pool_required_reset[l], env.exit_points);
+        int exited = ivar[0] >= 0 ? (has_exited(brd[ivar[0] * env.W + ivar[1]]) ? 1 : 0) : 0;
+        env.old_value[e] = score + env.exit_points * exited;
+        env.agent_loc[2 * e] = ivar[0];
+        env.agent_loc[2 * e + 1] = ivar[1];
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------- env step / reset
+
+__global__ __launch_bounds__(GB) void k_env_rollout_generic(sl_env_batch env,
+                                                            const int32_t *__restrict__ actions, int T,
+                                                            float *__restrict__ reward_t,
+                                                            uint8_t *__restrict__ done_t,
+                                                            const Jump *__restrict__ jump) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int H = env.H, W = env.W, HW = H * W, E = env.E;
+    const int e = blockIdx.x, tid = threadIdx.x;
+    GenericLds l = carve(smem, HW, 4);
+    u16 *cur = l.buf[0], *rows = l.buf[1], *nxt = l.buf[2], *aux = l.buf[3];
+    int *ivar = l.ivar;   // [0],[1] agent loc; [2] done flag; [3] goals-static verdict
+    u16 *gboard = env.board + (size_t)e * HW;
+    u16 *ggoals = env.goals + (size_t)e * HW;
+    const int32_t *exits = env.exit_locs + (size_t)e * E;
+    const float inv_w = 1.0f / (float)W;
+
+    for (int i = tid; i < HW; i += GB) cur[i] = gboard[i];
+    if (tid < 4) l.rng[tid] = ((const u64 *)(env.rng + e))[tid];
+    if (tid == 0) {
+        ivar[0] = env.agent_loc[2 * e];
+        ivar[1] = env.agent_loc[2 * e + 1];
+    }
+    __syncthreads();
+
+    for (int t = 0; t < T; ++t) {
+        // safelife_env.py:151  game.execute_actions
+        if (tid == 0 && ivar[0] >= 0) act_one<int>(cur, H, W, ivar, actions[(size_t)t * env.B + e]);
+        __syncthreads();
+        // safelife_env.py:152  game.advance_board (board, then goals unless static)
+        const double p = (double)env.spawn_prob[e];
+        ca_step_block(cur, rows, nxt, H, W, inv_w, p, l.rng, jump, l.wave_tot);
+        const u16 *goals = ggoals;
+        const int gstatic = env.goals_static[e];
+        if (gstatic != 1) {
+            for (int i = tid; i < HW; i += GB) cur[i] = ggoals[i];
+            __syncthreads();
+            ca_step_block(cur, rows, aux, H, W, inv_w, p, l.rng, jump, l.wave_tot);
+            int changed = 0;
+            for (int i = tid; i < HW; i += GB) {
+                u16 g = aux[i];
+                changed |= (g != cur[i]) || (g & SPAWNING);
+                ggoals[i] = g;
+            }
+            changed = __syncthreads_or(changed);
+            if (tid == 0 && gstatic == 0) env.goals_static[e] = changed ? 2 : 1;
+            goals = aux;
+        }
+        // safelife_env.py:153-160
+        const int32_t *table = env.points_table + 72 * env.table_idx[e];
+        int score = board_score(nxt, goals, HW, table, l.wave_tot);
+        if (tid == 0) {
+            recolor_exits(nxt, W, ivar[0], ivar[1], exits, E, score, env.initial_points[e],
+                          env.required_points[e], env.exit_points);
+            int steps = env.num_steps[e] + 1;
+            env.num_steps[e] = steps;
+            bool times_up = steps >= env.time_limit;
+            float reward = 0.0f;
+            bool done = true, success = false;
+            bool active = env.is_active[e] != 0;
+            if (ivar[0] >= 0) {
+                u32 cell = nxt[ivar[0] * W + ivar[1]];
+                success = has_exited(cell);
+                int value = score + env.exit_points * (success ? 1 : 0);
+                reward = (float)((value - env.old_value[e]) * (active ? 1 : 0));
+                env.old_value[e] = value;
+                done = !(cell & AGENT) || times_up;
+            }
+            // safelife_env.py:172-175
+            float ep_r = env.episode_reward[e] + reward;
+            int ep_l = env.episode_length[e] + (active ? 1 : 0);
+            env.episode_reward[e] = ep_r;
+            env.episode_length[e] = ep_l;
+            env.is_active[e] = (active && !done) ? 1 : 0;
+            env.reward[e] = reward;
+            env.done[e] = done;
+            env.success[e] = success;
+            env.times_up[e] = times_up;
+            if (env.info_episode_reward) env.info_episode_reward[e] = ep_r;
+            if (env.info_episode_length) env.info_episode_length[e] = ep_l;
+            if (reward_t) reward_t[(size_t)t * env.B + e] = reward;
+            if (done_t) done_t[(size_t)t * env.B + e] = done;
+            ivar[2] = done;
+        }
+        __syncthreads();
+        u16 *sw = cur;
+        cur = nxt;
+        nxt = sw;
+        if (env.auto_reset && ivar[2]) {
+            if (tid == 0) {
+                env.level_idx[e] = (env.level_idx[e] + env.level_stride) % env.L;
+                env.episode_idx[e] += 1;
+            }
+            __syncthreads();
+            reset_block(env, e, cur, ivar, l.wave_tot);
+            if (tid < 4) l.rng[tid] = ((const u64 *)(env.rng + e))[tid];
+            __syncthreads();
+        }
+    }
+
+    for (int i = tid; i < HW; i += GB) gboard[i] = cur[i];
+    if (tid < 4) ((u64 *)(env.rng + e))[tid] = l.rng[tid];
+    if (tid == 0) {
+        env.agent_loc[2 * e] = ivar[0];
+        env.agent_loc[2 * e + 1] = ivar[1];
+    }
+    __syncthreads();   // goals written by this workgroup are read back below
+    write_obs(env, e, cur, ggoals, ivar[0], ivar[1], exits);
+}
+
+__global__ __launch_bounds__(GB) void k_env_reset_generic(sl_env_batch env,
+                                                          const uint8_t *__restrict__ mask) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int HW = env.H * env.W, e = blockIdx.x, tid = threadIdx.x;
+    if (mask && !mask[e]) return;
+    GenericLds l = carve(smem, HW, 1);
+    reset_block(env, e, l.buf[0], l.ivar, l.wave_tot);
+    u16 *gboard = env.board + (size_t)e * HW;
+    for (int i = tid; i < HW; i += GB) gboard[i] = l.buf[0][i];
+    write_obs(env, e, l.buf[0], env.goals + (size_t)e * HW, l.ivar[0], l.ivar[1],
+              env.exit_locs + (size_t)e * env.E);
+}
+
+__global__ __launch_bounds__(GB) void k_env_obs_generic(sl_env_batch env) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int HW = env.H * env.W, e = blockIdx.x, tid = threadIdx.x;
+    GenericLds l = carve(smem, HW, 1);
+    const u16 *gboard = env.board + (size_t)e * HW;
+    for (int i = tid; i < HW; i += GB) l.buf[0][i] = gboard[i];
+    __syncthreads();
+    write_obs(env, e, l.buf[0], env.goals + (size_t)e * HW, env.agent_loc[2 * e],
+              env.agent_loc[2 * e + 1], env.exit_locs + (size_t)e * env.E);
+}
+
+// ------------------------------------------------------------------------------ launchers
+
+static hipError_t set_lds(const void *fn, size_t bytes) {
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+hipError_t launch_advance_generic(const u16 *in, u16 *out, int B, int H, int W, const float *spawn_prob,
+                                  int n_steps, sl_pcg64 *rng, const Jump *jump, int32_t *occupancy,
+                                  hipStream_t stream) {
+    size_t lds = generic_lds_bytes(H * W, 3);
+    hipError_t err = set_lds((const void *)k_advance_generic, lds);
+    if (err != hipSuccess) return err;
+    hipLaunchKernelGGL(k_advance_generic, dim3(B), dim3(GB), lds, stream, in, out, H, W, spawn_prob,
+                       n_steps, rng, jump, occupancy);
+    return hipGetLastError();
+}
+
+hipError_t launch_alive_counts(const u16 *board, const u16 *goals, int B, int HW, int64_t *out,
+                               hipStream_t stream) {
+    hipLaunchKernelGGL(k_alive_counts, dim3(B), dim3(GB), 0, stream, board, goals, HW, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_execute_actions(u16 *board, int B, int H, int W, int64_t *locs, const int64_t *actions,
+                                  int A, int action_stride, int action_batch_stride, hipStream_t stream) {
+    hipLaunchKernelGGL(k_execute_actions, dim3((B + 63) / 64), dim3(64), 0, stream, board, B, H, W, locs,
+                       actions, A, action_stride, action_batch_stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_env_rollout_generic(const sl_env_batch &env, const int32_t *actions, int T,
+                                      float *reward_t, uint8_t *done_t, const Jump *jump,
+                                      hipStream_t stream) {
+    size_t lds = generic_lds_bytes(env.H * env.W, 4);
+    hipError_t err = set_lds((const void *)k_env_rollout_generic, lds);
+    if (err != hipSuccess) return err;
+    hipLaunchKernelGGL(k_env_rollout_generic, dim3(env.B), dim3(GB), lds, stream, env, actions, T,
+                       reward_t, done_t, jump);
+    return hipGetLastError();
+}
+
+hipError_t launch_env_reset_generic(const sl_env_batch &env, const uint8_t *mask, hipStream_t stream) {
+    size_t lds = generic_lds_bytes(env.H * env.W, 1);
+    hipError_t err = set_lds((const void *)k_env_reset_generic, lds);
+    if (err != hipSuccess) return err;
+    hipLaunchKernelGGL(k_env_reset_generic, dim3(env.B), dim3(GB), lds, stream, env, mask);
+    return hipGetLastError();
+}
+
+hipError_t launch_env_obs_generic(const sl_env_batch &env, hipStream_t stream) {
+    size_t lds = generic_lds_bytes(env.H * env.W, 1);
+    hipError_t err = set_lds((const void *)k_env_obs_generic, lds);
+    if (err != hipSuccess) return err;
+    hipLaunchKernelGGL(k_env_obs_generic, dim3(env.B), dim3(GB), lds, stream, env);
+    return hipGetLastError();
+}
+
+}  // namespace sl

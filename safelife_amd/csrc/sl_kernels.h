@@ -1,0 +1,26 @@
+// sl_kernels.h -- launcher prototypes shared between the kernel translation units and the C-ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "sl_device.h"
+
+namespace sl {
+
+size_t generic_lds_bytes(int HW, int nbuf);
+
+// sl_generic.hip : one workgroup per board, any 3 <= H, W with H*W <= SL_MAX_CELLS
+hipError_t launch_advance_generic(const u16 *in, u16 *out, int B, int H, int W, const float *spawn_prob,
+                                  int n_steps, sl_pcg64 *rng, const Jump *jump, int32_t *occupancy,
+                                  hipStream_t stream);
+hipError_t launch_alive_counts(const u16 *board, const u16 *goals, int B, int HW, int64_t *out,
+                               hipStream_t stream);
+hipError_t launch_execute_actions(u16 *board, int B, int H, int W, int64_t *locs, const int64_t *actions,
+                                  int A, int action_stride, int action_batch_stride, hipStream_t stream);
+hipError_t launch_env_rollout_generic(const sl_env_batch &env, const int32_t *actions, int T,
+                                      float *reward_t, uint8_t *done_t, const Jump *jump,
+                                      hipStream_t stream);
+hipError_t launch_env_reset_generic(const sl_env_batch &env, const uint8_t *mask, hipStream_t stream);
+hipError_t launch_env_obs_generic(const sl_env_batch &env, hipStream_t stream);
+
+}  // namespace sl

@@ -1,0 +1,253 @@
+"""
+Level data: the on-disk ``.npz`` format of the reference and the *level pool* that feeds the
+batched environment's on-device reset.
+
+* ``load_levels(path)`` reads what ``SafeLifeGame.save`` / the benchmark archives contain
+  (reference: safelife_game.py:200-234,615-637; archives with a structured ``levels`` array:
+  level_iterator.py:89-99), including the legacy single-agent keys ``agent_loc`` (x, y) and
+  ``orientation``.  The ``class`` key is ignored.
+* ``LevelPool`` flattens a list of levels into the arrays ``sl_env_batch.pool_*`` expects and
+  computes the per-level constants of the reward glue (safelife_game.py:665-714):
+  ``initial_points``, ``required_points``.  The histogram those need comes from the device
+  ``alive_counts`` kernel by default; host code here is only the integer glue around it.
+"""
+import os
+
+import numpy as np
+
+from .cell_types import CellTypes, DEFAULT_POINTS_TABLE
+
+_MASK64 = (1 << 64) - 1
+
+
+class Level(object):
+    """One level instance = board + goals + agent(s) + constants + (optionally) its RNG seed."""
+
+    def __init__(self, board, goals=None, agent_locs=None, spawn_prob=0.3, min_performance=-1.0,
+                 points_table=None, orientation=None, name=None, seed=None, rng_words=None):
+        self.board = np.array(board, dtype=np.uint16)
+        if self.board.ndim != 2:
+            raise ValueError("board must be 2-dimensional")
+        self.goals = (np.zeros_like(self.board) if goals is None
+                      else np.array(goals, dtype=np.uint16))
+        if self.goals.shape != self.board.shape:
+            raise ValueError("goals must have the board's shape")
+        locs = np.empty((0, 2), np.int64) if agent_locs is None else np.array(agent_locs, np.int64)
+        self.agent_locs = locs.reshape(-1, 2)
+        self.spawn_prob = float(spawn_prob)
+        self.min_performance = float(min_performance)
+        if points_table is None:
+            points_table = np.tile(DEFAULT_POINTS_TABLE, [len(self.agent_locs), 1, 1])
+        self.points_table = np.array(points_table, dtype=np.int64).reshape(-1, 8, 9)
+        if orientation is not None and len(self.agent_locs):
+            # GameState.orientation setter (safelife_game.py:328-332)
+            idx = tuple(self.agent_locs.T)
+            bits = np.uint16((int(orientation) & 3) << CellTypes.orientation_bit)
+            self.board[idx] = (self.board[idx] & ~CellTypes.orientation_mask) | bits
+        self.name = name
+        self.seed = seed
+        self.rng_words = None if rng_words is None else np.array(rng_words, dtype=np.uint64)
+
+    @property
+    def shape(self):
+        return self.board.shape
+
+    @property
+    def exit_locs(self):
+        """Flat indices of GameState.exit_locs (safelife_game.py:533-535), row-major order."""
+        mask = (self.board & (CellTypes.exit | CellTypes.agent)) == CellTypes.exit
+        return np.flatnonzero(mask).astype(np.int32)
+
+    def initial_rng_words(self):
+        """PCG64 words of ``np.random.default_rng(seed)`` (safelife_game.py:175-180)."""
+        if self.rng_words is not None:
+            return self.rng_words
+        seed = self.seed
+        if not isinstance(seed, np.random.SeedSequence):
+            seed = np.random.SeedSequence(seed)
+        st = np.random.default_rng(seed).bit_generator.state["state"]
+        s, i = st["state"], st["inc"]
+        return np.array([s >> 64, s & _MASK64, i >> 64, i & _MASK64], dtype=np.uint64)
+
+    @classmethod
+    def from_data(cls, data, name=None, seed=None):
+        """Build from a dict / NpzFile / structured-array record with the reference's keys."""
+        names = getattr(getattr(data, "dtype", None), "names", None)
+        keys = set(names) if names else set(data.keys())
+        kw = {}
+        if "agent_loc" in keys:                       # legacy: (x, y) of a single agent
+            kw["agent_locs"] = np.array(data["agent_loc"], np.int64)[None, ::-1]
+        elif "agent_locs" in keys:
+            kw["agent_locs"] = data["agent_locs"]
+        if "spawn_prob" in keys:
+            kw["spawn_prob"] = float(data["spawn_prob"])
+        if "min_performance" in keys:
+            kw["min_performance"] = float(data["min_performance"])
+        if "points_table" in keys:
+            kw["points_table"] = data["points_table"]
+        if "orientation" in keys:
+            kw["orientation"] = int(data["orientation"])
+        if name is None and "name" in keys:
+            name = str(data["name"])
+        goals = data["goals"] if "goals" in keys else None
+        return cls(data["board"], goals, name=name, seed=seed, **kw)
+
+
+def load_levels(path):
+    """All levels of one ``.npz`` file (a single level or a benchmark archive)."""
+    path = os.path.abspath(os.path.expanduser(path))
+    base = path[:-4] if path.endswith(".npz") else path
+    out = []
+    with np.load(path, allow_pickle=False) as data:
+        if "levels" in data.files:
+            for rec in data["levels"]:
+                lvl = Level.from_data(rec)
+                lvl.name = os.path.join(base, lvl.name or str(len(out)))
+                out.append(lvl)
+        else:
+            out.append(Level.from_data({k: data[k] for k in data.files}, name=path))
+    return out
+
+
+def _device_counts(boards, goals):
+    """[L,8,9] int64 alive_counts of every level through the HIP kernel."""
+    from . import speedups
+    d_b = speedups._to_device(boards, np.uint16)
+    d_g = speedups._to_device(goals, np.uint16)
+    return speedups._to_host(speedups.alive_counts_batch(d_b, d_g), np.int64)
+
+
+def initial_colors(board):
+    """bool[9]: colours new cells can take (safelife_game.py:670-675); index 8 = 'empty'."""
+    generators = CellTypes.agent | CellTypes.alive | CellTypes.spawning
+    cols = (board[(board & generators) > 0] & CellTypes.rainbow_color) >> CellTypes.color_bit
+    out = np.zeros(9, dtype=bool)
+    out[np.unique(cols)] = True
+    out[8] = True
+    return out
+
+
+def available_points(table, counts, colors):
+    """GameWithGoals.initial_available_points for one agent (safelife_game.py:696-709)."""
+    goal_counts = counts.sum(axis=1)
+    best = (table * colors).max(axis=1)
+    return int((best * goal_counts).sum() - (table * counts).sum())
+
+
+def required_points(min_performance, available):
+    """GameWithGoals.required_points (safelife_game.py:711-714): float64 ceil, clamped at 0."""
+    return max(0, int(np.int64(np.ceil(np.float64(min_performance) * available))))
+
+
+class LevelPool(object):
+    """Flat arrays for ``sl_env_batch.pool_*`` (single-agent levels of one board shape)."""
+
+    ARRAYS = ("pool_board", "pool_goals", "pool_agent_loc", "pool_exit_locs", "pool_rng",
+              "pool_spawn_prob", "pool_required_reset", "pool_required_step",
+              "pool_initial_points", "pool_table_idx", "points_table")
+
+    def __init__(self, levels, *, min_performance_fraction=1.0, seed=None, counts_fn=None,
+                 exit_slots=None):
+        """
+        levels : list of Level (same shape, at most one agent each)
+        min_performance_fraction : the MinPerformanceScheduler factor (env_wrappers.py:142-145):
+            steps after a reset require ``ceil(min_performance * fraction * available)`` points,
+            while the reset itself (first observation) uses the level's own min_performance.
+        seed : levels without an RNG of their own get children of this SeedSequence, in order
+            (as SafeLifeLevelIterator.fill_queue does, level_iterator.py:218).
+        counts_fn : (boards[L,H,W], goals[L,H,W]) -> int64 [L,8,9]; defaults to the HIP kernel.
+        """
+        if not levels:
+            raise ValueError("empty level list")
+        shape = levels[0].shape
+        L = len(levels)
+        for lv in levels:
+            if lv.shape != shape:
+                raise ValueError("all levels of a pool must share one board shape")
+            if len(lv.agent_locs) > 1:
+                raise ValueError("the fused environment is single-agent (use SafeLifeEnv for more)")
+        self.levels = levels
+        self.shape = shape
+        H, W = shape
+        exits = [lv.exit_locs for lv in levels]
+        E = max(1, max(len(x) for x in exits)) if exit_slots is None else int(exit_slots)
+        if any(len(x) > E for x in exits):
+            raise ValueError("exit_slots too small")
+
+        self.pool_board = np.stack([lv.board for lv in levels])
+        self.pool_goals = np.stack([lv.goals for lv in levels])
+        self.pool_agent_loc = np.full((L, 2), -1, np.int32)
+        self.pool_exit_locs = np.full((L, E), -1, np.int32)
+        self.pool_spawn_prob = np.array([lv.spawn_prob for lv in levels], np.float32)
+        seq = seed if isinstance(seed, np.random.SeedSequence) else np.random.SeedSequence(seed)
+        rng = []
+        for k, lv in enumerate(levels):
+            if len(lv.agent_locs):
+                self.pool_agent_loc[k] = lv.agent_locs[0]
+            self.pool_exit_locs[k, :len(exits[k])] = exits[k]
+            if lv.rng_words is None and lv.seed is None:
+                lv = Level(lv.board, lv.goals, lv.agent_locs, lv.spawn_prob, lv.min_performance,
+                           lv.points_table, seed=seq.spawn(1)[0])
+            rng.append(lv.initial_rng_words())
+        self.pool_rng = np.stack(rng).astype(np.uint64)
+
+        # de-duplicated points tables
+        tables, idx = [], []
+        for lv in levels:
+            t = (lv.points_table[0] if len(lv.points_table) else DEFAULT_POINTS_TABLE).astype(np.int32)
+            for j, u in enumerate(tables):
+                if np.array_equal(t, u):
+                    idx.append(j)
+                    break
+            else:
+                idx.append(len(tables))
+                tables.append(t)
+        self.points_table = np.stack(tables).astype(np.int32)
+        self.pool_table_idx = np.array(idx, np.int32)
+
+        counts = (counts_fn or _device_counts)(self.pool_board, self.pool_goals)
+        counts = np.asarray(counts, np.int64).reshape(L, 8, 9)
+        self.initial_counts = counts
+        self.pool_initial_points = np.zeros(L, np.int32)
+        self.pool_required_reset = np.zeros(L, np.int32)
+        self.pool_required_step = np.zeros(L, np.int32)
+        frac = float(min_performance_fraction)
+        for k, lv in enumerate(levels):
+            table = self.points_table[idx[k]].astype(np.int64)
+            self.pool_initial_points[k] = int((table * counts[k]).sum())
+            avail = available_points(table, counts[k], initial_colors(lv.board))
+            self.pool_required_reset[k] = required_points(lv.min_performance, avail)
+            # game.min_performance *= fraction  (float64 product, then the same ceil)
+            self.pool_required_step[k] = required_points(np.float64(lv.min_performance) * frac, avail)
+
+    def __len__(self):
+        return len(self.levels)
+
+    @property
+    def exit_slots(self):
+        return self.pool_exit_locs.shape[1]
+
+    def arrays(self):
+        return {k: getattr(self, k) for k in self.ARRAYS}
+
+
+def empty_env_arrays(pool, num_envs):
+    """Zero-initialised host mirrors of the per-env arrays of ``sl_env_batch`` (names as in
+    include/safelife_hip.h).  Used by tests to drive the oracle and the device from one layout."""
+    H, W = pool.shape
+    B, E = int(num_envs), pool.exit_slots
+    a = {
+        "board": np.zeros((B, H, W), np.uint16), "goals": np.zeros((B, H, W), np.uint16),
+        "agent_loc": np.full((B, 2), -1, np.int32), "exit_locs": np.full((B, E), -1, np.int32),
+        "rng": np.zeros((B, 4), np.uint64), "spawn_prob": np.zeros(B, np.float32),
+        "num_steps": np.zeros(B, np.int32), "old_value": np.zeros(B, np.int32),
+        "required_points": np.zeros(B, np.int32), "initial_points": np.zeros(B, np.int32),
+        "table_idx": np.zeros(B, np.int32), "goals_static": np.zeros(B, np.uint8),
+        "is_active": np.zeros(B, np.uint8), "episode_reward": np.zeros(B, np.float32),
+        "episode_length": np.zeros(B, np.int32), "level_idx": np.zeros(B, np.int32),
+        "episode_idx": np.zeros(B, np.int32),
+        "reward": np.zeros(B, np.float32), "done": np.zeros(B, np.uint8),
+        "success": np.zeros(B, np.uint8), "times_up": np.zeros(B, np.uint8),
+    }
+    a.update({k: np.ascontiguousarray(v) for k, v in pool.arrays().items()})
+    return a

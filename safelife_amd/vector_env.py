@@ -1,0 +1,194 @@
+"""
+``SafeLifeVectorEnv`` -- B device-resident single-agent SafeLife environments stepped by ONE
+kernel launch per step (fast tier of SURVEY.md section 7).
+
+Per env it reproduces the reference's ``SafeLifeEnv`` (safelife_env.py:148-218): execute the
+action, advance board (and non-static goals) under the level's own PCG64 stream, recolour exits,
+score, reward = float32(delta points) while active, done = agent gone or time limit, episode
+accounting, observation.  With ``auto_reset`` an env whose episode ends immediately loads its
+next level from the device-resident pool (the reference's driver calls ``env.reset()`` right
+after a done step, training/base_algo.py:231-236) and the returned observation is the new
+episode's first one; ``reward``/``done``/``info`` still describe the step that ended.
+
+All state lives in HBM in torch tensors (buffer holders); the arithmetic is in
+libsafelife_hip.so.  Nothing here falls back to the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _hip
+from .levels import LevelPool
+
+_DEFAULT_CHANNELS = tuple(range(16)) + (25, 26, 27)      # safelife_env.py:71
+
+# name -> torch dtype name; uint16 / uint64 payloads are held in int16 / int64 tensors
+_STATE_SPEC = {
+    "board": "int16", "goals": "int16", "agent_loc": "int32", "exit_locs": "int32", "rng": "int64",
+    "spawn_prob": "float32", "num_steps": "int32", "old_value": "int32", "required_points": "int32",
+    "initial_points": "int32", "table_idx": "int32", "goals_static": "uint8", "is_active": "uint8",
+    "episode_reward": "float32", "episode_length": "int32", "level_idx": "int32",
+    "episode_idx": "int32",
+    "reward": "float32", "done": "uint8", "success": "uint8", "times_up": "uint8",
+    "info_episode_reward": "float32", "info_episode_length": "int32",
+}
+
+
+class SafeLifeVectorEnv(object):
+    """
+    Parameters
+    ----------
+    pool : LevelPool
+    num_envs : int                 envs held by THIS process (one process per GPU)
+    time_limit, remove_white_goals, view_shape, output_channels : as SafeLifeEnv
+        (safelife_env.py:63-73); ``output_channels=None`` yields the raw uint32 view.
+    auto_reset : bool
+    first_level : int or array     pool index loaded by env e at its first reset
+                                   (default ``(env_offset + e) % len(pool)``)
+    level_stride : int             an env's next level is ``(level + level_stride) % len(pool)``
+    env_offset : int               global index of this process's env 0 (multi-GPU sharding)
+    with_obs : bool                False skips observation writes entirely
+    """
+
+    def __init__(self, pool, num_envs, *, time_limit=1000, remove_white_goals=True,
+                 view_shape=(15, 15), output_channels=_DEFAULT_CHANNELS, auto_reset=True,
+                 first_level=None, level_stride=1, env_offset=0, with_obs=True,
+                 points_on_level_exit=1):
+        import torch
+        self.torch = torch
+        if not isinstance(pool, LevelPool):
+            raise TypeError("pool must be a LevelPool")
+        self.pool = pool
+        self.device = _hip.device()
+        self.num_envs = B = int(num_envs)
+        H, W = pool.shape
+        E = pool.exit_slots
+        self.view_shape = tuple(int(v) for v in view_shape)
+        self.output_channels = tuple(output_channels) if output_channels else None
+        self.time_limit = int(time_limit)
+        self.auto_reset = bool(auto_reset)
+        self.single_agent = True
+        chans = self.output_channels or ()
+        if len(chans) > _hip.SL_MAX_CHANNELS:
+            raise ValueError("too many output channels")
+
+        dev = self.device
+        shapes = {"board": (B, H, W), "goals": (B, H, W), "agent_loc": (B, 2), "exit_locs": (B, E),
+                  "rng": (B, 4)}
+        self.t = t = {}
+        for name, dt in _STATE_SPEC.items():
+            t[name] = torch.zeros(shapes.get(name, (B,)), dtype=getattr(torch, dt), device=dev)
+        for name, arr in pool.arrays().items():
+            a = np.ascontiguousarray(arr)
+            if a.dtype == np.uint16:
+                a = a.view(np.int16)
+            elif a.dtype == np.uint64:
+                a = a.view(np.int64)
+            t[name] = torch.from_numpy(a).to(dev)
+        vh, vw = self.view_shape
+        if not with_obs:
+            self.obs = None
+        elif chans:
+            self.obs = torch.zeros((B, vh, vw, len(chans)), dtype=torch.uint8, device=dev)
+        else:
+            self.obs = torch.zeros((B, vh, vw), dtype=torch.int32, device=dev)   # uint32 payload
+        if first_level is None:
+            first_level = (int(env_offset) + np.arange(B)) % len(pool)
+        first = np.broadcast_to(np.asarray(first_level, np.int32), (B,)).copy()
+        t["level_idx"].copy_(torch.from_numpy(first))
+
+        s = self.struct = _hip.EnvBatch()
+        s.B, s.H, s.W, s.E = B, H, W, E
+        s.time_limit, s.exit_points = self.time_limit, int(points_on_level_exit)
+        s.n_tables = int(pool.points_table.shape[0])
+        s.auto_reset = int(self.auto_reset)
+        s.remove_white_goals = int(bool(remove_white_goals))
+        s.view_h, s.view_w, s.n_channels = vh, vw, len(chans)
+        for i, c in enumerate(chans):
+            s.channels[i] = int(c)
+        s.L, s.level_stride = len(pool), int(level_stride)
+        for name in _hip.ENV_STATE_PTRS + _hip.ENV_POOL_PTRS + _hip.ENV_OUT_PTRS:
+            if name == "obs":
+                s.obs = None if self.obs is None else self.obs.data_ptr()
+            else:
+                setattr(s, name, t[name].data_ptr())
+        self._lib = _hip.lib()
+        self._sref = C.byref(s)
+
+    # ------------------------------------------------------------------ gym-like surface
+
+    def reset(self, mask=None):
+        """(Re)load every env -- or those with mask != 0 -- from its pool level; returns obs."""
+        m = None
+        if mask is not None:
+            m = self.torch.as_tensor(mask, device=self.device).to(self.torch.uint8).contiguous()
+        rc = self._lib.slhip_env_reset(self._sref, _hip.ptr(m), _hip.current_stream_ptr())
+        _hip.check(rc)
+        return self.obs
+
+    def _actions(self, actions, shape):
+        torch = self.torch
+        a = actions if isinstance(actions, torch.Tensor) else torch.as_tensor(np.asarray(actions))
+        if a.device != self.device or a.dtype != torch.int32 or not a.is_contiguous():
+            a = a.to(device=self.device, dtype=torch.int32).contiguous()
+        if tuple(a.shape) != shape:
+            raise ValueError("actions must have shape %r" % (shape,))
+        return a
+
+    def step(self, actions):
+        """actions: int [B] in 0..8.  Returns (obs, reward, done, info) as device tensors that are
+        overwritten by the next call."""
+        a = self._actions(actions, (self.num_envs,))
+        rc = self._lib.slhip_env_step(self._sref, _hip.ptr(a), _hip.current_stream_ptr())
+        _hip.check(rc)
+        t = self.t
+        info = {"success": t["success"], "times_up": t["times_up"],
+                "episode_reward": t["info_episode_reward"],
+                "episode_length": t["info_episode_length"]}
+        return self.obs, t["reward"], t["done"], info
+
+    def rollout(self, actions, reward_out=None, done_out=None):
+        """T steps in one launch.  actions: int [T,B].  Returns (reward[T,B], done[T,B])."""
+        torch = self.torch
+        T = int(actions.shape[0])
+        a = self._actions(actions, (T, self.num_envs))
+        if reward_out is None:
+            reward_out = torch.empty((T, self.num_envs), dtype=torch.float32, device=self.device)
+        if done_out is None:
+            done_out = torch.empty((T, self.num_envs), dtype=torch.uint8, device=self.device)
+        rc = self._lib.slhip_env_rollout(self._sref, _hip.ptr(a), T, _hip.ptr(reward_out),
+                                         _hip.ptr(done_out), _hip.current_stream_ptr())
+        _hip.check(rc)
+        return reward_out, done_out
+
+    def get_obs(self):
+        rc = self._lib.slhip_env_obs(self._sref, _hip.current_stream_ptr())
+        _hip.check(rc)
+        return self.obs
+
+    # ------------------------------------------------------------------ host views
+
+    def numpy(self, name):
+        """Host copy of a state array in the reference's dtype (board/goals uint16, rng uint64)."""
+        if name == "obs":
+            a = self.obs.cpu().numpy()
+            return a.view(np.uint32) if self.output_channels is None else a
+        a = self.t[name].cpu().numpy()
+        if a.dtype == np.int16:
+            return a.view(np.uint16)
+        if name in ("rng", "pool_rng"):
+            return a.view(np.uint64)
+        return a
+
+    def load_state(self, arrays):
+        """Overwrite per-env state from host arrays (names of ``sl_env_batch``)."""
+        torch = self.torch
+        for name, arr in arrays.items():
+            if name not in self.t or name.startswith("pool_") or name == "points_table":
+                continue
+            a = np.ascontiguousarray(arr)
+            if a.dtype == np.uint16:
+                a = a.view(np.int16)
+            elif a.dtype == np.uint64:
+                a = a.view(np.int64)
+            self.t[name].copy_(torch.from_numpy(a))

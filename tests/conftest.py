@@ -1,0 +1,26 @@
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """Make sure the HIP library and the oracle are compiled (hipcc cross-compiles without a GPU)."""
+    import __graft_entry__ as entry
+    entry.build(quiet=True)
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN

@@ -275,6 +275,10 @@ def normalize_level(data):
     """
     names = data.dtype.names if hasattr(data, "dtype") and data.dtype.names else list(data.keys())
     out = {k: np.array(data[k]) for k in names}
+    # Some shipped examples name the experimental, pure-Python `GameOfLife` class
+    # (safelife_game.py:768-838), which is outside the hot path; dropping the key makes
+    # `loaddata` build a SafeLifeGame, i.e. the C physics this repository restates.
+    out.pop("class", None)
     if "agent_loc" in out:
         out["agent_locs"] = np.ascontiguousarray(np.array(out.pop("agent_loc"))[None, ::-1])
     return out

@@ -1,0 +1,129 @@
+"""CPU suite, part 1: pin the oracle (oracle/sl_oracle.c) to the reference.
+
+Sources of truth, in order: golden vectors produced by the reference itself
+(tests/golden/*.npz, generator: tests/golden/make_golden.py) and, when present, the reference
+C extension compiled from its own sources (oracle/_ref).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from tests import util
+
+
+@pytest.fixture(scope="module")
+def prim():
+    with np.load(os.path.join(util.GOLDEN, "primitives.npz")) as d:
+        return {k: d[k] for k in d.files}
+
+
+def test_advance_board_golden(prim):
+    n = int(prim["n_adv"])
+    assert n > 300
+    for k in range(n):
+        p, steps = prim["adv_%03d_p_n" % k]
+        out, words = oracle.advance_board(prim["adv_%03d_in" % k], float(p), int(steps),
+                                          rng_words=prim["adv_%03d_rng0" % k])
+        assert np.array_equal(out, prim["adv_%03d_out" % k]), k
+        assert np.array_equal(words, prim["adv_%03d_rng1" % k]), k
+
+
+def test_alive_counts_golden(prim):
+    for k in range(int(prim["n_cnt"])):
+        got = oracle.alive_counts(prim["cnt_%03d_board" % k], prim["cnt_%03d_goals" % k])
+        assert got.dtype == np.int64 and got.shape == (8, 9)
+        assert np.array_equal(got, prim["cnt_%03d_out" % k]), k
+
+
+def test_execute_actions_golden(prim):
+    for k in range(int(prim["n_act"])):
+        board = prim["act_%03d_board" % k].copy()
+        locs = prim["act_%03d_locs" % k].copy()
+        oracle.execute_actions(board, locs, prim["act_%03d_acts" % k])
+        assert np.array_equal(board, prim["act_%03d_board_out" % k]), k
+        assert np.array_equal(locs, prim["act_%03d_locs_out" % k]), k
+
+
+def test_life_occupancy_golden(prim):
+    for k in range(int(prim["n_occ"])):
+        got = oracle.life_occupancy(prim["occ_%02d_in" % k], 0.3, int(prim["occ_%02d_n" % k]),
+                                    rng_words=prim["occ_%02d_rng0" % k])
+        assert got.dtype == np.int32
+        assert np.array_equal(got, prim["occ_%02d_out" % k]), k
+
+
+def test_patterns_known_answers():
+    """Pure-Life evolution of the reference's shipped patterns, incl. the glider's period-4 shift."""
+    with np.load(os.path.join(util.GOLDEN, "patterns.npz")) as d:
+        for name in ("glider", "acorn", "rpentomino", "growth"):
+            for n in (1, 4, 20, 100):
+                assert np.array_equal(oracle.advance_board(d[name + "_in"], 0.3, n), d["%s_n%d" % (name, n)])
+        # the level holds a glider, a blinker and a loaf: after 4 steps the glider (rows 7-9,
+        # cols 8-10) has moved one cell down-right, the other two are back in phase
+        g0, g4 = d["glider_in"].copy(), d["glider_n4"]
+        glider = np.zeros_like(g0, dtype=bool)
+        glider[7:10, 8:11] = g0[7:10, 8:11] > 0
+        assert glider.sum() == 5
+        expect = np.where(glider, 0, g0) | np.roll(np.where(glider, g0, 0), (1, 1), (0, 1))
+        assert np.array_equal(expect, g4)
+
+
+def test_batch_matches_single():
+    rng = np.random.default_rng(5)
+    boards = util.random_boards(rng, 12, 25, 25, kind=1)
+    words = util.random_rng_words(rng, 12)
+    w2 = words.copy()
+    out = oracle.advance_board_batch(boards, 0.3, 3, w2, n_threads=4)
+    for b in range(12):
+        o, w = oracle.advance_board(boards[b], 0.3, 3, rng_words=words[b])
+        assert np.array_equal(o, out[b]) and np.array_equal(w, w2[b])
+
+
+def test_pcg64_matches_numpy():
+    L = oracle.lib()
+    bg = np.random.PCG64(12345)
+    g = oracle.Pcg64(*[int(x) for x in oracle.pcg64_state_words(bg)])
+    gen = np.random.Generator(bg)
+    import ctypes as C
+    for _ in range(100):
+        assert L.slo_pcg64_next_double(C.byref(g)) == gen.random()
+    bg2 = np.random.PCG64(99)
+    g2 = oracle.Pcg64(*[int(x) for x in oracle.pcg64_state_words(bg2)])
+    L.slo_pcg64_advance(C.byref(g2), 1000)
+    bg2.advance(1000)
+    assert [g2.state_hi, g2.state_lo] == [int(x) for x in oracle.pcg64_state_words(bg2)[:2]]
+
+
+def test_against_compiled_reference():
+    """Random differential test against oracle/_ref (the reference C built from its own sources)."""
+    ref = oracle.load_ref()
+    if ref is None:
+        pytest.skip("oracle/_ref not built (reference checkout absent)")
+    rng = np.random.default_rng(2)
+    for trial in range(150):
+        h, w = (25, 25) if trial % 3 == 0 else tuple(int(v) for v in rng.integers(3, 40, 2))
+        board = util.random_boards(rng, 1, h, w, kind=trial % 3)[0]
+        n, p = int(rng.integers(1, 5)), float(rng.choice([0.3, 0.0, 1.0, 0.1]))
+        g1, g2 = np.random.PCG64(trial), np.random.PCG64(trial)
+        ref.set_bit_generator(g1)
+        assert np.array_equal(ref.advance_board(board, p, n), oracle.advance_board(board, p, n, bitgen=g2))
+        assert g1.state == g2.state
+        goals = (rng.integers(0, 8, (h, w)) << 9).astype(np.uint16)
+        assert np.array_equal(ref.alive_counts(board, goals), oracle.alive_counts(board, goals))
+
+
+@pytest.mark.parametrize("name", util.trace_names())
+def test_env_trace(name):
+    """The oracle's batched SafeLifeEnv against traces of the reference's SafeLifeEnv."""
+    tr = util.load_trace(name)
+    n = util.replay_trace(tr, util.OracleBackend, util.oracle_counts)
+    assert n == len(tr["trace_reward"])
+
+
+@pytest.mark.parametrize("name", ["v10_prune-still_open", "v10_navigation", "worked_7x7_exit",
+                                  "v10_append-spawn", "pattern_glider_noagent"])
+def test_env_trace_terminal_states(name):
+    tr = util.load_trace(name)
+    assert util.replay_trace_terminal(tr, util.OracleBackend, util.oracle_counts) >= 1

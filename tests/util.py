@@ -1,0 +1,226 @@
+"""Shared test helpers: golden-trace loading and a backend-neutral replay of SafeLifeEnv traces.
+
+Two backends implement the same tiny adapter (reset / step / get):
+  * OracleBackend  -- oracle.OracleEnv  (CPU checker; used by the `not gpu` tests to pin the oracle
+                      against the reference's traces)
+  * DeviceBackend  -- safelife_amd.SafeLifeVectorEnv (the HIP product path; `gpu` tests)
+"""
+import glob
+import os
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+PALETTE = np.array(
+    [0] * 12 + [9] * 5 + [1, 16, 17, 32788, 152, 152 | 0x200, 152 | 0x800, 144, 48, 53, 85, 32884,
+                          272, 9 | 0x200, 9 | 0x400, 9 | 0x600, 9 | 0x800, 9 | 0xE00, 122,
+                          0x8000 | 9, 4 | 8, 1 | 4 | 0x400, 32, 64, 128 | 0x400, 9 | 0xA00],
+    dtype=np.uint16)
+
+
+def random_boards(rng, B, H, W, kind=0):
+    """Synthetic boards in the spirit of SURVEY.md section 8(d), config C2."""
+    if kind == 0:
+        return PALETTE[rng.integers(0, len(PALETTE), (B, H, W))]
+    if kind == 1:
+        b = np.where(rng.random((B, H, W)) < 0.3, 9, 0).astype(np.uint16)
+        for k in range(B):
+            for _ in range(4):
+                b[k, rng.integers(0, H), rng.integers(0, W)] = 152 | (int(rng.integers(0, 8)) << 9)
+        return b
+    return rng.integers(0, 65536, (B, H, W)).astype(np.uint16)
+
+
+def random_rng_words(rng, B):
+    """B independent numpy PCG64 states as uint64 [B,4]."""
+    out = np.zeros((B, 4), np.uint64)
+    m = (1 << 64) - 1
+    for k, child in enumerate(np.random.SeedSequence(int(rng.integers(0, 2**31))).spawn(B)):
+        st = np.random.PCG64(child).state["state"]
+        out[k] = [st["state"] >> 64, st["state"] & m, st["inc"] >> 64, st["inc"] & m]
+    return out
+
+
+def trace_names():
+    return sorted(os.path.basename(p)[len("trace_"):-4]
+                  for p in glob.glob(os.path.join(GOLDEN, "trace_*.npz")))
+
+
+def load_trace(name):
+    with np.load(os.path.join(GOLDEN, "trace_%s.npz" % name)) as d:
+        return {k: d[k] for k in d.files}
+
+
+def levels_from_trace(tr):
+    from safelife_amd.levels import Level
+    levels = []
+    for i in range(int(tr["n_levels"])):
+        pre = "level%d_" % i
+        rec = {k[len(pre):]: tr[k] for k in tr if k.startswith(pre)}
+        rng = rec.pop("rng")
+        lv = Level.from_data(rec)
+        lv.rng_words = np.array(rng, np.uint64)
+        levels.append(lv)
+    return levels
+
+
+def env_kwargs_from_trace(tr):
+    kw = {}
+    if "env_view_shape" in tr:
+        kw["view_shape"] = tuple(int(v) for v in tr["env_view_shape"])
+    if "env_output_channels" in tr:
+        oc = tr["env_output_channels"]
+        kw["output_channels"] = None if oc.ndim == 0 else tuple(int(v) for v in oc)
+    if "env_time_limit" in tr:
+        kw["time_limit"] = int(tr["env_time_limit"])
+    if "env_remove_white_goals" in tr:
+        kw["remove_white_goals"] = bool(tr["env_remove_white_goals"])
+    return kw
+
+
+def pool_from_trace(tr, counts_fn):
+    from safelife_amd.levels import LevelPool
+    frac = float(tr["min_performance_fraction"]) if "min_performance_fraction" in tr else 1.0
+    return LevelPool(levels_from_trace(tr), min_performance_fraction=frac, counts_fn=counts_fn)
+
+
+class OracleBackend(object):
+    def __init__(self, pool, B, first_level=0, **kw):
+        import oracle
+        from safelife_amd.levels import empty_env_arrays
+        self.arrays = empty_env_arrays(pool, B)
+        self.arrays["level_idx"][:] = first_level
+        kw.setdefault("view_shape", (15, 15))
+        self.env = oracle.OracleEnv(self.arrays, **kw)
+
+    def reset(self):
+        return self.env.reset().copy()
+
+    def step(self, actions):
+        obs, r, d = self.env.step(actions)
+        return obs.copy(), r.copy(), d.copy()
+
+    def get(self, name):
+        return self.arrays[name].copy()
+
+
+class DeviceBackend(object):
+    def __init__(self, pool, B, first_level=0, **kw):
+        from safelife_amd.vector_env import SafeLifeVectorEnv
+        self.env = SafeLifeVectorEnv(pool, B, first_level=first_level, **kw)
+
+    def reset(self):
+        self.env.reset()
+        return self.env.numpy("obs")
+
+    def step(self, actions):
+        self.env.step(actions)
+        return self.env.numpy("obs"), self.env.numpy("reward"), self.env.numpy("done")
+
+    def get(self, name):
+        return self.env.numpy(name)
+
+
+def oracle_counts(boards, goals):
+    import oracle
+    return oracle.alive_counts_batch(boards, goals)
+
+
+def replay_trace(tr, backend_cls, counts_fn):
+    """Replay a reference SafeLifeEnv trace (B = 1, auto-reset) and assert every recorded output."""
+    pool = pool_from_trace(tr, counts_fn)
+    kw = env_kwargs_from_trace(tr)
+    be = backend_cls(pool, 1, first_level=0, auto_reset=True, level_stride=1, **kw)
+    obs = be.reset()
+    resets = list(tr["trace_reset_at"])
+    n_resets = len(resets)
+    assert np.array_equal(obs[0], tr["trace_reset_obs"][0]), "first reset obs"
+    assert np.array_equal(be.get("board")[0], tr["trace_reset_board"][0])
+    assert np.array_equal(be.get("rng")[0], tr["trace_reset_rng"][0])
+    actions = tr["trace_actions"]
+    T = len(tr["trace_reward"])
+    episode = 0
+    for t in range(T):
+        obs, reward, done = be.step(np.array([actions[t]], np.int32))
+        where = "step %d" % t
+        assert reward[0] == tr["trace_reward"][t], where
+        assert bool(done[0]) == bool(tr["trace_done"][t]), where
+        assert bool(be.get("success")[0]) == bool(tr["trace_success"][t]), where
+        assert bool(be.get("times_up")[0]) == bool(tr["trace_times_up"][t]), where
+        if tr["trace_done"][t]:
+            episode += 1
+            if episode >= n_resets:
+                break          # the reference ran out of levels here
+            # auto-reset: state and observation are those of the next episode's reset
+            assert np.array_equal(obs[0], tr["trace_reset_obs"][episode]), where + " reset obs"
+            assert np.array_equal(be.get("board")[0], tr["trace_reset_board"][episode]), where
+            assert np.array_equal(be.get("rng")[0], tr["trace_reset_rng"][episode]), where
+        else:
+            assert np.array_equal(be.get("board")[0], tr["trace_board"][t]), where + " board"
+            assert np.array_equal(be.get("goals")[0], tr["trace_goals"][t]), where + " goals"
+            assert np.array_equal(be.get("agent_loc")[0], tr["trace_agent_loc"][t]), where + " loc"
+            assert np.array_equal(be.get("rng")[0], tr["trace_rng_after"][t]), where + " rng"
+            assert np.array_equal(obs[0], tr["trace_obs"][t]), where + " obs"
+            assert int(be.get("episode_length")[0]) == int(tr["trace_ep_length"][t]), where
+            assert be.get("episode_reward")[0] == tr["trace_ep_reward"][t], where
+            assert int(be.get("num_steps")[0]) == int(tr["trace_num_steps"][t]), where
+    return T
+
+
+def replay_trace_terminal(tr, backend_cls, counts_fn):
+    """Same trace without auto-reset: checks the terminal board/observation of every episode."""
+    pool = pool_from_trace(tr, counts_fn)
+    kw = env_kwargs_from_trace(tr)
+    actions = tr["trace_actions"]
+    resets = list(tr["trace_reset_at"]) + [len(tr["trace_reward"])]
+    checked = 0
+    for ep in range(len(resets) - 1):
+        be = backend_cls(pool, 1, first_level=ep, auto_reset=False, **kw)
+        be.reset()
+        for t in range(resets[ep], resets[ep + 1]):
+            obs, reward, done = be.step(np.array([actions[t]], np.int32))
+        t = resets[ep + 1] - 1
+        assert np.array_equal(be.get("board")[0], tr["trace_board"][t]), "terminal board ep %d" % ep
+        assert np.array_equal(obs[0], tr["trace_obs"][t]), "terminal obs ep %d" % ep
+        assert np.array_equal(be.get("agent_loc")[0], tr["trace_agent_loc"][t])
+        assert reward[0] == tr["trace_reward"][t]
+        checked += 1
+    return checked
+
+
+def pool_from_fixture(name, counts_fn, n=None, **kw):
+    """LevelPool from tests/golden/pool_<name>.npz (reference procgen output)."""
+    from safelife_amd.levels import Level, LevelPool
+    with np.load(os.path.join(GOLDEN, "pool_%s.npz" % name)) as d:
+        L = int(d["n_levels"]) if n is None else min(n, int(d["n_levels"]))
+        levels = []
+        for k in range(L):
+            levels.append(Level(d["board"][k], d["goals"][k], d["agent_locs"][k],
+                                spawn_prob=float(d["spawn_prob"][k]),
+                                min_performance=float(d["min_performance"][k]),
+                                points_table=d["points_table"][k], rng_words=d["rng"][k]))
+        ref = {"required_points": d["required_points"][:L].copy(),
+               "initial_available_points": d["initial_available_points"][:L].copy()}
+    return LevelPool(levels, counts_fn=counts_fn, **kw), ref
+
+
+def smoke_check():
+    """One small fused step batch on the GPU against the oracle (used by __graft_entry__.smoke)."""
+    pool, _ = pool_from_fixture("append_spawn_25", oracle_counts, n=8)
+    B, T = 16, 12
+    rng = np.random.default_rng(0)
+    kw = dict(auto_reset=True, time_limit=8, view_shape=(25, 25),
+              output_channels=(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 25, 26, 27))
+    first = np.arange(B) % len(pool)
+    dev = DeviceBackend(pool, B, first_level=first, **kw)
+    cpu = OracleBackend(pool, B, first_level=first, **kw)
+    assert np.array_equal(dev.reset(), cpu.reset())
+    for t in range(T):
+        a = rng.integers(0, 9, B).astype(np.int32)
+        o1, r1, d1 = dev.step(a)
+        o2, r2, d2 = cpu.step(a)
+        assert np.array_equal(r1, r2) and np.array_equal(d1, d2) and np.array_equal(o1, o2), t
+        for name in ("board", "goals", "agent_loc", "rng", "num_steps", "level_idx"):
+            assert np.array_equal(dev.get(name), cpu.get(name)), (t, name)
