@@ -70,6 +70,10 @@ def lib():
             raise SafeLifeHipError(
                 "safelife_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        # One HIP runtime per process: torch ships its own libamdhip64.so.7 and must be loaded
+        # first so that this library binds to the same runtime (same SONAME) instead of pulling a
+        # second copy from /opt/rocm, which would then see no device.
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         L.slhip_abi_version.restype = C.c_int
         L.slhip_last_error.restype = C.c_char_p
