@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""
+bench.py -- env-steps/s of the batched SafeLife step() on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2]): 8192 envs x 25x25 per GPU,
+levels from the reference's `prune-still` procgen (fixture pool, cycled), uniform random actions,
+full step = execute_actions + advance_board + exit colours + score/reward/done + episode
+accounting + on-device auto-reset.  One "step" = ONE launch of the fused kernel over all envs of
+a rank.  Inputs are resident in HBM before the timed region.  Weak scaling: every rank owns 8192
+envs; the only cross-GPU traffic is the gather of (reward, done) to rank 0, batched every
+--gather-every steps on a side stream.
+
+Output: one JSON line on rank 0 (see README / the driver contract), with
+  roofline     -- algorithmic HBM bytes per launch / measured average launch duration (HIP events on
+                  the launch stream) against the 8 TB/s HBM3E peak
+  cpu_baseline -- the oracle (plain-C restatement, OpenMP over envs) timed on this host on a bounded
+                  sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+TRAIN_CHANNELS = (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 25, 26, 27)   # env_factory.py:301-327
+
+
+def load_pool(name, counts_fn, n=None):
+    from safelife_amd.levels import Level, LevelPool
+    path = os.path.join(REPO, "tests", "golden", "pool_%s.npz" % name)
+    with np.load(path) as d:
+        L = int(d["n_levels"]) if n is None else min(int(n), int(d["n_levels"]))
+        levels = [Level(d["board"][k], d["goals"][k], d["agent_locs"][k],
+                        spawn_prob=float(d["spawn_prob"][k]), min_performance=float(d["min_performance"][k]),
+                        points_table=d["points_table"][k], rng_words=d["rng"][k]) for k in range(L)]
+    return LevelPool(levels, counts_fn=counts_fn)
+
+
+def cpu_baseline(pool, envs, steps, seed):
+    """Oracle (CPU checker) timed on the same workload; bounded sample."""
+    import oracle
+    from safelife_amd.levels import empty_env_arrays
+    try:
+        threads = len(os.sched_getaffinity(0))
+    except AttributeError:
+        threads = os.cpu_count() or 1
+    try:   # cgroup v2 CPU quota, if any
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            threads = max(1, min(threads, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+    arrays = empty_env_arrays(pool, envs)
+    arrays["level_idx"][:] = np.arange(envs) % len(pool)
+    env = oracle.OracleEnv(arrays, time_limit=1000, auto_reset=True, level_stride=1,
+                           view_shape=(25, 25), output_channels=TRAIN_CHANNELS, with_obs=False)
+    env.reset()
+    rng = np.random.default_rng(seed)
+    acts = rng.integers(0, 9, (steps, envs)).astype(np.int32)
+    env.step(acts[0], n_threads=threads)            # warm
+    t0 = time.perf_counter()
+    for t in range(1, steps):
+        env.step(acts[t], n_threads=threads)
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    n1 = max(1, (steps - 1) // 8)
+    for t in range(n1):
+        env.step(acts[t], n_threads=1)
+    dt1 = time.perf_counter() - t1
+    return {
+        "value": envs * (steps - 1) / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+        "sample": "%d envs x %d steps of the same 25x25 prune-still workload (oracle/sl_oracle.c, OpenMP "
+                  "over envs, no observation); single thread: %.3g env-steps/s" % (
+                      envs, steps - 1, envs * n1 / dt1),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--envs", type=int, default=8192, help="envs per GPU")
+    ap.add_argument("--pool", default="prune_still_25")
+    ap.add_argument("--obs", type=int, default=0, help="1: also write the 25x25x15 uint8 observation")
+    ap.add_argument("--gather-every", type=int, default=32)
+    ap.add_argument("--cpu-baseline", type=int, default=1)
+    ap.add_argument("--cpu-steps", type=int, default=101)
+    ap.add_argument("--rollout", type=int, default=0,
+                    help="T>0: additionally time T-step fused rollouts (reported under 'extra')")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from safelife_amd import _hip
+    from safelife_amd.levels import _device_counts
+    from safelife_amd.vector_env import SafeLifeVectorEnv
+    from safelife_amd.sharding import RewardGather
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    dev = _hip.device()
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    B, K, W = args.envs, args.steps, args.warmup
+    pool = load_pool(args.pool, _device_counts)
+    H, Wd = pool.shape
+    env = SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25), output_channels=TRAIN_CHANNELS,
+                            auto_reset=True, level_stride=1, env_offset=rank * B, with_obs=bool(args.obs))
+    env.reset()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7 + rank)
+    actions = torch.randint(0, 9, (K + W, B), generator=gen, device=dev, dtype=torch.int32)
+    gather = RewardGather(env, every=args.gather_every, world=world, rank=rank)
+
+    def run(t0, n):
+        for t in range(t0, t0 + n):
+            gather.before_step(t)
+            env.step(actions[t])
+            gather.after_step(t)
+
+    run(0, W)
+    gather.flush()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t_start = time.perf_counter()
+    ev0.record()
+    run(W, K)
+    ev1.record()
+    gather.flush()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    kernel_ms = ev0.elapsed_time(ev1) / K          # average launch-to-launch duration on the stream
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    extra = {}
+    if args.rollout > 0:
+        T = args.rollout
+        reps = max(1, K // T)
+        a = actions[:T].contiguous()
+        env.rollout(a)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            env.rollout(a)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        extra["rollout_T"] = T
+        extra["rollout_env_steps_per_s_per_gpu"] = B * T / (ms * 1e-3)
+
+    if rank == 0:
+        bytes_per_step = 3 * H * Wd * 2 + (H * Wd * len(TRAIN_CHANNELS) if args.obs else 0)
+        achieved = bytes_per_step * B / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "env steps/sec (whole node), 8192x25x25 boards; bit-exact vs C advance_board",
+            "value": world * B * K / elapsed,
+            "unit": "env-steps/s",
+            "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u16", "data": "synthetic (reference-procgen prune-still level pool cycled on device, "
+                                    "uniform random actions)",
+            "config": {"workload": "C3: %d envs/GPU x %dx%d prune-still, fused step()+reward+auto-reset%s" % (
+                           B, H, Wd, " + 25x25x15 u8 obs" if args.obs else ", no observation"),
+                       "envs_per_gpu": B, "global_envs": world * B, "board": [H, Wd],
+                       "level_pool": len(pool), "parallelism": "envs sharded %d-way, reward/done gathered "
+                                                               "to rank 0 every %d steps" % (world, args.gather_every)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "fused env step", "bytes_per_env_step": bytes_per_step,
+                         "launch_ms": kernel_ms},
+        }
+        if extra:
+            out["extra"] = extra
+        if args.cpu_baseline and world == 1:
+            import oracle
+
+            def cpu_counts(b, g):
+                return oracle.alive_counts_batch(b, g)
+            out["cpu_baseline"] = cpu_baseline(load_pool(args.pool, cpu_counts), B, args.cpu_steps, 7)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

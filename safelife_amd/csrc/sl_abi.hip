@@ -1,5 +1,6 @@
 // sl_abi.hip -- the extern "C" boundary declared in include/safelife_hip.h: argument validation,
 // the per-device PCG64 jump table, and dispatch to the gfx950 kernels.
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -58,6 +59,16 @@ int jump_table(const sl::Jump **out) {
     return SL_OK;
 }
 
+// SAFELIFE_HIP_FORCE_GENERIC=1 routes every shape through the size-generic kernels (A/B testing of
+// the two device implementations against each other; both are HIP, neither is a fallback to CPU).
+bool force_generic() {
+    static const bool v = [] {
+        const char *e = getenv("SAFELIFE_HIP_FORCE_GENERIC");
+        return e && e[0] == '1';
+    }();
+    return v;
+}
+
 int check_board_shape(int B, int H, int W) {
     if (B < 0) return fail(SL_E_ARG, "negative batch size");
     if (H < 3 || W < 3) return fail(SL_E_SHAPE, "Board must be at least 3x3.");
@@ -110,8 +121,11 @@ int slhip_advance_board(const uint16_t *in, uint16_t *out, int B, int H, int W, 
     if (B == 0) return SL_OK;
     const sl::Jump *jump;
     if ((rc = jump_table(&jump))) return rc;
-    hipError_t err = sl::launch_advance_generic(in, out, B, H, W, spawn_prob, n_steps, rng, jump, nullptr,
-                                                (hipStream_t)stream);
+    hipError_t err = (sl::rowlane_supports(H, W) && !force_generic())
+                         ? sl::launch_advance_rowlane(in, out, B, H, W, spawn_prob, n_steps, rng, jump,
+                                                      (hipStream_t)stream)
+                         : sl::launch_advance_generic(in, out, B, H, W, spawn_prob, n_steps, rng, jump, nullptr,
+                                                      (hipStream_t)stream);
     return err == hipSuccess ? SL_OK : hip_fail(err, "advance_board launch");
 }
 
@@ -167,8 +181,11 @@ int slhip_env_rollout(const sl_env_batch *env, const int32_t *actions, int T, fl
     if (env->B == 0 || T == 0) return SL_OK;
     const sl::Jump *jump;
     if ((rc = jump_table(&jump))) return rc;
-    hipError_t err = sl::launch_env_rollout_generic(*env, actions, T, reward_t, done_t, jump,
-                                                    (hipStream_t)stream);
+    hipError_t err = (sl::rowlane_supports(env->H, env->W) && !force_generic())
+                         ? sl::launch_env_rollout_rowlane(*env, actions, T, reward_t, done_t, jump,
+                                                          (hipStream_t)stream)
+                         : sl::launch_env_rollout_generic(*env, actions, T, reward_t, done_t, jump,
+                                                          (hipStream_t)stream);
     return err == hipSuccess ? SL_OK : hip_fail(err, "env_step launch");
 }
 

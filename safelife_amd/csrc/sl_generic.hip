@@ -26,11 +26,6 @@ __device__ __forceinline__ int row_of(int i, int W, float inv_w) {
     return y;
 }
 
-__device__ __forceinline__ int pos_mod(int a, int n) {
-    int r = a % n;
-    return r < 0 ? r + n : r;
-}
-
 // ---------------------------------------------------------------------------------------------
 // One CA step of the board held in LDS `cur` into LDS `nxt` (`rows` is scratch), all GB threads.
 // rng: LDS {state_hi, state_lo, inc_hi, inc_lo}; advanced by the number of draws.
@@ -178,61 +173,6 @@ __global__ __launch_bounds__(GB) void k_alive_counts(const u16 *__restrict__ boa
 }
 
 // --------------------------------------------------------------------------- execute_actions
-
-// One agent's action on a board reachable through `board` (LDS or global).  loc = (row, col).
-template <typename LocT>
-__device__ void act_one(u16 *board, int H, int W, LocT *loc, int action) {
-    if (action == 0) return;
-    const int dir = (action - 1) & 3;                 // 0 up, 1 right, 2 down, 3 left
-    const int dy = (dir & 1) ? 0 : dir - 1;
-    const int dx = (dir & 1) ? 2 - dir : 0;
-    const int y0 = (int)(loc[0] % H), x0 = (int)(loc[1] % W);
-    u16 *here = board + y0 * W + x0;
-    if (!(*here & AGENT)) return;
-    u16 *ahead = board + pos_mod(y0 + dy, H) * W + pos_mod(x0 + dx, W);
-    u16 *ahead2 = board + pos_mod(y0 + 2 * dy, H) * W + pos_mod(x0 + 2 * dx, W);
-    u16 *behind = board + pos_mod(y0 - dy, H) * W + pos_mod(x0 - dx, W);
-    *here = (u16)((*here & ~ORIENT_MASK) | (dir << ORIENT_SHIFT));
-    const bool can_push = (~*here & *ahead & PUSHABLE) != 0;
-    if (action >= 5) {
-        if (*ahead == 0) {
-            *ahead = (u16)(ALIVE | DESTRUCTIBLE | (*here & COLORS));
-        } else if (*ahead & DESTRUCTIBLE) {
-            *ahead = (*ahead & AGENT) ? (u16)((*ahead ^ (AGENT | DESTRUCTIBLE)) | FROZEN) : (u16)0;
-        } else if (can_push) {
-            if (*ahead2 == 0) {
-                *ahead2 = *ahead;
-                *ahead = 0;
-            } else if (*ahead2 & EXIT) {
-                *ahead = 0;
-            }
-        }
-        return;
-    }
-    bool step_into = false, leave_only = false;
-    if (can_push) {
-        if (*ahead2 == 0) {
-            *ahead2 = *ahead;
-            step_into = true;
-        } else if (*ahead2 & EXIT) {
-            step_into = true;
-        }
-    } else if (*ahead == 0) {
-        step_into = true;
-    } else if ((*here & *ahead & EXIT) && !(*ahead & AGENT)) {
-        leave_only = true;
-    }
-    if (!step_into && !leave_only) return;
-    if (step_into) *ahead = *here;
-    loc[0] = (LocT)pos_mod(y0 + dy, H);
-    loc[1] = (LocT)pos_mod(x0 + dx, W);
-    if (~*here & *behind & PULLABLE) {
-        *here = *behind;
-        *behind = 0;
-    } else {
-        *here = 0;
-    }
-}
 
 __global__ void k_execute_actions(u16 *board, int B, int H, int W, int64_t *locs,
                                   const int64_t *__restrict__ actions, int A, int action_stride,

@@ -23,4 +23,11 @@ hipError_t launch_env_rollout_generic(const sl_env_batch &env, const int32_t *ac
 hipError_t launch_env_reset_generic(const sl_env_batch &env, const uint8_t *mask, hipStream_t stream);
 hipError_t launch_env_obs_generic(const sl_env_batch &env, hipStream_t stream);
 
+// sl_rowlane.hip : row-per-lane SWAR kernels for the shapes listed in SL_ROWLANE_SHAPES
+bool rowlane_supports(int H, int W);
+hipError_t launch_advance_rowlane(const u16 *in, u16 *out, int B, int H, int W, const float *spawn_prob,
+                                  int n_steps, sl_pcg64 *rng, const Jump *jump, hipStream_t stream);
+hipError_t launch_env_rollout_rowlane(const sl_env_batch &env, const int32_t *actions, int T, float *reward_t,
+                                      uint8_t *done_t, const Jump *jump, hipStream_t stream);
+
 }  // namespace sl

@@ -161,6 +161,13 @@ class SafeLifeVectorEnv(object):
         _hip.check(rc)
         return reward_out, done_out
 
+    def set_step_outputs(self, reward_ptr, done_ptr):
+        """Redirect the per-step ``reward`` / ``done`` outputs to caller-owned device memory
+        (``float32[B]`` / ``uint8[B]`` addresses); ``None`` restores the env's own tensors.
+        Used by sharding.RewardGather to have the kernel fill a packed send buffer directly."""
+        self.struct.reward = self.t["reward"].data_ptr() if reward_ptr is None else int(reward_ptr)
+        self.struct.done = self.t["done"].data_ptr() if done_ptr is None else int(done_ptr)
+
     def get_obs(self):
         rc = self._lib.slhip_env_obs(self._sref, _hip.current_stream_ptr())
         _hip.check(rc)
