@@ -137,7 +137,15 @@ typedef struct sl_env_batch {
     float *info_episode_reward;  /* [B] info['episode']['reward'] (value before any auto-reset) */
     int32_t *info_episode_length;/* [B] info['episode']['length'] */
     uint8_t *obs;                /* [B,vh,vw,C] uint8, or uint32 [B,vh,vw] if n_channels == 0; NULL = skip */
+    /* workspace */
+    int8_t *score_lut;           /* [n_tables,65536] per-cell score table derived from points_table by
+                                    slhip_env_prepare(); NULL => the size-generic kernels are used */
 } sl_env_batch;
+
+/* Derive env->score_lut from env->points_table (call once, and again whenever points_table changes).
+ * Synchronises the stream.  Returns SL_E_UNSUPPORTED when a table entry does not fit int8; the
+ * caller then passes score_lut = NULL and every shape runs on the size-generic kernels. */
+int slhip_env_prepare(const sl_env_batch *env, void *stream);
 
 /* SafeLifeEnv.reset() for the envs with mask[e] != 0 (mask NULL = all): loads pool level
  * level_idx[e] into slot e and writes its first observation. */

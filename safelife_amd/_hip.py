@@ -19,7 +19,7 @@ SL_E_SHAPE, SL_E_ARG, SL_E_HIP, SL_E_UNSUPPORTED = -1, -2, -3, -4
 EXPORTS = (
     "slhip_abi_version", "slhip_last_error", "slhip_device_count",
     "slhip_advance_board", "slhip_life_occupancy", "slhip_alive_counts", "slhip_execute_actions",
-    "slhip_env_reset", "slhip_env_step", "slhip_env_rollout", "slhip_env_obs",
+    "slhip_env_prepare", "slhip_env_reset", "slhip_env_step", "slhip_env_rollout", "slhip_env_obs",
 )
 
 
@@ -45,7 +45,7 @@ ENV_POOL_PTRS = ("pool_board", "pool_goals", "pool_agent_loc", "pool_exit_locs",
                  "pool_spawn_prob", "pool_required_reset", "pool_required_step",
                  "pool_initial_points", "pool_table_idx")
 ENV_OUT_PTRS = ("reward", "done", "success", "times_up", "info_episode_reward",
-                "info_episode_length", "obs")
+                "info_episode_length", "obs", "score_lut")
 
 
 class EnvBatch(C.Structure):
@@ -83,6 +83,7 @@ def lib():
         L.slhip_alive_counts.argtypes = [_p, _p, C.c_int, C.c_int, _p, _p]
         L.slhip_execute_actions.argtypes = [_p, C.c_int, C.c_int, C.c_int, _p, _p, C.c_int, C.c_int,
                                             C.c_int, _p]
+        L.slhip_env_prepare.argtypes = [C.POINTER(EnvBatch), _p]
         L.slhip_env_reset.argtypes = [C.POINTER(EnvBatch), _p, _p]
         L.slhip_env_step.argtypes = [C.POINTER(EnvBatch), _p, _p]
         L.slhip_env_rollout.argtypes = [C.POINTER(EnvBatch), _p, C.c_int, _p, _p, _p]

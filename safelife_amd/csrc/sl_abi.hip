@@ -1,5 +1,6 @@
 // sl_abi.hip -- the extern "C" boundary declared in include/safelife_hip.h: argument validation,
 // the per-device PCG64 jump table, and dispatch to the gfx950 kernels.
+#include <cstdint>
 #include <cstdlib>
 #include <mutex>
 #include <string>
@@ -121,7 +122,8 @@ int slhip_advance_board(const uint16_t *in, uint16_t *out, int B, int H, int W, 
     if (B == 0) return SL_OK;
     const sl::Jump *jump;
     if ((rc = jump_table(&jump))) return rc;
-    hipError_t err = (sl::rowlane_supports(H, W) && !force_generic())
+    const bool aligned = (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
+    hipError_t err = (sl::rowlane_supports(H, W) && aligned && !force_generic())
                          ? sl::launch_advance_rowlane(in, out, B, H, W, spawn_prob, n_steps, rng, jump,
                                                       (hipStream_t)stream)
                          : sl::launch_advance_generic(in, out, B, H, W, spawn_prob, n_steps, rng, jump, nullptr,
@@ -164,6 +166,21 @@ int slhip_execute_actions(uint16_t *board, int B, int H, int W, int64_t *locs, c
     return err == hipSuccess ? SL_OK : hip_fail(err, "execute_actions launch");
 }
 
+int slhip_env_prepare(const sl_env_batch *env, void *stream) {
+    int rc = check_env(env);
+    if (rc) return rc;
+    if (!env->score_lut) return fail(SL_E_ARG, "score_lut workspace is null");
+    std::vector<int32_t> host((size_t)env->n_tables * 72);
+    hipError_t err = hipMemcpyAsync(host.data(), env->points_table, host.size() * sizeof(int32_t),
+                                    hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (err == hipSuccess) err = hipStreamSynchronize((hipStream_t)stream);
+    if (err != hipSuccess) return hip_fail(err, "env_prepare copy");
+    for (int32_t v : host)
+        if (v < -128 || v > 127) return fail(SL_E_UNSUPPORTED, "points_table entry outside int8 range");
+    err = sl::launch_build_score_lut(env->points_table, env->n_tables, env->score_lut, (hipStream_t)stream);
+    return err == hipSuccess ? SL_OK : hip_fail(err, "env_prepare launch");
+}
+
 int slhip_env_reset(const sl_env_batch *env, const uint8_t *mask, void *stream) {
     int rc = check_env(env);
     if (rc) return rc;
@@ -181,7 +198,8 @@ int slhip_env_rollout(const sl_env_batch *env, const int32_t *actions, int T, fl
     if (env->B == 0 || T == 0) return SL_OK;
     const sl::Jump *jump;
     if ((rc = jump_table(&jump))) return rc;
-    hipError_t err = (sl::rowlane_supports(env->H, env->W) && !force_generic())
+    const bool aligned = (((uintptr_t)env->board | (uintptr_t)env->goals) & 15) == 0;
+    hipError_t err = (sl::rowlane_supports(env->H, env->W) && env->score_lut && aligned && !force_generic())
                          ? sl::launch_env_rollout_rowlane(*env, actions, T, reward_t, done_t, jump,
                                                           (hipStream_t)stream)
                          : sl::launch_env_rollout_generic(*env, actions, T, reward_t, done_t, jump,

@@ -1,302 +1,465 @@
 // sl_rowlane.hip -- the fast gfx950 path: one board ROW per lane, two cells per 32-bit register.
 //
 // Mapping (template on the board shape H x W, H <= 64):
-//   * a wavefront owns G = floor(64/H) consecutive boards; lane l = g*H + r holds row r of board g
-//     entirely in VGPRs as WP = (W+3)/2 words of two uint16 cells each, with one halo cell on either
-//     side ("ext" index e = x+1; word k holds e = 2k (low half) and e = 2k+1 (high half));
-//   * HBM <-> LDS traffic is lane-linear dwords over the wave's contiguous span of boards (fully
-//     coalesced, no per-row alignment constraints); LDS <-> register traffic converts between the
-//     flat layout and the row-per-lane layout (funnel shifts for odd row starts);
+//   * a 256-thread workgroup owns NB = 4*G consecutive boards (G = floor(64/H) per wavefront); lane
+//     l = g*H + r of a wave holds row r of its board g entirely in VGPRs as WP = (W+3)/2 words of two
+//     uint16 cells each, with one halo cell on either side ("ext" index e = x+1; word k holds
+//     e = 2k in its low half and e = 2k+1 in its high half);
+//   * HBM <-> LDS: the workgroup's boards are one contiguous, 16-byte aligned span that is moved with
+//     lane-linear 16-byte vectors (fully coalesced); LDS <-> registers converts between that flat
+//     image and the row-per-lane layout (funnel shifts absorb odd row starts);
 //   * the 3x3 neighbourhood reduction is the commutative merge of sl_device.h in SWAR form:
 //     horizontal neighbours are funnel shifts of adjacent registers, vertical neighbours come from
 //     the lanes above/below through ds_bpermute (wrap inside the board's lane group);
 //   * random draws (spawners) are rare: eligible cells are flagged in the fast pass and resolved in
 //     a wave-uniform slow path with a segmented prefix count + PCG64 jump, preserving the
 //     reference's row-major draw order (advance_board.c:115);
-//   * waves never synchronise with each other: no __syncthreads anywhere in this file.
+//   * the score sum(points_table * alive_counts) is a per-cell gather from a 2048-entry table
+//     indexed by the cell's relevant bits and the goal colour (slhip_env_prepare builds it);
+//   * the only workgroup barriers are the two around the HBM <-> LDS moves.
 //
-// Reference behaviour restated: advance_board.c:34-125 (CA step), :217-300 (actions, via act_one of
-// sl_generic), safelife_env.py:148-218 + safelife_game.py:505-552,684-719,746-761 (step / reset glue),
+// Reference behaviour restated: advance_board.c:34-125 (CA step), :217-300 (actions),
+// safelife_env.py:148-218 + safelife_game.py:505-552,684-719,746-761 (step / reset glue),
 // safelife_env.py:105-146 + helper_utils.py:42-75 (observation).
 #include "sl_device.h"
 #include "sl_kernels.h"
 
 namespace sl {
-
 namespace rl {
 
-typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr u32 M1 = 0x00010001u;
+constexpr int WAVES = 4;
 
-__device__ __forceinline__ u32 pk_add(u32 x, u32 y) {
-    us2 r = __builtin_bit_cast(us2, x) + __builtin_bit_cast(us2, y);
-    return __builtin_bit_cast(u32, r);
+// ---- instruction selection notes (measured with tools/ubench/valu_rate.hip on gfx950) -----------
+// Per wave64 instruction a SIMD spends 2 cycles on v_and/or/xor/add/sub/lshrrev/mov and on
+// v_bitop3_b32 with VGPR operands, and 4 cycles on everything else this kernel could use
+// (v_lshlrev, v_alignbit, v_perm, v_or3/v_and_or/v_lshl_or/v_add3, v_pk_*, v_mul_u32_u24, DPP, SDWA)
+// and on ANY VALU op with an SGPR operand.  Hence: three-input logic goes through bitop3, masks
+// live in VGPRs (vreg()), shifts are right shifts, and the cell layout below needs no funnel shifts.
+constexpr unsigned TA = 0xF0, TB = 0xCC, TC = 0xAA;      // truth-table columns of bitop3 operands
+#define SL_BO3(expr, a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), (unsigned)((expr)&0xFF))
+#define BO3_OR3(a, b, c) SL_BO3(TA | TB | TC, a, b, c)
+#define BO3_MAJ(a, b, c) SL_BO3((TA & TB) | (TA & TC) | (TB & TC), a, b, c)
+#define BO3_AND_OR(a, b, c) SL_BO3((TA & TB) | TC, a, b, c)            /* (a & b) | c */
+#define BO3_OR_AND(a, b, c) SL_BO3(TA | (TB & TC), a, b, c)            /* a | (b & c) */
+#define BO3_ORAND(a, b, c) SL_BO3((TA | TB) & TC, a, b, c)             /* (a | b) & c */
+#define BO3_INSERT(a, b, c) SL_BO3((TA & ~TC) | (TB & TC), a, b, c)    /* c ? b : a   */
+
+__device__ __forceinline__ u32 vreg(u32 c) {     // a constant the compiler must keep in a VGPR
+    u32 r = c;
+    asm volatile("" : "+v"(r));
+    return r;
 }
-__device__ __forceinline__ u32 pk_shr(u32 x, u32 sh) {
-    us2 r = __builtin_bit_cast(us2, x) >> __builtin_bit_cast(us2, sh);
-    return __builtin_bit_cast(u32, r);
-}
-__device__ __forceinline__ u32 maj3(u32 x, u32 y, u32 z) {
-    u32 d = x ^ y;
-    return (d & z) | (~d & x);          // v_bfi_b32
-}
-__device__ __forceinline__ u32 funnel(u32 hi, u32 lo, u32 sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 __device__ __forceinline__ u32 bperm(int byte_addr, u32 v) {
     return (u32)__builtin_amdgcn_ds_bpermute(byte_addr, (int)v);
+}
+__device__ __forceinline__ u32 rot16(u32 x) { return __builtin_amdgcn_alignbit(x, x, 16); }
+__device__ __forceinline__ u32 pack_lo_lo(u32 lo_src, u32 hi_src) {        // (lo(lo_src), lo(hi_src))
+    return __builtin_amdgcn_perm(hi_src, lo_src, 0x05040100u);
+}
+__device__ __forceinline__ u32 pack_hi_lo(u32 lo_src, u32 hi_src) {        // (hi(lo_src), lo(hi_src))
+    return __builtin_amdgcn_perm(hi_src, lo_src, 0x05040302u);
 }
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
 
+// Inclusive prefix sum across the 64 lanes with DPP row shifts / row broadcasts (no LDS traffic).
+__device__ __forceinline__ int wave_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1,3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+// Register layout of a row ("split halves"): WS = ceil(W/2) words; word k holds cell k in its low
+// half and cell k+WS in its high half (unused for k = WS-1 when W is odd).  The left / right
+// neighbours of both cells of word k are the two cells of word k-1 / k+1, so the horizontal pass
+// needs no intra-register shifts; only the seams (cells 0, WS-1, WS, W-1) need a byte permute.
 template <int H, int W>
 struct Geom {
     static constexpr int HW = H * W;
-    static constexpr int WP = (W + 3) / 2;
-    static constexpr int G0 = 64 / H;
-    // the wave's span of boards must be a whole number of dwords: G*HW even
-    static constexpr int G = (HW % 2 == 1 && G0 % 2 == 1) ? G0 - 1 : G0;
-    static_assert(G >= 1, "shape not supported by the row-per-lane path");
-    static constexpr int NL = G * H;                       // active lanes
-    static constexpr int ND = G * HW / 2;                  // dwords per wave span
-    static constexpr int NDI = (ND + 63) / 64;
+    static constexpr int WS = (W + 1) / 2;
+    static constexpr bool ODD = (W & 1) != 0;
+    static constexpr int G = 64 / H;                       // boards per wave
+    static_assert(G >= 1, "H must be <= 64");
+    static_assert(WS <= 16 && W >= 4 && H >= 4, "row-per-lane path: 4 <= W <= 32, H >= 4");
+    static constexpr int NL = G * H;                       // lanes in use
+    static constexpr int NB = WAVES * G;                   // boards per workgroup
+    static_assert((NB * HW) % 8 == 0, "workgroup span must be a multiple of 16 bytes");
+    static constexpr int SPAN = NB * HW * 2;               // bytes
     static constexpr int PAD = 16;
-    static constexpr int REGION = ((G * HW * 2 + 15) / 16) * 16 + 2 * PAD;
+    static constexpr int REGION = SPAN + 2 * PAD;
     static constexpr int OFF_BOARD = 0;
     static constexpr int OFF_GOALS = REGION;
-    static constexpr int OFF_TABLE = 2 * REGION;           // G x 72 int32
-    static constexpr int OFF_RNG = OFF_TABLE + G * 72 * 4; // G x 4 u64
-    static constexpr int WAVE_BYTES = OFF_RNG + G * 32;
-    static constexpr int LAST_WORD = W >> 1, LAST_HI = W & 1;          // cell x = W-1 (e = W)
-    static constexpr int RH_WORD = (W + 1) >> 1, RH_HI = (W + 1) & 1;  // right halo (e = W+1)
-    static constexpr u32 vmask(int k) {
-        return ((2 * k >= 1 && 2 * k <= W) ? 0x0000FFFFu : 0u) | ((2 * k + 1 <= W) ? 0xFFFF0000u : 0u);
-    }
+    static constexpr int OFF_RNG = 2 * REGION;             // NB x 4 u64
+    static constexpr int LDS_BYTES = OFF_RNG + NB * 32;
+    // validity of the halves of word k as a 0x0001-per-half mask
+    static constexpr u32 vm1(int k) { return (ODD && k == WS - 1) ? 0x00000001u : 0x00010001u; }
 };
 
-constexpr int WAVES = 4;   // waves per workgroup (independent of each other)
-
-// ---- LDS flat board  <->  row-per-lane registers ------------------------------------------------
-
-// Row r of board g from the flat uint16 image at `region` (+PAD) into ext words; halos fixed up.
 template <int H, int W>
-__device__ __forceinline__ void read_row(const unsigned char *region, int g, int r, u32 (&b)[Geom<H, W>::WP]) {
+using RowWords = u32[Geom<H, W>::WS];
+
+// ---- flat LDS image  <->  row-per-lane registers ------------------------------------------------
+// Two 16-bit LDS reads per word (gfx950 has SRAM-ECC, so d16_hi loads do not preserve the other
+// half and cannot merge in place).  The reads are volatile only to stop the compiler from fusing
+// neighbouring cells into wide ds_read_b64 accesses that would be misaligned for odd row starts.
+template <int H, int W>
+__device__ __forceinline__ void read_row(const unsigned char *region, int gb, int r, RowWords<H, W> &b) {
     using Gm = Geom<H, W>;
-    const int byte = Gm::PAD + 2 * (g * Gm::HW + r * W - 1);
-    const u32 *p = (const u32 *)(region + (byte & ~3));
-    const u32 sh = (byte & 2) * 8;
-    u32 raw[Gm::WP + 1];
+    typedef const volatile __attribute__((address_space(3))) u16 *lds_cv16;
+    lds_cv16 c = (lds_cv16)(region + Gm::PAD) + gb * Gm::HW + r * W;
+    u32 lo[Gm::WS], hi[Gm::WS];
 #pragma unroll
-    for (int j = 0; j <= Gm::WP; ++j) raw[j] = p[j];
+    for (int k = 0; k < Gm::WS; ++k) {
+        lo[k] = c[k];
+        hi[k] = (Gm::ODD && k == Gm::WS - 1) ? 0u : (u32)c[k + Gm::WS];
+    }
 #pragma unroll
-    for (int k = 0; k < Gm::WP; ++k) b[k] = funnel(raw[k + 1], raw[k], sh);
-    // halos: e = 0 <- cell W-1, e = W+1 <- cell 0; anything beyond is cleared
-    const u32 last = Gm::LAST_HI ? (b[Gm::LAST_WORD] >> 16) : (b[Gm::LAST_WORD] & 0xFFFFu);
-    const u32 first = b[0] >> 16;
-    b[0] = (b[0] & 0xFFFF0000u) | last;
-    if (Gm::RH_HI) b[Gm::RH_WORD] = (b[Gm::RH_WORD] & 0xFFFFu) | (first << 16);
-    else b[Gm::RH_WORD] = first;
+    for (int k = 0; k < Gm::WS; ++k) b[k] = lo[k] | (hi[k] << 16);
 }
 
-// Inverse of read_row for the W real cells of the row.
 template <int H, int W>
-__device__ __forceinline__ void write_row(unsigned char *region, int g, int r, const u32 (&n)[Geom<H, W>::WP]) {
+__device__ __forceinline__ void write_row(unsigned char *region, int gb, int r, const RowWords<H, W> &n) {
     using Gm = Geom<H, W>;
-    const int i1 = g * Gm::HW + r * W;            // uint16 index of cell x = 0
-    u16 *c16 = (u16 *)(region + Gm::PAD);
-    const bool odd = i1 & 1;
-    // dword j (from the first aligned one inside the row) holds e = (2j+1, 2j+2) if the row starts
-    // aligned, e = (2j+2, 2j+3) otherwise
-    u32 *d = (u32 *)(region + Gm::PAD + 2 * (i1 + (odd ? 1 : 0)));
-    constexpr int NF_EVEN = W / 2, NF_ODD = (W - 1) / 2;
+    u16 *c = (u16 *)(region + Gm::PAD) + gb * Gm::HW + r * W;
 #pragma unroll
-    for (int j = 0; j < NF_EVEN; ++j) {
-        u32 even_word = funnel(n[j + 1], n[j], 16);
-        u32 odd_word = n[j + 1];
-        if (j < NF_ODD) d[j] = odd ? odd_word : even_word;
-        else if (!odd) d[j] = even_word;
+    for (int k = 0; k < Gm::WS; ++k) {
+        c[k] = (u16)n[k];
+        if (!(Gm::ODD && k == Gm::WS - 1)) c[k + Gm::WS] = (u16)(n[k] >> 16);
     }
-    if (odd) {
-        c16[i1] = (u16)(n[0] >> 16);                               // e = 1
-        if ((W - 1) & 1) c16[i1 + W - 1] = Gm::LAST_HI ? (u16)(n[Gm::LAST_WORD] >> 16) : (u16)n[Gm::LAST_WORD];
-    } else if (W & 1) {
-        c16[i1 + W - 1] = Gm::LAST_HI ? (u16)(n[Gm::LAST_WORD] >> 16) : (u16)n[Gm::LAST_WORD];
+}
+
+// Left / right neighbour words of an array of per-cell words in the split layout.
+template <int H, int W>
+struct Seams {
+    u32 left0;      // neighbours to the left of word 0
+    u32 right_a;    // neighbours to the right of word WS-1
+    u32 right_b;    // (W odd) neighbours to the right of word WS-2
+};
+
+template <int H, int W>
+__device__ __forceinline__ Seams<H, W> make_seams(const RowWords<H, W> &q) {
+    using Gm = Geom<H, W>;
+    Seams<H, W> s;
+    if (Gm::ODD) {
+        // cells: word WS-2 = (WS-2, W-1), word WS-1 = (WS-1, -)
+        s.left0 = pack_hi_lo(q[Gm::WS - 2], q[Gm::WS - 1]);      // (cell W-1, cell WS-1)
+        s.right_b = pack_lo_lo(q[Gm::WS - 1], q[0]);             // right of (WS-2, W-1) = (WS-1, 0)
+        s.right_a = rot16(q[0]);                                 // right of (WS-1, -)   = (WS, -)
+    } else {
+        s.left0 = rot16(q[Gm::WS - 1]);                          // (cell W-1, cell WS-1)
+        s.right_a = rot16(q[0]);                                 // right of (WS-1, W-1) = (WS, 0)
+        s.right_b = 0;
     }
+    return s;
+}
+
+template <int H, int W>
+__device__ __forceinline__ u32 left_of(const RowWords<H, W> &q, const Seams<H, W> &s, int k) {
+    return k == 0 ? s.left0 : q[k - 1];
+}
+template <int H, int W>
+__device__ __forceinline__ u32 right_of(const RowWords<H, W> &q, const Seams<H, W> &s, int k) {
+    using Gm = Geom<H, W>;
+    if (k == Gm::WS - 1) return s.right_a;
+    if (Gm::ODD && k == Gm::WS - 2) return s.right_b;
+    return q[k + 1];
+}
+
+struct Consts {         // masks held in VGPRs for the whole kernel
+    u32 m1, once, anya, three, spawn, eight;
+};
+__device__ __forceinline__ Consts make_consts() {
+    Consts c;
+    c.m1 = vreg(0x00010001u);
+    c.once = vreg(0x0E080E08u);     // bit 3 (destructible|exit) and the colour bits 9-11
+    c.anya = vreg(0x00E100E1u);     // alive + preserving/inhibiting/spawning
+    c.three = vreg(0x00030003u);
+    c.spawn = vreg(0x00800080u);
+    c.eight = vreg(0x00080008u);
+    return c;
 }
 
 // ---- one CA step on registers ---------------------------------------------------------------------
-// b: ext words with halos.  n: new cells; halves whose outcome needs a random draw hold the spawned
-// value tentatively and are flagged in elig (bit k = low half of word k, bit 16+k = high half;
-// word index k/16).  up/dn: ds_bpermute byte addresses of the lanes holding rows r-1 / r+1.
+// b: the row's cells (split layout).  n: new cells; halves whose outcome needs a random draw hold
+// the spawned value tentatively and are flagged in `elig` (after the loop, word k's flags sit at bits
+// WS-1-k (low half) and 16+WS-1-k (high half)).  up/dn: ds_bpermute byte addresses of rows r-1 / r+1.
+//
+// Per cell two 16-bit summaries are folded over the 3x3 block (advance_board.c:12-32 restated):
+//   o: bit 0 alive | bit 3 (destructible|exit) if alive | bits 5-7 preserving/inhibiting/spawning |
+//      bits 9-11 colour if alive          -> OR gives "seen once", majority gives "seen twice",
+//      and plain integer addition of the words counts the alive bits in bits 0-2 (no field above
+//      can carry across a 16-bit half: every half stays below 0x3000)
+//   w: colour bits of spawner cells, plus, after each pass, the "seen twice" bits -- all at the
+//      cells' native bit positions, so the new cell is assembled without shifts.
 template <int H, int W>
-__device__ __forceinline__ u32 ca_rows(const u32 (&b)[Geom<H, W>::WP], u32 (&n)[Geom<H, W>::WP],
-                                       u32 (&elig)[(Geom<H, W>::WP + 15) / 16], int up, int dn) {
+__device__ __forceinline__ void ca_rows(const RowWords<H, W> &b, RowWords<H, W> &n, u32 &elig, int up, int dn,
+                                        const Consts &c) {
     using Gm = Geom<H, W>;
-    constexpr int WP = Gm::WP;
-    u32 s[WP], a[WP];
+    constexpr int WS = Gm::WS;
+    RowWords<H, W> o, w;
 #pragma unroll
-    for (int k = 0; k < WP; ++k) {
-        u32 t = b[k] | ((b[k] & 0x00080008u) << 5);           // destructible -> bit 8
-        a[k] = t & M1;
-        u32 am = a[k] * 0x0F00u;                              // once-mask where alive
-        u32 spm = ((t >> 7) & M1) * 0xE000u;                  // twice-colour mask where spawning
-        s[k] = (t & 0x00E000E0u) | (t & am) | ((t << 4) & spm);
-    }
-#pragma unroll
-    for (int j = 0; j < (WP + 15) / 16; ++j) elig[j] = 0;
-    u32 any = 0;
-#pragma unroll
-    for (int k = 0; k < WP; ++k) {
-        if (Gm::vmask(k) == 0) {
-            n[k] = 0;
-            continue;
-        }
-        const u32 sl = k > 0 ? s[k - 1] : 0u, sr = k + 1 < WP ? s[k + 1] : 0u;
-        const u32 al = k > 0 ? a[k - 1] : 0u, ar = k + 1 < WP ? a[k + 1] : 0u;
-        const u32 L = funnel(s[k], sl, 16), R = funnel(sr, s[k], 16);
-        const u32 cl = funnel(a[k], al, 16), cr = funnel(ar, a[k], 16);
-        const u32 rc = (L | s[k] | R) | ((maj3(L, s[k], R) & 0x0F000F00u) << 4) | (cl + a[k] + cr);
-        const u32 U = bperm(up, rc), D = bperm(dn, rc);
-        const u32 X = U | rc | D;
-        const u32 F = (X & 0xFFE0FFE0u) | ((maj3(U, rc, D) & 0x0F000F00u) << 4);
-        const u32 cnt = pk_add(pk_add(U, rc), D) & 0x000F000Fu;
-        const u32 s34 = pk_shr(0x00180018u, cnt) & M1;
-        const u32 is3 = pk_shr(0x00080008u, cnt) & M1;
+    for (int k = 0; k < WS; ++k) {
         const u32 bb = b[k];
-        const u32 alive = bb & M1;
-        const u32 frozen = (bb >> 4) & M1;
-        const u32 keep_a = frozen | ((X >> 5) & M1) | s34;
-        const u32 keep_d = frozen | ((X >> 6) & M1);
-        const u32 born = is3 & ~keep_d & ~alive;
-        const u32 el = ((X >> 7) & M1) & ~(keep_d | is3 | alive) & (Gm::vmask(k) & M1);
-        const u32 keep = ((alive & keep_a) | (~alive & ~born & ~el)) & M1;
-        const u32 newcol = (F >> 4) & 0x0E000E00u;
-        const u32 newborn = M1 | newcol | ((F >> 9) & 0x00080008u);
-        const u32 newspawn = M1 | 0x00080008u | newcol;
-        n[k] = (bb & (keep * 0xFFFFu)) | (newborn & (born * 0xFFFFu)) | (newspawn & (el * 0xFFFFu));
-        elig[k / 16] |= el << (k % 16);
-        any |= el;
+        const u32 m = __umul24(bb & c.m1, 0x0E08u) + c.anya;        // once-bits where alive | always-bits
+        o[k] = BO3_ORAND(bb, (bb >> 5) & c.eight, m);               // exit (bit 8) joins destructible on bit 3
+        w[k] = bb & __umul24(bb & c.spawn, 0x1Cu);                  // colours of spawners
     }
-    return any;
+    const Seams<H, W> so = make_seams<H, W>(o), sw = make_seams<H, W>(w);
+    elig = 0;
+#pragma unroll
+    for (int k = 0; k < WS; ++k) {
+        const u32 oL = left_of<H, W>(o, so, k), oR = right_of<H, W>(o, so, k);
+        const u32 wL = left_of<H, W>(w, sw, k), wR = right_of<H, W>(w, sw, k);
+        // row pass
+        const u32 xo = BO3_OR3(oL, o[k], oR);
+        const u32 mj = BO3_MAJ(oL, o[k], oR);
+        const u32 xw = BO3_OR3(wL, w[k], wR);
+        const u32 wr = BO3_OR_AND(xw, mj, c.once);
+        const u32 cs = oL + o[k] + oR;                               // bits 0-1: alive cells in the row triple
+        const u32 ro = BO3_INSERT(xo, cs, c.three);
+        // column pass
+        const u32 Uo = bperm(up, ro), Do = bperm(dn, ro);
+        const u32 Uw = bperm(up, wr), Dw = bperm(dn, wr);
+        const u32 X = BO3_OR3(Uo, ro, Do);
+        const u32 m2 = BO3_MAJ(Uo, ro, Do);
+        const u32 xw2 = BO3_OR3(Uw, wr, Dw);
+        const u32 tw = BO3_OR_AND(xw2, m2, c.once);                  // seen twice: bit 3 + colours
+        const u32 sum = Uo + ro + Do;                                // bits 0-2: alive count mod 8
+        const u32 c1 = sum >> 1, c2 = sum >> 2;
+        const u32 s34 = SL_BO3((TA & TB & ~TC) | (~TA & ~TB & TC), sum, c1, c2);   // count in {3,4}
+        const u32 is3 = SL_BO3(TA & TB & ~TC, sum, c1, c2);
+        // rule (advance_board.c:94-124), evaluated at bit 0 of each half
+        const u32 bb = b[k];
+        const u32 fr = bb >> 4, pr = X >> 5, ih = X >> 6, sp = X >> 7;
+        const u32 keep_a = BO3_OR3(fr, pr, s34);
+        const u32 keep_d = fr | ih;
+        const u32 born = SL_BO3(TA & ~TB & ~TC, is3, keep_d, bb);
+        const u32 e1 = SL_BO3(TA & ~TB & ~TC, sp, keep_d, is3);
+        const u32 vm = Gm::vm1(k) == 0x00010001u ? c.m1 : vreg(Gm::vm1(k));
+        const u32 el = SL_BO3(TA & ~TB & TC, e1, bb, vm);            // needs a random draw
+        const u32 ne = born | el;
+        const u32 kp = SL_BO3((TA & TB) | (~TA & ~TC), bb, keep_a, ne);
+        const u32 KM = __umul24(kp & c.m1, 0xFFFFu);
+        const u32 NM = __umul24(ne & c.m1, 0xFFFFu);
+        const u32 nv = BO3_AND_OR(tw, c.once, c.m1);                 // alive + inherited colours / destructible
+        const u32 nm = BO3_AND_OR(nv, NM, __umul24(el, 8u));         // spawned cells are always destructible
+        n[k] = BO3_AND_OR(bb, KM, nm);
+        elig = elig + elig + el;
+    }
 }
 
-// Resolve the flagged halves with the board's PCG64 stream, row-major (wave-uniform call).
-// rng_lds: G x {state_hi, state_lo, inc_hi, inc_lo} in LDS; advanced by the draws consumed.
 template <int H, int W>
-__device__ void resolve_draws(const u32 (&b)[Geom<H, W>::WP], u32 (&n)[Geom<H, W>::WP],
-                              const u32 (&elig)[(Geom<H, W>::WP + 15) / 16], u64 *rng_lds, int g, int r,
-                              int lane, double p, const Jump *__restrict__ jump) {
+__device__ __forceinline__ bool flagged_lo(u32 elig, int k) { return (elig >> (Geom<H, W>::WS - 1 - k)) & 1u; }
+template <int H, int W>
+__device__ __forceinline__ bool flagged_hi(u32 elig, int k) { return (elig >> (16 + Geom<H, W>::WS - 1 - k)) & 1u; }
+
+// Resolve the flagged halves with each board's PCG64 stream, row-major (wave-uniform call).
+// rng_lds: this wave's G x {state_hi, state_lo, inc_hi, inc_lo}; advanced by the draws consumed.
+template <int H, int W>
+__device__ void resolve_draws(const RowWords<H, W> &b, RowWords<H, W> &n, u32 elig, u64 *rng_lds, int g,
+                              bool lead, double p, const Jump *__restrict__ jump) {
     using Gm = Geom<H, W>;
-    constexpr int WP = Gm::WP;
-    int mine = 0;
+    constexpr int WS = Gm::WS;
+    const int mine = __popc(elig);
+    const int incl = wave_scan(mine);
+    int before = 0, total = 0;
 #pragma unroll
-    for (int j = 0; j < (WP + 15) / 16; ++j) mine += __popc(elig[j]);
-    int incl = mine;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        int t = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += t;
+    for (int q = 0; q < Gm::G; ++q) {
+        const int lo = q ? __builtin_amdgcn_readlane(incl, q * H - 1) : 0;
+        const int hi = __builtin_amdgcn_readlane(incl, q * H + H - 1);
+        if (g == q) {
+            before = lo;
+            total = hi - lo;
+        }
     }
-    const int first_lane = g * H;
-    int before_group = (int)bperm(4 * (first_lane > 0 ? first_lane - 1 : 0), (u32)incl);
-    if (first_lane == 0) before_group = 0;
-    const int total = (int)bperm(4 * (first_lane + H - 1), (u32)incl) - before_group;
-    const int excl = incl - mine - before_group;
+    const int excl = incl - mine - before;
     const U128 st = {rng_lds[4 * g + 0], rng_lds[4 * g + 1]}, inc = {rng_lds[4 * g + 2], rng_lds[4 * g + 3]};
-    wave_sync();     // everyone has read the old state before the leader replaces it
+    wave_sync();     // every lane has read the old state before a leader replaces it
     if (mine > 0) {
         U128 cur = pcg_jump(jump, excl, st, inc);
+        // row-major order inside the row: cells 0..WS-1 are the low halves, WS..W-1 the high halves
 #pragma unroll
-        for (int k = 0; k < WP; ++k) {
-            if ((elig[k / 16] >> (k % 16)) & 1u) {
+        for (int k = 0; k < WS; ++k) {
+            if (flagged_lo<H, W>(elig, k)) {
                 cur = pcg_step(cur, inc);
                 if (!(pcg_output_double(cur) < p)) n[k] = (n[k] & 0xFFFF0000u) | (b[k] & 0x0000FFFFu);
             }
-            if ((elig[k / 16] >> (16 + k % 16)) & 1u) {
+        }
+#pragma unroll
+        for (int k = 0; k < WS; ++k) {
+            if (flagged_hi<H, W>(elig, k)) {
                 cur = pcg_step(cur, inc);
                 if (!(pcg_output_double(cur) < p)) n[k] = (n[k] & 0x0000FFFFu) | (b[k] & 0xFFFF0000u);
             }
         }
     }
-    if (r == 0 && total > 0) {
-        U128 s2 = pcg_jump(jump, total, st, inc);
+    if (lead && total > 0) {
+        const U128 s2 = pcg_jump(jump, total, st, inc);
         rng_lds[4 * g + 0] = s2.hi;
         rng_lds[4 * g + 1] = s2.lo;
     }
     wave_sync();
 }
 
-// sum(points_table * alive_counts) contribution of one row (valid halves only); table in LDS.
+// Sum of a per-lane value over the lanes of the caller's board (every lane gets its board's total).
+template <int H, int G>
+__device__ __forceinline__ int group_total(int v, int g) {
+    const int incl = wave_scan(v);
+    int total = 0;
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+        const int lo = q ? __builtin_amdgcn_readlane(incl, q * H - 1) : 0;
+        const int hi = __builtin_amdgcn_readlane(incl, q * H + H - 1);
+        if (g == q) total = hi - lo;
+    }
+    return total;
+}
+
+// ---- score ----------------------------------------------------------------------------------------
+// sum(points_table * alive_counts) as one byte gather per cell.  The table index is the cell itself
+// masked to the bits that matter (alive 0, pushable 2, destructible 3, frozen 4, colour 9-11,
+// pullable 15) with the goal colour dropped into the free bits 5-7, so forming it costs one bitop3
+// per two cells.  Entries the filter of advance_board.c:201 excludes hold 0
+// (slhip_env_prepare builds the table; points must fit int8 for this path).
+constexpr u32 SCORE_CELL_MASK = 0x8E1D8E1Du;
+__device__ __forceinline__ u32 goal_shift(u32 g) { return (g >> 4) & 0x00E000E0u; }
+
 template <int H, int W>
-__device__ __forceinline__ int row_score(const u32 (&n)[Geom<H, W>::WP], const u32 (&gl)[Geom<H, W>::WP],
-                                         const int *table) {
+__device__ __forceinline__ int row_score(const RowWords<H, W> &n, const RowWords<H, W> &gsh,
+                                         const int8_t *__restrict__ lut, u32 lut_base, u32 cell_mask) {
     using Gm = Geom<H, W>;
     int s = 0;
 #pragma unroll
-    for (int k = 0; k < Gm::WP; ++k) {
-        if (Gm::vmask(k) == 0) continue;
-        const u32 c = n[k];
-        const u32 gc = (gl[k] >> 9) & 0x00070007u;
-        const u32 alive = c & M1;
-        const u32 col = (((c >> 9) & 0x00070007u) & (alive * 0xFu)) | (0x00080008u & ~(alive * 0xFu));
-        const u32 bin = gc * 9u + col;                       // < 72 per half, no carry across halves
-        const u32 movable = ((c >> 2) | (c >> 3) | (c >> 15)) & M1;
-        const u32 counted = (~(c >> 4) | movable) & M1;      // !(frozen && !movable)
-        if (Gm::vmask(k) & 0xFFFFu) s += (counted & 1u) ? table[bin & 0xFFu] : 0;
-        if (Gm::vmask(k) >> 16) s += (counted >> 16) ? table[bin >> 16] : 0;
+    for (int k = 0; k < Gm::WS; ++k) {
+        const u32 idx = BO3_AND_OR(n[k], cell_mask, gsh[k]);
+        s += lut[lut_base + (idx & 0xFFFFu)];
+        if (!(Gm::ODD && k == Gm::WS - 1)) s += lut[lut_base + (idx >> 16)];
     }
     return s;
 }
 
-// Segmented (per board) sum of a per-lane value; every lane of the group gets its board's total.
-template <int H>
-__device__ __forceinline__ int group_sum(int v, int g, int lane) {
-    int incl = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        int t = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += t;
+// ---- execute_actions for one agent with the four touched cells gathered up front ----------------
+// (advance_board.c:217-300; valid for H, W >= 4 where the four cells are distinct)
+__device__ __forceinline__ int wrap1(int v, int n) { return v < 0 ? v + n : (v >= n ? v - n : v); }
+
+__device__ __forceinline__ void act_gather(u16 *board, int H, int W, int &ly, int &lx, int action) {
+    const int dir = (action - 1) & 3;
+    const int dy = (dir & 1) ? 0 : dir - 1, dx = (dir & 1) ? 2 - dir : 0;
+    const int y1 = wrap1(ly + dy, H), x1 = wrap1(lx + dx, W);
+    const int i0 = ly * W + lx, i1 = y1 * W + x1;
+    const int i2 = wrap1(ly + 2 * dy, H) * W + wrap1(lx + 2 * dx, W);
+    const int i3 = wrap1(ly - dy, H) * W + wrap1(lx - dx, W);
+    u32 c0 = board[i0], c1 = board[i1], c2 = board[i2], c3 = board[i3];
+    if (action == 0 || !(c0 & AGENT)) return;
+    c0 = (c0 & ~ORIENT_MASK) | ((u32)dir << ORIENT_SHIFT);
+    const bool can_push = (~c0 & c1 & PUSHABLE) != 0;
+    if (action >= 5) {
+        if (c1 == 0) {
+            c1 = ALIVE | DESTRUCTIBLE | (c0 & COLORS);
+        } else if (c1 & DESTRUCTIBLE) {
+            c1 = (c1 & AGENT) ? ((c1 ^ (AGENT | DESTRUCTIBLE)) | FROZEN) : 0u;
+        } else if (can_push) {
+            if (c2 == 0) {
+                c2 = c1;
+                c1 = 0;
+            } else if (c2 & EXIT) {
+                c1 = 0;
+            }
+        }
+    } else {
+        bool step_into = false, leave_only = false;
+        if (can_push) {
+            if (c2 == 0) {
+                c2 = c1;
+                step_into = true;
+            } else if (c2 & EXIT) {
+                step_into = true;
+            }
+        } else if (c1 == 0) {
+            step_into = true;
+        } else if ((c0 & c1 & EXIT) && !(c1 & AGENT)) {
+            leave_only = true;
+        }
+        if (step_into || leave_only) {
+            if (step_into) c1 = c0;
+            ly = y1;
+            lx = x1;
+            if (~c0 & c3 & PULLABLE) {
+                c0 = c3;
+                c3 = 0;
+            } else {
+                c0 = 0;
+            }
+        }
     }
-    const int first_lane = g * H;
-    int before = (int)bperm(4 * (first_lane > 0 ? first_lane - 1 : 0), (u32)incl);
-    if (first_lane == 0) before = 0;
-    return (int)bperm(4 * (first_lane + H - 1), (u32)incl) - before;
+    board[i0] = (u16)c0;
+    board[i1] = (u16)c1;
+    board[i2] = (u16)c2;
+    board[i3] = (u16)c3;
 }
 
-__device__ __forceinline__ u32 obs_word(u32 b, u32 g, int remove_white) {
-    u32 gc = g & COLORS;
-    if (remove_white && gc == COLORS) gc = 0;
-    return b | (gc << 16);
+// update_exit_colors for the board of a leader lane, on the flat LDS image.
+__device__ __forceinline__ void recolor_exits_lds(u16 *board, int W, int ly, int lx, const int32_t *exits, int E,
+                                                  int score, int initial, int required, int exit_points) {
+    bool any_can = false;
+    if (ly >= 0) {
+        u16 *cell = board + ly * W + lx;
+        const u32 c = *cell;
+        int earned = score - initial + (has_exited(c) ? exit_points : 0);
+        if (earned < 0) earned = 0;
+        const bool can = (c & AGENT) && earned >= required;
+        *cell = (u16)((c & ~EXIT) | (can ? EXIT : 0u));
+        any_can = can;
+    }
+    const u16 paint = (u16)(FROZEN | EXIT | (any_can ? COLOR_R : 0u));
+    for (int k = 0; k < E; ++k) {
+        const int ex = exits[k];
+        if (ex >= 0) board[ex] = paint;
+    }
 }
 
-// ---- wave span <-> HBM ----------------------------------------------------------------------------
+// ---- workgroup span <-> HBM -----------------------------------------------------------------------
 
 template <int H, int W>
-__device__ __forceinline__ void load_span(const u16 *__restrict__ src, unsigned char *region, int nb, int lane) {
+__device__ __forceinline__ void load_span(const u16 *__restrict__ src, unsigned char *region, int nbb, int tid) {
     using Gm = Geom<H, W>;
-    const u32 *s32 = (const u32 *)src;
-    u32 *d32 = (u32 *)(region + Gm::PAD);
-    const int nd = nb * Gm::HW / 2;
-    u32 v[Gm::NDI];
+    const int bytes = nbb * Gm::HW * 2;
+    const int nv = bytes >> 4;
+    const u32x4 *s = (const u32x4 *)src;
+    u32x4 *d = (u32x4 *)(region + Gm::PAD);
+    constexpr int NVI = (Gm::SPAN / 16 + 64 * WAVES - 1) / (64 * WAVES);
+    u32x4 v[NVI];
 #pragma unroll
-    for (int i = 0; i < Gm::NDI; ++i) v[i] = (lane + 64 * i < nd) ? s32[lane + 64 * i] : 0u;
+    for (int i = 0; i < NVI; ++i)
+        if (tid + 64 * WAVES * i < nv) v[i] = s[tid + 64 * WAVES * i];
 #pragma unroll
-    for (int i = 0; i < Gm::NDI; ++i)
-        if (lane + 64 * i < nd) d32[lane + 64 * i] = v[i];
-    if (((nb * Gm::HW) & 1) && lane == 0) ((u16 *)d32)[nb * Gm::HW - 1] = src[nb * Gm::HW - 1];
+    for (int i = 0; i < NVI; ++i)
+        if (tid + 64 * WAVES * i < nv) d[tid + 64 * WAVES * i] = v[i];
+    const int rem = (bytes & 15) >> 1;                 // tail workgroup only
+    if (tid < rem) ((u16 *)d)[nv * 8 + tid] = src[nv * 8 + tid];
 }
 
 template <int H, int W>
-__device__ __forceinline__ void store_span(u16 *__restrict__ dst, const unsigned char *region, int nb, int lane) {
+__device__ __forceinline__ void store_span(u16 *__restrict__ dst, const unsigned char *region, int nbb, int tid) {
     using Gm = Geom<H, W>;
-    u32 *d32 = (u32 *)dst;
-    const u32 *s32 = (const u32 *)(region + Gm::PAD);
-    const int nd = nb * Gm::HW / 2;
+    const int bytes = nbb * Gm::HW * 2;
+    const int nv = bytes >> 4;
+    u32x4 *d = (u32x4 *)dst;
+    const u32x4 *s = (const u32x4 *)(region + Gm::PAD);
+    constexpr int NVI = (Gm::SPAN / 16 + 64 * WAVES - 1) / (64 * WAVES);
 #pragma unroll
-    for (int i = 0; i < Gm::NDI; ++i)
-        if (lane + 64 * i < nd) d32[lane + 64 * i] = s32[lane + 64 * i];
-    if (((nb * Gm::HW) & 1) && lane == 0) dst[nb * Gm::HW - 1] = ((const u16 *)s32)[nb * Gm::HW - 1];
+    for (int i = 0; i < NVI; ++i)
+        if (tid + 64 * WAVES * i < nv) d[tid + 64 * WAVES * i] = s[tid + 64 * WAVES * i];
+    const int rem = (bytes & 15) >> 1;
+    if (tid < rem) dst[nv * 8 + tid] = ((const u16 *)s)[nv * 8 + tid];
 }
 
 // ---- advance_board --------------------------------------------------------------------------------
@@ -308,119 +471,97 @@ __global__ __launch_bounds__(64 * WAVES) void k_advance_rowlane(const u16 *__res
                                                                 const Jump *__restrict__ jump) {
     using Gm = Geom<H, W>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned char *lds = smem + wave * Gm::WAVE_BYTES;
-    const int e0 = (blockIdx.x * WAVES + wave) * Gm::G;
-    if (e0 >= B) return;
-    const int nb = min(Gm::G, B - e0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int e0b = blockIdx.x * Gm::NB;
+    const int nbb = min(Gm::NB, B - e0b);
     int g = 0;
 #pragma unroll
     for (int q = 1; q < Gm::G; ++q) g += (lane >= q * H) ? 1 : 0;
     const int r = lane - g * H;
-    const bool live = lane < Gm::NL && g < nb;
+    const int gb = wave * Gm::G + g;
+    const bool live = lane < Gm::NL && gb < nbb;
+    const unsigned e = e0b + (live ? gb : 0);
     const int up = 4 * (live ? (r == 0 ? lane + H - 1 : lane - 1) : lane);
     const int dn = 4 * (live ? (r == H - 1 ? lane - (H - 1) : lane + 1) : lane);
-    u64 *rng_lds = (u64 *)(lds + Gm::OFF_RNG);
-    unsigned char *board = lds + Gm::OFF_BOARD;
+    unsigned char *board = smem + Gm::OFF_BOARD;
+    u64 *rng_lds = (u64 *)(smem + Gm::OFF_RNG) + 4 * Gm::G * wave;
 
-    load_span<H, W>(in + (size_t)e0 * Gm::HW, board, nb, lane);
-    if (lane < 4 * nb) rng_lds[lane] = ((const u64 *)(rng + e0))[lane];
-    const double p = live ? (double)spawn_prob[e0 + g] : 0.0;
-    wave_sync();
-    u32 b[Gm::WP], n[Gm::WP], elig[(Gm::WP + 15) / 16];
-    if (live) read_row<H, W>(board, g, r, b);
-    else
+    load_span<H, W>(in + (size_t)e0b * Gm::HW, board, nbb, tid);
+    if (lane < 4 * Gm::G && wave * Gm::G + (lane >> 2) < nbb)
+        rng_lds[lane] = ((const u64 *)(rng + e0b + wave * Gm::G))[lane];
+    const double p = live ? (double)spawn_prob[e] : 0.0;
+    __syncthreads();
+    const Consts cst = make_consts();
+    RowWords<H, W> b, n;
+    u32 elig;
 #pragma unroll
-        for (int k = 0; k < Gm::WP; ++k) b[k] = 0;
+    for (int k = 0; k < Gm::WS; ++k) b[k] = 0;
+    if (live) read_row<H, W>(board, gb, r, b);
     for (int s = 0; s < n_steps; ++s) {
-        u32 any = ca_rows<H, W>(b, n, elig, up, dn);
-        if (!live) any = 0;
-        if (__ballot(any != 0)) {
-            if (!live)
+        ca_rows<H, W>(b, n, elig, up, dn, cst);
+        if (!live) elig = 0;
+        if (__ballot(elig != 0)) resolve_draws<H, W>(b, n, elig, rng_lds, live ? g : 0, live && r == 0, p, jump);
 #pragma unroll
-                for (int j = 0; j < (Gm::WP + 15) / 16; ++j) elig[j] = 0;
-            resolve_draws<H, W>(b, n, elig, rng_lds, live ? g : 0, live ? r : 1, lane, p, jump);
-        }
-        // next step's input: new cells + refreshed halos
-#pragma unroll
-        for (int k = 0; k < Gm::WP; ++k) b[k] = n[k];
-        const u32 last = Gm::LAST_HI ? (b[Gm::LAST_WORD] >> 16) : (b[Gm::LAST_WORD] & 0xFFFFu);
-        const u32 first = b[0] >> 16;
-        b[0] = (b[0] & 0xFFFF0000u) | last;
-        if (Gm::RH_HI) b[Gm::RH_WORD] = (b[Gm::RH_WORD] & 0xFFFFu) | (first << 16);
-        else b[Gm::RH_WORD] = first;
+        for (int k = 0; k < Gm::WS; ++k) b[k] = n[k];
     }
-    if (live) write_row<H, W>(board, g, r, b);
-    wave_sync();
-    store_span<H, W>(out + (size_t)e0 * Gm::HW, board, nb, lane);
-    if (lane < 4 * nb) ((u64 *)(rng + e0))[lane] = rng_lds[lane];
+    if (live) write_row<H, W>(board, gb, r, b);
+    __syncthreads();
+    store_span<H, W>(out + (size_t)e0b * Gm::HW, board, nbb, tid);
+    if (lane < 4 * Gm::G && wave * Gm::G + (lane >> 2) < nbb)
+        ((u64 *)(rng + e0b + wave * Gm::G))[lane] = rng_lds[lane];
 }
 
 // ---- fused env step / rollout ---------------------------------------------------------------------
 
-// update_exit_colors for the board of a leader lane, on the flat LDS image.
-__device__ __forceinline__ void recolor_exits_lds(u16 *board, int W, int ly, int lx, const int32_t *exits, int E,
-                                                  int score, int initial, int required, int exit_points) {
-    bool any_can = false;
-    if (ly >= 0) {
-        u16 *cell = board + ly * W + lx;
-        int earned = score - initial + exit_points * (has_exited(*cell) ? 1 : 0);
-        if (earned < 0) earned = 0;
-        bool can = (*cell & AGENT) && earned >= required;
-        *cell = (u16)((*cell & ~EXIT) | (can ? EXIT : 0u));
-        any_can = can;
-    }
-    const u16 paint = (u16)(FROZEN | EXIT | (any_can ? COLOR_R : 0u));
-    for (int k = 0; k < E; ++k) {
-        int ex = exits[k];
-        if (ex >= 0) board[ex] = paint;
-    }
-}
-
 template <int H, int W>
-__global__ __launch_bounds__(64 * WAVES) void k_env_rollout_rowlane(sl_env_batch env,
+__global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_batch env,
                                                                     const int32_t *__restrict__ actions, int T,
                                                                     float *__restrict__ reward_t,
                                                                     uint8_t *__restrict__ done_t,
                                                                     const Jump *__restrict__ jump) {
     using Gm = Geom<H, W>;
-    constexpr int WP = Gm::WP, HW = Gm::HW;
+    constexpr int WS = Gm::WS, HW = Gm::HW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned char *lds = smem + wave * Gm::WAVE_BYTES;
-    const int B = env.B, E = env.E;
-    const int e0 = (blockIdx.x * WAVES + wave) * Gm::G;
-    if (e0 >= B) return;
-    const int nb = min(Gm::G, B - e0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned B = env.B;
+    const int E = env.E;
+    const int e0b = blockIdx.x * Gm::NB;
+    const int nbb = min(Gm::NB, (int)B - e0b);
     int g = 0;
 #pragma unroll
     for (int q = 1; q < Gm::G; ++q) g += (lane >= q * H) ? 1 : 0;
     const int r = lane - g * H;
-    const bool live = lane < Gm::NL && g < nb;
+    const int gb = wave * Gm::G + g;
+    const bool live = lane < Gm::NL && gb < nbb;
     const bool leader = live && r == 0;
-    const int e = e0 + (live ? g : 0);
+    const unsigned e = e0b + (live ? gb : 0);
     const int up = 4 * (live ? (r == 0 ? lane + H - 1 : lane - 1) : lane);
     const int dn = 4 * (live ? (r == H - 1 ? lane - (H - 1) : lane + 1) : lane);
-    unsigned char *board = lds + Gm::OFF_BOARD, *goals = lds + Gm::OFF_GOALS;
-    u16 *board16 = (u16 *)(board + Gm::PAD) + (live ? g : 0) * HW;
-    int *table = (int *)(lds + Gm::OFF_TABLE) + (live ? g : 0) * 72;
-    u64 *rng_lds = (u64 *)(lds + Gm::OFF_RNG);
+    unsigned char *board = smem + Gm::OFF_BOARD, *goals = smem + Gm::OFF_GOALS;
+    u16 *board16 = (u16 *)(board + Gm::PAD) + (live ? gb : 0) * HW;
+    u64 *rng_lds = (u64 *)(smem + Gm::OFF_RNG) + 4 * Gm::G * wave;
+    const int8_t *__restrict__ lut = env.score_lut;
+    const Consts cst = make_consts();
+    const u32 cell_mask = vreg(SCORE_CELL_MASK);
 
-    load_span<H, W>(env.board + (size_t)e0 * HW, board, nb, lane);
-    load_span<H, W>(env.goals + (size_t)e0 * HW, goals, nb, lane);
-    if (lane < 4 * nb) rng_lds[lane] = ((const u64 *)(env.rng + e0))[lane];
+    load_span<H, W>(env.board + (size_t)e0b * HW, board, nbb, tid);
+    load_span<H, W>(env.goals + (size_t)e0b * HW, goals, nbb, tid);
+    if (lane < 4 * Gm::G && wave * Gm::G + (lane >> 2) < nbb)
+        rng_lds[lane] = ((const u64 *)(env.rng + e0b + wave * Gm::G))[lane];
     // per-board scalars live in the leader lane's registers for the whole launch
     int ly = -1, lx = -1, steps = 0, old_value = 0, required = 0, initial = 0, ep_len = 0, gstatic = 1;
+    int level = 0, episodes = 0, action = 0;
     float ep_rew = 0.0f;
     bool active = false;
     double p = 0.0;
-    int tidx = 0, level = 0, episodes = 0;
+    u32 lut_base = 0;
     if (live) {
         p = (double)env.spawn_prob[e];
         gstatic = env.goals_static[e];
-        tidx = env.table_idx[e];
+        lut_base = (u32)env.table_idx[e] << 16;
         level = env.level_idx[e];
     }
+    const int32_t *exits = env.exit_locs + (size_t)e * E;
     if (leader) {
         ly = env.agent_loc[2 * e];
         lx = env.agent_loc[2 * e + 1];
@@ -432,72 +573,60 @@ __global__ __launch_bounds__(64 * WAVES) void k_env_rollout_rowlane(sl_env_batch
         ep_rew = env.episode_reward[e];
         active = env.is_active[e] != 0;
         episodes = env.episode_idx[e];
+        action = actions[e];
     }
-    if (live) {
-        for (int i = r; i < 72; i += H) table[i] = env.points_table[72 * tidx + i];
-    }
-    wave_sync();
+    __syncthreads();
 
-    u32 b[WP], n[WP], gl[WP], elig[(WP + 15) / 16];
+    RowWords<H, W> b, n, gsh;
+    u32 elig;
 #pragma unroll
-    for (int k = 0; k < WP; ++k) b[k] = n[k] = gl[k] = 0;
-    if (live) read_row<H, W>(goals, g, r, gl);
+    for (int k = 0; k < WS; ++k) b[k] = n[k] = gsh[k] = 0;
+    if (live) {
+        read_row<H, W>(goals, gb, r, b);
+#pragma unroll
+        for (int k = 0; k < WS; ++k) gsh[k] = goal_shift(b[k]);
+    }
     bool goals_dirty = false;
-    const int32_t *exits = env.exit_locs + (size_t)e * E;
 
     for (int t = 0; t < T; ++t) {
         // safelife_env.py:151
         if (leader && ly >= 0) {
-            int loc[2] = {ly, lx};
-            act_one<int>(board16, H, W, loc, actions[(size_t)t * B + e]);
-            ly = loc[0];
-            lx = loc[1];
+            if (t > 0) action = actions[(size_t)t * B + e];
+            act_gather(board16, H, W, ly, lx, action);
         }
         wave_sync();
-        if (live) read_row<H, W>(board, g, r, b);
-        // safelife_env.py:152 : board, then goals unless static
-        u32 any = ca_rows<H, W>(b, n, elig, up, dn);
-        if (!live) any = 0;
-        if (__ballot(any != 0)) {
-            if (!live)
+        // safelife_env.py:152 : board first, then goals unless they are static (safelife_game.py:746-761)
+        const bool dyn = live && gstatic != 1;
+        const int passes = __ballot(dyn) ? 2 : 1;
+#pragma nounroll
+        for (int pass = 0; pass < passes; ++pass) {
+            const bool mine = live && (pass == 0 || dyn);
+            unsigned char *img = pass == 0 ? board : goals;
+            if (mine) read_row<H, W>(img, gb, r, b);
+            ca_rows<H, W>(b, n, elig, up, dn, cst);
+            if (!mine) elig = 0;
+            if (__ballot(elig != 0)) resolve_draws<H, W>(b, n, elig, rng_lds, live ? g : 0, leader, p, jump);
+            if (pass == 1) {
+                u32 diff = 0;
 #pragma unroll
-                for (int j = 0; j < (WP + 15) / 16; ++j) elig[j] = 0;
-            resolve_draws<H, W>(b, n, elig, rng_lds, live ? g : 0, live ? r : 1, lane, p, jump);
+                for (int k = 0; k < WS; ++k)
+                    diff |= ((n[k] ^ b[k]) | (n[k] & 0x00800080u)) & (Gm::vm1(k) * 0xFFFFu);
+                const int changed = group_total<H, Gm::G>(mine && diff ? 1 : 0, live ? g : 0);
+                if (mine) {
+                    if (gstatic == 0) gstatic = changed ? 2 : 1;
+#pragma unroll
+                    for (int k = 0; k < WS; ++k) gsh[k] = goal_shift(n[k]);
+                    goals_dirty = true;
+                }
+            }
+            if (mine) write_row<H, W>(img, gb, r, n);
         }
-        if (__ballot(live && gstatic != 1)) {
-            u32 gn[WP], gel[(WP + 15) / 16];
-            u32 gany = ca_rows<H, W>(gl, gn, gel, up, dn);
-            const bool dyn = live && gstatic != 1;
-            if (!dyn) gany = 0;
-            if (__ballot(gany != 0)) {
-                if (!dyn)
-#pragma unroll
-                    for (int j = 0; j < (WP + 15) / 16; ++j) gel[j] = 0;
-                resolve_draws<H, W>(gl, gn, gel, rng_lds, live ? g : 0, live ? r : 1, lane, p, jump);
-            }
-            u32 diff = 0;
-#pragma unroll
-            for (int k = 0; k < WP; ++k) {
-                u32 vm = Gm::vmask(k);
-                diff |= ((gn[k] ^ gl[k]) | (gn[k] & 0x00800080u)) & vm;
-            }
-            const int changed = group_sum<H>(dyn && diff ? 1 : 0, live ? g : 0, lane);
-            if (dyn) {
-                if (gstatic == 0) gstatic = changed ? 2 : 1;
-#pragma unroll
-                for (int k = 0; k < WP; ++k) gl[k] = gn[k];
-                const u32 last = Gm::LAST_HI ? (gl[Gm::LAST_WORD] >> 16) : (gl[Gm::LAST_WORD] & 0xFFFFu);
-                const u32 first = gl[0] >> 16;
-                gl[0] = (gl[0] & 0xFFFF0000u) | last;
-                if (Gm::RH_HI) gl[Gm::RH_WORD] = (gl[Gm::RH_WORD] & 0xFFFFu) | (first << 16);
-                else gl[Gm::RH_WORD] = first;
-                write_row<H, W>(goals, g, r, gl);
-                goals_dirty = true;
-            }
+        if (passes == 2) {               // board rows back into n for scoring
+            wave_sync();
+            if (live) read_row<H, W>(board, gb, r, n);
         }
         // safelife_env.py:153-160
-        const int score = group_sum<H>(live ? row_score<H, W>(n, gl, table) : 0, live ? g : 0, lane);
-        if (live) write_row<H, W>(board, g, r, n);
+        const int score = group_total<H, Gm::G>(live ? row_score<H, W>(n, gsh, lut, lut_base, cell_mask) : 0, live ? g : 0);
         wave_sync();
         bool done = false;
         if (leader) {
@@ -508,9 +637,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_env_rollout_rowlane(sl_env_batch
             bool success = false;
             done = true;
             if (ly >= 0) {
-                u32 cell = board16[ly * W + lx];
+                const u32 cell = board16[ly * W + lx];
                 success = has_exited(cell);
-                int value = score + env.exit_points * (success ? 1 : 0);
+                const int value = score + (success ? env.exit_points : 0);
                 reward = (float)((value - old_value) * (active ? 1 : 0));
                 old_value = value;
                 done = !(cell & AGENT) || times_up;
@@ -529,42 +658,43 @@ __global__ __launch_bounds__(64 * WAVES) void k_env_rollout_rowlane(sl_env_batch
         }
         // on-device auto-reset (training/base_algo.py:231-236 calls env.reset() after a done step)
         if (env.auto_reset && __ballot(leader && done)) {
-            const int flag = group_sum<H>(leader && done ? 1 : 0, live ? g : 0, lane);
+            const int flag = group_total<H, Gm::G>(leader && done ? 1 : 0, live ? g : 0);
             const bool mine = live && flag != 0;
-            int lvl = 0;
             if (mine) {
-                lvl = level = (level + env.level_stride) % env.L;
-                const u16 *pb = env.pool_board + (size_t)lvl * HW, *pg = env.pool_goals + (size_t)lvl * HW;
-                u16 *gdst = (u16 *)(goals + Gm::PAD) + g * HW;
+                level = (level + env.level_stride) % env.L;
+                const u16 *pb = env.pool_board + (size_t)level * HW, *pg = env.pool_goals + (size_t)level * HW;
+                u16 *gdst = (u16 *)(goals + Gm::PAD) + gb * HW;
                 for (int i = r; i < HW; i += H) {
                     board16[i] = pb[i];
                     gdst[i] = pg[i];
                 }
-                tidx = env.pool_table_idx[lvl];
-                for (int i = r; i < 72; i += H) table[i] = env.points_table[72 * tidx + i];
-                p = (double)env.pool_spawn_prob[lvl];
+                lut_base = (u32)env.pool_table_idx[level] << 16;
+                p = (double)env.pool_spawn_prob[level];
                 gstatic = 0;
-                if (r < 4) rng_lds[4 * g + r] = ((const u64 *)(env.pool_rng + lvl))[r];
-                for (int k = r; k < E; k += H) env.exit_locs[(size_t)e * E + k] = env.pool_exit_locs[(size_t)lvl * E + k];
+                if (r < 4) rng_lds[4 * g + r] = ((const u64 *)(env.pool_rng + level))[r];
+                for (int k = r; k < E; k += H)
+                    env.exit_locs[(size_t)e * E + k] = env.pool_exit_locs[(size_t)level * E + k];
                 goals_dirty = true;
             }
             wave_sync();
             if (mine) {
-                read_row<H, W>(board, g, r, n);
-                read_row<H, W>(goals, g, r, gl);
+                read_row<H, W>(goals, gb, r, b);
+#pragma unroll
+                for (int k = 0; k < WS; ++k) gsh[k] = goal_shift(b[k]);
+                read_row<H, W>(board, gb, r, n);
             }
-            const int s0 = group_sum<H>(mine ? row_score<H, W>(n, gl, table) : 0, live ? g : 0, lane);
+            const int s0 = group_total<H, Gm::G>(mine ? row_score<H, W>(n, gsh, lut, lut_base, cell_mask) : 0, live ? g : 0);
             if (mine && r == 0) {
                 episodes += 1;
-                exits = env.pool_exit_locs + (size_t)lvl * E;   // never written by this launch
-                ly = env.pool_agent_loc[2 * lvl];
-                lx = env.pool_agent_loc[2 * lvl + 1];
-                initial = env.pool_initial_points[lvl];
-                recolor_exits_lds(board16, W, ly, lx, env.pool_exit_locs + (size_t)lvl * E, E, s0, initial,
-                                  env.pool_required_reset[lvl], env.exit_points);
-                int exited = ly >= 0 ? (has_exited(board16[ly * W + lx]) ? 1 : 0) : 0;
+                exits = env.pool_exit_locs + (size_t)level * E;   // never written by this launch
+                ly = env.pool_agent_loc[2 * level];
+                lx = env.pool_agent_loc[2 * level + 1];
+                initial = env.pool_initial_points[level];
+                recolor_exits_lds(board16, W, ly, lx, exits, E, s0, initial, env.pool_required_reset[level],
+                                  env.exit_points);
+                const int exited = ly >= 0 ? (has_exited(board16[ly * W + lx]) ? 1 : 0) : 0;
                 old_value = s0 + env.exit_points * exited;
-                required = env.pool_required_step[lvl];
+                required = env.pool_required_step[level];
                 steps = 0;
                 active = true;
                 ep_rew = 0.0f;
@@ -575,45 +705,49 @@ __global__ __launch_bounds__(64 * WAVES) void k_env_rollout_rowlane(sl_env_batch
     }
 
     // write-back
-    wave_sync();
-    store_span<H, W>(env.board + (size_t)e0 * HW, board, nb, lane);
-    if (__ballot(goals_dirty)) store_span<H, W>(env.goals + (size_t)e0 * HW, goals, nb, lane);
-    if (lane < 4 * nb) ((u64 *)(env.rng + e0))[lane] = rng_lds[lane];
-    if (live) {
-        if (r == 0) {
-            env.agent_loc[2 * e] = ly;
-            env.agent_loc[2 * e + 1] = lx;
-            env.num_steps[e] = steps;
-            env.old_value[e] = old_value;
-            env.required_points[e] = required;
-            env.initial_points[e] = initial;
-            env.episode_length[e] = ep_len;
-            env.episode_reward[e] = ep_rew;
-            env.is_active[e] = active ? 1 : 0;
-            env.goals_static[e] = (uint8_t)gstatic;
-            env.table_idx[e] = tidx;
-            env.spawn_prob[e] = (float)p;
-            env.level_idx[e] = level;
-            env.episode_idx[e] = episodes;
-        }
+    if (leader) {
+        env.goals_static[e] = (uint8_t)gstatic;
+        env.table_idx[e] = (int)(lut_base >> 16);
+        env.spawn_prob[e] = (float)p;
+        env.level_idx[e] = level;
+        env.agent_loc[2 * e] = ly;
+        env.agent_loc[2 * e + 1] = lx;
+        env.num_steps[e] = steps;
+        env.old_value[e] = old_value;
+        env.required_points[e] = required;
+        env.initial_points[e] = initial;
+        env.episode_length[e] = ep_len;
+        env.episode_reward[e] = ep_rew;
+        env.is_active[e] = active ? 1 : 0;
+        env.episode_idx[e] = episodes;
     }
+    const int dirty = __syncthreads_or(goals_dirty);
+    store_span<H, W>(env.board + (size_t)e0b * HW, board, nbb, tid);
+    if (dirty) store_span<H, W>(env.goals + (size_t)e0b * HW, goals, nbb, tid);
+    if (lane < 4 * Gm::G && wave * Gm::G + (lane >> 2) < nbb)
+        ((u64 *)(env.rng + e0b + wave * Gm::G))[lane] = rng_lds[lane];
 
-    // observation (safelife_env.py:105-146) from the LDS images
+    // observation (safelife_env.py:105-146) from the LDS images, one wave per G boards
     if (env.obs) {
         const int vh = env.view_h, vw = env.view_w, C = env.n_channels, nv = vh * vw;
         const u16 *b16 = (const u16 *)(board + Gm::PAD), *g16 = (const u16 *)(goals + Gm::PAD);
-        for (int q = 0; q < nb; ++q) {
-            const int eq = e0 + q;
-            const int qy = (int)bperm(4 * (q * H), (u32)ly), qx = (int)bperm(4 * (q * H), (u32)lx);
+        const u64 exq = (u64)(uintptr_t)exits;
+        for (int q = 0; q < Gm::G; ++q) {
+            const int gq = wave * Gm::G + q;
+            if (gq >= nbb) break;
+            const unsigned eq = e0b + gq;
+            const int qy = __builtin_amdgcn_readlane(ly, q * H), qx = __builtin_amdgcn_readlane(lx, q * H);
             const int y0 = qy >= 0 ? qy : 0, x0 = qy >= 0 ? qx : 0;
-            const u64 exq = (u64)(uintptr_t)exits;
-            const int32_t *ex = (const int32_t *)(uintptr_t)(((u64)bperm(4 * (q * H), (u32)(exq >> 32)) << 32) |
-                                                             (u64)bperm(4 * (q * H), (u32)exq));
-            const u16 *bq = b16 + q * HW, *gq = g16 + q * HW;
+            const int32_t *ex = (const int32_t *)(uintptr_t)(
+                ((u64)(u32)__builtin_amdgcn_readlane((int)(exq >> 32), q * H) << 32) |
+                (u64)(u32)__builtin_amdgcn_readlane((int)exq, q * H));
+            const u16 *bq = b16 + gq * HW, *gq16 = g16 + gq * HW;
             for (int v = lane; v < nv; v += 64) {
                 const int vy = v / vw, vx = v - vy * vw;
                 const int sy = pos_mod(y0 - vh / 2 + vy, H), sx = pos_mod(x0 - vw / 2 + vx, W);
-                u32 word = obs_word(bq[sy * W + sx], gq[sy * W + sx], env.remove_white_goals);
+                u32 g0 = gq16[sy * W + sx] & COLORS;
+                if (env.remove_white_goals && g0 == COLORS) g0 = 0;
+                u32 word = bq[sy * W + sx] | (g0 << 16);
                 for (int k = 0; k < E; ++k) {
                     const int xk = ex[k];
                     if (xk < 0) continue;
@@ -622,7 +756,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_env_rollout_rowlane(sl_env_batch
                     int jx = pos_mod(ix - x0 + W / 2, W) - W / 2 + vw / 2;
                     jy = min(max(jy, 0), vh - 1);
                     jx = min(max(jx, 0), vw - 1);
-                    if (jy == vy && jx == vx) word = obs_word(bq[xk], gq[xk], env.remove_white_goals);
+                    if (jy == vy && jx == vx) {
+                        u32 g1 = gq16[xk] & COLORS;
+                        if (env.remove_white_goals && g1 == COLORS) g1 = 0;
+                        word = bq[xk] | (g1 << 16);
+                    }
                 }
                 if (C == 0) {
                     ((u32 *)env.obs)[(size_t)eq * nv + v] = word;
@@ -635,16 +773,30 @@ __global__ __launch_bounds__(64 * WAVES) void k_env_rollout_rowlane(sl_env_batch
     }
 }
 
+// ---- score table ------------------------------------------------------------------------------------
+
+__global__ void k_build_score_lut(const int32_t *__restrict__ points_table, int n_tables, int8_t *__restrict__ lut) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_tables * 65536) return;
+    const int t = i >> 16, idx = i & 0xFFFF;
+    int v = 0;
+    if ((idx & ~0x8EFD) == 0) {           // only the bit combinations a masked cell | goal can produce
+        const bool alive = idx & 1, pushable = idx & 4, destr = idx & 8, frozen = idx & 16, pullable = idx & 0x8000;
+        const int gc = (idx >> 5) & 7, col = (idx >> 9) & 7;
+        const bool excluded = frozen && !(pullable || pushable || destr);
+        v = excluded ? 0 : points_table[t * 72 + gc * 9 + (alive ? col : 8)];
+    }
+    lut[i] = (int8_t)v;
+}
+
 template <int H, int W>
 static hipError_t launch_advance_t(const u16 *in, u16 *out, int B, const float *spawn_prob, int n_steps,
                                    sl_pcg64 *rng, const Jump *jump, hipStream_t stream) {
     using Gm = Geom<H, W>;
-    const size_t lds = (size_t)WAVES * Gm::WAVE_BYTES;
     auto fn = k_advance_rowlane<H, W>;
-    hipError_t err = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t err = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, Gm::LDS_BYTES);
     if (err != hipSuccess) return err;
-    const int per_block = WAVES * Gm::G;
-    hipLaunchKernelGGL(fn, dim3((B + per_block - 1) / per_block), dim3(64 * WAVES), lds, stream, in, out, B,
+    hipLaunchKernelGGL(fn, dim3((B + Gm::NB - 1) / Gm::NB), dim3(64 * WAVES), Gm::LDS_BYTES, stream, in, out, B,
                        spawn_prob, n_steps, rng, jump);
     return hipGetLastError();
 }
@@ -653,13 +805,11 @@ template <int H, int W>
 static hipError_t launch_rollout_t(const sl_env_batch &env, const int32_t *actions, int T, float *reward_t,
                                    uint8_t *done_t, const Jump *jump, hipStream_t stream) {
     using Gm = Geom<H, W>;
-    const size_t lds = (size_t)WAVES * Gm::WAVE_BYTES;
     auto fn = k_env_rollout_rowlane<H, W>;
-    hipError_t err = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t err = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, Gm::LDS_BYTES);
     if (err != hipSuccess) return err;
-    const int per_block = WAVES * Gm::G;
-    hipLaunchKernelGGL(fn, dim3((env.B + per_block - 1) / per_block), dim3(64 * WAVES), lds, stream, env, actions,
-                       T, reward_t, done_t, jump);
+    hipLaunchKernelGGL(fn, dim3((env.B + Gm::NB - 1) / Gm::NB), dim3(64 * WAVES), Gm::LDS_BYTES, stream, env,
+                       actions, T, reward_t, done_t, jump);
     return hipGetLastError();
 }
 
@@ -672,6 +822,12 @@ bool rowlane_supports(int H, int W) {
     SL_ROWLANE_SHAPES(X)
 #undef X
     return false;
+}
+
+hipError_t launch_build_score_lut(const int32_t *points_table, int n_tables, int8_t *lut, hipStream_t stream) {
+    const int n = n_tables * 65536;
+    hipLaunchKernelGGL(rl::k_build_score_lut, dim3((n + 255) / 256), dim3(256), 0, stream, points_table, n_tables, lut);
+    return hipGetLastError();
 }
 
 hipError_t launch_advance_rowlane(const u16 *in, u16 *out, int B, int H, int W, const float *spawn_prob,

@@ -107,6 +107,7 @@ class SafeLifeVectorEnv(object):
         for i, c in enumerate(chans):
             s.channels[i] = int(c)
         s.L, s.level_stride = len(pool), int(level_stride)
+        t["score_lut"] = torch.zeros((s.n_tables, 65536), dtype=torch.int8, device=dev)
         for name in _hip.ENV_STATE_PTRS + _hip.ENV_POOL_PTRS + _hip.ENV_OUT_PTRS:
             if name == "obs":
                 s.obs = None if self.obs is None else self.obs.data_ptr()
@@ -114,6 +115,11 @@ class SafeLifeVectorEnv(object):
                 setattr(s, name, t[name].data_ptr())
         self._lib = _hip.lib()
         self._sref = C.byref(s)
+        rc = self._lib.slhip_env_prepare(self._sref, _hip.current_stream_ptr())
+        if rc == _hip.SL_E_UNSUPPORTED:
+            s.score_lut = None          # points outside int8: every shape runs the size-generic kernels
+        else:
+            _hip.check(rc)
 
     # ------------------------------------------------------------------ gym-like surface
 
