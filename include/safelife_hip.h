@@ -138,7 +138,7 @@ typedef struct sl_env_batch {
     int32_t *info_episode_length;/* [B] info['episode']['length'] */
     uint8_t *obs;                /* [B,vh,vw,C] uint8, or uint32 [B,vh,vw] if n_channels == 0; NULL = skip */
     /* workspace */
-    int8_t *score_lut;           /* [n_tables,65536] per-cell score table derived from points_table by
+    int8_t *score_lut;           /* [n_tables,4096+65536] per-cell score tables derived from points_table by
                                     slhip_env_prepare(); NULL => the size-generic kernels are used */
 } sl_env_batch;
 

@@ -31,6 +31,17 @@ typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WAVES = 4;
 
+// -DSL_TRACE: phase timestamps (s_memtime) of wave 0 of every workgroup are written to the
+// `reward_t` argument, reinterpreted as long long [grid, 16] (profiling builds only).
+#ifdef SL_TRACE
+#define SL_STAMP(i)                                                                     \
+    do {                                                                                \
+        if (threadIdx.x == 0 && reward_t) ((long long *)reward_t)[blockIdx.x * 16 + (i)] = (long long)__builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define SL_STAMP(i) do {} while (0)
+#endif
+
 // ---- instruction selection notes (measured with tools/ubench/valu_rate.hip on gfx950) -----------
 // Per wave64 instruction a SIMD spends 2 cycles on v_and/or/xor/add/sub/lshrrev/mov and on
 // v_bitop3_b32 with VGPR operands, and 4 cycles on everything else this kernel could use
@@ -98,7 +109,10 @@ struct Geom {
     static constexpr int OFF_BOARD = 0;
     static constexpr int OFF_GOALS = REGION;
     static constexpr int OFF_RNG = 2 * REGION;             // NB x 4 u64
-    static constexpr int LDS_BYTES = OFF_RNG + NB * 32;
+    static constexpr int OFF_GSH = OFF_RNG + NB * 32;      // per lane WS words: goal colours, pre-shifted
+    static constexpr int OFF_LUT = OFF_GSH + WAVES * 64 * WS * 4;   // 4 KiB compact score table
+    static constexpr int LDS_BYTES = OFF_LUT + 4096;
+    static constexpr int LDS_ADVANCE = OFF_RNG + NB * 32;  // advance_board needs no score state
     // validity of the halves of word k as a 0x0001-per-half mask
     static constexpr u32 vm1(int k) { return (ODD && k == WS - 1) ? 0x00000001u : 0x00010001u; }
 };
@@ -327,21 +341,31 @@ __device__ __forceinline__ int group_total(int v, int g) {
 // sum(points_table * alive_counts) as one byte gather per cell.  The table index is the cell itself
 // masked to the bits that matter (alive 0, pushable 2, destructible 3, frozen 4, colour 9-11,
 // pullable 15) with the goal colour dropped into the free bits 5-7, so forming it costs one bitop3
-// per two cells.  Entries the filter of advance_board.c:201 excludes hold 0
-// (slhip_env_prepare builds the table; points must fit int8 for this path).
+// per two cells.  Entries the filter of advance_board.c:201 excludes hold 0.  Two forms of the table
+// (slhip_env_prepare builds both; points must fit int8):
+//   * 16-bit index, 64 KiB per points table, gathered from global memory (any number of tables);
+//   * 12-bit index (pullable folded onto bit 8), 4 KiB, copied to LDS when the batch uses ONE table.
 constexpr u32 SCORE_CELL_MASK = 0x8E1D8E1Du;
+constexpr int SCORE_LUT_BYTES = 4096 + 65536;     // per points table: compact form, then wide form
 __device__ __forceinline__ u32 goal_shift(u32 g) { return (g >> 4) & 0x00E000E0u; }
 
-template <int H, int W>
-__device__ __forceinline__ int row_score(const RowWords<H, W> &n, const RowWords<H, W> &gsh,
-                                         const int8_t *__restrict__ lut, u32 lut_base, u32 cell_mask) {
+template <int H, int W, bool LDS_LUT>
+__device__ __forceinline__ int row_score(const RowWords<H, W> &n, const u32 *gsh_lane,
+                                         const int8_t *__restrict__ lut, u32 lut_base, const int8_t *lds_lut,
+                                         u32 cell_mask, u32 c100) {
     using Gm = Geom<H, W>;
     int s = 0;
 #pragma unroll
     for (int k = 0; k < Gm::WS; ++k) {
-        const u32 idx = BO3_AND_OR(n[k], cell_mask, gsh[k]);
-        s += lut[lut_base + (idx & 0xFFFFu)];
-        if (!(Gm::ODD && k == Gm::WS - 1)) s += lut[lut_base + (idx >> 16)];
+        u32 idx = BO3_AND_OR(n[k], cell_mask, gsh_lane[k]);
+        if (LDS_LUT) {
+            idx = BO3_AND_OR(n[k] >> 7, c100, idx) & 0x0FFF0FFFu;       // pullable -> bit 8, drop bit 15
+            s += lds_lut[idx & 0xFFFFu];
+            if (!(Gm::ODD && k == Gm::WS - 1)) s += lds_lut[idx >> 16];
+        } else {
+            s += lut[lut_base + (idx & 0xFFFFu)];
+            if (!(Gm::ODD && k == Gm::WS - 1)) s += lut[lut_base + (idx >> 16)];
+        }
     }
     return s;
 }
@@ -407,8 +431,9 @@ __device__ __forceinline__ void act_gather(u16 *board, int H, int W, int &ly, in
 }
 
 // update_exit_colors for the board of a leader lane, on the flat LDS image.
-__device__ __forceinline__ void recolor_exits_lds(u16 *board, int W, int ly, int lx, const int32_t *exits, int E,
-                                                  int score, int initial, int required, int exit_points) {
+__device__ __forceinline__ void recolor_exits_lds(u16 *board, int W, int ly, int lx, const int32_t *exits,
+                                                  int exit0, int E, int score, int initial, int required,
+                                                  int exit_points) {
     bool any_can = false;
     if (ly >= 0) {
         u16 *cell = board + ly * W + lx;
@@ -420,7 +445,8 @@ __device__ __forceinline__ void recolor_exits_lds(u16 *board, int W, int ly, int
         any_can = can;
     }
     const u16 paint = (u16)(FROZEN | EXIT | (any_can ? COLOR_R : 0u));
-    for (int k = 0; k < E; ++k) {
+    if (exit0 >= 0) board[exit0] = paint;         // slot 0 was prefetched; the usual level has one exit
+    for (int k = 1; k < E; ++k) {
         const int ex = exits[k];
         if (ex >= 0) board[ex] = paint;
     }
@@ -513,12 +539,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_advance_rowlane(const u16 *__res
 
 // ---- fused env step / rollout ---------------------------------------------------------------------
 
-template <int H, int W>
+template <int H, int W, bool LDS_LUT>
 __global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_batch env,
-                                                                    const int32_t *__restrict__ actions, int T,
-                                                                    float *__restrict__ reward_t,
-                                                                    uint8_t *__restrict__ done_t,
-                                                                    const Jump *__restrict__ jump) {
+                                                                       const int32_t *__restrict__ actions, int T,
+                                                                       float *__restrict__ reward_t,
+                                                                       uint8_t *__restrict__ done_t,
+                                                                       const Jump *__restrict__ jump) {
     using Gm = Geom<H, W>;
     constexpr int WS = Gm::WS, HW = Gm::HW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -540,17 +566,17 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_ba
     unsigned char *board = smem + Gm::OFF_BOARD, *goals = smem + Gm::OFF_GOALS;
     u16 *board16 = (u16 *)(board + Gm::PAD) + (live ? gb : 0) * HW;
     u64 *rng_lds = (u64 *)(smem + Gm::OFF_RNG) + 4 * Gm::G * wave;
-    const int8_t *__restrict__ lut = env.score_lut;
+    u32 *gsh_lane = (u32 *)(smem + Gm::OFF_GSH) + (wave * 64 + lane) * WS;
+    const int8_t *lds_lut = (const int8_t *)(smem + Gm::OFF_LUT);
+    const int8_t *__restrict__ lut = env.score_lut + 4096;        // wide form of table t at + t * SCORE_LUT_BYTES
     const Consts cst = make_consts();
-    const u32 cell_mask = vreg(SCORE_CELL_MASK);
+    const u32 cell_mask = vreg(SCORE_CELL_MASK), c100 = vreg(0x01000100u);
 
-    load_span<H, W>(env.board + (size_t)e0b * HW, board, nbb, tid);
-    load_span<H, W>(env.goals + (size_t)e0b * HW, goals, nbb, tid);
-    if (lane < 4 * Gm::G && wave * Gm::G + (lane >> 2) < nbb)
-        rng_lds[lane] = ((const u64 *)(env.rng + e0b + wave * Gm::G))[lane];
-    // per-board scalars live in the leader lane's registers for the whole launch
+    SL_STAMP(0);
+    // per-board scalars live in the leader lane's registers for the whole launch; their loads are
+    // issued before the bulk loads so that they are not queued behind them
     int ly = -1, lx = -1, steps = 0, old_value = 0, required = 0, initial = 0, ep_len = 0, gstatic = 1;
-    int level = 0, episodes = 0, action = 0;
+    int level = 0, episodes = 0, action = 0, exit0 = -1;
     float ep_rew = 0.0f;
     bool active = false;
     double p = 0.0;
@@ -558,7 +584,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_ba
     if (live) {
         p = (double)env.spawn_prob[e];
         gstatic = env.goals_static[e];
-        lut_base = (u32)env.table_idx[e] << 16;
+        lut_base = (u32)env.table_idx[e] * (u32)SCORE_LUT_BYTES;
         level = env.level_idx[e];
     }
     const int32_t *exits = env.exit_locs + (size_t)e * E;
@@ -574,19 +600,28 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_ba
         active = env.is_active[e] != 0;
         episodes = env.episode_idx[e];
         action = actions[e];
+        exit0 = exits[0];
     }
+    if (lane < 4 * Gm::G && wave * Gm::G + (lane >> 2) < nbb)
+        rng_lds[lane] = ((const u64 *)(env.rng + e0b + wave * Gm::G))[lane];
+    if (LDS_LUT) ((u32x4 *)(smem + Gm::OFF_LUT))[tid] = ((const u32x4 *)env.score_lut)[tid];   // 256 x 16 B
+    load_span<H, W>(env.board + (size_t)e0b * HW, board, nbb, tid);
+    load_span<H, W>(env.goals + (size_t)e0b * HW, goals, nbb, tid);
+    SL_STAMP(1);
     __syncthreads();
+    SL_STAMP(2);
 
-    RowWords<H, W> b, n, gsh;
+    RowWords<H, W> b;
     u32 elig;
 #pragma unroll
-    for (int k = 0; k < WS; ++k) b[k] = n[k] = gsh[k] = 0;
+    for (int k = 0; k < WS; ++k) b[k] = 0;
     if (live) {
         read_row<H, W>(goals, gb, r, b);
 #pragma unroll
-        for (int k = 0; k < WS; ++k) gsh[k] = goal_shift(b[k]);
+        for (int k = 0; k < WS; ++k) gsh_lane[k] = goal_shift(b[k]);
     }
     bool goals_dirty = false;
+    SL_STAMP(3);
 
     for (int t = 0; t < T; ++t) {
         // safelife_env.py:151
@@ -595,6 +630,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_ba
             act_gather(board16, H, W, ly, lx, action);
         }
         wave_sync();
+        SL_STAMP(4);
         // safelife_env.py:152 : board first, then goals unless they are static (safelife_game.py:746-761)
         const bool dyn = live && gstatic != 1;
         const int passes = __ballot(dyn) ? 2 : 1;
@@ -603,34 +639,47 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_ba
             const bool mine = live && (pass == 0 || dyn);
             unsigned char *img = pass == 0 ? board : goals;
             if (mine) read_row<H, W>(img, gb, r, b);
-            ca_rows<H, W>(b, n, elig, up, dn, cst);
+            ca_rows<H, W>(b, b, elig, up, dn, cst);          // in place: b now holds the new cells
             if (!mine) elig = 0;
-            if (__ballot(elig != 0)) resolve_draws<H, W>(b, n, elig, rng_lds, live ? g : 0, leader, p, jump);
+            if (__ballot(elig != 0)) {
+                RowWords<H, W> old;                          // failed draws keep the old cell: re-read it
+#pragma unroll
+                for (int k = 0; k < WS; ++k) old[k] = 0;
+                if (mine) read_row<H, W>(img, gb, r, old);
+                resolve_draws<H, W>(old, b, elig, rng_lds, live ? g : 0, leader, p, jump);
+            }
             if (pass == 1) {
                 u32 diff = 0;
+                if (mine) {
+                    RowWords<H, W> old;
+                    read_row<H, W>(img, gb, r, old);
 #pragma unroll
-                for (int k = 0; k < WS; ++k)
-                    diff |= ((n[k] ^ b[k]) | (n[k] & 0x00800080u)) & (Gm::vm1(k) * 0xFFFFu);
+                    for (int k = 0; k < WS; ++k)
+                        diff |= ((b[k] ^ old[k]) | (b[k] & 0x00800080u)) & (Gm::vm1(k) * 0xFFFFu);
+                }
                 const int changed = group_total<H, Gm::G>(mine && diff ? 1 : 0, live ? g : 0);
                 if (mine) {
                     if (gstatic == 0) gstatic = changed ? 2 : 1;
 #pragma unroll
-                    for (int k = 0; k < WS; ++k) gsh[k] = goal_shift(n[k]);
+                    for (int k = 0; k < WS; ++k) gsh_lane[k] = goal_shift(b[k]);
                     goals_dirty = true;
                 }
             }
-            if (mine) write_row<H, W>(img, gb, r, n);
+            if (mine) write_row<H, W>(img, gb, r, b);
         }
-        if (passes == 2) {               // board rows back into n for scoring
+        if (passes == 2) {               // board rows back into registers for scoring
             wave_sync();
-            if (live) read_row<H, W>(board, gb, r, n);
+            if (live) read_row<H, W>(board, gb, r, b);
         }
+        SL_STAMP(5);
         // safelife_env.py:153-160
-        const int score = group_total<H, Gm::G>(live ? row_score<H, W>(n, gsh, lut, lut_base, cell_mask) : 0, live ? g : 0);
+        const int score = group_total<H, Gm::G>(
+            live ? row_score<H, W, LDS_LUT>(b, gsh_lane, lut, lut_base, lds_lut, cell_mask, c100) : 0, live ? g : 0);
         wave_sync();
+        SL_STAMP(6);
         bool done = false;
         if (leader) {
-            recolor_exits_lds(board16, W, ly, lx, exits, E, score, initial, required, env.exit_points);
+            recolor_exits_lds(board16, W, ly, lx, exits, exit0, E, score, initial, required, env.exit_points);
             steps += 1;
             const bool times_up = steps >= env.time_limit;
             float reward = 0.0f;
@@ -653,8 +702,10 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_ba
             env.times_up[e] = times_up;
             if (env.info_episode_reward) env.info_episode_reward[e] = ep_rew;
             if (env.info_episode_length) env.info_episode_length[e] = ep_len;
+#ifndef SL_TRACE
             if (reward_t) reward_t[(size_t)t * B + e] = reward;
             if (done_t) done_t[(size_t)t * B + e] = done;
+#endif
         }
         // on-device auto-reset (training/base_algo.py:231-236 calls env.reset() after a done step)
         if (env.auto_reset && __ballot(leader && done)) {
@@ -668,7 +719,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_ba
                     board16[i] = pb[i];
                     gdst[i] = pg[i];
                 }
-                lut_base = (u32)env.pool_table_idx[level] << 16;
+                lut_base = (u32)env.pool_table_idx[level] * (u32)SCORE_LUT_BYTES;
                 p = (double)env.pool_spawn_prob[level];
                 gstatic = 0;
                 if (r < 4) rng_lds[4 * g + r] = ((const u64 *)(env.pool_rng + level))[r];
@@ -680,17 +731,20 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_ba
             if (mine) {
                 read_row<H, W>(goals, gb, r, b);
 #pragma unroll
-                for (int k = 0; k < WS; ++k) gsh[k] = goal_shift(b[k]);
-                read_row<H, W>(board, gb, r, n);
+                for (int k = 0; k < WS; ++k) gsh_lane[k] = goal_shift(b[k]);
+                read_row<H, W>(board, gb, r, b);
             }
-            const int s0 = group_total<H, Gm::G>(mine ? row_score<H, W>(n, gsh, lut, lut_base, cell_mask) : 0, live ? g : 0);
+            const int s0 = group_total<H, Gm::G>(
+                mine ? row_score<H, W, LDS_LUT>(b, gsh_lane, lut, lut_base, lds_lut, cell_mask, c100) : 0,
+                live ? g : 0);
             if (mine && r == 0) {
                 episodes += 1;
                 exits = env.pool_exit_locs + (size_t)level * E;   // never written by this launch
+                exit0 = exits[0];
                 ly = env.pool_agent_loc[2 * level];
                 lx = env.pool_agent_loc[2 * level + 1];
                 initial = env.pool_initial_points[level];
-                recolor_exits_lds(board16, W, ly, lx, exits, E, s0, initial, env.pool_required_reset[level],
+                recolor_exits_lds(board16, W, ly, lx, exits, exit0, E, s0, initial, env.pool_required_reset[level],
                                   env.exit_points);
                 const int exited = ly >= 0 ? (has_exited(board16[ly * W + lx]) ? 1 : 0) : 0;
                 old_value = s0 + env.exit_points * exited;
@@ -704,10 +758,11 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_ba
         }
     }
 
+    SL_STAMP(7);
     // write-back
     if (leader) {
         env.goals_static[e] = (uint8_t)gstatic;
-        env.table_idx[e] = (int)(lut_base >> 16);
+        env.table_idx[e] = (int)(lut_base / (u32)SCORE_LUT_BYTES);
         env.spawn_prob[e] = (float)p;
         env.level_idx[e] = level;
         env.agent_loc[2 * e] = ly;
@@ -722,11 +777,13 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_ba
         env.episode_idx[e] = episodes;
     }
     const int dirty = __syncthreads_or(goals_dirty);
+    SL_STAMP(8);
     store_span<H, W>(env.board + (size_t)e0b * HW, board, nbb, tid);
     if (dirty) store_span<H, W>(env.goals + (size_t)e0b * HW, goals, nbb, tid);
     if (lane < 4 * Gm::G && wave * Gm::G + (lane >> 2) < nbb)
         ((u64 *)(env.rng + e0b + wave * Gm::G))[lane] = rng_lds[lane];
 
+    SL_STAMP(9);
     // observation (safelife_env.py:105-146) from the LDS images, one wave per G boards
     if (env.obs) {
         const int vh = env.view_h, vw = env.view_w, C = env.n_channels, nv = vh * vw;
@@ -777,10 +834,20 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_ba
 
 __global__ void k_build_score_lut(const int32_t *__restrict__ points_table, int n_tables, int8_t *__restrict__ lut) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_tables * 65536) return;
-    const int t = i >> 16, idx = i & 0xFFFF;
+    if (i >= n_tables * SCORE_LUT_BYTES) return;
+    const int t = i / SCORE_LUT_BYTES, j = i - t * SCORE_LUT_BYTES;
+    int idx;                       // decoded to the wide index: pullable on bit 15
+    bool valid;
+    if (j < 4096) {                // compact form: pullable on bit 8
+        idx = (j & 0x0EFF) | ((j & 0x100) << 7);
+        idx &= ~0x100;
+        valid = (j & ~0x0FFD) == 0;
+    } else {
+        idx = j - 4096;
+        valid = (idx & ~0x8EFD) == 0;
+    }
     int v = 0;
-    if ((idx & ~0x8EFD) == 0) {           // only the bit combinations a masked cell | goal can produce
+    if (valid) {
         const bool alive = idx & 1, pushable = idx & 4, destr = idx & 8, frozen = idx & 16, pullable = idx & 0x8000;
         const int gc = (idx >> 5) & 7, col = (idx >> 9) & 7;
         const bool excluded = frozen && !(pullable || pushable || destr);
@@ -794,9 +861,9 @@ static hipError_t launch_advance_t(const u16 *in, u16 *out, int B, const float *
                                    sl_pcg64 *rng, const Jump *jump, hipStream_t stream) {
     using Gm = Geom<H, W>;
     auto fn = k_advance_rowlane<H, W>;
-    hipError_t err = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, Gm::LDS_BYTES);
+    hipError_t err = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, Gm::LDS_ADVANCE);
     if (err != hipSuccess) return err;
-    hipLaunchKernelGGL(fn, dim3((B + Gm::NB - 1) / Gm::NB), dim3(64 * WAVES), Gm::LDS_BYTES, stream, in, out, B,
+    hipLaunchKernelGGL(fn, dim3((B + Gm::NB - 1) / Gm::NB), dim3(64 * WAVES), Gm::LDS_ADVANCE, stream, in, out, B,
                        spawn_prob, n_steps, rng, jump);
     return hipGetLastError();
 }
@@ -805,7 +872,7 @@ template <int H, int W>
 static hipError_t launch_rollout_t(const sl_env_batch &env, const int32_t *actions, int T, float *reward_t,
                                    uint8_t *done_t, const Jump *jump, hipStream_t stream) {
     using Gm = Geom<H, W>;
-    auto fn = k_env_rollout_rowlane<H, W>;
+    auto fn = env.n_tables == 1 ? k_env_rollout_rowlane<H, W, true> : k_env_rollout_rowlane<H, W, false>;
     hipError_t err = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, Gm::LDS_BYTES);
     if (err != hipSuccess) return err;
     hipLaunchKernelGGL(fn, dim3((env.B + Gm::NB - 1) / Gm::NB), dim3(64 * WAVES), Gm::LDS_BYTES, stream, env,
@@ -825,7 +892,7 @@ bool rowlane_supports(int H, int W) {
 }
 
 hipError_t launch_build_score_lut(const int32_t *points_table, int n_tables, int8_t *lut, hipStream_t stream) {
-    const int n = n_tables * 65536;
+    const int n = n_tables * rl::SCORE_LUT_BYTES;
     hipLaunchKernelGGL(rl::k_build_score_lut, dim3((n + 255) / 256), dim3(256), 0, stream, points_table, n_tables, lut);
     return hipGetLastError();
 }

@@ -107,7 +107,7 @@ class SafeLifeVectorEnv(object):
         for i, c in enumerate(chans):
             s.channels[i] = int(c)
         s.L, s.level_stride = len(pool), int(level_stride)
-        t["score_lut"] = torch.zeros((s.n_tables, 65536), dtype=torch.int8, device=dev)
+        t["score_lut"] = torch.zeros((s.n_tables, 4096 + 65536), dtype=torch.int8, device=dev)
         for name in _hip.ENV_STATE_PTRS + _hip.ENV_POOL_PTRS + _hip.ENV_OUT_PTRS:
             if name == "obs":
                 s.obs = None if self.obs is None else self.obs.data_ptr()
