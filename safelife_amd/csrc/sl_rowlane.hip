@@ -36,7 +36,7 @@ constexpr int WAVES = 4;
 #ifdef SL_TRACE
 #define SL_STAMP(i)                                                                     \
     do {                                                                                \
-        if (threadIdx.x == 0 && reward_t) ((long long *)reward_t)[blockIdx.x * 16 + (i)] = (long long)__builtin_readcyclecounter(); \
+        if (threadIdx.x == 0 && reward_t) ((long long *)reward_t)[blockIdx.x * 16 + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); \
     } while (0)
 #else
 #define SL_STAMP(i) do {} while (0)
@@ -604,7 +604,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_ba
     }
     if (lane < 4 * Gm::G && wave * Gm::G + (lane >> 2) < nbb)
         rng_lds[lane] = ((const u64 *)(env.rng + e0b + wave * Gm::G))[lane];
-    if (LDS_LUT) ((u32x4 *)(smem + Gm::OFF_LUT))[tid] = ((const u32x4 *)env.score_lut)[tid];   // 256 x 16 B
+    if (LDS_LUT && tid < 256) ((u32x4 *)(smem + Gm::OFF_LUT))[tid] = ((const u32x4 *)env.score_lut)[tid];   // 256 x 16 B
     load_span<H, W>(env.board + (size_t)e0b * HW, board, nbb, tid);
     load_span<H, W>(env.goals + (size_t)e0b * HW, goals, nbb, tid);
     SL_STAMP(1);
