@@ -1,0 +1,150 @@
+"""
+``SafeLifeEnv`` look-alike (compat tier): the reference's gym surface, one env per object, driven by
+any iterator of ``SafeLifeGame`` objects (safelife/safelife_env.py:13-218).  Observation, reward,
+done and the ``info`` dict are produced exactly as the reference produces them; the physics calls go
+to the GPU through ``safelife_amd.speedups``.
+
+``gym`` is optional: without it ``action_space`` / ``observation_space`` are small stand-ins with the
+same attributes (n / shape / dtype / low / high).
+
+Side-effect scores (``should_calculate_side_effects``) need pyemd's earth-mover distance, which is
+outside the hot path; the occupancy tensors they are built from are available
+as ``safelife_amd.side_effects.occupancy_pair``.  The default here is therefore False.
+"""
+import numpy as np
+
+from .cell_types import CellTypes
+from .levels import SafeLifeLevelIterator
+
+try:                                                  # pragma: no cover - gym is not in this image
+    from gym import Env as _Env, spaces as _spaces
+except ImportError:
+    class _Env(object):
+        pass
+
+    class _Space(object):
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+
+    class _spaces(object):
+        @staticmethod
+        def Discrete(n):
+            return _Space(n=n, shape=(), dtype=np.int64)
+
+        @staticmethod
+        def Box(low, high, shape, dtype):
+            return _Space(low=low, high=high, shape=tuple(shape), dtype=np.dtype(dtype))
+
+
+def recenter_view(board, view_size, center, move_to_perimeter=None):
+    """Toroidal crop centred on `center`; cells of `move_to_perimeter` that fall outside the view are
+    painted on its border (safelife/helper_utils.py:42-75)."""
+    h, w = view_size
+    bh, bw = board.shape
+    y0, x0 = center
+    rows = (np.arange(h) + y0 - h // 2) % bh
+    cols = (np.arange(w) + x0 - w // 2) % bw
+    view = board[np.ix_(rows, cols)]
+    if move_to_perimeter is not None:
+        iy, ix = move_to_perimeter
+        jy = (iy - y0 + bh // 2) % bh - bh // 2
+        jx = (ix - x0 + bw // 2) % bw - bw // 2
+        jy = np.clip(jy + h // 2, 0, h - 1)
+        jx = np.clip(jx + w // 2, 0, w - 1)
+        view[jy, jx] = board[iy, ix]
+    return view
+
+
+class SafeLifeEnv(_Env):
+    game = None
+    single_agent = True
+    time_limit = 1000
+    remove_white_goals = True
+    view_shape = (15, 15)
+    output_channels = tuple(range(16)) + (25, 26, 27)
+    side_effect_weights = None
+    should_calculate_side_effects = False
+
+    def __init__(self, level_iterator, **kwargs):
+        if isinstance(level_iterator, str):
+            level_iterator = SafeLifeLevelIterator(level_iterator)
+        self.level_iterator = level_iterator
+        for key, val in kwargs.items():
+            if key.startswith("_") or not hasattr(self, key) or callable(getattr(self, key)):
+                raise ValueError("Unrecognized parameter: '%s'" % (key,))
+            setattr(self, key, val)
+        self.action_space = _spaces.Discrete(9)
+        if self.output_channels is None:
+            self.observation_space = _spaces.Box(low=0, high=2**15, shape=self.view_shape, dtype=np.uint32)
+        else:
+            self.observation_space = _spaces.Box(
+                low=0, high=1, shape=tuple(self.view_shape) + (len(self.output_channels),), dtype=np.uint8)
+
+    def get_obs(self, board=None, goals=None, agent_locs=None):
+        board = self.game.board if board is None else board
+        goals = self.game.goals if goals is None else goals
+        agent_locs = self.game.agent_locs if agent_locs is None else agent_locs
+        if self.single_agent:
+            agent_locs = agent_locs[:1] if len(agent_locs) > 0 else np.array([[0, 0]])
+        word = board.astype(np.uint32)
+        colors = goals & CellTypes.rainbow_color
+        if self.remove_white_goals:
+            colors = colors * (colors != CellTypes.rainbow_color)
+        word = word + (colors.astype(np.uint32) << 16)
+        views = np.stack([recenter_view(word, self.view_shape, loc, self.game.exit_locs) for loc in agent_locs])
+        if self.output_channels:
+            shift = np.array(list(self.output_channels), dtype=np.uint32)
+            views = ((views[..., None] & (np.uint32(1) << shift)) >> shift).astype(np.uint8)
+        return views[0] if self.single_agent else views
+
+    def step(self, actions):
+        assert self.game is not None, "Game state is not initialized."
+        self.game.execute_actions(actions)
+        self.game.advance_board()
+        self.game.update_exit_colors()
+
+        times_up = self.game.num_steps >= self.time_limit
+        new_game_value = self.game.current_points()
+        reward = (new_game_value - self._old_game_value) * self._is_active
+        self._old_game_value = new_game_value
+        success = self.game.has_exited()
+        done = ~self.game.agent_is_active() | times_up
+        if self.single_agent:
+            if len(reward) == 0:
+                reward, done, success = 0, True, False
+            else:
+                reward, done, success = reward[0], done[0], success[0]
+        reward = np.float32(reward)
+        self.episode_reward += reward
+        self.episode_length += self._is_active
+        self._is_active &= ~done
+        episode_info = {"length": self.episode_length, "reward": self.episode_reward, "success": success}
+        if self.side_effects is not None:
+            episode_info["side_effects"] = self.side_effects
+        return self.get_obs(), reward, done, {
+            "board": self.game.board,
+            "goals": self.game.goals,
+            "agent_locs": self.game.agent_locs,
+            "times_up": times_up,
+            "episode": episode_info,
+        }
+
+    def reset(self):
+        self.game = next(self.level_iterator)
+        self.game.revert()
+        self.game.update_exit_colors()
+        self._old_game_value = self.game.current_points()
+        if self.single_agent:
+            self._is_active = True
+            self.episode_length = 0
+            self.episode_reward = 0
+        else:
+            num_agents = len(self.game.agent_locs)
+            self._is_active = np.ones(num_agents, dtype=bool)
+            self.episode_length = np.zeros(num_agents, dtype=int)
+            self.episode_reward = np.zeros(num_agents, dtype=np.float32)
+        self.side_effects = None
+        return self.get_obs()
+
+    def close(self):
+        pass

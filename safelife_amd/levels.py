@@ -58,6 +58,12 @@ class Level(object):
         mask = (self.board & (CellTypes.exit | CellTypes.agent)) == CellTypes.exit
         return np.flatnonzero(mask).astype(np.int32)
 
+    def as_data(self):
+        """dict in the reference's serialised form (safelife_game.py:200-209,615-620)."""
+        return {"board": self.board.copy(), "goals": self.goals.copy(), "agent_locs": self.agent_locs.copy(),
+                "spawn_prob": self.spawn_prob, "min_performance": self.min_performance,
+                "points_table": self.points_table.copy()}
+
     def initial_rng_words(self):
         """PCG64 words of ``np.random.default_rng(seed)`` (safelife_game.py:175-180)."""
         if self.rng_words is not None:
@@ -107,6 +113,43 @@ def load_levels(path):
         else:
             out.append(Level.from_data({k: data[k] for k in data.files}, name=path))
     return out
+
+
+class SafeLifeLevelIterator(object):
+    """Yields ``SafeLifeGame`` objects from ``.npz`` level files / archives, each with its own child
+    of the iterator's SeedSequence (the static-file half of the reference's iterator,
+    level_iterator.py:148-266).  Procedural generation (``.yaml`` specs) is outside the hot path: feed
+    generated levels as files, or use ``LevelPool`` for the device-resident environments."""
+
+    def __init__(self, *paths, repeat_levels=False, seed=None):
+        self.levels = []
+        for path in paths:
+            for lv in load_levels(path):
+                self.levels.append(lv)
+        if not self.levels:
+            raise FileNotFoundError("No levels found for %r" % (paths,))
+        self.repeat_levels = repeat_levels
+        self.idx = 0
+        self.seed(seed)
+
+    def seed(self, seed):
+        if not isinstance(seed, np.random.SeedSequence):
+            seed = np.random.SeedSequence(seed)
+        self._seed = seed
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        from .game import SafeLifeGame
+        if self.idx >= len(self.levels) and not self.repeat_levels:
+            raise StopIteration
+        lv = self.levels[self.idx % len(self.levels)]
+        self.idx += 1
+        game = SafeLifeGame.loaddata(lv.as_data())
+        game.file_name = lv.name
+        game.seed = self._seed.spawn(1)[0]
+        return game
 
 
 def _device_counts(boards, goals):

@@ -273,3 +273,53 @@ def test_full_size_env_checksum_vs_oracle():
         assert np.array_equal(r1, cpu.get("reward")) and np.array_equal(d1, cpu.get("done")), t
     assert np.array_equal(dev.get("board"), cpu.get("board"))
     assert np.array_equal(dev.get("obs"), cpu.env.obs)
+
+
+# ------------------------------------------------------------------ compat tier (one env at a time)
+
+def _compat_games(tr):
+    from safelife_amd.game import SafeLifeGame
+    games = []
+    for lv in util.levels_from_trace(tr):
+        game = SafeLifeGame.loaddata(lv.as_data())
+        bg = np.random.PCG64(0)
+        oracle.pcg64_set_state_words(bg, lv.rng_words)
+        game._rng = np.random.Generator(bg)
+        games.append(game)
+    return games
+
+
+@pytest.mark.parametrize("name", ["c1_append_still_1", "append_still_1_chan19", "v01_append-stochastic-1",
+                                  "ex_sokuban", "ex_containment", "v10_prune-still_open", "v10_append-dynamic",
+                                  "worked_7x7_exit", "pattern_glider_noagent", "view33_prune_still_2"])
+def test_compat_env_trace(name):
+    """safelife_amd.env.SafeLifeEnv + game.SafeLifeGame (reference-shaped classes over the GPU
+    speedups) reproduce the reference's own SafeLifeEnv step for step, info dict included."""
+    from safelife_amd.env import SafeLifeEnv
+    tr = util.load_trace(name)
+    kw = util.env_kwargs_from_trace(tr)
+    env = SafeLifeEnv(iter(_compat_games(tr)), **kw)
+    obs = env.reset()
+    assert np.array_equal(obs, tr["trace_reset_obs"][0])
+    episode = 0
+    T = min(len(tr["trace_reward"]), 400)
+    for t in range(T):
+        obs, reward, done, info = env.step(int(tr["trace_actions"][t]))
+        where = "step %d" % t
+        assert isinstance(reward, np.float32) and reward == tr["trace_reward"][t], where
+        assert bool(done) == bool(tr["trace_done"][t]), where
+        assert np.array_equal(obs, tr["trace_obs"][t]), where
+        assert np.array_equal(info["board"], tr["trace_board"][t]), where
+        assert np.array_equal(info["goals"], tr["trace_goals"][t]), where
+        assert bool(info["times_up"]) == bool(tr["trace_times_up"][t]), where
+        assert int(info["episode"]["length"]) == int(tr["trace_ep_length"][t]), where
+        assert info["episode"]["reward"] == tr["trace_ep_reward"][t], where
+        assert bool(info["episode"]["success"]) == bool(tr["trace_success"][t]), where
+        if len(info["agent_locs"]):
+            assert np.array_equal(info["agent_locs"][0], tr["trace_agent_loc"][t]), where
+        if done:
+            episode += 1
+            if episode >= len(tr["trace_reset_at"]):
+                break
+            obs = env.reset()
+            assert np.array_equal(obs, tr["trace_reset_obs"][episode]), where
