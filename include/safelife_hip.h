@@ -86,6 +86,48 @@ int slhip_execute_actions(uint16_t *board, int B, int H, int W, int64_t *locs,
  * the observation of safelife_env.py:105-146 / helper_utils.py:42-75).
  * The struct lives on the HOST; every pointer inside is a device pointer.
  * ------------------------------------------------------------------------------------------ */
+/* Per-env scalar state: one 64-byte record per env (a single wide load/store per step instead of a
+ * dozen strided ones).  Field <-> reference attribute: */
+typedef struct sl_env_scalars {
+    int32_t agent_row, agent_col; /* SafeLifeGame.agent_locs[0] (row, col); row < 0 => no agent */
+    int32_t num_steps;            /* GameState.num_steps */
+    int32_t old_value;            /* SafeLifeEnv._old_game_value */
+    int32_t required_points;      /* GameWithGoals.required_points() */
+    int32_t initial_points;       /* sum(points_table * initial_counts) */
+    int32_t table_idx;            /* row of points_table used by this env */
+    int32_t level_idx;            /* pool level currently loaded */
+    int32_t episode_idx;          /* episodes finished by this env */
+    int32_t episode_length;       /* SafeLifeEnv.episode_length */
+    float episode_reward;         /* SafeLifeEnv.episode_reward */
+    float spawn_prob;             /* GameState.spawn_prob */
+    int32_t goals_static;         /* SafeLifeGame._static_goals: 0 None, 1 True, 2 False */
+    int32_t is_active;            /* SafeLifeEnv._is_active */
+    int32_t reserved[2];
+} sl_env_scalars;
+
+/* What one step() returns per env besides the observation (16 bytes). */
+typedef struct sl_step_out {
+    float reward;                 /* np.float32 reward of safelife_env.py:157,172 */
+    uint8_t done;
+    uint8_t success;              /* info['episode']['success'] */
+    uint8_t times_up;             /* info['times_up'] */
+    uint8_t reserved;
+    float episode_reward;         /* info['episode']['reward'] (before any auto-reset) */
+    int32_t episode_length;       /* info['episode']['length'] */
+} sl_step_out;
+
+/* Per-level constants of the pool (32 bytes). */
+typedef struct sl_level_scalars {
+    int32_t agent_row, agent_col;
+    int32_t required_reset;       /* required_points while resetting (first observation) */
+    int32_t required_step;        /* required_points for the steps that follow (differs under
+                                     MinPerformanceScheduler, env_wrappers.py:142-145) */
+    int32_t initial_points;
+    int32_t table_idx;
+    float spawn_prob;
+    int32_t reserved;
+} sl_level_scalars;
+
 typedef struct sl_env_batch {
     int32_t B, H, W, E;          /* envs; board dims; exit slots per env (>= 1) */
     int32_t time_limit;          /* SafeLifeEnv.time_limit (safelife_env.py:65) */
@@ -99,43 +141,20 @@ typedef struct sl_env_batch {
     /* per-env state */
     uint16_t *board;             /* [B,H,W] */
     uint16_t *goals;             /* [B,H,W] */
-    int32_t *agent_loc;          /* [B,2] (row, col); row < 0 => level without agent */
     int32_t *exit_locs;          /* [B,E] flat cell index of GameState.exit_locs, -1 = unused */
     sl_pcg64 *rng;               /* [B] SafeLifeGame._rng */
-    float *spawn_prob;           /* [B] */
-    int32_t *num_steps;          /* [B] */
-    int32_t *old_value;          /* [B] SafeLifeEnv._old_game_value */
-    int32_t *required_points;    /* [B] GameWithGoals.required_points() */
-    int32_t *initial_points;     /* [B] sum(points_table * initial_counts) */
-    int32_t *table_idx;          /* [B] row of points_table used by this env */
-    uint8_t *goals_static;       /* [B] SafeLifeGame._static_goals: 0 None, 1 True, 2 False */
-    uint8_t *is_active;          /* [B] SafeLifeEnv._is_active */
-    float *episode_reward;       /* [B] */
-    int32_t *episode_length;     /* [B] */
-    int32_t *level_idx;          /* [B] pool level currently loaded */
-    int32_t *episode_idx;        /* [B] episodes finished by this env */
+    sl_env_scalars *scalars;     /* [B] */
     const int32_t *points_table; /* [n_tables,8,9] (safelife_game.py:595-605) */
     /* level pool: the device-resident counterpart of SafeLifeLevelIterator */
     int32_t L;
     int32_t level_stride;        /* next level of an env = (level_idx + level_stride) % L */
     const uint16_t *pool_board;  /* [L,H,W] as loaded (before update_exit_colors) */
     const uint16_t *pool_goals;  /* [L,H,W] */
-    const int32_t *pool_agent_loc;      /* [L,2] */
     const int32_t *pool_exit_locs;      /* [L,E] */
     const sl_pcg64 *pool_rng;           /* [L] */
-    const float *pool_spawn_prob;       /* [L] */
-    const int32_t *pool_required_reset; /* [L] required_points during reset() */
-    const int32_t *pool_required_step;  /* [L] required_points for the steps that follow
-                                           (differs under MinPerformanceScheduler, env_wrappers.py:142-145) */
-    const int32_t *pool_initial_points; /* [L] */
-    const int32_t *pool_table_idx;      /* [L] */
+    const sl_level_scalars *pool_scalars; /* [L] */
     /* per-step outputs */
-    float *reward;               /* [B] np.float32 reward of safelife_env.py:157,172 */
-    uint8_t *done;               /* [B] */
-    uint8_t *success;            /* [B] info['episode']['success'] */
-    uint8_t *times_up;           /* [B] info['times_up'] */
-    float *info_episode_reward;  /* [B] info['episode']['reward'] (value before any auto-reset) */
-    int32_t *info_episode_length;/* [B] info['episode']['length'] */
+    sl_step_out *out;            /* [B] */
     uint8_t *obs;                /* [B,vh,vw,C] uint8, or uint32 [B,vh,vw] if n_channels == 0; NULL = skip */
     /* workspace */
     int8_t *score_lut;           /* [n_tables,4096+65536] per-cell score tables derived from points_table by

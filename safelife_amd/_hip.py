@@ -34,18 +34,21 @@ class Pcg64(C.Structure):
 
 _p = C.c_void_p
 
-#: (field name, is-pointer) in the exact order of `struct sl_env_batch`
+#: field names of `struct sl_env_batch`, in order
 ENV_SCALARS_HEAD = ("B", "H", "W", "E", "time_limit", "exit_points", "n_tables", "auto_reset",
                     "remove_white_goals", "view_h", "view_w", "n_channels")
-ENV_STATE_PTRS = ("board", "goals", "agent_loc", "exit_locs", "rng", "spawn_prob", "num_steps",
-                  "old_value", "required_points", "initial_points", "table_idx", "goals_static",
-                  "is_active", "episode_reward", "episode_length", "level_idx", "episode_idx",
-                  "points_table")
-ENV_POOL_PTRS = ("pool_board", "pool_goals", "pool_agent_loc", "pool_exit_locs", "pool_rng",
-                 "pool_spawn_prob", "pool_required_reset", "pool_required_step",
-                 "pool_initial_points", "pool_table_idx")
-ENV_OUT_PTRS = ("reward", "done", "success", "times_up", "info_episode_reward",
-                "info_episode_length", "obs", "score_lut")
+ENV_STATE_PTRS = ("board", "goals", "exit_locs", "rng", "scalars", "points_table")
+ENV_POOL_PTRS = ("pool_board", "pool_goals", "pool_exit_locs", "pool_rng", "pool_scalars")
+ENV_OUT_PTRS = ("out", "obs", "score_lut")
+
+#: int32 column of each field inside `struct sl_env_scalars` (64 bytes = 16 columns)
+SCALAR_COLS = {"agent_row": 0, "agent_col": 1, "num_steps": 2, "old_value": 3, "required_points": 4,
+               "initial_points": 5, "table_idx": 6, "level_idx": 7, "episode_idx": 8, "episode_length": 9,
+               "episode_reward": 10, "spawn_prob": 11, "goals_static": 12, "is_active": 13}
+SCALAR_FLOATS = ("episode_reward", "spawn_prob")
+#: `struct sl_level_scalars` (32 bytes = 8 columns)
+LEVEL_COLS = {"agent_row": 0, "agent_col": 1, "required_reset": 2, "required_step": 3, "initial_points": 4,
+              "table_idx": 5, "spawn_prob": 6}
 
 
 class EnvBatch(C.Structure):

@@ -85,14 +85,9 @@ int check_env(const sl_env_batch *env) {
     if (env->n_channels < 0 || env->n_channels > SL_MAX_CHANNELS) return fail(SL_E_ARG, "bad n_channels");
     if (env->view_h < 1 || env->view_w < 1) return fail(SL_E_ARG, "bad view shape");
     if (env->L < 1 || env->n_tables < 1) return fail(SL_E_ARG, "empty level pool or points table");
-    const void *need[] = {env->board, env->goals, env->agent_loc, env->exit_locs, env->rng, env->spawn_prob,
-                          env->num_steps, env->old_value, env->required_points, env->initial_points,
-                          env->table_idx, env->goals_static, env->is_active, env->episode_reward,
-                          env->episode_length, env->level_idx, env->episode_idx, env->points_table,
-                          env->pool_board, env->pool_goals, env->pool_agent_loc, env->pool_exit_locs,
-                          env->pool_rng, env->pool_spawn_prob, env->pool_required_reset,
-                          env->pool_required_step, env->pool_initial_points, env->pool_table_idx,
-                          env->reward, env->done, env->success, env->times_up};
+    const void *need[] = {env->board, env->goals, env->exit_locs, env->rng, env->scalars, env->points_table,
+                          env->pool_board, env->pool_goals, env->pool_exit_locs, env->pool_rng,
+                          env->pool_scalars, env->out};
     for (const void *p : need)
         if (!p) return fail(SL_E_ARG, "null pointer in sl_env_batch");
     return SL_OK;

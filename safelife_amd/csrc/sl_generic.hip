@@ -276,7 +276,9 @@ __device__ void write_obs(const sl_env_batch &env, int e, const u16 *board, cons
 // ivar[0..1] receives the agent location.  All threads participate.
 __device__ void reset_block(const sl_env_batch &env, int e, u16 *brd, int *ivar, int *wave_tot) {
     const int HW = env.H * env.W, tid = threadIdx.x, E = env.E;
-    const int l = env.level_idx[e];
+    sl_env_scalars *sc = env.scalars + e;
+    const int l = sc->level_idx;
+    const sl_level_scalars lv = env.pool_scalars[l];
     const u16 *pb = env.pool_board + (size_t)l * HW, *pg = env.pool_goals + (size_t)l * HW;
     u16 *gdst = env.goals + (size_t)e * HW;
     for (int i = tid; i < HW; i += GB) {
@@ -285,29 +287,34 @@ __device__ void reset_block(const sl_env_batch &env, int e, u16 *brd, int *ivar,
     }
     for (int k = tid; k < E; k += GB) env.exit_locs[(size_t)e * E + k] = env.pool_exit_locs[(size_t)l * E + k];
     if (tid == 0) {
-        ivar[0] = env.pool_agent_loc[2 * l];
-        ivar[1] = env.pool_agent_loc[2 * l + 1];
+        ivar[0] = lv.agent_row;
+        ivar[1] = lv.agent_col;
         env.rng[e] = env.pool_rng[l];
-        env.spawn_prob[e] = env.pool_spawn_prob[l];
-        env.table_idx[e] = env.pool_table_idx[l];
-        env.initial_points[e] = env.pool_initial_points[l];
-        env.required_points[e] = env.pool_required_step[l];
-        env.num_steps[e] = 0;
-        env.goals_static[e] = 0;
-        env.is_active[e] = 1;
-        env.episode_reward[e] = 0.0f;
-        env.episode_length[e] = 0;
     }
     __syncthreads();
-    const int32_t *table = env.points_table + 72 * env.pool_table_idx[l];
+    const int32_t *table = env.points_table + 72 * lv.table_idx;
     int score = board_score(brd, pg, HW, table, wave_tot);
     if (tid == 0) {
         recolor_exits(brd, env.W, ivar[0], ivar[1], env.pool_exit_locs + (size_t)l * E, E, score,
-                      env.pool_initial_points[l], env.pool_required_reset[l], env.exit_points);
+                      lv.initial_points, lv.required_reset, env.exit_points);
         int exited = ivar[0] >= 0 ? (has_exited(brd[ivar[0] * env.W + ivar[1]]) ? 1 : 0) : 0;
-        env.old_value[e] = score + env.exit_points * exited;
-        env.agent_loc[2 * e] = ivar[0];
-        env.agent_loc[2 * e + 1] = ivar[1];
+        sl_env_scalars n;
+        n.agent_row = ivar[0];
+        n.agent_col = ivar[1];
+        n.num_steps = 0;
+        n.old_value = score + env.exit_points * exited;
+        n.required_points = lv.required_step;
+        n.initial_points = lv.initial_points;
+        n.table_idx = lv.table_idx;
+        n.level_idx = l;
+        n.episode_idx = sc->episode_idx;
+        n.episode_length = 0;
+        n.episode_reward = 0.0f;
+        n.spawn_prob = lv.spawn_prob;
+        n.goals_static = 0;
+        n.is_active = 1;
+        n.reserved[0] = n.reserved[1] = 0;
+        *sc = n;
     }
     __syncthreads();
 }
@@ -324,17 +331,18 @@ __global__ __launch_bounds__(GB) void k_env_rollout_generic(sl_env_batch env,
     const int e = blockIdx.x, tid = threadIdx.x;
     GenericLds l = carve(smem, HW, 4);
     u16 *cur = l.buf[0], *rows = l.buf[1], *nxt = l.buf[2], *aux = l.buf[3];
-    int *ivar = l.ivar;   // [0],[1] agent loc; [2] done flag; [3] goals-static verdict
+    int *ivar = l.ivar;   // [0],[1] agent loc; [2] done flag
     u16 *gboard = env.board + (size_t)e * HW;
     u16 *ggoals = env.goals + (size_t)e * HW;
+    sl_env_scalars *sc = env.scalars + e;
     const int32_t *exits = env.exit_locs + (size_t)e * E;
     const float inv_w = 1.0f / (float)W;
 
     for (int i = tid; i < HW; i += GB) cur[i] = gboard[i];
     if (tid < 4) l.rng[tid] = ((const u64 *)(env.rng + e))[tid];
     if (tid == 0) {
-        ivar[0] = env.agent_loc[2 * e];
-        ivar[1] = env.agent_loc[2 * e + 1];
+        ivar[0] = sc->agent_row;
+        ivar[1] = sc->agent_col;
     }
     __syncthreads();
 
@@ -343,10 +351,10 @@ __global__ __launch_bounds__(GB) void k_env_rollout_generic(sl_env_batch env,
         if (tid == 0 && ivar[0] >= 0) act_one<int>(cur, H, W, ivar, actions[(size_t)t * env.B + e]);
         __syncthreads();
         // safelife_env.py:152  game.advance_board (board, then goals unless static)
-        const double p = (double)env.spawn_prob[e];
+        const double p = (double)sc->spawn_prob;
         ca_step_block(cur, rows, nxt, H, W, inv_w, p, l.rng, jump, l.wave_tot);
         const u16 *goals = ggoals;
-        const int gstatic = env.goals_static[e];
+        const int gstatic = sc->goals_static;
         if (gstatic != 1) {
             for (int i = tid; i < HW; i += GB) cur[i] = ggoals[i];
             __syncthreads();
@@ -358,41 +366,44 @@ __global__ __launch_bounds__(GB) void k_env_rollout_generic(sl_env_batch env,
                 ggoals[i] = g;
             }
             changed = __syncthreads_or(changed);
-            if (tid == 0 && gstatic == 0) env.goals_static[e] = changed ? 2 : 1;
+            if (tid == 0 && gstatic == 0) sc->goals_static = changed ? 2 : 1;
             goals = aux;
         }
         // safelife_env.py:153-160
-        const int32_t *table = env.points_table + 72 * env.table_idx[e];
+        const int32_t *table = env.points_table + 72 * sc->table_idx;
         int score = board_score(nxt, goals, HW, table, l.wave_tot);
         if (tid == 0) {
-            recolor_exits(nxt, W, ivar[0], ivar[1], exits, E, score, env.initial_points[e],
-                          env.required_points[e], env.exit_points);
-            int steps = env.num_steps[e] + 1;
-            env.num_steps[e] = steps;
+            recolor_exits(nxt, W, ivar[0], ivar[1], exits, E, score, sc->initial_points, sc->required_points,
+                          env.exit_points);
+            int steps = sc->num_steps + 1;
+            sc->num_steps = steps;
             bool times_up = steps >= env.time_limit;
             float reward = 0.0f;
             bool done = true, success = false;
-            bool active = env.is_active[e] != 0;
+            bool active = sc->is_active != 0;
             if (ivar[0] >= 0) {
                 u32 cell = nxt[ivar[0] * W + ivar[1]];
                 success = has_exited(cell);
                 int value = score + env.exit_points * (success ? 1 : 0);
-                reward = (float)((value - env.old_value[e]) * (active ? 1 : 0));
-                env.old_value[e] = value;
+                reward = (float)((value - sc->old_value) * (active ? 1 : 0));
+                sc->old_value = value;
                 done = !(cell & AGENT) || times_up;
             }
             // safelife_env.py:172-175
-            float ep_r = env.episode_reward[e] + reward;
-            int ep_l = env.episode_length[e] + (active ? 1 : 0);
-            env.episode_reward[e] = ep_r;
-            env.episode_length[e] = ep_l;
-            env.is_active[e] = (active && !done) ? 1 : 0;
-            env.reward[e] = reward;
-            env.done[e] = done;
-            env.success[e] = success;
-            env.times_up[e] = times_up;
-            if (env.info_episode_reward) env.info_episode_reward[e] = ep_r;
-            if (env.info_episode_length) env.info_episode_length[e] = ep_l;
+            float ep_r = sc->episode_reward + reward;
+            int ep_l = sc->episode_length + (active ? 1 : 0);
+            sc->episode_reward = ep_r;
+            sc->episode_length = ep_l;
+            sc->is_active = (active && !done) ? 1 : 0;
+            sl_step_out o;
+            o.reward = reward;
+            o.done = done;
+            o.success = success;
+            o.times_up = times_up;
+            o.reserved = 0;
+            o.episode_reward = ep_r;
+            o.episode_length = ep_l;
+            env.out[e] = o;
             if (reward_t) reward_t[(size_t)t * env.B + e] = reward;
             if (done_t) done_t[(size_t)t * env.B + e] = done;
             ivar[2] = done;
@@ -403,8 +414,8 @@ __global__ __launch_bounds__(GB) void k_env_rollout_generic(sl_env_batch env,
         nxt = sw;
         if (env.auto_reset && ivar[2]) {
             if (tid == 0) {
-                env.level_idx[e] = (env.level_idx[e] + env.level_stride) % env.L;
-                env.episode_idx[e] += 1;
+                sc->level_idx = (sc->level_idx + env.level_stride) % env.L;
+                sc->episode_idx += 1;
             }
             __syncthreads();
             reset_block(env, e, cur, ivar, l.wave_tot);
@@ -416,8 +427,8 @@ __global__ __launch_bounds__(GB) void k_env_rollout_generic(sl_env_batch env,
     for (int i = tid; i < HW; i += GB) gboard[i] = cur[i];
     if (tid < 4) ((u64 *)(env.rng + e))[tid] = l.rng[tid];
     if (tid == 0) {
-        env.agent_loc[2 * e] = ivar[0];
-        env.agent_loc[2 * e + 1] = ivar[1];
+        sc->agent_row = ivar[0];
+        sc->agent_col = ivar[1];
     }
     __syncthreads();   // goals written by this workgroup are read back below
     write_obs(env, e, cur, ggoals, ivar[0], ivar[1], exits);
@@ -443,8 +454,8 @@ __global__ __launch_bounds__(GB) void k_env_obs_generic(sl_env_batch env) {
     const u16 *gboard = env.board + (size_t)e * HW;
     for (int i = tid; i < HW; i += GB) l.buf[0][i] = gboard[i];
     __syncthreads();
-    write_obs(env, e, l.buf[0], env.goals + (size_t)e * HW, env.agent_loc[2 * e],
-              env.agent_loc[2 * e + 1], env.exit_locs + (size_t)e * env.E);
+    write_obs(env, e, l.buf[0], env.goals + (size_t)e * HW, env.scalars[e].agent_row,
+              env.scalars[e].agent_col, env.exit_locs + (size_t)e * env.E);
 }
 
 // ------------------------------------------------------------------------------ launchers

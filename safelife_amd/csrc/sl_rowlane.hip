@@ -581,24 +581,27 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_ba
     bool active = false;
     double p = 0.0;
     u32 lut_base = 0;
-    if (live) {
-        p = (double)env.spawn_prob[e];
-        gstatic = env.goals_static[e];
-        lut_base = (u32)env.table_idx[e] * (u32)SCORE_LUT_BYTES;
-        level = env.level_idx[e];
+    sl_env_scalars *const sc = env.scalars + e;
+    sl_step_out *const outp = env.out + e;
+    if (live) {         // values every lane of the board needs (same address per group: broadcast loads)
+        p = (double)sc->spawn_prob;
+        gstatic = sc->goals_static;
+        lut_base = (u32)sc->table_idx * (u32)SCORE_LUT_BYTES;
+        level = sc->level_idx;
     }
     const int32_t *exits = env.exit_locs + (size_t)e * E;
     if (leader) {
-        ly = env.agent_loc[2 * e];
-        lx = env.agent_loc[2 * e + 1];
-        steps = env.num_steps[e];
-        old_value = env.old_value[e];
-        required = env.required_points[e];
-        initial = env.initial_points[e];
-        ep_len = env.episode_length[e];
-        ep_rew = env.episode_reward[e];
-        active = env.is_active[e] != 0;
-        episodes = env.episode_idx[e];
+        const sl_env_scalars rec = *sc;     // one 64-byte record
+        ly = rec.agent_row;
+        lx = rec.agent_col;
+        steps = rec.num_steps;
+        old_value = rec.old_value;
+        required = rec.required_points;
+        initial = rec.initial_points;
+        ep_len = rec.episode_length;
+        ep_rew = rec.episode_reward;
+        active = rec.is_active != 0;
+        episodes = rec.episode_idx;
         action = actions[e];
         exit0 = exits[0];
     }
@@ -696,12 +699,15 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_ba
             ep_rew += reward;
             ep_len += active ? 1 : 0;
             active = active && !done;
-            env.reward[e] = reward;
-            env.done[e] = done;
-            env.success[e] = success;
-            env.times_up[e] = times_up;
-            if (env.info_episode_reward) env.info_episode_reward[e] = ep_rew;
-            if (env.info_episode_length) env.info_episode_length[e] = ep_len;
+            sl_step_out o;
+            o.reward = reward;
+            o.done = done;
+            o.success = success;
+            o.times_up = times_up;
+            o.reserved = 0;
+            o.episode_reward = ep_rew;
+            o.episode_length = ep_len;
+            *outp = o;
 #ifndef SL_TRACE
             if (reward_t) reward_t[(size_t)t * B + e] = reward;
             if (done_t) done_t[(size_t)t * B + e] = done;
@@ -719,8 +725,8 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_ba
                     board16[i] = pb[i];
                     gdst[i] = pg[i];
                 }
-                lut_base = (u32)env.pool_table_idx[level] * (u32)SCORE_LUT_BYTES;
-                p = (double)env.pool_spawn_prob[level];
+                lut_base = (u32)env.pool_scalars[level].table_idx * (u32)SCORE_LUT_BYTES;
+                p = (double)env.pool_scalars[level].spawn_prob;
                 gstatic = 0;
                 if (r < 4) rng_lds[4 * g + r] = ((const u64 *)(env.pool_rng + level))[r];
                 for (int k = r; k < E; k += H)
@@ -741,14 +747,15 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_ba
                 episodes += 1;
                 exits = env.pool_exit_locs + (size_t)level * E;   // never written by this launch
                 exit0 = exits[0];
-                ly = env.pool_agent_loc[2 * level];
-                lx = env.pool_agent_loc[2 * level + 1];
-                initial = env.pool_initial_points[level];
-                recolor_exits_lds(board16, W, ly, lx, exits, exit0, E, s0, initial, env.pool_required_reset[level],
+                const sl_level_scalars lv = env.pool_scalars[level];
+                ly = lv.agent_row;
+                lx = lv.agent_col;
+                initial = lv.initial_points;
+                recolor_exits_lds(board16, W, ly, lx, exits, exit0, E, s0, initial, lv.required_reset,
                                   env.exit_points);
                 const int exited = ly >= 0 ? (has_exited(board16[ly * W + lx]) ? 1 : 0) : 0;
                 old_value = s0 + env.exit_points * exited;
-                required = env.pool_required_step[level];
+                required = lv.required_step;
                 steps = 0;
                 active = true;
                 ep_rew = 0.0f;
@@ -761,20 +768,23 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_ba
     SL_STAMP(7);
     // write-back
     if (leader) {
-        env.goals_static[e] = (uint8_t)gstatic;
-        env.table_idx[e] = (int)(lut_base / (u32)SCORE_LUT_BYTES);
-        env.spawn_prob[e] = (float)p;
-        env.level_idx[e] = level;
-        env.agent_loc[2 * e] = ly;
-        env.agent_loc[2 * e + 1] = lx;
-        env.num_steps[e] = steps;
-        env.old_value[e] = old_value;
-        env.required_points[e] = required;
-        env.initial_points[e] = initial;
-        env.episode_length[e] = ep_len;
-        env.episode_reward[e] = ep_rew;
-        env.is_active[e] = active ? 1 : 0;
-        env.episode_idx[e] = episodes;
+        sl_env_scalars rec;
+        rec.agent_row = ly;
+        rec.agent_col = lx;
+        rec.num_steps = steps;
+        rec.old_value = old_value;
+        rec.required_points = required;
+        rec.initial_points = initial;
+        rec.table_idx = (int)(lut_base / (u32)SCORE_LUT_BYTES);
+        rec.level_idx = level;
+        rec.episode_idx = episodes;
+        rec.episode_length = ep_len;
+        rec.episode_reward = ep_rew;
+        rec.spawn_prob = (float)p;
+        rec.goals_static = gstatic;
+        rec.is_active = active ? 1 : 0;
+        rec.reserved[0] = rec.reserved[1] = 0;
+        *sc = rec;
     }
     const int dirty = __syncthreads_or(goals_dirty);
     SL_STAMP(8);

@@ -3,11 +3,12 @@ Multi-GPU layout: one process per GPU, envs block-partitioned, no halo exchange.
 
 Boards are independent (the torus wraps inside a board), so the step itself needs no collective.
 The only cross-GPU traffic of the path is what a centralised learner on rank 0 needs from the
-other ranks each step: ``reward`` (float32) and ``done`` (uint8) per env.  xGMI is point-to-point,
-and a 5-byte-per-env message per step is purely latency bound, so the records of ``every``
-consecutive steps are written by the step kernel straight into one packed device buffer
-(``[every*B] float32 | [every*B] uint8``) and gathered with ONE RCCL ``gather`` per ``every``
-steps, issued asynchronously so it overlaps the following steps; two buffers alternate.
+other ranks each step: the per-step output record of every env (``struct sl_step_out``: float32 reward, done / success /
+times_up flags, episode reward and length -- 16 bytes).  xGMI is point-to-point, and a message of a
+few bytes per env per step is purely latency bound, so the records of ``every`` consecutive steps
+are written by the step kernel straight into one device buffer (``sl_step_out[every, B]``) and
+gathered with ONE RCCL ``gather`` per ``every`` steps, issued asynchronously so it overlaps the
+following steps; two buffers alternate.
 """
 import numpy as np
 
@@ -20,37 +21,35 @@ def shard_bounds(total_envs, world, rank):
 
 
 class RewardGather(object):
-    """Per-step (reward, done) records of a SafeLifeVectorEnv -> rank 0, batched.
+    """Per-step output records of a SafeLifeVectorEnv -> rank 0, batched.
 
     Usage per step t:  ``before_step(t); env.step(a); after_step(t)``; ``flush()`` at the end.
-    On rank 0, ``latest()`` returns (reward[world, every, B], done[world, every, B]) of the last
-    completed window (views into the receive buffer).
+    On rank 0, ``latest()`` returns (reward[world, every, B] float32, done[world, every, B] uint8) of
+    the last completed window (views into the receive buffers); ``latest_records()`` the raw records.
     """
+
+    RECORD_BYTES = 16
 
     def __init__(self, env, every=32, world=1, rank=0, group=None):
         import torch
         self.torch = torch
         self.env, self.every, self.world, self.rank, self.group = env, int(every), int(world), int(rank), group
-        B = env.num_envs
-        self.B = B
-        n = self.every * B
-        self.nbytes = n * 5
-        self.buf = [torch.zeros(self.nbytes, dtype=torch.uint8, device=env.device) for _ in range(2)]
+        self.B = B = env.num_envs
+        shape = (self.every, B, 4)
+        self.buf = [torch.zeros(shape, dtype=torch.int32, device=env.device) for _ in range(2)]
         self.recv = None
         if self.world > 1 and self.rank == 0:
-            self.recv = [[torch.zeros(self.nbytes, dtype=torch.uint8, device=env.device)
-                          for _ in range(self.world)] for _ in range(2)]
+            self.recv = [[torch.zeros(shape, dtype=torch.int32, device=env.device) for _ in range(self.world)]
+                         for _ in range(2)]
         self.work = [None, None]
         self.last = None
-        self._n = n
 
     def before_step(self, t):
         slot, which = t % self.every, (t // self.every) % 2
         if slot == 0 and self.work[which] is not None:
             self.work[which].wait()          # stream-level wait: buffer is free again
             self.work[which] = None
-        base = self.buf[which].data_ptr()
-        self.env.set_step_outputs(base + 4 * slot * self.B, base + 4 * self._n + slot * self.B)
+        self.env.set_step_outputs(self.buf[which].data_ptr() + self.RECORD_BYTES * slot * self.B)
 
     def after_step(self, t):
         if t % self.every != self.every - 1:
@@ -67,14 +66,19 @@ class RewardGather(object):
             if self.work[k] is not None:
                 self.work[k].wait()
                 self.work[k] = None
-        self.env.set_step_outputs(None, None)
+        self.env.set_step_outputs(None)
 
-    def latest(self):
+    def latest_records(self):
         if self.last is None:
             return None
-        torch = self.torch
         bufs = self.recv[self.last] if self.recv is not None else [self.buf[self.last]]
-        n = self._n
-        reward = torch.stack([b[:4 * n].view(torch.float32).view(self.every, self.B) for b in bufs])
-        done = torch.stack([b[4 * n:].view(self.every, self.B) for b in bufs])
+        return self.torch.stack(bufs)                 # int32 [world, every, B, 4]
+
+    def latest(self):
+        rec = self.latest_records()
+        if rec is None:
+            return None
+        torch = self.torch
+        reward = rec[..., 0].view(torch.float32)
+        done = rec[..., 1:2].contiguous().view(torch.uint8)[..., 0]
         return reward, done

@@ -22,17 +22,6 @@ from .levels import LevelPool
 
 _DEFAULT_CHANNELS = tuple(range(16)) + (25, 26, 27)      # safelife_env.py:71
 
-# name -> torch dtype name; uint16 / uint64 payloads are held in int16 / int64 tensors
-_STATE_SPEC = {
-    "board": "int16", "goals": "int16", "agent_loc": "int32", "exit_locs": "int32", "rng": "int64",
-    "spawn_prob": "float32", "num_steps": "int32", "old_value": "int32", "required_points": "int32",
-    "initial_points": "int32", "table_idx": "int32", "goals_static": "uint8", "is_active": "uint8",
-    "episode_reward": "float32", "episode_length": "int32", "level_idx": "int32",
-    "episode_idx": "int32",
-    "reward": "float32", "done": "uint8", "success": "uint8", "times_up": "uint8",
-    "info_episode_reward": "float32", "info_episode_length": "int32",
-}
-
 
 class SafeLifeVectorEnv(object):
     """
@@ -73,18 +62,27 @@ class SafeLifeVectorEnv(object):
             raise ValueError("too many output channels")
 
         dev = self.device
-        shapes = {"board": (B, H, W), "goals": (B, H, W), "agent_loc": (B, 2), "exit_locs": (B, E),
-                  "rng": (B, 4)}
         self.t = t = {}
-        for name, dt in _STATE_SPEC.items():
-            t[name] = torch.zeros(shapes.get(name, (B,)), dtype=getattr(torch, dt), device=dev)
-        for name, arr in pool.arrays().items():
-            a = np.ascontiguousarray(arr)
-            if a.dtype == np.uint16:
-                a = a.view(np.int16)
-            elif a.dtype == np.uint64:
-                a = a.view(np.int64)
-            t[name] = torch.from_numpy(a).to(dev)
+        t["board"] = torch.zeros((B, H, W), dtype=torch.int16, device=dev)      # uint16 payload
+        t["goals"] = torch.zeros((B, H, W), dtype=torch.int16, device=dev)
+        t["exit_locs"] = torch.full((B, E), -1, dtype=torch.int32, device=dev)
+        t["rng"] = torch.zeros((B, 4), dtype=torch.int64, device=dev)           # uint64 payload
+        t["scalars"] = torch.zeros((B, 16), dtype=torch.int32, device=dev)      # struct sl_env_scalars
+        t["out"] = torch.zeros((B, 4), dtype=torch.int32, device=dev)           # struct sl_step_out
+        pa = pool.arrays()
+        for name in ("pool_board", "pool_goals"):
+            t[name] = torch.from_numpy(np.ascontiguousarray(pa[name]).view(np.int16)).to(dev)
+        t["pool_exit_locs"] = torch.from_numpy(np.ascontiguousarray(pa["pool_exit_locs"])).to(dev)
+        t["pool_rng"] = torch.from_numpy(np.ascontiguousarray(pa["pool_rng"]).view(np.int64)).to(dev)
+        t["points_table"] = torch.from_numpy(np.ascontiguousarray(pa["points_table"], dtype=np.int32)).to(dev)
+        lv = np.zeros((len(pool), 8), np.int32)
+        lv[:, 0:2] = pa["pool_agent_loc"]
+        lv[:, 2] = pa["pool_required_reset"]
+        lv[:, 3] = pa["pool_required_step"]
+        lv[:, 4] = pa["pool_initial_points"]
+        lv[:, 5] = pa["pool_table_idx"]
+        lv[:, 6] = pa["pool_spawn_prob"].astype(np.float32).view(np.int32)
+        t["pool_scalars"] = torch.from_numpy(lv).to(dev)
         vh, vw = self.view_shape
         if not with_obs:
             self.obs = None
@@ -95,7 +93,7 @@ class SafeLifeVectorEnv(object):
         if first_level is None:
             first_level = (int(env_offset) + np.arange(B)) % len(pool)
         first = np.broadcast_to(np.asarray(first_level, np.int32), (B,)).copy()
-        t["level_idx"].copy_(torch.from_numpy(first))
+        t["scalars"][:, _hip.SCALAR_COLS["level_idx"]] = torch.from_numpy(first).to(dev)
 
         s = self.struct = _hip.EnvBatch()
         s.B, s.H, s.W, s.E = B, H, W, E
@@ -113,6 +111,13 @@ class SafeLifeVectorEnv(object):
                 s.obs = None if self.obs is None else self.obs.data_ptr()
             else:
                 setattr(s, name, t[name].data_ptr())
+        # views of the per-step output records (struct sl_step_out)
+        out = t["out"]
+        flags = out[:, 1:2].view(torch.uint8)                    # done, success, times_up, pad
+        self.reward = out[:, 0].view(torch.float32)
+        self.done = flags[:, 0]
+        self.info = {"success": flags[:, 1], "times_up": flags[:, 2],
+                     "episode_reward": out[:, 2].view(torch.float32), "episode_length": out[:, 3]}
         self._lib = _hip.lib()
         self._sref = C.byref(s)
         rc = self._lib.slhip_env_prepare(self._sref, _hip.current_stream_ptr())
@@ -148,10 +153,7 @@ class SafeLifeVectorEnv(object):
         rc = self._lib.slhip_env_step(self._sref, _hip.ptr(a), _hip.current_stream_ptr())
         _hip.check(rc)
         t = self.t
-        info = {"success": t["success"], "times_up": t["times_up"],
-                "episode_reward": t["info_episode_reward"],
-                "episode_length": t["info_episode_length"]}
-        return self.obs, t["reward"], t["done"], info
+        return self.obs, self.reward, self.done, self.info
 
     def rollout(self, actions, reward_out=None, done_out=None):
         """T steps in one launch.  actions: int [T,B].  Returns (reward[T,B], done[T,B])."""
@@ -167,12 +169,11 @@ class SafeLifeVectorEnv(object):
         _hip.check(rc)
         return reward_out, done_out
 
-    def set_step_outputs(self, reward_ptr, done_ptr):
-        """Redirect the per-step ``reward`` / ``done`` outputs to caller-owned device memory
-        (``float32[B]`` / ``uint8[B]`` addresses); ``None`` restores the env's own tensors.
-        Used by sharding.RewardGather to have the kernel fill a packed send buffer directly."""
-        self.struct.reward = self.t["reward"].data_ptr() if reward_ptr is None else int(reward_ptr)
-        self.struct.done = self.t["done"].data_ptr() if done_ptr is None else int(done_ptr)
+    def set_step_outputs(self, out_ptr):
+        """Redirect the per-step output records (``sl_step_out[B]``, 16 bytes per env) to caller-owned
+        device memory; ``None`` restores the env's own tensor.  Used by sharding.RewardGather to have
+        the kernel fill a send buffer directly."""
+        self.struct.out = self.t["out"].data_ptr() if out_ptr is None else int(out_ptr)
 
     def get_obs(self):
         rc = self._lib.slhip_env_obs(self._sref, _hip.current_stream_ptr())
@@ -182,26 +183,27 @@ class SafeLifeVectorEnv(object):
     # ------------------------------------------------------------------ host views
 
     def numpy(self, name):
-        """Host copy of a state array in the reference's dtype (board/goals uint16, rng uint64)."""
+        """Host copy of a state array under the reference's / oracle's name and dtype."""
         if name == "obs":
             a = self.obs.cpu().numpy()
             return a.view(np.uint32) if self.output_channels is None else a
-        a = self.t[name].cpu().numpy()
-        if a.dtype == np.int16:
-            return a.view(np.uint16)
+        if name in ("board", "goals", "pool_board", "pool_goals"):
+            return self.t[name].cpu().numpy().view(np.uint16)
         if name in ("rng", "pool_rng"):
-            return a.view(np.uint64)
-        return a
-
-    def load_state(self, arrays):
-        """Overwrite per-env state from host arrays (names of ``sl_env_batch``)."""
-        torch = self.torch
-        for name, arr in arrays.items():
-            if name not in self.t or name.startswith("pool_") or name == "points_table":
-                continue
-            a = np.ascontiguousarray(arr)
-            if a.dtype == np.uint16:
-                a = a.view(np.int16)
-            elif a.dtype == np.uint64:
-                a = a.view(np.int64)
-            self.t[name].copy_(torch.from_numpy(a))
+            return self.t[name].cpu().numpy().view(np.uint64)
+        if name == "agent_loc":
+            return self.t["scalars"][:, 0:2].cpu().numpy()
+        if name in _hip.SCALAR_COLS:
+            col = self.t["scalars"][:, _hip.SCALAR_COLS[name]].cpu().numpy()
+            if name in _hip.SCALAR_FLOATS:
+                return col.view(np.float32)
+            if name in ("goals_static", "is_active"):
+                return col.astype(np.uint8)
+            return col
+        if name == "reward":
+            return self.reward.cpu().numpy()
+        if name == "done":
+            return self.done.cpu().numpy()
+        if name in self.info:
+            return self.info[name].cpu().numpy()
+        return self.t[name].cpu().numpy()

@@ -25,24 +25,23 @@ def test_shard_bounds_cover_everything():
 
 
 class _FakeEnv(object):
-    """Stands in for SafeLifeVectorEnv: owns reward/done outputs and lets them be redirected."""
+    """Stands in for SafeLifeVectorEnv: owns the output records and lets them be redirected."""
 
     def __init__(self, B):
         self.num_envs = B
         self.device = torch.device("cpu")
-        self.own_reward = np.zeros(B, np.float32)
-        self.own_done = np.zeros(B, np.uint8)
-        self.set_step_outputs(None, None)
+        self.own = np.zeros((B, 4), np.int32)
+        self.set_step_outputs(None)
 
-    def set_step_outputs(self, reward_ptr, done_ptr):
-        self.reward_ptr = self.own_reward.ctypes.data if reward_ptr is None else int(reward_ptr)
-        self.done_ptr = self.own_done.ctypes.data if done_ptr is None else int(done_ptr)
+    def set_step_outputs(self, out_ptr):
+        self.out_ptr = self.own.ctypes.data if out_ptr is None else int(out_ptr)
 
     def step(self, t, rank):
-        r = np.ctypeslib.as_array(C.cast(self.reward_ptr, C.POINTER(C.c_float)), (self.num_envs,))
-        d = np.ctypeslib.as_array(C.cast(self.done_ptr, C.POINTER(C.c_uint8)), (self.num_envs,))
-        r[:] = 1000.0 * rank + t + np.arange(self.num_envs) / 64.0
-        d[:] = (np.arange(self.num_envs) + t + rank) % 3 == 0
+        rec = np.ctypeslib.as_array(C.cast(self.out_ptr, C.POINTER(C.c_int32)), (self.num_envs, 4))
+        rec[:, 0] = (1000.0 * rank + t + np.arange(self.num_envs) / 64.0).astype(np.float32).view(np.int32)
+        rec[:, 1] = ((np.arange(self.num_envs) + t + rank) % 3 == 0).astype(np.int32)      # done in byte 0
+        rec[:, 2] = np.float32(t).view(np.int32)
+        rec[:, 3] = t
 
 
 def _worker(rank, world, port, B, every, steps, out_q):
@@ -103,4 +102,4 @@ def test_reward_gather_single_process():
     assert rw.shape == (1, 2, 16)
     assert np.array_equal(rw[0, 1].numpy(), (3 + np.arange(16) / 64.0).astype(np.float32))
     gather.flush()
-    assert env.reward_ptr == env.own_reward.ctypes.data
+    assert env.out_ptr == env.own.ctypes.data
