@@ -178,6 +178,14 @@ def main():
     if rank == 0:
         bytes_per_step = 3 * H * Wd * 2 + (H * Wd * len(TRAIN_CHANNELS) if args.obs else 0)
         achieved = bytes_per_step * B / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        try:    # HBM bytes per launch from the committed PMC passes (tools/pmc_run.sh), if they match this run
+            with open(os.path.join(REPO, "profiles", "traffic_latest.json")) as f:
+                tj = json.load(f)
+            if tj.get("envs_per_gpu") == B and tj.get("obs") == int(bool(args.obs)):
+                traffic = tj["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         out = {
             "metric": "env steps/sec (whole node), 8192x25x25 boards; bit-exact vs C advance_board",
             "value": world * B * K / elapsed,
@@ -193,7 +201,7 @@ def main():
                        "level_pool": len(pool), "parallelism": "envs sharded %d-way, reward/done gathered "
                                                                "to rank 0 every %d steps" % (world, args.gather_every)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "fused env step", "bytes_per_env_step": bytes_per_step,
                          "launch_ms": kernel_ms},
         }
