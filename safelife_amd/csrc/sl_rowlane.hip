@@ -582,7 +582,6 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_ba
     double p = 0.0;
     u32 lut_base = 0;
     sl_env_scalars *const sc = env.scalars + e;
-    sl_step_out *const outp = env.out + e;
     if (live) {         // values every lane of the board needs (same address per group: broadcast loads)
         p = (double)sc->spawn_prob;
         gstatic = sc->goals_static;
@@ -707,7 +706,9 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_ba
             o.reserved = 0;
             o.episode_reward = ep_rew;
             o.episode_length = ep_len;
-            *outp = o;
+            unsigned e3 = e;
+            asm volatile("" : "+v"(e3));
+            env.out[e3] = o;
 #ifndef SL_TRACE
             if (reward_t) reward_t[(size_t)t * B + e] = reward;
             if (done_t) done_t[(size_t)t * B + e] = done;
@@ -784,7 +785,9 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_ba
         rec.goals_static = gstatic;
         rec.is_active = active ? 1 : 0;
         rec.reserved[0] = rec.reserved[1] = 0;
-        *sc = rec;
+        unsigned e2 = e;                      // recompute the record address here instead of keeping
+        asm volatile("" : "+v"(e2));          // a 64-bit pointer alive (and spilled) across the kernel
+        env.scalars[e2] = rec;
     }
     const int dirty = __syncthreads_or(goals_dirty);
     SL_STAMP(8);
@@ -883,8 +886,12 @@ static hipError_t launch_rollout_t(const sl_env_batch &env, const int32_t *actio
                                    uint8_t *done_t, const Jump *jump, hipStream_t stream) {
     using Gm = Geom<H, W>;
     auto fn = env.n_tables == 1 ? k_env_rollout_rowlane<H, W, true> : k_env_rollout_rowlane<H, W, false>;
-    hipError_t err = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, Gm::LDS_BYTES);
-    if (err != hipSuccess) return err;
+    static bool configured[2] = {false, false};       // the attribute is sticky: set it once per variant
+    if (!configured[env.n_tables == 1]) {
+        hipError_t err = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, Gm::LDS_BYTES);
+        if (err != hipSuccess) return err;
+        configured[env.n_tables == 1] = true;
+    }
     hipLaunchKernelGGL(fn, dim3((env.B + Gm::NB - 1) / Gm::NB), dim3(64 * WAVES), Gm::LDS_BYTES, stream, env,
                        actions, T, reward_t, done_t, jump);
     return hipGetLastError();
