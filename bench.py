@@ -114,7 +114,7 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     dev = _hip.device()
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -214,7 +214,7 @@ def main():
                 return oracle.alive_counts_batch(b, g)
             out["cpu_baseline"] = cpu_baseline(load_pool(args.pool, cpu_counts), B, args.cpu_steps, 7)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

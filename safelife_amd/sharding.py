@@ -10,6 +10,8 @@ are written by the step kernel straight into one device buffer (``sl_step_out[ev
 gathered with ONE RCCL ``gather`` per ``every`` steps, issued asynchronously so it overlaps the
 following steps; two buffers alternate.
 """
+import os
+
 import numpy as np
 
 
@@ -38,7 +40,10 @@ class RewardGather(object):
         shape = (self.every, B, 4)
         self.buf = [torch.zeros(shape, dtype=torch.int32, device=env.device) for _ in range(2)]
         self.recv = None
-        if self.world > 1 and self.rank == 0:
+        # SAFELIFE_FORCE_GATHER=1 issues the collective even with one rank (exercises the RCCL path
+        # on a single-GPU box)
+        self.force = os.environ.get("SAFELIFE_FORCE_GATHER", "0") == "1"
+        if (self.world > 1 or self.force) and self.rank == 0:
             self.recv = [[torch.zeros(shape, dtype=torch.int32, device=env.device) for _ in range(self.world)]
                          for _ in range(2)]
         self.work = [None, None]
@@ -56,7 +61,7 @@ class RewardGather(object):
             return
         which = (t // self.every) % 2
         self.last = which
-        if self.world > 1:
+        if self.world > 1 or self.force:
             import torch.distributed as dist
             self.work[which] = dist.gather(self.buf[which], self.recv[which] if self.rank == 0 else None,
                                            dst=0, group=self.group, async_op=True)
