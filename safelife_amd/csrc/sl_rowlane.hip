@@ -454,23 +454,33 @@ __device__ __forceinline__ void recolor_exits_lds(u16 *board, int W, int ly, int
 
 // ---- workgroup span <-> HBM -----------------------------------------------------------------------
 
+typedef __attribute__((address_space(1))) const void *glds_src_t;
+typedef __attribute__((address_space(3))) void *glds_dst_t;
+
+// `bytes` of global memory -> LDS with the asynchronous global_load_lds DMA (16 bytes per lane,
+// 1 KiB per wave instruction, no VGPR staging, no ds_write).  Chunk c of 1 KiB is moved by wave
+// c % WAVES.  Completion: the vmcnt(0) the compiler places in front of the next __syncthreads().
+template <int MAX_BYTES>
+__device__ __forceinline__ void dma_to_lds(const unsigned char *__restrict__ src, unsigned char *dst, int bytes,
+                                           int lane, int wave) {
+    const int nv = bytes >> 4;
+    constexpr int NCH = (MAX_BYTES + 1023) / 1024;
+#pragma unroll
+    for (int j = 0; j < (NCH + WAVES - 1) / WAVES; ++j) {
+        const int c = wave + WAVES * j;
+        if (c * 64 + lane < nv)
+            __builtin_amdgcn_global_load_lds((glds_src_t)(src + c * 1024 + lane * 16), (glds_dst_t)(dst + c * 1024), 16,
+                                             0, 0);
+    }
+}
+
 template <int H, int W>
 __device__ __forceinline__ void load_span(const u16 *__restrict__ src, unsigned char *region, int nbb, int tid) {
     using Gm = Geom<H, W>;
     const int bytes = nbb * Gm::HW * 2;
-    const int nv = bytes >> 4;
-    const u32x4 *s = (const u32x4 *)src;
-    u32x4 *d = (u32x4 *)(region + Gm::PAD);
-    constexpr int NVI = (Gm::SPAN / 16 + 64 * WAVES - 1) / (64 * WAVES);
-    u32x4 v[NVI];
-#pragma unroll
-    for (int i = 0; i < NVI; ++i)
-        if (tid + 64 * WAVES * i < nv) v[i] = s[tid + 64 * WAVES * i];
-#pragma unroll
-    for (int i = 0; i < NVI; ++i)
-        if (tid + 64 * WAVES * i < nv) d[tid + 64 * WAVES * i] = v[i];
-    const int rem = (bytes & 15) >> 1;                 // tail workgroup only
-    if (tid < rem) ((u16 *)d)[nv * 8 + tid] = src[nv * 8 + tid];
+    dma_to_lds<Gm::SPAN>((const unsigned char *)src, region + Gm::PAD, bytes, tid & 63, tid >> 6);
+    const int nv = bytes >> 4, rem = (bytes & 15) >> 1;          // leftover cells: tail workgroup only
+    if (tid < rem) ((u16 *)(region + Gm::PAD))[nv * 8 + tid] = src[nv * 8 + tid];
 }
 
 template <int H, int W>
@@ -606,7 +616,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_ba
     }
     if (lane < 4 * Gm::G && wave * Gm::G + (lane >> 2) < nbb)
         rng_lds[lane] = ((const u64 *)(env.rng + e0b + wave * Gm::G))[lane];
-    if (LDS_LUT && tid < 256) ((u32x4 *)(smem + Gm::OFF_LUT))[tid] = ((const u32x4 *)env.score_lut)[tid];   // 256 x 16 B
+    if (LDS_LUT) dma_to_lds<4096>((const unsigned char *)env.score_lut, smem + Gm::OFF_LUT, 4096, lane, wave);
     load_span<H, W>(env.board + (size_t)e0b * HW, board, nbb, tid);
     load_span<H, W>(env.goals + (size_t)e0b * HW, goals, nbb, tid);
     SL_STAMP(1);
