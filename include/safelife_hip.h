@@ -138,6 +138,10 @@ typedef struct sl_env_batch {
     int32_t view_h, view_w;      /* SafeLifeEnv.view_shape */
     int32_t n_channels;          /* len(output_channels); 0 => raw uint32 view */
     int32_t channels[SL_MAX_CHANNELS];
+    int32_t spawner_free;        /* !=0: the caller guarantees that no board or goal array of the batch and
+                                    of the pool holds a SPAWNING cell (the rules never create one), which
+                                    lets the kernels drop the random-draw machinery; 0 = no promise */
+    int32_t reserved0;
     /* per-env state */
     uint16_t *board;             /* [B,H,W] */
     uint16_t *goals;             /* [B,H,W] */

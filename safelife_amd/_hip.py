@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsafelife_hip.so")
+# SAFELIFE_HIP_LIB selects another build of the same library (A/B runs of kernel variants)
+LIB_PATH = os.environ.get("SAFELIFE_HIP_LIB") or os.path.join(_HERE, "libsafelife_hip.so")
 
 SL_MAX_CELLS = 16384
 SL_MAX_CHANNELS = 32
@@ -44,7 +45,7 @@ ENV_OUT_PTRS = ("out", "obs", "score_lut")
 #: int32 column of each field inside `struct sl_env_scalars` (64 bytes = 16 columns)
 SCALAR_COLS = {"agent_row": 0, "agent_col": 1, "num_steps": 2, "old_value": 3, "required_points": 4,
                "initial_points": 5, "table_idx": 6, "level_idx": 7, "episode_idx": 8, "episode_length": 9,
-               "episode_reward": 10, "spawn_prob": 11, "goals_static": 12, "is_active": 13}
+               "episode_reward": 10, "spawn_prob": 11, "goals_static": 12, "is_active": 13, "flags": 14}
 SCALAR_FLOATS = ("episode_reward", "spawn_prob")
 #: `struct sl_level_scalars` (32 bytes = 8 columns)
 LEVEL_COLS = {"agent_row": 0, "agent_col": 1, "required_reset": 2, "required_step": 3, "initial_points": 4,
@@ -54,7 +55,7 @@ LEVEL_COLS = {"agent_row": 0, "agent_col": 1, "required_reset": 2, "required_ste
 class EnvBatch(C.Structure):
     _fields_ = (
         [(n, C.c_int32) for n in ENV_SCALARS_HEAD]
-        + [("channels", C.c_int32 * SL_MAX_CHANNELS)]
+        + [("channels", C.c_int32 * SL_MAX_CHANNELS), ("spawner_free", C.c_int32), ("reserved0", C.c_int32)]
         + [(n, _p) for n in ENV_STATE_PTRS]
         + [("L", C.c_int32), ("level_stride", C.c_int32)]
         + [(n, _p) for n in ENV_POOL_PTRS]

@@ -213,7 +213,7 @@ __device__ __forceinline__ Consts make_consts() {
 //      can carry across a 16-bit half: every half stays below 0x3000)
 //   w: colour bits of spawner cells, plus, after each pass, the "seen twice" bits -- all at the
 //      cells' native bit positions, so the new cell is assembled without shifts.
-template <int H, int W>
+template <int H, int W, bool SPAWN>
 __device__ __forceinline__ void ca_rows(const RowWords<H, W> &b, RowWords<H, W> &n, u32 &elig, int up, int dn,
                                         const Consts &c) {
     using Gm = Geom<H, W>;
@@ -224,9 +224,11 @@ __device__ __forceinline__ void ca_rows(const RowWords<H, W> &b, RowWords<H, W> 
         const u32 bb = b[k];
         const u32 m = __umul24(bb & c.m1, 0x0E08u) + c.anya;        // once-bits where alive | always-bits
         o[k] = BO3_ORAND(bb, (bb >> 5) & c.eight, m);               // exit (bit 8) joins destructible on bit 3
-        w[k] = bb & __umul24(bb & c.spawn, 0x1Cu);                  // colours of spawners
+        w[k] = SPAWN ? (bb & __umul24(bb & c.spawn, 0x1Cu)) : 0u;   // colours of spawners
     }
-    const Seams<H, W> so = make_seams<H, W>(o), sw = make_seams<H, W>(w);
+    const Seams<H, W> so = make_seams<H, W>(o);
+    Seams<H, W> sw = {0u, 0u, 0u};
+    if (SPAWN) sw = make_seams<H, W>(w);
     elig = 0;
 #pragma unroll
     for (int k = 0; k < WS; ++k) {
@@ -235,8 +237,7 @@ __device__ __forceinline__ void ca_rows(const RowWords<H, W> &b, RowWords<H, W> 
         // row pass
         const u32 xo = BO3_OR3(oL, o[k], oR);
         const u32 mj = BO3_MAJ(oL, o[k], oR);
-        const u32 xw = BO3_OR3(wL, w[k], wR);
-        const u32 wr = BO3_OR_AND(xw, mj, c.once);
+        const u32 wr = SPAWN ? BO3_OR_AND(BO3_OR3(wL, w[k], wR), mj, c.once) : (mj & c.once);
         const u32 cs = oL + o[k] + oR;                               // bits 0-1: alive cells in the row triple
         const u32 ro = BO3_INSERT(xo, cs, c.three);
         // column pass
@@ -252,21 +253,25 @@ __device__ __forceinline__ void ca_rows(const RowWords<H, W> &b, RowWords<H, W> 
         const u32 is3 = SL_BO3(TA & TB & ~TC, sum, c1, c2);
         // rule (advance_board.c:94-124), evaluated at bit 0 of each half
         const u32 bb = b[k];
-        const u32 fr = bb >> 4, pr = X >> 5, ih = X >> 6, sp = X >> 7;
+        const u32 fr = bb >> 4, pr = X >> 5, ih = X >> 6;
         const u32 keep_a = BO3_OR3(fr, pr, s34);
         const u32 keep_d = fr | ih;
         const u32 born = SL_BO3(TA & ~TB & ~TC, is3, keep_d, bb);
-        const u32 e1 = SL_BO3(TA & ~TB & ~TC, sp, keep_d, is3);
-        const u32 vm = Gm::vm1(k) == 0x00010001u ? c.m1 : vreg(Gm::vm1(k));
-        const u32 el = SL_BO3(TA & ~TB & TC, e1, bb, vm);            // needs a random draw
-        const u32 ne = born | el;
+        u32 el = 0;                                                  // needs a random draw
+        if (SPAWN) {
+            const u32 e1 = SL_BO3(TA & ~TB & ~TC, X >> 7, keep_d, is3);
+            const u32 vm = Gm::vm1(k) == 0x00010001u ? c.m1 : vreg(Gm::vm1(k));
+            el = SL_BO3(TA & ~TB & TC, e1, bb, vm);
+        }
+        const u32 ne = SPAWN ? (born | el) : born;
         const u32 kp = SL_BO3((TA & TB) | (~TA & ~TC), bb, keep_a, ne);
         const u32 KM = __umul24(kp & c.m1, 0xFFFFu);
         const u32 NM = __umul24(ne & c.m1, 0xFFFFu);
         const u32 nv = BO3_AND_OR(tw, c.once, c.m1);                 // alive + inherited colours / destructible
-        const u32 nm = BO3_AND_OR(nv, NM, __umul24(el, 8u));         // spawned cells are always destructible
+        const u32 nm = SPAWN ? BO3_AND_OR(nv, NM, __umul24(el, 8u))  // spawned cells are always destructible
+                             : (nv & NM);
         n[k] = BO3_AND_OR(bb, KM, nm);
-        elig = elig + elig + el;
+        if (SPAWN) elig = elig + elig + el;
     }
 }
 
@@ -534,7 +539,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_advance_rowlane(const u16 *__res
     for (int k = 0; k < Gm::WS; ++k) b[k] = 0;
     if (live) read_row<H, W>(board, gb, r, b);
     for (int s = 0; s < n_steps; ++s) {
-        ca_rows<H, W>(b, n, elig, up, dn, cst);
+        ca_rows<H, W, true>(b, n, elig, up, dn, cst);
         if (!live) elig = 0;
         if (__ballot(elig != 0)) resolve_draws<H, W>(b, n, elig, rng_lds, live ? g : 0, live && r == 0, p, jump);
 #pragma unroll
@@ -549,7 +554,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_advance_rowlane(const u16 *__res
 
 // ---- fused env step / rollout ---------------------------------------------------------------------
 
-template <int H, int W, bool LDS_LUT>
+template <int H, int W, bool LDS_LUT, bool SPAWN>
 __global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_batch env,
                                                                        const int32_t *__restrict__ actions, int T,
                                                                        float *__restrict__ reward_t,
@@ -651,9 +656,9 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_ba
             const bool mine = live && (pass == 0 || dyn);
             unsigned char *img = pass == 0 ? board : goals;
             if (mine) read_row<H, W>(img, gb, r, b);
-            ca_rows<H, W>(b, b, elig, up, dn, cst);          // in place: b now holds the new cells
+            ca_rows<H, W, SPAWN>(b, b, elig, up, dn, cst);   // in place: b now holds the new cells
             if (!mine) elig = 0;
-            if (__ballot(elig != 0)) {
+            if (SPAWN && __ballot(elig != 0)) {
                 RowWords<H, W> old;                          // failed draws keep the old cell: re-read it
 #pragma unroll
                 for (int k = 0; k < WS; ++k) old[k] = 0;
@@ -895,12 +900,17 @@ template <int H, int W>
 static hipError_t launch_rollout_t(const sl_env_batch &env, const int32_t *actions, int T, float *reward_t,
                                    uint8_t *done_t, const Jump *jump, hipStream_t stream) {
     using Gm = Geom<H, W>;
-    auto fn = env.n_tables == 1 ? k_env_rollout_rowlane<H, W, true> : k_env_rollout_rowlane<H, W, false>;
-    static bool configured[2] = {false, false};       // the attribute is sticky: set it once per variant
-    if (!configured[env.n_tables == 1]) {
+    const int variant = (env.n_tables == 1 ? 1 : 0) | (env.spawner_free ? 2 : 0);
+    void (*fn)(sl_env_batch, const int32_t *, int, float *, uint8_t *, const Jump *) =
+        variant == 3   ? k_env_rollout_rowlane<H, W, true, false>
+        : variant == 2 ? k_env_rollout_rowlane<H, W, false, false>
+        : variant == 1 ? k_env_rollout_rowlane<H, W, true, true>
+                       : k_env_rollout_rowlane<H, W, false, true>;
+    static bool configured[4] = {false, false, false, false};   // the attribute is sticky: set it once
+    if (!configured[variant]) {
         hipError_t err = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, Gm::LDS_BYTES);
         if (err != hipSuccess) return err;
-        configured[env.n_tables == 1] = true;
+        configured[variant] = true;
     }
     hipLaunchKernelGGL(fn, dim3((env.B + Gm::NB - 1) / Gm::NB), dim3(64 * WAVES), Gm::LDS_BYTES, stream, env,
                        actions, T, reward_t, done_t, jump);

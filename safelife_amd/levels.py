@@ -219,6 +219,8 @@ class LevelPool(object):
 
         self.pool_board = np.stack([lv.board for lv in levels])
         self.pool_goals = np.stack([lv.goals for lv in levels])
+        #: spawners are never created by the rules, so a pool without any stays free of random draws
+        self.has_spawner = bool(((self.pool_board | self.pool_goals) & CellTypes.spawning).any())
         self.pool_agent_loc = np.full((L, 2), -1, np.int32)
         self.pool_exit_locs = np.full((L, E), -1, np.int32)
         self.pool_spawn_prob = np.array([lv.spawn_prob for lv in levels], np.float32)

@@ -105,6 +105,7 @@ class SafeLifeVectorEnv(object):
         for i, c in enumerate(chans):
             s.channels[i] = int(c)
         s.L, s.level_stride = len(pool), int(level_stride)
+        s.spawner_free = int(not pool.has_spawner)
         t["score_lut"] = torch.zeros((s.n_tables, 4096 + 65536), dtype=torch.int8, device=dev)
         for name in _hip.ENV_STATE_PTRS + _hip.ENV_POOL_PTRS + _hip.ENV_OUT_PTRS:
             if name == "obs":
