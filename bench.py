@@ -94,7 +94,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--envs", type=int, default=8192, help="envs per GPU")
     ap.add_argument("--pool", default="prune_still_25")
-    ap.add_argument("--obs", type=int, default=0, help="1: also write the 25x25x15 uint8 observation")
+    ap.add_argument("--obs", type=int, default=0,
+                    help="1: also write the 25x25x15 uint8 observation; 2: the raw 25x25 uint32 view")
     ap.add_argument("--gather-every", type=int, default=32)
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-steps", type=int, default=101)
@@ -121,7 +122,8 @@ def main():
     B, K, W = args.envs, args.steps, args.warmup
     pool = load_pool(args.pool, _device_counts)
     H, Wd = pool.shape
-    env = SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25), output_channels=TRAIN_CHANNELS,
+    env = SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25),
+                            output_channels=None if args.obs == 2 else TRAIN_CHANNELS,
                             auto_reset=True, level_stride=1, env_offset=rank * B, with_obs=bool(args.obs))
     env.reset()
     gen = torch.Generator(device=dev)
@@ -176,13 +178,14 @@ def main():
         extra["rollout_env_steps_per_s_per_gpu"] = B * T / (ms * 1e-3)
 
     if rank == 0:
-        bytes_per_step = 3 * H * Wd * 2 + (H * Wd * len(TRAIN_CHANNELS) if args.obs else 0)
+        obs_bytes = {0: 0, 1: H * Wd * len(TRAIN_CHANNELS), 2: H * Wd * 4}[args.obs]
+        bytes_per_step = 3 * H * Wd * 2 + obs_bytes
         achieved = bytes_per_step * B / (kernel_ms * 1e-3) / 1e9
         traffic = None
         try:    # HBM bytes per launch from the committed PMC passes (tools/pmc_run.sh), if they match this run
             with open(os.path.join(REPO, "profiles", "traffic_latest.json")) as f:
                 tj = json.load(f)
-            if tj.get("envs_per_gpu") == B and tj.get("obs") == int(bool(args.obs)):
+            if tj.get("envs_per_gpu") == B and tj.get("obs") == args.obs:
                 traffic = tj["hbm_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             pass
@@ -196,7 +199,7 @@ def main():
             "dtype": "u16", "data": "synthetic (reference-procgen prune-still level pool cycled on device, "
                                     "uniform random actions)",
             "config": {"workload": "C3: %d envs/GPU x %dx%d prune-still, fused step()+reward+auto-reset%s" % (
-                           B, H, Wd, " + 25x25x15 u8 obs" if args.obs else ", no observation"),
+                           B, H, Wd, {0: ", no observation", 1: " + 25x25x15 u8 obs", 2: " + 25x25 u32 view"}[args.obs]),
                        "envs_per_gpu": B, "global_envs": world * B, "board": [H, Wd],
                        "level_pool": len(pool), "parallelism": "envs sharded %d-way, reward/done gathered "
                                                                "to rank 0 every %d steps" % (world, args.gather_every)},

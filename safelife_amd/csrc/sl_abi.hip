@@ -194,7 +194,8 @@ int slhip_env_rollout(const sl_env_batch *env, const int32_t *actions, int T, fl
     const sl::Jump *jump;
     if ((rc = jump_table(&jump))) return rc;
     const bool aligned = (((uintptr_t)env->board | (uintptr_t)env->goals) & 15) == 0;
-    hipError_t err = (sl::rowlane_supports(env->H, env->W) && env->score_lut && aligned && !force_generic())
+    hipError_t err = (sl::rowlane_supports(env->H, env->W) && env->score_lut && aligned && env->E <= 8 &&
+                      !force_generic())
                          ? sl::launch_env_rollout_rowlane(*env, actions, T, reward_t, done_t, jump,
                                                           (hipStream_t)stream)
                          : sl::launch_env_rollout_generic(*env, actions, T, reward_t, done_t, jump,

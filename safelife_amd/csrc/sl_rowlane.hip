@@ -552,6 +552,188 @@ __global__ __launch_bounds__(64 * WAVES) void k_advance_rowlane(const u16 *__res
         ((u64 *)(rng + e0b + wave * Gm::G))[lane] = rng_lds[lane];
 }
 
+// ---- observation ------------------------------------------------------------------------------------
+constexpr int OBS_MAX_EXITS = 8;                       // exit slots handled by the fast obs path
+constexpr int OBS_PAR_INTS = 2 + 2 * OBS_MAX_EXITS;
+
+typedef u32 u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef u32 u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
+typedef u32 u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+
+__device__ __forceinline__ int div_small(int i, int n, float inv_n) {     // i / n for 0 <= i < 2^20
+    int q = (int)(((float)i + 0.5f) * inv_n);
+    if (q * n > i) --q;
+    if ((q + 1) * n <= i) ++q;
+    return q;
+}
+
+// Position of a cell of the workgroup's cell stream (c = board_in_block * view_cells + view_cell),
+// advanced cell by cell without divisions.
+struct ObsCursor {
+    int bq, v, vy, vx;
+    __device__ __forceinline__ void init(int c, int nv, int vw, float inv_nv, float inv_vw) {
+        bq = div_small(c, nv, inv_nv);
+        v = c - bq * nv;
+        vy = div_small(v, vw, inv_vw);
+        vx = v - vy * vw;
+    }
+    // jump `step` cells ahead; (qy, qx) = divmod(step, vw) precomputed by the caller
+    __device__ __forceinline__ void advance(int step, int qy, int qx, int nv, int vw, int vh) {
+        v += step;
+        vx += qx;
+        vy += qy;
+        if (vx >= vw) {
+            vx -= vw;
+            ++vy;
+        }
+        while (v >= nv) {          // (v - nv) / vw == vy - vh because nv == vh * vw
+            v -= nv;
+            vy -= vh;
+            ++bq;
+        }
+    }
+    __device__ __forceinline__ void next(int nv, int vw) {
+        ++v;
+        ++vx;
+        if (vx == vw) {
+            vx = 0;
+            ++vy;
+        }
+        if (v == nv) {
+            v = vy = vx = 0;
+            ++bq;
+        }
+    }
+};
+
+// Observation word (board | goal colour << 16) at a cursor position.
+template <int H, int W>
+__device__ __forceinline__ u32 obs_fetch(const sl_env_batch &env, const unsigned char *smem, const ObsCursor &cu,
+                                         int n_exits) {
+    using Gm = Geom<H, W>;
+    const int vw = env.view_w, vh = env.view_h;
+    const int *pp = (const int *)(smem + Gm::OFF_GSH) + cu.bq * OBS_PAR_INTS;
+    const u16 *b16 = (const u16 *)(smem + Gm::OFF_BOARD + Gm::PAD) + cu.bq * Gm::HW;
+    const u16 *g16 = (const u16 *)(smem + Gm::OFF_GOALS + Gm::PAD) + cu.bq * Gm::HW;
+    const int sy = pos_mod(pp[0] - vh / 2 + cu.vy, H), sx = pos_mod(pp[1] - vw / 2 + cu.vx, W);
+    int cell = sy * W + sx;
+    for (int k = 0; k < n_exits; ++k)             // later exits overwrite earlier ones, as numpy does
+        if (pp[2 + k] == cu.v) cell = pp[2 + OBS_MAX_EXITS + k];
+    u32 g = g16[cell] & COLORS;
+    if (env.remove_white_goals && g == COLORS) g = 0;
+    return (u32)b16[cell] | (g << 16);
+}
+
+// The four channel bytes [4g, 4g+4) of a cell as one dword (missing channels give 0).
+template <int C>
+__device__ __forceinline__ u32 obs_bytes(const sl_env_batch &env, u32 word, int g) {
+    const int c0 = env.channels[4 * g];
+    const int n = C - 4 * g >= 4 ? 4 : C - 4 * g;
+    bool run = true;
+    for (int t = 1; t < n; ++t) run = run && env.channels[4 * g + t] == c0 + t;
+    if (run)      // consecutive bits: spread a nibble over four bytes with one multiply
+        return (((word >> c0) & ((1u << n) - 1u)) * 0x00204081u) & 0x01010101u;
+    u32 d = 0;
+    for (int t = 0; t < n; ++t) d |= ((word >> env.channels[4 * g + t]) & 1u) << (8 * t);
+    return d;
+}
+
+template <int C>
+struct ObsSel {
+    // byte i of the 4*C-byte group of four cells lives in padded dword (i / C) * P + ((i % C) >> 2), byte (i % C) & 3
+    static constexpr int P = (C + 3) / 4;
+    static constexpr int src(int i) { return (i / C) * P + ((i % C) >> 2); }
+    static constexpr int first(int j) { return src(4 * j); }
+    static constexpr int second(int j) {
+        for (int t = 1; t < 4; ++t)
+            if (src(4 * j + t) != src(4 * j)) return src(4 * j + t);
+        return src(4 * j);
+    }
+    static constexpr bool two_sources(int j) {
+        for (int t = 0; t < 4; ++t)
+            if (src(4 * j + t) != first(j) && src(4 * j + t) != second(j)) return false;
+        return true;
+    }
+    static constexpr bool ok() {
+        for (int j = 0; j < C; ++j)
+            if (!two_sources(j)) return false;
+        return true;
+    }
+    static constexpr u32 selector(int j) {      // v_perm_b32 selector: bytes 0-3 = first source, 4-7 = second
+        u32 sel = 0;
+        for (int t = 0; t < 4; ++t) {
+            const int i = 4 * j + t;
+            const u32 byte = (u32)((i % C) & 3) + (src(i) == first(j) ? 0u : 4u);
+            sel |= byte << (8 * t);
+        }
+        return sel;
+    }
+};
+
+// Observation of the workgroup's boards.  C = 15 / 19: uint8 channels, four cells (4*C bytes, a whole
+// number of dwords) per lane, assembled in registers and written with wide stores; C = 0: any other
+// channel list (byte stores) and the raw uint32 view.
+template <int H, int W, int C>
+__device__ __forceinline__ void write_obs_block(const sl_env_batch &env, const unsigned char *smem, int e0b,
+                                                int nbb, int tid) {
+    const int nv = env.view_h * env.view_w, vw = env.view_w;
+    const float inv_nv = 1.0f / (float)nv, inv_vw = 1.0f / (float)vw;
+    const int ncell = nbb * nv;
+    const int n_exits = min(env.E, OBS_MAX_EXITS);
+    ObsCursor cu;
+    if constexpr (C == 0) {
+        const int nc = env.n_channels;
+        const int qy = (64 * WAVES) / vw, qx = (64 * WAVES) - qy * vw;
+        cu.init(tid, nv, vw, inv_nv, inv_vw);
+        for (int c = tid; c < ncell; c += 64 * WAVES, cu.advance(64 * WAVES, qy, qx, nv, vw, env.view_h)) {
+            const u32 word = obs_fetch<H, W>(env, smem, cu, n_exits);
+            if (nc == 0) {
+                ((u32 *)env.obs)[(size_t)e0b * nv + c] = word;
+            } else {
+                uint8_t *o = env.obs + ((size_t)e0b * nv + c) * nc;
+                for (int k = 0; k < nc; ++k) o[k] = (word >> env.channels[k]) & 1u;
+            }
+        }
+    } else {
+        using Sel = ObsSel<C>;
+        constexpr int P = Sel::P;
+        u32 *dst = (u32 *)(env.obs + (size_t)e0b * nv * C);      // e0b is a multiple of 8: dword aligned
+        const int ngroup = ncell / 4;
+        constexpr int STEP = 4 * 64 * WAVES - 4;              // after the 4 next() calls of a group
+        const int qy = STEP / vw, qx = STEP - qy * vw;
+        cu.init(4 * tid, nv, vw, inv_nv, inv_vw);
+        for (int u = tid; u < ngroup; u += 64 * WAVES, cu.advance(STEP, qy, qx, nv, vw, env.view_h)) {
+            u32 pad[4 * P];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const u32 word = obs_fetch<H, W>(env, smem, cu, n_exits);
+#pragma unroll
+                for (int g = 0; g < P; ++g) pad[q * P + g] = obs_bytes<C>(env, word, g);
+                cu.next(nv, vw);
+            }
+            u32 out[C];
+#pragma unroll
+            for (int j = 0; j < C; ++j) {
+                static_assert(Sel::ok(), "obs packing needs at most two source dwords per output dword");
+                out[j] = __builtin_amdgcn_perm(pad[Sel::second(j)], pad[Sel::first(j)], Sel::selector(j));
+            }
+            u32 *o = dst + (size_t)u * C;
+            int j = 0;
+#pragma unroll
+            for (; j + 4 <= C; j += 4) *(u32x4_a4 *)(o + j) = u32x4_a4{out[j], out[j + 1], out[j + 2], out[j + 3]};
+            if constexpr (C % 4 == 3) *(u32x3_a4 *)(o + C - 3) = u32x3_a4{out[C - 3], out[C - 2], out[C - 1]};
+            if constexpr (C % 4 == 2) *(u32x2_a4 *)(o + C - 2) = u32x2_a4{out[C - 2], out[C - 1]};
+            if constexpr (C % 4 == 1) o[C - 1] = out[C - 1];
+        }
+        for (int c = 4 * ngroup + tid; c < ncell; c += 64 * WAVES) {      // tail workgroup leftovers
+            cu.init(c, nv, vw, inv_nv, inv_vw);
+            const u32 word = obs_fetch<H, W>(env, smem, cu, n_exits);
+            uint8_t *o = env.obs + ((size_t)e0b * nv + c) * C;
+            for (int k = 0; k < C; ++k) o[k] = (word >> env.channels[k]) & 1u;
+        }
+    }
+}
+
 // ---- fused env step / rollout ---------------------------------------------------------------------
 
 template <int H, int W, bool LDS_LUT, bool SPAWN>
@@ -812,49 +994,35 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_ba
         ((u64 *)(env.rng + e0b + wave * Gm::G))[lane] = rng_lds[lane];
 
     SL_STAMP(9);
-    // observation (safelife_env.py:105-146) from the LDS images, one wave per G boards
+    // observation (safelife_env.py:105-146) from the LDS images of the final state
     if (env.obs) {
-        const int vh = env.view_h, vw = env.view_w, C = env.n_channels, nv = vh * vw;
-        const u16 *b16 = (const u16 *)(board + Gm::PAD), *g16 = (const u16 *)(goals + Gm::PAD);
-        const u64 exq = (u64)(uintptr_t)exits;
-        for (int q = 0; q < Gm::G; ++q) {
-            const int gq = wave * Gm::G + q;
-            if (gq >= nbb) break;
-            const unsigned eq = e0b + gq;
-            const int qy = __builtin_amdgcn_readlane(ly, q * H), qx = __builtin_amdgcn_readlane(lx, q * H);
-            const int y0 = qy >= 0 ? qy : 0, x0 = qy >= 0 ? qx : 0;
-            const int32_t *ex = (const int32_t *)(uintptr_t)(
-                ((u64)(u32)__builtin_amdgcn_readlane((int)(exq >> 32), q * H) << 32) |
-                (u64)(u32)__builtin_amdgcn_readlane((int)exq, q * H));
-            const u16 *bq = b16 + gq * HW, *gq16 = g16 + gq * HW;
-            for (int v = lane; v < nv; v += 64) {
-                const int vy = v / vw, vx = v - vy * vw;
-                const int sy = pos_mod(y0 - vh / 2 + vy, H), sx = pos_mod(x0 - vw / 2 + vx, W);
-                u32 g0 = gq16[sy * W + sx] & COLORS;
-                if (env.remove_white_goals && g0 == COLORS) g0 = 0;
-                u32 word = bq[sy * W + sx] | (g0 << 16);
-                for (int k = 0; k < E; ++k) {
-                    const int xk = ex[k];
-                    if (xk < 0) continue;
+        // per board: view centre and, per exit slot, the view cell it is painted on + its board cell
+        int *par = (int *)(smem + Gm::OFF_GSH);                 // goal words are dead by now
+        if (leader) {
+            int *pp = par + gb * OBS_PAR_INTS;
+            const int y0 = ly >= 0 ? ly : 0, x0 = ly >= 0 ? lx : 0;
+            const int vh = env.view_h, vw = env.view_w;
+            pp[0] = y0;
+            pp[1] = x0;
+            for (int k = 0; k < OBS_MAX_EXITS; ++k) {
+                int tv = -1, xk = -1;
+                if (k < E) xk = k == 0 ? exit0 : exits[k];
+                if (xk >= 0) {      // helper_utils.py:64-74: offset wrapped into [-H/2, H/2), clipped to the view
                     const int iy = xk / W, ix = xk - iy * W;
                     int jy = pos_mod(iy - y0 + H / 2, H) - H / 2 + vh / 2;
                     int jx = pos_mod(ix - x0 + W / 2, W) - W / 2 + vw / 2;
                     jy = min(max(jy, 0), vh - 1);
                     jx = min(max(jx, 0), vw - 1);
-                    if (jy == vy && jx == vx) {
-                        u32 g1 = gq16[xk] & COLORS;
-                        if (env.remove_white_goals && g1 == COLORS) g1 = 0;
-                        word = bq[xk] | (g1 << 16);
-                    }
+                    tv = jy * vw + jx;
                 }
-                if (C == 0) {
-                    ((u32 *)env.obs)[(size_t)eq * nv + v] = word;
-                } else {
-                    uint8_t *o = env.obs + ((size_t)eq * nv + v) * C;
-                    for (int c = 0; c < C; ++c) o[c] = (word >> env.channels[c]) & 1u;
-                }
+                pp[2 + k] = tv;
+                pp[2 + OBS_MAX_EXITS + k] = xk;
             }
         }
+        __syncthreads();
+        if (env.n_channels == 15) write_obs_block<H, W, 15>(env, smem, e0b, nbb, tid);
+        else if (env.n_channels == 19) write_obs_block<H, W, 19>(env, smem, e0b, nbb, tid);
+        else write_obs_block<H, W, 0>(env, smem, e0b, nbb, tid);
     }
 }
 
