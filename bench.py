@@ -99,8 +99,10 @@ def main():
     ap.add_argument("--gather-every", type=int, default=32)
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-steps", type=int, default=101)
-    ap.add_argument("--rollout", type=int, default=0,
+    ap.add_argument("--rollout", type=int, default=32,
                     help="T>0: additionally time T-step fused rollouts (reported under 'extra')")
+    ap.add_argument("--extras", type=int, default=1,
+                    help="1: also time the step with observations (reported under 'extra'; 1 GPU only)")
     args = ap.parse_args()
 
     import torch
@@ -176,6 +178,27 @@ def main():
         ms = e0.elapsed_time(e1) / reps
         extra["rollout_T"] = T
         extra["rollout_env_steps_per_s_per_gpu"] = B * T / (ms * 1e-3)
+        extra["rollout_us_per_step"] = ms * 1e3 / T
+    if args.extras and world == 1:
+        # the same step with the two observation formats of the reference (SafeLifeEnv.output_channels)
+        for tag, chans in (("obs_u8_25x25x15", TRAIN_CHANNELS), ("obs_u32_view_25x25", None)):
+            env2 = SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25), output_channels=chans,
+                                     auto_reset=True, level_stride=1, with_obs=True)
+            env2.reset()
+            for t in range(20):
+                env2.step(actions[t])
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = min(K, 200)
+            e0.record()
+            for t in range(n):
+                env2.step(actions[t])
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / n * 1e3
+            extra[tag + "_us_per_step"] = us
+            extra[tag + "_env_steps_per_s"] = B / (us * 1e-6)
+            del env2
 
     if rank == 0:
         obs_bytes = {0: 0, 1: H * Wd * len(TRAIN_CHANNELS), 2: H * Wd * 4}[args.obs]

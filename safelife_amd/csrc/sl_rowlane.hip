@@ -1087,7 +1087,7 @@ static hipError_t launch_rollout_t(const sl_env_batch &env, const int32_t *actio
 
 }  // namespace rl
 
-#define SL_ROWLANE_SHAPES(X) X(25, 25) X(26, 26)
+#define SL_ROWLANE_SHAPES(X) X(25, 25) X(26, 26) X(15, 15) X(20, 20) X(10, 10)
 
 bool rowlane_supports(int H, int W) {
 #define X(h, w) if (H == h && W == w) return true;

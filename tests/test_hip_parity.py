@@ -113,6 +113,7 @@ def test_side_effect_occupancy_tensors(sp):
 # ------------------------------------------------------------------ primitives vs oracle, seeded
 
 @pytest.mark.parametrize("shape,B", [((25, 25), 1024), ((26, 26), 300), ((64, 64), 64), ((3, 3), 50),
+                                     ((15, 15), 130), ((20, 20), 77), ((10, 10), 100), ((25, 25), 5),
                                      ((5, 64), 33), ((64, 5), 33), ((10, 33), 40), ((31, 17), 40),
                                      ((100, 100), 6), ((128, 128), 2)])
 @pytest.mark.parametrize("kind", [0, 1, 2])
