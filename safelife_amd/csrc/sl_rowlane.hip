@@ -801,8 +801,8 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_ba
         action = actions[e];
         exit0 = exits[0];
     }
-    if (lane < 4 * Gm::G && wave * Gm::G + (lane >> 2) < nbb)
-        rng_lds[lane] = ((const u64 *)(env.rng + e0b + wave * Gm::G))[lane];
+    // everything bulky goes through the LDS DMA: nothing below waits before the barrier
+    dma_to_lds<Gm::NB * 32>((const unsigned char *)(env.rng + e0b), smem + Gm::OFF_RNG, nbb * 32, lane, wave);
     if (LDS_LUT) dma_to_lds<4096>((const unsigned char *)env.score_lut, smem + Gm::OFF_LUT, 4096, lane, wave);
     load_span<H, W>(env.board + (size_t)e0b * HW, board, nbb, tid);
     load_span<H, W>(env.goals + (size_t)e0b * HW, goals, nbb, tid);
