@@ -16,7 +16,14 @@ cellular-automaton step of ``safelife/speedups_src`` and the integer glue of
 Importing the package needs neither torch nor a GPU; calling any compute entry point without
 ``libsafelife_hip.so`` or without a HIP device raises (there is no CPU fallback).
 """
-from .cell_types import CellTypes, DEFAULT_POINTS_TABLE  # noqa: F401
+import os as _os
+
+# Kernel arguments in device memory instead of host-coherent memory: the fused step kernel takes a
+# ~600-byte argument struct and starts ~5 us earlier per launch this way (measured on MI355X).  Must
+# be set before the HIP runtime initialises, i.e. before torch is imported.
+_os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
+from .cell_types import CellTypes, DEFAULT_POINTS_TABLE  # noqa: F401,E402
 
 __version__ = "0.1.0"
 
