@@ -31,12 +31,13 @@ typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WAVES = 4;
 
-// -DSL_TRACE: phase timestamps (s_memtime) of wave 0 of every workgroup are written to the
-// `reward_t` argument, reinterpreted as long long [grid, 16] (profiling builds only).
+// -DSL_TRACE: phase timestamps (s_memrealtime) of every wave are written to the `reward_t`
+// argument, reinterpreted as long long [grid * WAVES, 16] (profiling builds only).
 #ifdef SL_TRACE
 #define SL_STAMP(i)                                                                     \
     do {                                                                                \
-        if (threadIdx.x == 0 && reward_t) ((long long *)reward_t)[blockIdx.x * 16 + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); \
+        if ((threadIdx.x & 63) == 0 && reward_t)                                        \
+            ((long long *)reward_t)[(blockIdx.x * WAVES + (threadIdx.x >> 6)) * 16 + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); \
     } while (0)
 #else
 #define SL_STAMP(i) do {} while (0)
@@ -92,15 +93,26 @@ __device__ __forceinline__ int wave_scan(int v) {
 // half and cell k+WS in its high half (unused for k = WS-1 when W is odd).  The left / right
 // neighbours of both cells of word k are the two cells of word k-1 / k+1, so the horizontal pass
 // needs no intra-register shifts; only the seams (cells 0, WS-1, WS, W-1) need a byte permute.
+enum { V_BPERM = 0, V_SHIFT = 1, V_ROTATE = 2 };
+
 template <int H, int W>
 struct Geom {
     static constexpr int HW = H * W;
     static constexpr int WS = (W + 1) / 2;
     static constexpr bool ODD = (W & 1) != 0;
-    static constexpr int G = 64 / H;                       // boards per wave
+    // Rows above / below a lane's row (VERT):
+    //   V_SHIFT   every board also keeps copies of its last and first row in a lane in front of and a
+    //             lane behind its H row lanes, so both neighbours are one DPP wave shift away (no LDS
+    //             traffic).  Chosen when the two extra lanes per board do not cost a board per wave.
+    //   V_ROTATE  H == 64: one board fills the wave, the torus is a DPP wave rotate.
+    //   V_BPERM   ds_bpermute with per-lane addresses that wrap inside the board's lane group.
+    static constexpr int VERT = H == 64 ? V_ROTATE : (64 / (H + 2) == 64 / H ? V_SHIFT : V_BPERM);
+    static constexpr int GL = H + (VERT == V_SHIFT ? 2 : 0);   // lanes per board
+    static constexpr int G = 64 / GL;                      // boards per wave
     static_assert(G >= 1, "H must be <= 64");
-    static_assert(WS <= 16 && W >= 4 && H >= 4, "row-per-lane path: 4 <= W <= 32, H >= 4");
-    static constexpr int NL = G * H;                       // lanes in use
+    static_assert(WS <= 32 && W >= 4 && H >= 4, "row-per-lane path: 4 <= W <= 64, H >= 4");
+    static constexpr int WAVES_PER_SIMD = WS <= 16 ? 4 : 2;   // VGPR budget: 128 / 256 registers
+    static constexpr int NL = G * GL;                      // lanes in use
     static constexpr int NB = WAVES * G;                   // boards per workgroup
     static_assert((NB * HW) % 8 == 0, "workgroup span must be a multiple of 16 bytes");
     static constexpr int SPAN = NB * HW * 2;               // bytes
@@ -187,6 +199,56 @@ __device__ __forceinline__ u32 right_of(const RowWords<H, W> &q, const Seams<H, 
     return q[k + 1];
 }
 
+// Which row of which board a lane holds.
+template <int H, int W>
+struct LaneMap {
+    int g, r;           // board within the wave, row
+    bool real;          // the lane owns row r (false: halo copy, V_SHIFT only)
+    int up, dn;         // V_BPERM: ds_bpermute byte addresses of the lanes holding rows r-1 / r+1
+    __device__ __forceinline__ LaneMap(int lane) {
+        using Gm = Geom<H, W>;
+        g = 0;
+#pragma unroll
+        for (int q = 1; q < Gm::G; ++q) g += (lane >= q * Gm::GL) ? 1 : 0;
+        const int j = lane - g * Gm::GL;
+        if (Gm::VERT == V_SHIFT) {
+            real = j >= 1 && j <= H;
+            r = j == 0 ? H - 1 : (j == H + 1 ? 0 : j - 1);
+        } else {
+            real = true;
+            r = j;
+        }
+        const bool in = lane < Gm::NL;
+        real = real && in;
+        if (!in) r = 0;
+        up = 4 * (in ? (r == 0 ? lane + H - 1 : lane - 1) : lane);
+        dn = 4 * (in ? (r == H - 1 ? lane - (H - 1) : lane + 1) : lane);
+    }
+    // first / last lane of board q's group and the lane of its row 0
+    static constexpr int first_lane(int q) { return q * Geom<H, W>::GL; }
+    static constexpr int last_lane(int q) { return q * Geom<H, W>::GL + Geom<H, W>::GL - 1; }
+};
+
+template <int VERT>
+__device__ __forceinline__ u32 from_above(int up, u32 v) {      // the value held by the lane of row r-1
+    if (VERT == V_SHIFT) return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, true);    // wave_shr:1
+    if (VERT == V_ROTATE) return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x13C, 0xF, 0xF, false);  // wave_ror:1
+    return bperm(up, v);
+}
+template <int VERT>
+__device__ __forceinline__ u32 from_below(int dn, u32 v) {      // the value held by the lane of row r+1
+    if (VERT == V_SHIFT) return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, true);    // wave_shl:1
+    if (VERT == V_ROTATE) return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x134, 0xF, 0xF, false);  // wave_rol:1
+    return bperm(dn, v);
+}
+
+struct Elig {           // cells whose outcome needs a random draw: one bit per cell of the row
+    u32 lo, hi;         // word k: low half -> lo bit WS-1-k, high half -> hi bit WS-1-k (WS > 16), or
+                        // lo bit 16+WS-1-k with hi unused (WS <= 16)
+    __device__ __forceinline__ bool any() const { return (lo | hi) != 0; }
+    __device__ __forceinline__ void clear() { lo = hi = 0; }
+};
+
 struct Consts {         // masks held in VGPRs for the whole kernel
     u32 m1, once, anya, three, spawn, eight;
 };
@@ -214,7 +276,7 @@ __device__ __forceinline__ Consts make_consts() {
 //   w: colour bits of spawner cells, plus, after each pass, the "seen twice" bits -- all at the
 //      cells' native bit positions, so the new cell is assembled without shifts.
 template <int H, int W, bool SPAWN>
-__device__ __forceinline__ void ca_rows(const RowWords<H, W> &b, RowWords<H, W> &n, u32 &elig, int up, int dn,
+__device__ __forceinline__ void ca_rows(const RowWords<H, W> &b, RowWords<H, W> &n, Elig &elig, int up, int dn,
                                         const Consts &c) {
     using Gm = Geom<H, W>;
     constexpr int WS = Gm::WS;
@@ -229,7 +291,7 @@ __device__ __forceinline__ void ca_rows(const RowWords<H, W> &b, RowWords<H, W> 
     const Seams<H, W> so = make_seams<H, W>(o);
     Seams<H, W> sw = {0u, 0u, 0u};
     if (SPAWN) sw = make_seams<H, W>(w);
-    elig = 0;
+    elig.clear();
 #pragma unroll
     for (int k = 0; k < WS; ++k) {
         const u32 oL = left_of<H, W>(o, so, k), oR = right_of<H, W>(o, so, k);
@@ -241,8 +303,8 @@ __device__ __forceinline__ void ca_rows(const RowWords<H, W> &b, RowWords<H, W> 
         const u32 cs = oL + o[k] + oR;                               // bits 0-1: alive cells in the row triple
         const u32 ro = BO3_INSERT(xo, cs, c.three);
         // column pass
-        const u32 Uo = bperm(up, ro), Do = bperm(dn, ro);
-        const u32 Uw = bperm(up, wr), Dw = bperm(dn, wr);
+        const u32 Uo = from_above<Gm::VERT>(up, ro), Do = from_below<Gm::VERT>(dn, ro);
+        const u32 Uw = from_above<Gm::VERT>(up, wr), Dw = from_below<Gm::VERT>(dn, wr);
         const u32 X = BO3_OR3(Uo, ro, Do);
         const u32 m2 = BO3_MAJ(Uo, ro, Do);
         const u32 xw2 = BO3_OR3(Uw, wr, Dw);
@@ -271,29 +333,38 @@ __device__ __forceinline__ void ca_rows(const RowWords<H, W> &b, RowWords<H, W> 
         const u32 nm = SPAWN ? BO3_AND_OR(nv, NM, __umul24(el, 8u))  // spawned cells are always destructible
                              : (nv & NM);
         n[k] = BO3_AND_OR(bb, KM, nm);
-        if (SPAWN) elig = elig + elig + el;
+        if (SPAWN) {
+            if (WS <= 16) {
+                elig.lo = elig.lo + elig.lo + el;       // both halves fit one word (hi flags at 16 + ...)
+            } else {
+                elig.lo = elig.lo + elig.lo + (el & 1u);
+                elig.hi = elig.hi + elig.hi + (el >> 16);
+            }
+        }
     }
 }
 
 template <int H, int W>
-__device__ __forceinline__ bool flagged_lo(u32 elig, int k) { return (elig >> (Geom<H, W>::WS - 1 - k)) & 1u; }
+__device__ __forceinline__ bool flagged_lo(const Elig &elig, int k) { return (elig.lo >> (Geom<H, W>::WS - 1 - k)) & 1u; }
 template <int H, int W>
-__device__ __forceinline__ bool flagged_hi(u32 elig, int k) { return (elig >> (16 + Geom<H, W>::WS - 1 - k)) & 1u; }
+__device__ __forceinline__ bool flagged_hi(const Elig &elig, int k) {
+    return Geom<H, W>::WS <= 16 ? (elig.lo >> (16 + Geom<H, W>::WS - 1 - k)) & 1u : (elig.hi >> (Geom<H, W>::WS - 1 - k)) & 1u;
+}
 
 // Resolve the flagged halves with each board's PCG64 stream, row-major (wave-uniform call).
 // rng_lds: this wave's G x {state_hi, state_lo, inc_hi, inc_lo}; advanced by the draws consumed.
 template <int H, int W>
-__device__ void resolve_draws(const RowWords<H, W> &b, RowWords<H, W> &n, u32 elig, u64 *rng_lds, int g,
+__device__ void resolve_draws(const RowWords<H, W> &b, RowWords<H, W> &n, const Elig &elig, u64 *rng_lds, int g,
                               bool lead, double p, const Jump *__restrict__ jump) {
     using Gm = Geom<H, W>;
     constexpr int WS = Gm::WS;
-    const int mine = __popc(elig);
+    const int mine = __popc(elig.lo) + __popc(elig.hi);
     const int incl = wave_scan(mine);
     int before = 0, total = 0;
 #pragma unroll
     for (int q = 0; q < Gm::G; ++q) {
-        const int lo = q ? __builtin_amdgcn_readlane(incl, q * H - 1) : 0;
-        const int hi = __builtin_amdgcn_readlane(incl, q * H + H - 1);
+        const int lo = q ? __builtin_amdgcn_readlane(incl, LaneMap<H, W>::first_lane(q) - 1) : 0;
+        const int hi = __builtin_amdgcn_readlane(incl, LaneMap<H, W>::last_lane(q));
         if (g == q) {
             before = lo;
             total = hi - lo;
@@ -329,14 +400,15 @@ __device__ void resolve_draws(const RowWords<H, W> &b, RowWords<H, W> &n, u32 el
 }
 
 // Sum of a per-lane value over the lanes of the caller's board (every lane gets its board's total).
-template <int H, int G>
+template <int H, int W>
 __device__ __forceinline__ int group_total(int v, int g) {
+    constexpr int G = Geom<H, W>::G;
     const int incl = wave_scan(v);
     int total = 0;
 #pragma unroll
     for (int q = 0; q < G; ++q) {
-        const int lo = q ? __builtin_amdgcn_readlane(incl, q * H - 1) : 0;
-        const int hi = __builtin_amdgcn_readlane(incl, q * H + H - 1);
+        const int lo = q ? __builtin_amdgcn_readlane(incl, LaneMap<H, W>::first_lane(q) - 1) : 0;
+        const int hi = __builtin_amdgcn_readlane(incl, LaneMap<H, W>::last_lane(q));
         if (g == q) total = hi - lo;
     }
     return total;
@@ -506,7 +578,7 @@ __device__ __forceinline__ void store_span(u16 *__restrict__ dst, const unsigned
 // ---- advance_board --------------------------------------------------------------------------------
 
 template <int H, int W>
-__global__ __launch_bounds__(64 * WAVES) void k_advance_rowlane(const u16 *__restrict__ in, u16 *__restrict__ out,
+__global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_advance_rowlane(const u16 *__restrict__ in, u16 *__restrict__ out,
                                                                 int B, const float *__restrict__ spawn_prob,
                                                                 int n_steps, sl_pcg64 *rng,
                                                                 const Jump *__restrict__ jump) {
@@ -515,15 +587,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_advance_rowlane(const u16 *__res
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int e0b = blockIdx.x * Gm::NB;
     const int nbb = min(Gm::NB, B - e0b);
-    int g = 0;
-#pragma unroll
-    for (int q = 1; q < Gm::G; ++q) g += (lane >= q * H) ? 1 : 0;
-    const int r = lane - g * H;
+    const LaneMap<H, W> lm(lane);
+    const int g = lm.g, r = lm.r, up = lm.up, dn = lm.dn;
     const int gb = wave * Gm::G + g;
-    const bool live = lane < Gm::NL && gb < nbb;
+    const bool rowl = lane < Gm::NL && gb < nbb;       // holds a row (its own or a halo copy)
+    const bool live = rowl && lm.real;
     const unsigned e = e0b + (live ? gb : 0);
-    const int up = 4 * (live ? (r == 0 ? lane + H - 1 : lane - 1) : lane);
-    const int dn = 4 * (live ? (r == H - 1 ? lane - (H - 1) : lane + 1) : lane);
     unsigned char *board = smem + Gm::OFF_BOARD;
     u64 *rng_lds = (u64 *)(smem + Gm::OFF_RNG) + 4 * Gm::G * wave;
 
@@ -534,16 +603,22 @@ __global__ __launch_bounds__(64 * WAVES) void k_advance_rowlane(const u16 *__res
     __syncthreads();
     const Consts cst = make_consts();
     RowWords<H, W> b, n;
-    u32 elig;
+    Elig elig;
 #pragma unroll
     for (int k = 0; k < Gm::WS; ++k) b[k] = 0;
-    if (live) read_row<H, W>(board, gb, r, b);
+    if (rowl) read_row<H, W>(board, gb, r, b);
     for (int s = 0; s < n_steps; ++s) {
         ca_rows<H, W, true>(b, n, elig, up, dn, cst);
-        if (!live) elig = 0;
-        if (__ballot(elig != 0)) resolve_draws<H, W>(b, n, elig, rng_lds, live ? g : 0, live && r == 0, p, jump);
+        if (!live) elig.clear();
+        if (__ballot(elig.any())) resolve_draws<H, W>(b, n, elig, rng_lds, live ? g : 0, live && r == 0, p, jump);
 #pragma unroll
         for (int k = 0; k < Gm::WS; ++k) b[k] = n[k];
+        if (Gm::VERT == V_SHIFT && s + 1 < n_steps) {      // refresh the halo copies through LDS
+            if (live) write_row<H, W>(board, gb, r, b);
+            wave_sync();
+            if (rowl && !lm.real) read_row<H, W>(board, gb, r, b);
+            wave_sync();
+        }
     }
     if (live) write_row<H, W>(board, gb, r, b);
     __syncthreads();
@@ -737,7 +812,7 @@ __device__ __forceinline__ void write_obs_block(const sl_env_batch &env, const u
 // ---- fused env step / rollout ---------------------------------------------------------------------
 
 template <int H, int W, bool LDS_LUT, bool SPAWN>
-__global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_batch env,
+__global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_env_rollout_rowlane(sl_env_batch env,
                                                                        const int32_t *__restrict__ actions, int T,
                                                                        float *__restrict__ reward_t,
                                                                        uint8_t *__restrict__ done_t,
@@ -750,20 +825,21 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_ba
     const int E = env.E;
     const int e0b = blockIdx.x * Gm::NB;
     const int nbb = min(Gm::NB, (int)B - e0b);
-    int g = 0;
-#pragma unroll
-    for (int q = 1; q < Gm::G; ++q) g += (lane >= q * H) ? 1 : 0;
-    const int r = lane - g * H;
+    const LaneMap<H, W> lm(lane);
+    const int g = lm.g, r = lm.r, up = lm.up, dn = lm.dn;
     const int gb = wave * Gm::G + g;
-    const bool live = lane < Gm::NL && gb < nbb;
+    const bool rowl = lane < Gm::NL && gb < nbb;       // holds a row: its own, or a halo copy (V_SHIFT)
+    const bool live = rowl && lm.real;                 // owns row r of board gb
     const bool leader = live && r == 0;
-    const unsigned e = e0b + (live ? gb : 0);
-    const int up = 4 * (live ? (r == 0 ? lane + H - 1 : lane - 1) : lane);
-    const int dn = 4 * (live ? (r == H - 1 ? lane - (H - 1) : lane + 1) : lane);
+    const unsigned e = e0b + (rowl ? gb : 0);
     unsigned char *board = smem + Gm::OFF_BOARD, *goals = smem + Gm::OFF_GOALS;
     u16 *board16 = (u16 *)(board + Gm::PAD) + (live ? gb : 0) * HW;
     u64 *rng_lds = (u64 *)(smem + Gm::OFF_RNG) + 4 * Gm::G * wave;
-    u32 *gsh_lane = (u32 *)(smem + Gm::OFF_GSH) + (wave * 64 + lane) * WS;
+    // goal colours of the lane's row, pre-shifted for the score index: in registers where the
+    // budget allows (spawner-free variants: 119 VGPRs; 64-wide boards run 2 waves/SIMD), else in LDS
+    constexpr bool GSH_REG = !SPAWN || Gm::WAVES_PER_SIMD < 4;
+    u32 gsh_reg[GSH_REG ? WS : 1];
+    u32 *gsh_lane = GSH_REG ? gsh_reg : (u32 *)(smem + Gm::OFF_GSH) + (wave * 64 + lane) * WS;
     const int8_t *lds_lut = (const int8_t *)(smem + Gm::OFF_LUT);
     const int8_t *__restrict__ lut = env.score_lut + 4096;        // wide form of table t at + t * SCORE_LUT_BYTES
     const Consts cst = make_consts();
@@ -779,7 +855,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_ba
     double p = 0.0;
     u32 lut_base = 0;
     sl_env_scalars *const sc = env.scalars + e;
-    if (live) {         // values every lane of the board needs (same address per group: broadcast loads)
+    if (rowl) {         // values every lane of the board needs (same address per group: broadcast loads)
         p = (double)sc->spawn_prob;
         gstatic = sc->goals_static;
         lut_base = (u32)sc->table_idx * (u32)SCORE_LUT_BYTES;
@@ -811,7 +887,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_ba
     SL_STAMP(2);
 
     RowWords<H, W> b;
-    u32 elig;
+    Elig elig;
 #pragma unroll
     for (int k = 0; k < WS; ++k) b[k] = 0;
     if (live) {
@@ -831,16 +907,17 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_ba
         wave_sync();
         SL_STAMP(4);
         // safelife_env.py:152 : board first, then goals unless they are static (safelife_game.py:746-761)
-        const bool dyn = live && gstatic != 1;
+        const bool dyn = rowl && gstatic != 1;
         const int passes = __ballot(dyn) ? 2 : 1;
 #pragma nounroll
         for (int pass = 0; pass < passes; ++pass) {
-            const bool mine = live && (pass == 0 || dyn);
+            const bool has = rowl && (pass == 0 || dyn);     // row to advance (halo copies included)
+            const bool mine = has && lm.real;
             unsigned char *img = pass == 0 ? board : goals;
-            if (mine) read_row<H, W>(img, gb, r, b);
+            if (has) read_row<H, W>(img, gb, r, b);
             ca_rows<H, W, SPAWN>(b, b, elig, up, dn, cst);   // in place: b now holds the new cells
-            if (!mine) elig = 0;
-            if (SPAWN && __ballot(elig != 0)) {
+            if (!mine) elig.clear();
+            if (SPAWN && __ballot(elig.any())) {
                 RowWords<H, W> old;                          // failed draws keep the old cell: re-read it
 #pragma unroll
                 for (int k = 0; k < WS; ++k) old[k] = 0;
@@ -856,9 +933,9 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_ba
                     for (int k = 0; k < WS; ++k)
                         diff |= ((b[k] ^ old[k]) | (b[k] & 0x00800080u)) & (Gm::vm1(k) * 0xFFFFu);
                 }
-                const int changed = group_total<H, Gm::G>(mine && diff ? 1 : 0, live ? g : 0);
+                const int changed = group_total<H, W>(mine && diff ? 1 : 0, rowl ? g : 0);
+                if (has && gstatic == 0) gstatic = changed ? 2 : 1;
                 if (mine) {
-                    if (gstatic == 0) gstatic = changed ? 2 : 1;
 #pragma unroll
                     for (int k = 0; k < WS; ++k) gsh_lane[k] = goal_shift(b[k]);
                     goals_dirty = true;
@@ -872,7 +949,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_ba
         }
         SL_STAMP(5);
         // safelife_env.py:153-160
-        const int score = group_total<H, Gm::G>(
+        const int score = group_total<H, W>(
             live ? row_score<H, W, LDS_LUT>(b, gsh_lane, lut, lut_base, lds_lut, cell_mask, c100) : 0, live ? g : 0);
         wave_sync();
         SL_STAMP(6);
@@ -913,8 +990,9 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_ba
         }
         // on-device auto-reset (training/base_algo.py:231-236 calls env.reset() after a done step)
         if (env.auto_reset && __ballot(leader && done)) {
-            const int flag = group_total<H, Gm::G>(leader && done ? 1 : 0, live ? g : 0);
+            const int flag = group_total<H, W>(leader && done ? 1 : 0, rowl ? g : 0);
             const bool mine = live && flag != 0;
+            if (rowl && flag != 0) gstatic = 0;
             if (mine) {
                 level = (level + env.level_stride) % env.L;
                 const u16 *pb = env.pool_board + (size_t)level * HW, *pg = env.pool_goals + (size_t)level * HW;
@@ -938,7 +1016,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_ba
                 for (int k = 0; k < WS; ++k) gsh_lane[k] = goal_shift(b[k]);
                 read_row<H, W>(board, gb, r, b);
             }
-            const int s0 = group_total<H, Gm::G>(
+            const int s0 = group_total<H, W>(
                 mine ? row_score<H, W, LDS_LUT>(b, gsh_lane, lut, lut_base, lds_lut, cell_mask, c100) : 0,
                 live ? g : 0);
             if (mine && r == 0) {
@@ -994,6 +1072,15 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_env_rollout_rowlane(sl_env_ba
         ((u64 *)(env.rng + e0b + wave * Gm::G))[lane] = rng_lds[lane];
 
     SL_STAMP(9);
+#ifdef SL_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SL_STAMP(10);       // this wave's stores acknowledged
+    if ((threadIdx.x & 63) == 0 && reward_t) {
+        long long *tr = (long long *)reward_t + (blockIdx.x * WAVES + (threadIdx.x >> 6)) * 16;
+        tr[11] = __builtin_amdgcn_s_getreg(20 | (31 << 11));   // XCC_ID
+        tr[12] = __builtin_amdgcn_s_getreg(4 | (31 << 11));    // HW_ID
+    }
+#endif
     // observation (safelife_env.py:105-146) from the LDS images of the final state
     if (env.obs) {
         // per board: view centre and, per exit slot, the view cell it is painted on + its board cell
@@ -1087,7 +1174,7 @@ static hipError_t launch_rollout_t(const sl_env_batch &env, const int32_t *actio
 
 }  // namespace rl
 
-#define SL_ROWLANE_SHAPES(X) X(25, 25) X(26, 26) X(15, 15) X(20, 20) X(10, 10)
+#define SL_ROWLANE_SHAPES(X) X(25, 25) X(26, 26) X(15, 15) X(20, 20) X(10, 10) X(64, 64)
 
 bool rowlane_supports(int H, int W) {
 #define X(h, w) if (H == h && W == w) return true;

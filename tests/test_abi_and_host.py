@@ -101,7 +101,7 @@ def test_level_archive(tmp_path):
     assert lvls[2].name.endswith(os.path.join("arch", "lv2"))
 
 
-@pytest.mark.parametrize("name", ["prune_still_25", "append_spawn_25", "append_still_26"])
+@pytest.mark.parametrize("name", ["prune_still_25", "append_spawn_25", "append_still_26", "navigation_64"])
 def test_pool_constants_match_reference(name):
     """required_points / initial_available_points of the reference's own procgen levels."""
     pool, ref = util.pool_from_fixture(name, util.oracle_counts)

@@ -188,6 +188,9 @@ ENV_STATE = ("board", "goals", "agent_loc", "exit_locs", "rng", "num_steps", "ol
     ("append_spawn_25", 512, 150, dict(time_limit=70, view_shape=(15, 15))),
     ("append_still_26", 200, 120, dict(time_limit=50, view_shape=(9, 33), output_channels=None,
                                        remove_white_goals=False)),
+    ("navigation_64", 96, 90, dict(time_limit=40, view_shape=(25, 25),
+                                   output_channels=(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 25, 26, 27))),
+    ("navigation_64", 40, 60, dict(time_limit=25, view_shape=(64, 64), output_channels=None)),
 ])
 def test_env_batch_vs_oracle(pool_name, B, T, kw):
     pool, _ = util.pool_from_fixture(pool_name, _device_counts, min_performance_fraction=0.05)
