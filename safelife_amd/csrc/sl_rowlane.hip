@@ -846,42 +846,34 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
     const u32 cell_mask = vreg(SCORE_CELL_MASK), c100 = vreg(0x01000100u);
 
     SL_STAMP(0);
-    // per-board scalars live in the leader lane's registers for the whole launch; their loads are
-    // issued before the bulk loads so that they are not queued behind them
-    int ly = -1, lx = -1, steps = 0, old_value = 0, required = 0, initial = 0, ep_len = 0, gstatic = 1;
-    int level = 0, episodes = 0, action = 0, exit0 = -1;
-    float ep_rew = 0.0f;
-    bool active = false;
-    double p = 0.0;
-    u32 lut_base = 0;
+    // Prologue, written so that nothing waits before the bulk loads are in flight:
+    //  * the kernel arguments the loads need are fetched in one batch (the compiler otherwise sinks
+    //    each s_load next to its first use: six dependent scalar-cache round trips in a row);
+    //  * the per-board record is loaded by EVERY lane, unconditionally (a load inside `if (leader)`
+    //    is waited for at the end of that block, in front of the DMA issue).  Only the leader lane's
+    //    copy of the per-episode fields is ever used or updated.
+    const u16 *k_board = env.board, *k_goals = env.goals;
+    const sl_pcg64 *k_rng = env.rng;
+    const int8_t *k_lut = env.score_lut;
     sl_env_scalars *const sc = env.scalars + e;
-    if (rowl) {         // values every lane of the board needs (same address per group: broadcast loads)
-        p = (double)sc->spawn_prob;
-        gstatic = sc->goals_static;
-        lut_base = (u32)sc->table_idx * (u32)SCORE_LUT_BYTES;
-        level = sc->level_idx;
-    }
     const int32_t *exits = env.exit_locs + (size_t)e * E;
-    if (leader) {
-        const sl_env_scalars rec = *sc;     // one 64-byte record
-        ly = rec.agent_row;
-        lx = rec.agent_col;
-        steps = rec.num_steps;
-        old_value = rec.old_value;
-        required = rec.required_points;
-        initial = rec.initial_points;
-        ep_len = rec.episode_length;
-        ep_rew = rec.episode_reward;
-        active = rec.is_active != 0;
-        episodes = rec.episode_idx;
-        action = actions[e];
-        exit0 = exits[0];
-    }
-    // everything bulky goes through the LDS DMA: nothing below waits before the barrier
-    dma_to_lds<Gm::NB * 32>((const unsigned char *)(env.rng + e0b), smem + Gm::OFF_RNG, nbb * 32, lane, wave);
-    if (LDS_LUT) dma_to_lds<4096>((const unsigned char *)env.score_lut, smem + Gm::OFF_LUT, 4096, lane, wave);
-    load_span<H, W>(env.board + (size_t)e0b * HW, board, nbb, tid);
-    load_span<H, W>(env.goals + (size_t)e0b * HW, goals, nbb, tid);
+    const int32_t *k_act = actions + e;
+    asm volatile("" ::"s"(k_board), "s"(k_goals), "s"(k_rng), "s"(k_lut));
+    const sl_env_scalars rec = *sc;     // one 64-byte record (same address within a board: broadcast)
+    int action = *k_act;
+    int exit0 = exits[0];
+    // everything bulky goes through the LDS DMA
+    dma_to_lds<Gm::NB * 32>((const unsigned char *)(k_rng + e0b), smem + Gm::OFF_RNG, nbb * 32, lane, wave);
+    if (LDS_LUT) dma_to_lds<4096>((const unsigned char *)k_lut, smem + Gm::OFF_LUT, 4096, lane, wave);
+    load_span<H, W>(k_board + (size_t)e0b * HW, board, nbb, tid);
+    load_span<H, W>(k_goals + (size_t)e0b * HW, goals, nbb, tid);
+    int ly = rec.agent_row, lx = rec.agent_col, steps = rec.num_steps, old_value = rec.old_value;
+    int required = rec.required_points, initial = rec.initial_points, ep_len = rec.episode_length;
+    int gstatic = rec.goals_static, level = rec.level_idx, episodes = rec.episode_idx;
+    float ep_rew = rec.episode_reward;
+    bool active = rec.is_active != 0;
+    double p = (double)rec.spawn_prob;
+    u32 lut_base = (u32)rec.table_idx * (u32)SCORE_LUT_BYTES;
     SL_STAMP(1);
     __syncthreads();
     SL_STAMP(2);
