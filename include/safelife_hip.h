@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SL_ABI_VERSION 1
+#define SL_ABI_VERSION 2
 #define SL_MAX_CELLS 16384        /* H*W limit of one board */
 #define SL_MAX_CHANNELS 32
 
@@ -102,7 +102,9 @@ typedef struct sl_env_scalars {
     float spawn_prob;             /* GameState.spawn_prob */
     int32_t goals_static;         /* SafeLifeGame._static_goals: 0 None, 1 True, 2 False */
     int32_t is_active;            /* SafeLifeEnv._is_active */
-    int32_t reserved[2];
+    int32_t exit_open_at_reset;   /* can_exit() during the reset's update_exit_colors (the exit paint of
+                                     SimpleSideEffectPenalty's starting-state baseline) */
+    int32_t reserved;
 } sl_env_scalars;
 
 /* What one step() returns per env besides the observation (16 bytes). */
@@ -127,6 +129,48 @@ typedef struct sl_level_scalars {
     float spawn_prob;
     int32_t reserved;
 } sl_level_scalars;
+
+/* Training-wrapper math of safelife/env_wrappers.py, applied per env inside the step in the order
+ * of training/env_factory.py:277-283:
+ *   MovementBonusWrapper   :32-98   reward += movement_bonus * speed**power [- movement_bonus]
+ *   ExtraExitBonus         :120-128 reward += done * bonus * episode_reward   (unless times_up)
+ *   SimpleSideEffectPenalty:150-213 reward -= penalty_coef * (side_effect - last_side_effect),
+ *                                   baseline = "starting-state" (the board right after reset)
+ * (MinPerformanceScheduler :131-147 has no per-step arithmetic: sl_level_scalars.required_step.)
+ * The wrapped reward is float64, as in the reference (np.float32 + np.float64), evaluated with the
+ * same operations in the same order; speed**power comes from a host-built table so no pow() runs on
+ * the device.  flags == 0 switches all of it off.  The "inaction" baseline draws from the
+ * process-wide generator in the reference, has no per-env stream, and is not offered here. */
+#define SL_WRAP_MOVEMENT 1
+#define SL_WRAP_AS_PENALTY 2            /* MovementBonusWrapper.as_penalty */
+#define SL_WRAP_EXIT_BONUS 4
+#define SL_WRAP_SIDE_EFFECT 8
+#define SL_WRAP_IGNORE_REWARD_CELLS 16  /* SimpleSideEffectPenalty.ignore_reward_cells */
+#define SL_WRAP_MAX_PERIOD 8
+
+typedef struct sl_wrap_state {    /* per env, 48 bytes */
+    int32_t n_prior;              /* positions held by MovementBonusWrapper's deque (<= period) */
+    int32_t last_side_effect;     /* SimpleSideEffectPenalty.last_side_effect */
+    int16_t prior[SL_WRAP_MAX_PERIOD][2];   /* (row, col), oldest first */
+    int32_t reserved[2];
+} sl_wrap_state;
+
+typedef struct sl_wrappers {
+    int32_t flags;                /* SL_WRAP_* */
+    int32_t move_period;          /* movement_bonus_period, 1..SL_WRAP_MAX_PERIOD */
+    int32_t move_table_len;       /* >= H + W + move_period */
+    int32_t reserved;
+    double move_bonus;            /* movement_bonus */
+    double exit_bonus;            /* ExtraExitBonus.bonus */
+    double penalty_coef;          /* SimpleSideEffectPenalty.penalty_coef */
+    const double *move_table;     /* [move_table_len]: movement_bonus * (d / period) ** power, d = 0.. */
+    sl_wrap_state *state;         /* [B] */
+    double *shaped_reward;        /* [B] out: what the outermost wrapper's step() returns as reward */
+    double *shaped_reward_t;      /* [T,B] per-step copy for slhip_env_rollout, or NULL */
+    uint32_t *pool_baseline;      /* workspace [L, H, (W+1)/2]: every pool level as it stands right after
+                                     reset, player bits cleared, in the row kernels' register layout;
+                                     filled by slhip_env_prepare() (needed with SL_WRAP_SIDE_EFFECT) */
+} sl_wrappers;
 
 typedef struct sl_env_batch {
     int32_t B, H, W, E;          /* envs; board dims; exit slots per env (>= 1) */
@@ -163,9 +207,11 @@ typedef struct sl_env_batch {
     /* workspace */
     int8_t *score_lut;           /* [n_tables,4096+65536] per-cell score tables derived from points_table by
                                     slhip_env_prepare(); NULL => the size-generic kernels are used */
+    sl_wrappers wrap;            /* training wrappers; wrap.flags == 0 => none */
 } sl_env_batch;
 
-/* Derive env->score_lut from env->points_table (call once, and again whenever points_table changes).
+/* Derive env->score_lut from env->points_table, and env->wrap.pool_baseline from the level pool
+ * (call once, and again whenever points_table or the pool changes).
  * Synchronises the stream.  Returns SL_E_UNSUPPORTED when a table entry does not fit int8; the
  * caller then passes score_lut = NULL and every shape runs on the size-generic kernels. */
 int slhip_env_prepare(const sl_env_batch *env, void *stream);

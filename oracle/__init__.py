@@ -90,6 +90,30 @@ class EnvBatch(C.Structure):
     ]
 
 
+_f64p = C.POINTER(C.c_double)
+
+WRAP_MOVEMENT, WRAP_AS_PENALTY, WRAP_EXIT_BONUS, WRAP_SIDE_EFFECT, WRAP_IGNORE_REWARD_CELLS = 1, 2, 4, 8, 16
+
+
+class Wrappers(C.Structure):
+    _fields_ = [
+        ("flags", C.c_int32), ("move_period", C.c_int32), ("move_table_len", C.c_int32), ("reserved", C.c_int32),
+        ("move_bonus", C.c_double), ("exit_bonus", C.c_double), ("penalty_coef", C.c_double),
+        ("move_table", _f64p), ("n_prior", _i32p), ("prior", _i32p), ("last_side_effect", _i32p),
+        ("baseline", _u16p), ("shaped_reward", _f64p),
+    ]
+
+
+def movement_table(bonus, period, power, length):
+    """movement_bonus * speed**power for every distance 0..length-1, evaluated by numpy exactly as
+    env_wrappers.py:85-87 does (float64 scalars), so no pow() is ever taken off the host."""
+    out = np.zeros(length, np.float64)
+    for d in range(length):
+        speed = np.sum((np.array([d]) / period)[:1])
+        out[d] = bonus * speed ** power
+    return out
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -117,6 +141,8 @@ def lib():
         L.slo_env_reset.argtypes = [C.POINTER(EnvBatch), C.c_void_p]
         L.slo_env_step.argtypes = [C.POINTER(EnvBatch), C.c_void_p, C.c_int]
         L.slo_env_obs.argtypes = [C.POINTER(EnvBatch), C.c_int]
+        L.slo_env_reset_wrapped.argtypes = [C.POINTER(EnvBatch), C.POINTER(Wrappers), C.c_void_p]
+        L.slo_env_step_wrapped.argtypes = [C.POINTER(EnvBatch), C.POINTER(Wrappers), C.c_void_p, C.c_int]
         _LIB = L
     return _LIB
 
@@ -324,14 +350,41 @@ class OracleEnv:
             setattr(s, k, C.cast(_ptr(a[k]), ftype))
         s.obs = C.cast(_ptr(self.obs), _u8p) if self.obs is not None else None
 
+    def set_wrappers(self, movement_bonus=None, movement_bonus_power=1e-100, movement_bonus_period=4,
+                     as_penalty=True, exit_bonus=None, penalty_coef=None, ignore_reward_cells=False):
+        """Training wrappers of env_factory.py:277-283 (None = wrapper absent)."""
+        B, H, W = self.s.B, self.s.H, self.s.W
+        w = self.w = Wrappers()
+        self.wa = wa = {
+            "n_prior": np.zeros(B, np.int32), "prior": np.zeros((B, 8, 2), np.int32),
+            "last_side_effect": np.zeros(B, np.int32), "baseline": np.zeros((B, H, W), np.uint16),
+            "shaped_reward": np.zeros(B, np.float64),
+            "move_table": movement_table(movement_bonus or 0.0, movement_bonus_period,
+                                         movement_bonus_power, H + W + movement_bonus_period + 1),
+        }
+        w.flags = ((WRAP_MOVEMENT if movement_bonus is not None else 0)
+                   | (WRAP_AS_PENALTY if as_penalty else 0)
+                   | (WRAP_EXIT_BONUS if exit_bonus is not None else 0)
+                   | (WRAP_SIDE_EFFECT if penalty_coef is not None else 0)
+                   | (WRAP_IGNORE_REWARD_CELLS if ignore_reward_cells else 0))
+        w.move_period = movement_bonus_period
+        w.move_table_len = len(wa["move_table"])
+        w.move_bonus = movement_bonus or 0.0
+        w.exit_bonus = exit_bonus or 0.0
+        w.penalty_coef = penalty_coef or 0.0
+        for k in ("move_table", "n_prior", "prior", "last_side_effect", "baseline", "shaped_reward"):
+            setattr(w, k, C.cast(_ptr(wa[k]), dict(Wrappers._fields_)[k]))
+
     def reset(self, mask=None):
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
-        lib().slo_env_reset(C.byref(self.s), None if m is None else _ptr(m))
+        w = C.byref(self.w) if getattr(self, "w", None) is not None else None
+        lib().slo_env_reset_wrapped(C.byref(self.s), w, None if m is None else _ptr(m))
         return self.obs
 
     def step(self, actions, n_threads=1):
         acts = np.ascontiguousarray(actions, dtype=np.int32)
         assert acts.shape == (self.s.B,)
-        rc = lib().slo_env_step(C.byref(self.s), _ptr(acts), n_threads)
+        w = C.byref(self.w) if getattr(self, "w", None) is not None else None
+        rc = lib().slo_env_step_wrapped(C.byref(self.s), w, _ptr(acts), n_threads)
         assert rc == 0, rc
         return self.obs, self.a["reward"], self.a["done"]

@@ -35,6 +35,7 @@ enum {
     C_SPAWNING = 1 << 7,
     C_EXIT = 1 << 8,
     C_COLOR_R = 1 << 9,
+    C_COLOR_B = 1 << 11,
     C_COLORS = 7 << 9,
     C_ORIENT_SHIFT = 12,
     C_ORIENT = 3 << 12,
@@ -458,14 +459,93 @@ static void reset_one(slo_env_batch *env, int e) {
     env->episode_length[e] = 0;
 }
 
-int slo_env_reset(slo_env_batch *env, const uint8_t *mask) {
+/* ------------------------------------------------ training wrappers */
+
+#define C_PLAYER (C_AGENT | C_DESTRUCTIBLE | C_FROZEN | C_PRESERVING | C_INHIBITING)  /* CellTypes.player */
+
+/* wrappers' reset(): env_wrappers.py:94-98 (deque of prior positions) and :168-172 (baseline) */
+static void wrap_reset_one(slo_env_batch *env, slo_wrappers *w, int e) {
+    size_t n = (size_t)env->H * env->W;
+    w->n_prior[e] = 1;
+    w->prior[16 * e + 0] = env->agent_loc[2 * e];
+    w->prior[16 * e + 1] = env->agent_loc[2 * e + 1];
+    w->last_side_effect[e] = 0;
+    if (w->baseline) memcpy(w->baseline + e * n, env->board + e * n, n * sizeof(uint16_t));
+    w->shaped_reward[e] = 0.0;
+}
+
+/* The three wrappers' step(), innermost first, on the state step_one() left behind. */
+static void wrap_step_one(slo_env_batch *env, slo_wrappers *w, int e) {
+    int H = env->H, W = env->W, E = env->E;
+    size_t n = (size_t)H * W;
+    double r = (double)env->reward[e];
+    const int32_t *loc = env->agent_loc + 2 * e;
+    if (w->flags & SLO_WRAP_MOVEMENT) {            /* env_wrappers.py:67-92 */
+        int per = w->move_period, np_ = w->n_prior[e];
+        int32_t *q = w->prior + 16 * e;
+        int dist;
+        if (loc[0] < 0) {
+            dist = -1;                             /* no agent: speed = sum(empty) = 0 */
+        } else if (np_ >= per) {
+            dist = abs(loc[0] - q[0]) + abs(loc[1] - q[1]);        /* prior[-n] is the oldest */
+        } else if (np_ > 0) {
+            dist = abs(loc[0] - q[0]) + abs(loc[1] - q[1]) + (per - np_);
+        } else {
+            dist = per;
+        }
+        double bonus = dist < 0 ? w->move_table[0] : w->move_table[dist];
+        r = r + bonus;
+        if (w->flags & SLO_WRAP_AS_PENALTY) r = r - w->move_bonus;
+        /* deque(maxlen=period).append */
+        if (np_ >= per) {
+            memmove(q, q + 2, (size_t)(per - 1) * 2 * sizeof(int32_t));
+            np_ = per - 1;
+        }
+        q[2 * np_] = loc[0];
+        q[2 * np_ + 1] = loc[1];
+        w->n_prior[e] = np_ + 1;
+    }
+    if ((w->flags & SLO_WRAP_EXIT_BONUS) && !env->times_up[e])     /* env_wrappers.py:124-128 */
+        r = r + (double)(env->done[e] ? 1 : 0) * w->exit_bonus * (double)env->episode_reward[e];
+    if (w->flags & SLO_WRAP_SIDE_EFFECT) {         /* env_wrappers.py:174-213 */
+        const uint16_t *board = env->board + e * n, *goals = env->goals + e * n;
+        const uint16_t *base = w->baseline + e * n;
+        const int32_t *exits = env->exit_locs + (size_t)e * E;
+        int32_t side = 0;
+        for (size_t i = 0; i < n; i++) {
+            int is_exit = 0;
+            for (int k = 0; k < E; k++) is_exit |= (exits[k] == (int32_t)i);
+            if (is_exit) continue;                 /* board[i1,i2] = baseline_board[i1,i2] */
+            uint16_t b = board[i] & (uint16_t)~C_PLAYER, b0 = base[i] & (uint16_t)~C_PLAYER;
+            int unchanged = b == b0;
+            if (w->flags & SLO_WRAP_IGNORE_REWARD_CELLS) {
+                const uint16_t red_life = C_ALIVE | C_COLOR_R;
+                int start_red = (b0 & red_life) == red_life, end_red = (b & red_life) == red_life;
+                int goal_cell = (goals[i] & C_COLORS) == C_COLOR_B;
+                int end_alive = (b & red_life) == C_ALIVE;
+                side += !(unchanged || (start_red && !end_red) || (goal_cell && end_alive));
+            } else {
+                side += !unchanged;
+            }
+        }
+        int32_t delta = side - w->last_side_effect[e];
+        r = r - (double)delta * w->penalty_coef;
+        w->last_side_effect[e] = side;
+    }
+    w->shaped_reward[e] = r;
+}
+
+int slo_env_reset_wrapped(slo_env_batch *env, slo_wrappers *wrap, const uint8_t *mask) {
     for (int e = 0; e < env->B; e++) {
         if (mask && !mask[e]) continue;
         reset_one(env, e);
+        if (wrap) wrap_reset_one(env, wrap, e);
         make_obs(env, e);
     }
     return 0;
 }
+
+int slo_env_reset(slo_env_batch *env, const uint8_t *mask) { return slo_env_reset_wrapped(env, NULL, mask); }
 
 int slo_env_obs(slo_env_batch *env, int n_threads) {
     int nt = pick_threads(n_threads);
@@ -531,7 +611,12 @@ static void step_one(slo_env_batch *env, int e, int action, uint16_t *scratch) {
 }
 
 int slo_env_step(slo_env_batch *env, const int32_t *actions, int n_threads) {
+    return slo_env_step_wrapped(env, NULL, actions, n_threads);
+}
+
+int slo_env_step_wrapped(slo_env_batch *env, slo_wrappers *wrap, const int32_t *actions, int n_threads) {
     if (env->H < 3 || env->W < 3) return -1;
+    if (wrap && (wrap->move_period < 1 || wrap->move_period > SLO_WRAP_MAX_PERIOD)) return -1;
     size_t n = (size_t)env->H * env->W;
     int nt = pick_threads(n_threads);
 #pragma omp parallel num_threads(nt)
@@ -540,10 +625,16 @@ int slo_env_step(slo_env_batch *env, const int32_t *actions, int n_threads) {
 #pragma omp for schedule(static)
         for (int e = 0; e < env->B; e++) {
             step_one(env, e, actions[e], scratch);
+            if (wrap) wrap_step_one(env, wrap, e);
             if (env->auto_reset && env->done[e]) {
                 env->level_idx[e] = (env->level_idx[e] + env->level_stride) % env->L;
                 env->episode_idx[e] += 1;
                 reset_one(env, e);
+                if (wrap) {
+                    double keep = wrap->shaped_reward[e];
+                    wrap_reset_one(env, wrap, e);
+                    wrap->shaped_reward[e] = keep;
+                }
             }
             make_obs(env, e);
         }

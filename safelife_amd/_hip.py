@@ -45,11 +45,31 @@ ENV_OUT_PTRS = ("out", "obs", "score_lut")
 #: int32 column of each field inside `struct sl_env_scalars` (64 bytes = 16 columns)
 SCALAR_COLS = {"agent_row": 0, "agent_col": 1, "num_steps": 2, "old_value": 3, "required_points": 4,
                "initial_points": 5, "table_idx": 6, "level_idx": 7, "episode_idx": 8, "episode_length": 9,
-               "episode_reward": 10, "spawn_prob": 11, "goals_static": 12, "is_active": 13, "flags": 14}
+               "episode_reward": 10, "spawn_prob": 11, "goals_static": 12, "is_active": 13,
+               "exit_open_at_reset": 14}
 SCALAR_FLOATS = ("episode_reward", "spawn_prob")
 #: `struct sl_level_scalars` (32 bytes = 8 columns)
 LEVEL_COLS = {"agent_row": 0, "agent_col": 1, "required_reset": 2, "required_step": 3, "initial_points": 4,
               "table_idx": 5, "spawn_prob": 6}
+
+
+WRAP_MOVEMENT, WRAP_AS_PENALTY, WRAP_EXIT_BONUS, WRAP_SIDE_EFFECT, WRAP_IGNORE_REWARD_CELLS = 1, 2, 4, 8, 16
+WRAP_MAX_PERIOD = 8
+
+
+class WrapState(C.Structure):
+    """`struct sl_wrap_state` (48 bytes)."""
+    _fields_ = [("n_prior", C.c_int32), ("last_side_effect", C.c_int32),
+                ("prior", C.c_int16 * (2 * WRAP_MAX_PERIOD)), ("reserved", C.c_int32 * 2)]
+
+
+class Wrappers(C.Structure):
+    """`struct sl_wrappers`."""
+    _fields_ = [("flags", C.c_int32), ("move_period", C.c_int32), ("move_table_len", C.c_int32),
+                ("reserved", C.c_int32),
+                ("move_bonus", C.c_double), ("exit_bonus", C.c_double), ("penalty_coef", C.c_double),
+                ("move_table", _p), ("state", _p), ("shaped_reward", _p), ("shaped_reward_t", _p),
+                ("pool_baseline", _p)]
 
 
 class EnvBatch(C.Structure):
@@ -60,6 +80,7 @@ class EnvBatch(C.Structure):
         + [("L", C.c_int32), ("level_stride", C.c_int32)]
         + [(n, _p) for n in ENV_POOL_PTRS]
         + [(n, _p) for n in ENV_OUT_PTRS]
+        + [("wrap", Wrappers)]
     )
 
 

@@ -90,6 +90,19 @@ int check_env(const sl_env_batch *env) {
                           env->pool_scalars, env->out};
     for (const void *p : need)
         if (!p) return fail(SL_E_ARG, "null pointer in sl_env_batch");
+    const sl_wrappers &w = env->wrap;
+    if (w.flags) {
+        if (w.flags & ~(SL_WRAP_MOVEMENT | SL_WRAP_AS_PENALTY | SL_WRAP_EXIT_BONUS | SL_WRAP_SIDE_EFFECT |
+                        SL_WRAP_IGNORE_REWARD_CELLS))
+            return fail(SL_E_ARG, "unknown bit in wrap.flags");
+        if (!w.state || !w.shaped_reward) return fail(SL_E_ARG, "wrap.state / wrap.shaped_reward is null");
+        if (w.flags & SL_WRAP_MOVEMENT) {
+            if (w.move_period < 1 || w.move_period > SL_WRAP_MAX_PERIOD)
+                return fail(SL_E_ARG, "wrap.move_period outside 1..SL_WRAP_MAX_PERIOD");
+            if (!w.move_table || w.move_table_len < env->H + env->W + w.move_period)
+                return fail(SL_E_ARG, "wrap.move_table missing or shorter than H + W + move_period");
+        }
+    }
     return SL_OK;
 }
 
@@ -173,6 +186,8 @@ int slhip_env_prepare(const sl_env_batch *env, void *stream) {
     for (int32_t v : host)
         if (v < -128 || v > 127) return fail(SL_E_UNSUPPORTED, "points_table entry outside int8 range");
     err = sl::launch_build_score_lut(env->points_table, env->n_tables, env->score_lut, (hipStream_t)stream);
+    if (err == hipSuccess && env->wrap.pool_baseline)
+        err = sl::launch_build_baseline(*env, (hipStream_t)stream);
     return err == hipSuccess ? SL_OK : hip_fail(err, "env_prepare launch");
 }
 
@@ -194,8 +209,13 @@ int slhip_env_rollout(const sl_env_batch *env, const int32_t *actions, int T, fl
     const sl::Jump *jump;
     if ((rc = jump_table(&jump))) return rc;
     const bool aligned = (((uintptr_t)env->board | (uintptr_t)env->goals) & 15) == 0;
+    // the row kernels take the wrapper math when its workspace is there (side-effect baseline)
+    const bool wrap_ok =
+        !env->wrap.flags ||
+        ((!(env->wrap.flags & SL_WRAP_SIDE_EFFECT) || env->wrap.pool_baseline) &&
+         (((uintptr_t)env->wrap.state | (uintptr_t)env->wrap.move_table) & 15) == 0);
     hipError_t err = (sl::rowlane_supports(env->H, env->W) && env->score_lut && aligned && env->E <= 8 &&
-                      !force_generic())
+                      wrap_ok && !force_generic())
                          ? sl::launch_env_rollout_rowlane(*env, actions, T, reward_t, done_t, jump,
                                                           (hipStream_t)stream)
                          : sl::launch_env_rollout_generic(*env, actions, T, reward_t, done_t, jump,

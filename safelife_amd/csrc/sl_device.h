@@ -28,11 +28,13 @@ enum : u32 {
     SPAWNING = 1u << 7,
     EXIT = 1u << 8,
     COLOR_R = 1u << 9,
+    COLOR_B = 1u << 11,
     COLORS = 7u << 9,
     ORIENT_SHIFT = 12,
     ORIENT_MASK = 3u << 12,
     PULLABLE = 1u << 15,
     MOVABLE_OR_DESTRUCTIBLE = DESTRUCTIBLE | PUSHABLE | PULLABLE,
+    PLAYER = AGENT | DESTRUCTIBLE | FROZEN | PRESERVING | INHIBITING,   // CellTypes.player (122)
 };
 
 // summary / accumulator fields (advance_board.c:6-9)
@@ -195,6 +197,88 @@ __device__ void act_one(u16 *board, int H, int W, LocT *loc, int action) {
     } else {
         *here = 0;
     }
+}
+
+// ---- training wrappers (env_wrappers.py) ----------------------------------------------------------
+
+// A pool level's cell as it stands right after SafeLifeEnv.reset() (update_exit_colors applied):
+// SimpleSideEffectPenalty's "starting-state" baseline (env_wrappers.py:168-172), player bits cleared.
+__device__ __forceinline__ u32 baseline_cell(u32 pool_cell, bool is_exit, bool exit_open) {
+    u32 c = pool_cell;
+    if (is_exit) c = FROZEN | EXIT | (exit_open ? COLOR_R : 0u);               // safelife_game.py:548-552
+    else if (c & AGENT) c = (c & ~EXIT) | (exit_open ? EXIT : 0u);             // safelife_game.py:543-547
+    return c & 0xFFFFu & ~PLAYER;
+}
+
+// One cell's contribution to SimpleSideEffectPenalty's count (env_wrappers.py:186-208); b and b0 have
+// their player bits cleared already.
+__device__ __forceinline__ int side_effect_cell(u32 b, u32 b0, u32 goal, bool ignore_reward_cells) {
+    if (b == b0) return 0;
+    if (ignore_reward_cells) {
+        const u32 red_life = ALIVE | COLOR_R;
+        const bool start_red = (b0 & red_life) == red_life, end_red = (b & red_life) == red_life;
+        const bool goal_cell = (goal & COLORS) == COLOR_B, end_alive = (b & red_life) == ALIVE;
+        if ((start_red && !end_red) || (goal_cell && end_alive)) return 0;
+    }
+    return 1;
+}
+
+// MovementBonusWrapper / ExtraExitBonus / SimpleSideEffectPenalty step() for one env, innermost
+// first, in float64 with the reference's operation order (env_wrappers.py:67-92,124-128,210-213).
+// `side_effect` is the count of differing cells (ignored without SL_WRAP_SIDE_EFFECT).
+// MT: anything indexable that yields the movement table's doubles (global or LDS pointer).
+template <typename MT>
+__device__ __forceinline__ double wrap_step(const sl_wrappers &w, sl_wrap_state &st, MT move_table, float reward,
+                                            bool done, bool times_up, float episode_reward, int ly, int lx,
+                                            int side_effect) {
+#pragma clang fp contract(off)      // numpy rounds the product and the sum separately: no fused multiply-add
+    double r = (double)reward;
+    if (w.flags & SL_WRAP_MOVEMENT) {
+        const int per = w.move_period;
+        int np_ = st.n_prior;
+        int d = 0;                                      // no agent: speed = sum(empty) = 0
+        if (ly >= 0) {
+            const int dr = ly - st.prior[0][0], dc = lx - st.prior[0][1];
+            d = (dr < 0 ? -dr : dr) + (dc < 0 ? -dc : dc);
+            if (np_ < per) d += per - np_;              // "as if it had been moving before entering"
+        }
+        r = r + move_table[d];
+        if (w.flags & SL_WRAP_AS_PENALTY) r = r - w.move_bonus;
+        if (np_ >= per) {                               // deque(maxlen=per).append
+#pragma unroll
+            for (int k = 0; k + 1 < SL_WRAP_MAX_PERIOD; ++k) {
+                st.prior[k][0] = st.prior[k + 1][0];
+                st.prior[k][1] = st.prior[k + 1][1];
+            }
+            np_ = per - 1;
+        }
+#pragma unroll
+        for (int k = 0; k < SL_WRAP_MAX_PERIOD; ++k)
+            if (k == np_) {
+                st.prior[k][0] = (int16_t)ly;
+                st.prior[k][1] = (int16_t)lx;
+            }
+        st.n_prior = np_ + 1;
+    }
+    if ((w.flags & SL_WRAP_EXIT_BONUS) && !times_up)
+        r = r + (done ? 1.0 : 0.0) * w.exit_bonus * (double)episode_reward;
+    if (w.flags & SL_WRAP_SIDE_EFFECT) {
+        const int delta = side_effect - st.last_side_effect;
+        r = r - (double)delta * w.penalty_coef;
+        st.last_side_effect = side_effect;
+    }
+    return r;
+}
+
+// wrappers' reset() (env_wrappers.py:94-98,168-172)
+__device__ __forceinline__ void wrap_reset(sl_wrap_state &st, int ly, int lx) {
+#pragma unroll
+    for (int k = 0; k < SL_WRAP_MAX_PERIOD; ++k) st.prior[k][0] = st.prior[k][1] = 0;
+    st.n_prior = 1;
+    st.prior[0][0] = (int16_t)ly;
+    st.prior[0][1] = (int16_t)lx;
+    st.last_side_effect = 0;
+    st.reserved[0] = st.reserved[1] = 0;
 }
 
 }  // namespace sl

@@ -219,7 +219,7 @@ __device__ int board_score(const u16 *board, const u16 *goals, int HW,
 }
 
 // GameState.update_exit_colors (safelife_game.py:537-552), single agent, by thread 0.
-__device__ void recolor_exits(u16 *board, int W, int ly, int lx, const int32_t *exits, int E,
+__device__ bool recolor_exits(u16 *board, int W, int ly, int lx, const int32_t *exits, int E,
                               int score, int initial, int required, int exit_points) {
     bool any_can = false;
     if (ly >= 0) {
@@ -235,6 +235,7 @@ __device__ void recolor_exits(u16 *board, int W, int ly, int lx, const int32_t *
         int ex = exits[k];
         if (ex >= 0) board[ex] = paint;
     }
+    return any_can;
 }
 
 // SafeLifeEnv.get_obs for env e from the board in LDS; goals through `goals` (LDS or global).
@@ -295,8 +296,8 @@ __device__ void reset_block(const sl_env_batch &env, int e, u16 *brd, int *ivar,
     const int32_t *table = env.points_table + 72 * lv.table_idx;
     int score = board_score(brd, pg, HW, table, wave_tot);
     if (tid == 0) {
-        recolor_exits(brd, env.W, ivar[0], ivar[1], env.pool_exit_locs + (size_t)l * E, E, score,
-                      lv.initial_points, lv.required_reset, env.exit_points);
+        const bool open = recolor_exits(brd, env.W, ivar[0], ivar[1], env.pool_exit_locs + (size_t)l * E, E,
+                                        score, lv.initial_points, lv.required_reset, env.exit_points);
         int exited = ivar[0] >= 0 ? (has_exited(brd[ivar[0] * env.W + ivar[1]]) ? 1 : 0) : 0;
         sl_env_scalars n;
         n.agent_row = ivar[0];
@@ -313,8 +314,10 @@ __device__ void reset_block(const sl_env_batch &env, int e, u16 *brd, int *ivar,
         n.spawn_prob = lv.spawn_prob;
         n.goals_static = 0;
         n.is_active = 1;
-        n.reserved[0] = n.reserved[1] = 0;
+        n.exit_open_at_reset = open ? 1 : 0;
+        n.reserved = 0;
         *sc = n;
+        if (env.wrap.flags) wrap_reset(env.wrap.state[e], ivar[0], ivar[1]);
     }
     __syncthreads();
 }
@@ -407,8 +410,39 @@ __global__ __launch_bounds__(GB) void k_env_rollout_generic(sl_env_batch env,
             if (reward_t) reward_t[(size_t)t * env.B + e] = reward;
             if (done_t) done_t[(size_t)t * env.B + e] = done;
             ivar[2] = done;
+            ivar[3] = __float_as_int(reward);
+            ivar[4] = times_up;
+            ivar[5] = __float_as_int(ep_r);
         }
         __syncthreads();
+        if (env.wrap.flags) {       // env_wrappers.py: movement bonus, exit bonus, side-effect penalty
+            int side = 0;
+            if (env.wrap.flags & SL_WRAP_SIDE_EFFECT) {
+                // exit cells never count (env_wrappers.py:191-193): flag them in the free `rows` buffer
+                for (int i = tid; i < HW; i += GB) rows[i] = 0;
+                __syncthreads();
+                for (int k = tid; k < E; k += GB)
+                    if (exits[k] >= 0) rows[exits[k]] = 1;
+                __syncthreads();
+                const u16 *pb = env.pool_board + (size_t)sc->level_idx * HW;
+                const bool open = sc->exit_open_at_reset != 0;
+                const bool ignore = (env.wrap.flags & SL_WRAP_IGNORE_REWARD_CELLS) != 0;
+                int mine = 0;
+                for (int i = tid; i < HW; i += GB)
+                    if (!rows[i])
+                        mine += side_effect_cell(nxt[i] & 0xFFFFu & ~PLAYER, baseline_cell(pb[i], false, open),
+                                                 goals[i], ignore);
+                side = block_sum(mine, l.wave_tot);
+            }
+            if (tid == 0) {
+                const double shaped = wrap_step(env.wrap, env.wrap.state[e], env.wrap.move_table,
+                                                __int_as_float(ivar[3]), ivar[2] != 0, ivar[4] != 0,
+                                                __int_as_float(ivar[5]), ivar[0], ivar[1], side);
+                env.wrap.shaped_reward[e] = shaped;
+                if (env.wrap.shaped_reward_t) env.wrap.shaped_reward_t[(size_t)t * env.B + e] = shaped;
+            }
+            __syncthreads();
+        }
         u16 *sw = cur;
         cur = nxt;
         nxt = sw;

@@ -26,6 +26,7 @@ hipError_t launch_env_obs_generic(const sl_env_batch &env, hipStream_t stream);
 // sl_rowlane.hip : row-per-lane SWAR kernels for the shapes listed in SL_ROWLANE_SHAPES
 bool rowlane_supports(int H, int W);
 hipError_t launch_build_score_lut(const int32_t *points_table, int n_tables, int8_t *lut, hipStream_t stream);
+hipError_t launch_build_baseline(const sl_env_batch &env, hipStream_t stream);
 hipError_t launch_advance_rowlane(const u16 *in, u16 *out, int B, int H, int W, const float *spawn_prob,
                                   int n_steps, sl_pcg64 *rng, const Jump *jump, hipStream_t stream);
 hipError_t launch_env_rollout_rowlane(const sl_env_batch &env, const int32_t *actions, int T, float *reward_t,

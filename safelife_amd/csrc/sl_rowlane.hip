@@ -124,6 +124,14 @@ struct Geom {
     static constexpr int OFF_GSH = OFF_RNG + NB * 32;      // per lane WS words: goal colours, pre-shifted
     static constexpr int OFF_LUT = OFF_GSH + WAVES * 64 * WS * 4;   // 4 KiB compact score table
     static constexpr int LDS_BYTES = OFF_LUT + 4096;
+    // training wrappers (WRAP variants only): per-board sl_wrap_state, the movement table, and -- when the
+    // goal words occupy OFF_GSH -- the baseline rows of the side-effect count
+    static constexpr int OFF_WST = LDS_BYTES;
+    static constexpr int MVT_N = (H + W + SL_WRAP_MAX_PERIOD + 1) & ~1;        // doubles staged
+    static constexpr int OFF_MVT = OFF_WST + NB * (int)sizeof(sl_wrap_state);
+    static constexpr int OFF_BASE = OFF_MVT + MVT_N * 8;
+    static constexpr int LDS_WRAP_GSHREG = OFF_BASE;                           // baseline rows reuse OFF_GSH
+    static constexpr int LDS_WRAP_GSHLDS = OFF_BASE + WAVES * 64 * WS * 4;
     static constexpr int LDS_ADVANCE = OFF_RNG + NB * 32;  // advance_board needs no score state
     // validity of the halves of word k as a 0x0001-per-half mask
     static constexpr u32 vm1(int k) { return (ODD && k == WS - 1) ? 0x00000001u : 0x00010001u; }
@@ -447,6 +455,40 @@ __device__ __forceinline__ int row_score(const RowWords<H, W> &n, const u32 *gsh
     return s;
 }
 
+// ---- SimpleSideEffectPenalty: cells of the lane's row that differ from the baseline row ------------
+// (env_wrappers.py:186-208).  b: the board row; base: the baseline row, player bits already cleared;
+// gsh: the row's goal colours on bits 5-7 of each half.  Exit cells are NOT excluded here: they all
+// carry the same paint, so the leader subtracts them (see the kernel).
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+template <int H, int W>
+__device__ __forceinline__ int row_side_effect(const RowWords<H, W> &b, const u32 *base_col, const u32 *gsh,
+                                               bool ignore_reward_cells, u32 not_player, u32 m1) {
+    using Gm = Geom<H, W>;
+    u32 acc = 0;
+#pragma unroll
+    for (int k = 0; k < Gm::WS; ++k) {
+        const u32 b0 = base_col[k * 64];
+        u32 x = SL_BO3((TA ^ TB) & TC, b[k], b0, not_player);
+        if (Gm::ODD && k == Gm::WS - 1) x &= 0x0000FFFFu;
+        const u16x2 one = {1, 1};
+        u16x2 nzv = __builtin_elementwise_min(__builtin_bit_cast(u16x2, x), one);      // v_pk_min_u16: half != 0
+        u32 nz = __builtin_bit_cast(u32, nzv);
+        if (ignore_reward_cells) {
+            const u32 bb = b[k];
+            // everything at bit 0 of each half; red_life = ALIVE | COLOR_R
+            const u32 start_red = b0 & (b0 >> 9), end_red = bb & (bb >> 9);             // (x & red_life) == red_life
+            const u32 end_alive = bb & ~(bb >> 9);                                      // (b & red_life) == ALIVE
+            const u32 g = gsh[k];
+            const u32 blue_goal = (g >> 7) & ~(g >> 6) & ~(g >> 5);                     // goal colour == blue
+            const u32 excuse = (start_red & ~end_red) | (blue_goal & end_alive);
+            nz &= ~excuse & m1;
+        }
+        acc += nz;
+    }
+    return (int)((acc & 0xFFFFu) + (acc >> 16));
+}
+
 // ---- execute_actions for one agent with the four touched cells gathered up front ----------------
 // (advance_board.c:217-300; valid for H, W >= 4 where the four cells are distinct)
 __device__ __forceinline__ int wrap1(int v, int n) { return v < 0 ? v + n : (v >= n ? v - n : v); }
@@ -508,9 +550,9 @@ __device__ __forceinline__ void act_gather(u16 *board, int H, int W, int &ly, in
 }
 
 // update_exit_colors for the board of a leader lane, on the flat LDS image.
-__device__ __forceinline__ void recolor_exits_lds(u16 *board, int W, int ly, int lx, const int32_t *exits,
+__device__ __forceinline__ bool recolor_exits_lds(u16 *board, int W, int ly, int lx, const int32_t *exits,
                                                   int exit0, int E, int score, int initial, int required,
-                                                  int exit_points) {
+                                                  int exit_points, int *n_exits = nullptr) {
     bool any_can = false;
     if (ly >= 0) {
         u16 *cell = board + ly * W + lx;
@@ -522,11 +564,20 @@ __device__ __forceinline__ void recolor_exits_lds(u16 *board, int W, int ly, int
         any_can = can;
     }
     const u16 paint = (u16)(FROZEN | EXIT | (any_can ? COLOR_R : 0u));
-    if (exit0 >= 0) board[exit0] = paint;         // slot 0 was prefetched; the usual level has one exit
+    int nx = 0;
+    if (exit0 >= 0) {                             // slot 0 was prefetched; the usual level has one exit
+        board[exit0] = paint;
+        nx = 1;
+    }
     for (int k = 1; k < E; ++k) {
         const int ex = exits[k];
-        if (ex >= 0) board[ex] = paint;
+        if (ex >= 0) {
+            board[ex] = paint;
+            ++nx;
+        }
     }
+    if (n_exits) *n_exits = nx;
+    return any_can;
 }
 
 // ---- workgroup span <-> HBM -----------------------------------------------------------------------
@@ -811,7 +862,7 @@ __device__ __forceinline__ void write_obs_block(const sl_env_batch &env, const u
 
 // ---- fused env step / rollout ---------------------------------------------------------------------
 
-template <int H, int W, bool LDS_LUT, bool SPAWN>
+template <int H, int W, bool LDS_LUT, bool SPAWN, bool WRAP>
 __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_env_rollout_rowlane(sl_env_batch env,
                                                                        const int32_t *__restrict__ actions, int T,
                                                                        float *__restrict__ reward_t,
@@ -841,6 +892,10 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
     u32 gsh_reg[GSH_REG ? WS : 1];
     u32 *gsh_lane = GSH_REG ? gsh_reg : (u32 *)(smem + Gm::OFF_GSH) + (wave * 64 + lane) * WS;
     const int8_t *lds_lut = (const int8_t *)(smem + Gm::OFF_LUT);
+    // wrappers: this wave's baseline rows, word k of lane l at [k * 64 + l] (the layout the b32 DMA writes)
+    unsigned char *base_rows = smem + (GSH_REG ? Gm::OFF_GSH : Gm::OFF_BASE) + wave * 64 * WS * 4;
+    sl_wrap_state *wst = (sl_wrap_state *)(smem + Gm::OFF_WST);
+    const double *mvt = (const double *)(smem + Gm::OFF_MVT);
     const int8_t *__restrict__ lut = env.score_lut + 4096;        // wide form of table t at + t * SCORE_LUT_BYTES
     const Consts cst = make_consts();
     const u32 cell_mask = vreg(SCORE_CELL_MASK), c100 = vreg(0x01000100u);
@@ -867,6 +922,14 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
     if (LDS_LUT) dma_to_lds<4096>((const unsigned char *)k_lut, smem + Gm::OFF_LUT, 4096, lane, wave);
     load_span<H, W>(k_board + (size_t)e0b * HW, board, nbb, tid);
     load_span<H, W>(k_goals + (size_t)e0b * HW, goals, nbb, tid);
+    if (WRAP) {
+        dma_to_lds<Gm::NB * (int)sizeof(sl_wrap_state)>((const unsigned char *)(env.wrap.state + e0b),
+                                                        smem + Gm::OFF_WST, nbb * (int)sizeof(sl_wrap_state),
+                                                        lane, wave);
+        if (env.wrap.flags & SL_WRAP_MOVEMENT)
+            dma_to_lds<Gm::MVT_N * 8>((const unsigned char *)env.wrap.move_table, smem + Gm::OFF_MVT,
+                                      min(env.wrap.move_table_len & ~1, Gm::MVT_N) * 8, lane, wave);
+    }
     int ly = rec.agent_row, lx = rec.agent_col, steps = rec.num_steps, old_value = rec.old_value;
     int required = rec.required_points, initial = rec.initial_points, ep_len = rec.episode_length;
     int gstatic = rec.goals_static, level = rec.level_idx, episodes = rec.episode_idx;
@@ -874,6 +937,7 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
     bool active = rec.is_active != 0;
     double p = (double)rec.spawn_prob;
     u32 lut_base = (u32)rec.table_idx * (u32)SCORE_LUT_BYTES;
+    int open0 = rec.exit_open_at_reset;                 // exit paint of the side-effect baseline
     SL_STAMP(1);
     __syncthreads();
     SL_STAMP(2);
@@ -891,6 +955,13 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
     SL_STAMP(3);
 
     for (int t = 0; t < T; ++t) {
+        if (WRAP && (env.wrap.flags & SL_WRAP_SIDE_EFFECT)) {
+            // baseline row (level, r) of every lane -> LDS, asynchronously; read after the CA pass
+            const u32 *src = env.wrap.pool_baseline + ((size_t)level * H + r) * WS;
+#pragma unroll
+            for (int k = 0; k < WS; ++k)
+                __builtin_amdgcn_global_load_lds((glds_src_t)(src + k), (glds_dst_t)(base_rows + k * 256), 4, 0, 0);
+        }
         // safelife_env.py:151
         if (leader && ly >= 0) {
             if (t > 0) action = actions[(size_t)t * B + e];
@@ -946,8 +1017,12 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
         wave_sync();
         SL_STAMP(6);
         bool done = false;
+        float w_reward = 0.0f;          // WRAP: this step's outputs, kept for the wrapper stage below
+        bool w_times_up = false, w_open = false;
+        int w_exits = 0;
         if (leader) {
-            recolor_exits_lds(board16, W, ly, lx, exits, exit0, E, score, initial, required, env.exit_points);
+            w_open = recolor_exits_lds(board16, W, ly, lx, exits, exit0, E, score, initial, required,
+                                       env.exit_points, WRAP ? &w_exits : nullptr);
             steps += 1;
             const bool times_up = steps >= env.time_limit;
             float reward = 0.0f;
@@ -964,6 +1039,8 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
             ep_rew += reward;
             ep_len += active ? 1 : 0;
             active = active && !done;
+            w_reward = reward;
+            w_times_up = times_up;
             sl_step_out o;
             o.reward = reward;
             o.done = done;
@@ -979,6 +1056,31 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
             if (reward_t) reward_t[(size_t)t * B + e] = reward;
             if (done_t) done_t[(size_t)t * B + e] = done;
 #endif
+        }
+        if (WRAP) {     // env_wrappers.py: movement bonus, exit bonus, side-effect penalty (float64)
+            int side = 0;
+            if (env.wrap.flags & SL_WRAP_SIDE_EFFECT) {
+                wave_sync();                                     // the leader's exit repaint is in LDS
+                int mine = 0;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // baseline rows have landed
+                if (live) {
+                    read_row<H, W>(board, gb, r, b);
+                    mine = row_side_effect<H, W>(b, (const u32 *)base_rows + lane, gsh_lane,
+                                                 (env.wrap.flags & SL_WRAP_IGNORE_REWARD_CELLS) != 0,
+                                                 vreg(~(PLAYER | (PLAYER << 16))), cst.m1);
+                }
+                side = group_total<H, W>(mine, rowl ? g : 0);
+            }
+            if (leader) {
+                // exit cells are ignored by the reference; here they all differ from the baseline (its
+                // exits carry the reset's paint) or none does
+                if (w_open != (open0 != 0)) side -= w_exits;
+                const double shaped = wrap_step(env.wrap, wst[gb], mvt, w_reward, done, w_times_up, ep_rew, ly, lx, side);
+                unsigned e4 = e;
+                asm volatile("" : "+v"(e4));
+                env.wrap.shaped_reward[e4] = shaped;
+                if (env.wrap.shaped_reward_t) env.wrap.shaped_reward_t[(size_t)t * B + e4] = shaped;
+            }
         }
         // on-device auto-reset (training/base_algo.py:231-236 calls env.reset() after a done step)
         if (env.auto_reset && __ballot(leader && done)) {
@@ -1019,8 +1121,9 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
                 ly = lv.agent_row;
                 lx = lv.agent_col;
                 initial = lv.initial_points;
-                recolor_exits_lds(board16, W, ly, lx, exits, exit0, E, s0, initial, lv.required_reset,
-                                  env.exit_points);
+                open0 = recolor_exits_lds(board16, W, ly, lx, exits, exit0, E, s0, initial, lv.required_reset,
+                                          env.exit_points) ? 1 : 0;
+                if (WRAP) wrap_reset(wst[gb], ly, lx);
                 const int exited = ly >= 0 ? (has_exited(board16[ly * W + lx]) ? 1 : 0) : 0;
                 old_value = s0 + env.exit_points * exited;
                 required = lv.required_step;
@@ -1051,7 +1154,8 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
         rec.spawn_prob = (float)p;
         rec.goals_static = gstatic;
         rec.is_active = active ? 1 : 0;
-        rec.reserved[0] = rec.reserved[1] = 0;
+        rec.exit_open_at_reset = open0;
+        rec.reserved = 0;
         unsigned e2 = e;                      // recompute the record address here instead of keeping
         asm volatile("" : "+v"(e2));          // a 64-bit pointer alive (and spilled) across the kernel
         env.scalars[e2] = rec;
@@ -1062,6 +1166,8 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
     if (dirty) store_span<H, W>(env.goals + (size_t)e0b * HW, goals, nbb, tid);
     if (lane < 4 * Gm::G && wave * Gm::G + (lane >> 2) < nbb)
         ((u64 *)(env.rng + e0b + wave * Gm::G))[lane] = rng_lds[lane];
+    if (WRAP && tid < nbb * (int)(sizeof(sl_wrap_state) / 4))
+        ((u32 *)(env.wrap.state + e0b))[tid] = ((const u32 *)wst)[tid];
 
     SL_STAMP(9);
 #ifdef SL_TRACE
@@ -1131,6 +1237,33 @@ __global__ void k_build_score_lut(const int32_t *__restrict__ points_table, int 
     lut[i] = (int8_t)v;
 }
 
+// ---- side-effect baseline of every pool level, in the row kernels' register layout ------------------
+// One thread per (level, row).  Cell values: sl_device.h baseline_cell().
+__global__ void k_build_baseline(sl_env_batch env) {
+    const int H = env.H, W = env.W, WS = (W + 1) / 2, E = env.E;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= env.L * H) return;
+    const int l = i / H, r = i - l * H;
+    const sl_level_scalars lv = env.pool_scalars[l];
+    const u16 *pb = env.pool_board + (size_t)l * H * W;
+    const int32_t *px = env.pool_exit_locs + (size_t)l * E;
+    // can_exit() during reset: nothing earned yet (safelife_game.py:716-719)
+    const bool open = lv.agent_row >= 0 && (pb[lv.agent_row * W + lv.agent_col] & AGENT) && 0 >= lv.required_reset;
+    u32 *dst = env.wrap.pool_baseline + (size_t)i * WS;
+    for (int k = 0; k < WS; ++k) {
+        u32 word = 0;
+        for (int half = 0; half < 2; ++half) {
+            const int c = k + half * WS;
+            if (c >= W) continue;
+            const int idx = r * W + c;
+            bool is_exit = false;
+            for (int q = 0; q < E; ++q) is_exit |= px[q] == idx;
+            word |= baseline_cell(pb[idx], is_exit, open) << (16 * half);
+        }
+        dst[k] = word;
+    }
+}
+
 template <int H, int W>
 static hipError_t launch_advance_t(const u16 *in, u16 *out, int B, const float *spawn_prob, int n_steps,
                                    sl_pcg64 *rng, const Jump *jump, hipStream_t stream) {
@@ -1147,20 +1280,24 @@ template <int H, int W>
 static hipError_t launch_rollout_t(const sl_env_batch &env, const int32_t *actions, int T, float *reward_t,
                                    uint8_t *done_t, const Jump *jump, hipStream_t stream) {
     using Gm = Geom<H, W>;
-    const int variant = (env.n_tables == 1 ? 1 : 0) | (env.spawner_free ? 2 : 0);
-    void (*fn)(sl_env_batch, const int32_t *, int, float *, uint8_t *, const Jump *) =
-        variant == 3   ? k_env_rollout_rowlane<H, W, true, false>
-        : variant == 2 ? k_env_rollout_rowlane<H, W, false, false>
-        : variant == 1 ? k_env_rollout_rowlane<H, W, true, true>
-                       : k_env_rollout_rowlane<H, W, false, true>;
-    static bool configured[4] = {false, false, false, false};   // the attribute is sticky: set it once
+    const int variant = (env.n_tables == 1 ? 1 : 0) | (env.spawner_free ? 2 : 0) | (env.wrap.flags ? 4 : 0);
+    typedef void (*kernel_t)(sl_env_batch, const int32_t *, int, float *, uint8_t *, const Jump *);
+    static const kernel_t table[8] = {
+        k_env_rollout_rowlane<H, W, false, true, false>, k_env_rollout_rowlane<H, W, true, true, false>,
+        k_env_rollout_rowlane<H, W, false, false, false>, k_env_rollout_rowlane<H, W, true, false, false>,
+        k_env_rollout_rowlane<H, W, false, true, true>,  k_env_rollout_rowlane<H, W, true, true, true>,
+        k_env_rollout_rowlane<H, W, false, false, true>,  k_env_rollout_rowlane<H, W, true, false, true>};
+    const kernel_t fn = table[variant];
+    const bool spawn = !(variant & 2), gsh_reg = !spawn || Gm::WAVES_PER_SIMD < 4;
+    const int lds = !(variant & 4) ? Gm::LDS_BYTES : (gsh_reg ? Gm::LDS_WRAP_GSHREG : Gm::LDS_WRAP_GSHLDS);
+    static bool configured[8] = {};               // the attribute is sticky: set it once
     if (!configured[variant]) {
-        hipError_t err = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, Gm::LDS_BYTES);
+        hipError_t err = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (err != hipSuccess) return err;
         configured[variant] = true;
     }
-    hipLaunchKernelGGL(fn, dim3((env.B + Gm::NB - 1) / Gm::NB), dim3(64 * WAVES), Gm::LDS_BYTES, stream, env,
-                       actions, T, reward_t, done_t, jump);
+    hipLaunchKernelGGL(fn, dim3((env.B + Gm::NB - 1) / Gm::NB), dim3(64 * WAVES), lds, stream, env, actions, T,
+                       reward_t, done_t, jump);
     return hipGetLastError();
 }
 
@@ -1178,6 +1315,12 @@ bool rowlane_supports(int H, int W) {
 hipError_t launch_build_score_lut(const int32_t *points_table, int n_tables, int8_t *lut, hipStream_t stream) {
     const int n = n_tables * rl::SCORE_LUT_BYTES;
     hipLaunchKernelGGL(rl::k_build_score_lut, dim3((n + 255) / 256), dim3(256), 0, stream, points_table, n_tables, lut);
+    return hipGetLastError();
+}
+
+hipError_t launch_build_baseline(const sl_env_batch &env, hipStream_t stream) {
+    const int n = env.L * env.H;
+    hipLaunchKernelGGL(rl::k_build_baseline, dim3((n + 255) / 256), dim3(256), 0, stream, env);
     return hipGetLastError();
 }
 

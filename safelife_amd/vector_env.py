@@ -37,12 +37,21 @@ class SafeLifeVectorEnv(object):
     level_stride : int             an env's next level is ``(level + level_stride) % len(pool)``
     env_offset : int               global index of this process's env 0 (multi-GPU sharding)
     with_obs : bool                False skips observation writes entirely
+    wrappers : dict or None        training-wrapper math of the reference's env_wrappers.py, fused into the
+                                   step (stacked as training/env_factory.py:277-283 does); keys, all
+                                   optional: ``movement_bonus``, ``movement_bonus_power``,
+                                   ``movement_bonus_period``, ``as_penalty`` (MovementBonusWrapper),
+                                   ``exit_bonus`` (ExtraExitBonus.bonus), ``penalty_coef``,
+                                   ``ignore_reward_cells`` (SimpleSideEffectPenalty, starting-state
+                                   baseline).  A wrapper is active when its coefficient is not None.
+                                   The wrapped float64 reward is ``env.shaped_reward`` after each step.
+                                   (MinPerformanceScheduler = ``LevelPool(min_performance_fraction=...)``.)
     """
 
     def __init__(self, pool, num_envs, *, time_limit=1000, remove_white_goals=True,
                  view_shape=(15, 15), output_channels=_DEFAULT_CHANNELS, auto_reset=True,
                  first_level=None, level_stride=1, env_offset=0, with_obs=True,
-                 points_on_level_exit=1):
+                 points_on_level_exit=1, wrappers=None):
         import torch
         self.torch = torch
         if not isinstance(pool, LevelPool):
@@ -119,6 +128,9 @@ class SafeLifeVectorEnv(object):
         self.done = flags[:, 0]
         self.info = {"success": flags[:, 1], "times_up": flags[:, 2],
                      "episode_reward": out[:, 2].view(torch.float32), "episode_length": out[:, 3]}
+        self.shaped_reward = None
+        if wrappers:
+            self._setup_wrappers(dict(wrappers))
         self._lib = _hip.lib()
         self._sref = C.byref(s)
         rc = self._lib.slhip_env_prepare(self._sref, _hip.current_stream_ptr())
@@ -126,6 +138,49 @@ class SafeLifeVectorEnv(object):
             s.score_lut = None          # points outside int8: every shape runs the size-generic kernels
         else:
             _hip.check(rc)
+
+    def _setup_wrappers(self, cfg):
+        torch, t, s, dev = self.torch, self.t, self.struct, self.device
+        known = {"movement_bonus", "movement_bonus_power", "movement_bonus_period", "as_penalty", "exit_bonus",
+                 "penalty_coef", "ignore_reward_cells"}
+        if set(cfg) - known:
+            raise ValueError("unknown wrapper option(s): %s" % sorted(set(cfg) - known))
+        B, (H, W) = self.num_envs, self.pool.shape
+        bonus, period = cfg.get("movement_bonus"), int(cfg.get("movement_bonus_period", 4))
+        power = cfg.get("movement_bonus_power", 1e-100)
+        if not 1 <= period <= _hip.WRAP_MAX_PERIOD:
+            raise ValueError("movement_bonus_period must be in 1..%d" % _hip.WRAP_MAX_PERIOD)
+        w = s.wrap
+        w.flags = ((_hip.WRAP_MOVEMENT if bonus is not None else 0)
+                   | (_hip.WRAP_AS_PENALTY if cfg.get("as_penalty", True) else 0)
+                   | (_hip.WRAP_EXIT_BONUS if cfg.get("exit_bonus") is not None else 0)
+                   | (_hip.WRAP_SIDE_EFFECT if cfg.get("penalty_coef") is not None else 0)
+                   | (_hip.WRAP_IGNORE_REWARD_CELLS if cfg.get("ignore_reward_cells") else 0))
+        if not w.flags & (_hip.WRAP_MOVEMENT | _hip.WRAP_EXIT_BONUS | _hip.WRAP_SIDE_EFFECT):
+            w.flags = 0
+            return
+        # movement_bonus * speed**power for every reachable distance, evaluated on the host by numpy with
+        # the reference's own expression (env_wrappers.py:83-87): no pow() ever runs on the device
+        n_tab = (H + W + period + 2) & ~1
+        table = np.zeros(n_tab, np.float64)
+        if bonus is not None:
+            for d in range(n_tab):
+                speed = np.sum((np.array([d]) / period)[:1])
+                table[d] = bonus * speed ** power
+        t["move_table"] = torch.from_numpy(table).to(dev)
+        t["wrap_state"] = torch.zeros((B, 12), dtype=torch.int32, device=dev)         # struct sl_wrap_state
+        t["shaped_reward"] = torch.zeros(B, dtype=torch.float64, device=dev)
+        t["pool_baseline"] = torch.zeros((len(self.pool), H, (W + 1) // 2), dtype=torch.int32, device=dev)
+        w.move_period, w.move_table_len = period, n_tab
+        w.move_bonus = float(bonus or 0.0)
+        w.exit_bonus = float(cfg.get("exit_bonus") or 0.0)
+        w.penalty_coef = float(cfg.get("penalty_coef") or 0.0)
+        w.move_table = t["move_table"].data_ptr()
+        w.state = t["wrap_state"].data_ptr()
+        w.shaped_reward = t["shaped_reward"].data_ptr()
+        w.shaped_reward_t = None
+        w.pool_baseline = t["pool_baseline"].data_ptr()
+        self.shaped_reward = t["shaped_reward"]
 
     # ------------------------------------------------------------------ gym-like surface
 
@@ -165,8 +220,12 @@ class SafeLifeVectorEnv(object):
             reward_out = torch.empty((T, self.num_envs), dtype=torch.float32, device=self.device)
         if done_out is None:
             done_out = torch.empty((T, self.num_envs), dtype=torch.uint8, device=self.device)
+        if self.shaped_reward is not None:      # wrapped reward of every step: env.shaped_reward_t [T,B]
+            self.shaped_reward_t = torch.empty((T, self.num_envs), dtype=torch.float64, device=self.device)
+            self.struct.wrap.shaped_reward_t = self.shaped_reward_t.data_ptr()
         rc = self._lib.slhip_env_rollout(self._sref, _hip.ptr(a), T, _hip.ptr(reward_out),
                                          _hip.ptr(done_out), _hip.current_stream_ptr())
+        self.struct.wrap.shaped_reward_t = None
         _hip.check(rc)
         return reward_out, done_out
 

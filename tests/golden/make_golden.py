@@ -210,16 +210,37 @@ def level_record(game):
 
 def run_trace(R, games, actions, env_kw, wrappers=None, min_perf_fraction=None):
     """Drive the reference SafeLifeEnv over `games` (one episode each, in order) with the
-    action stream; auto-reset on done like training/base_algo.py:231-236."""
+    action stream; auto-reset on done like training/base_algo.py:231-236.
+
+    `wrappers`: dict(movement=dict(...)|None, exit_bonus=float|None, side_effect=dict(...)|None):
+    the reference's own env_wrappers stacked in the order of training/env_factory.py:277-283; the
+    reward the outermost wrapper returns is recorded as `shaped_reward` (float64) next to the inner
+    SafeLifeEnv reward."""
     SafeLifeEnv = R.env.SafeLifeEnv
     it = iter(games)
     env = SafeLifeEnv(it, **env_kw)
     wrapped = env
+    inner = {}
+    if wrappers is not None:
+        inner_step = env.step
+
+        def recording_step(a):
+            ret = inner_step(a)
+            inner["reward"] = ret[1]
+            return ret
+        env.step = recording_step
+        W = R.wrappers
+        if wrappers.get("movement") is not None:
+            wrapped = W.MovementBonusWrapper(wrapped, **wrappers["movement"])
+        if wrappers.get("exit_bonus") is not None:
+            wrapped = W.ExtraExitBonus(wrapped, bonus=wrappers["exit_bonus"])
+        if wrappers.get("side_effect") is not None:
+            wrapped = W.SimpleSideEffectPenalty(wrapped, **wrappers["side_effect"])
     if min_perf_fraction is not None:
-        wrapped = R.wrappers.MinPerformanceScheduler(env, min_performance_fraction=min_perf_fraction)
+        wrapped = R.wrappers.MinPerformanceScheduler(wrapped, min_performance_fraction=min_perf_fraction)
     rec = {k: [] for k in ("obs", "reward", "done", "board", "goals", "agent_loc", "times_up",
                            "ep_length", "ep_reward", "success", "reset_obs", "reset_board",
-                           "reset_rng", "reset_required", "rng_after", "num_steps")}
+                           "reset_rng", "reset_required", "rng_after", "num_steps", "shaped_reward")}
 
     def note_reset(obs):
         rec["reset_obs"].append(obs.copy())
@@ -234,6 +255,10 @@ def run_trace(R, games, actions, env_kw, wrappers=None, min_perf_fraction=None):
     for t, a in enumerate(actions):
         obs, reward, done, info = wrapped.step(int(a))
         rec["obs"].append(obs.copy())
+        if wrappers is not None:
+            assert isinstance(reward, (float, np.floating)), type(reward)
+            rec["shaped_reward"].append(np.float64(reward))
+            reward = inner["reward"]
         rec["reward"].append(np.float32(reward))
         rec["done"].append(bool(done))
         rec["board"].append(info["board"].copy())
@@ -325,30 +350,97 @@ def greedy_actions(R, game, rng, n, p_random=0.35):
     return acts
 
 
+def trace_blob(R, name, level_datas, seeds, actions, env_kw, min_perf_fraction=None, wrappers=None):
+    Game = R.game.SafeLifeGame
+    games = [seeded(Game.loaddata(d), s) for d, s in zip(level_datas, seeds)]
+    tr = run_trace(R, games, actions, env_kw, wrappers=wrappers, min_perf_fraction=min_perf_fraction)
+    games2 = [seeded(Game.loaddata(d), s) for d, s in zip(level_datas, seeds)]
+    blob = {}
+    for i, g in enumerate(games2):
+        for k, v in level_record(g).items():
+            blob["level%d_%s" % (i, k)] = v
+        blob["level%d_rng" % i] = words(g._rng.bit_generator)
+    blob["n_levels"] = np.array(len(games2))
+    for k, v in tr.items():
+        blob["trace_" + k] = v
+    for k, v in env_kw.items():
+        blob["env_" + k] = np.array(-1 if v is None else v)
+    if min_perf_fraction is not None:
+        blob["min_performance_fraction"] = np.array(min_perf_fraction)
+    if wrappers is not None:
+        mv, se = wrappers.get("movement"), wrappers.get("side_effect")
+        if mv is not None:
+            blob["wrap_movement"] = np.array([mv.get("movement_bonus", 0.1), mv.get("movement_bonus_power", 1e-100),
+                                              mv.get("movement_bonus_period", 4), float(mv.get("as_penalty", True))])
+        if wrappers.get("exit_bonus") is not None:
+            blob["wrap_exit_bonus"] = np.array(float(wrappers["exit_bonus"]))
+        if se is not None:
+            assert se.get("baseline", "starting-state") == "starting-state"
+            blob["wrap_side_effect"] = np.array([se.get("penalty_coef", 0.0), float(se.get("ignore_reward_cells", False))])
+    print("trace %-28s steps=%4d episodes=%d sum_reward=%.1f success=%d%s" % (
+        name, len(tr["reward"]), len(tr["reset_at"]), tr["reward"].sum(), tr["success"].sum(),
+        "" if wrappers is None else " shaped_sum=%.4f" % tr["shaped_reward"].sum()))
+    return blob
+
+
+def gen_wrapper_traces(R, out):
+    """Reference env_wrappers stacked as in training/env_factory.py:277-283 over the reference env."""
+    Game = R.game.SafeLifeGame
+    rng = np.random.default_rng(177)
+    no_se = dict(should_calculate_side_effects=False)
+    kw = dict(view_shape=(25, 25), output_channels=None, time_limit=100, **no_se)
+    traces = {}
+    training = dict(movement=dict(as_penalty=True), exit_bonus=0.5,
+                    side_effect=dict(baseline="starting-state", penalty_coef=0.3))
+    # the training stack on archives where the agent reaches open exits and on stochastic ones
+    for arch, n_lv, first, frac in (("prune-still", 6, 20, None), ("append-spawn", 5, 20, None),
+                                    ("append-still", 4, 40, 0.02), ("navigation", 3, 10, 0.5)):
+        with np.load(os.path.join(REFERENCE, "safelife/levels/benchmarks/v1.0/%s.npz" % arch)) as d:
+            levels = [normalize_level(d["levels"][first + i]) for i in range(n_lv)]
+        if frac is None:
+            for l in levels:
+                l["min_performance"] = np.float64(-1)
+        seeds = [500 + i for i in range(n_lv)]
+        games = [seeded(Game.loaddata(l), sd) for l, sd in zip(levels, seeds)]
+        acts = []
+        for g in games:
+            acts += greedy_actions(R, g, rng, 120, p_random=0.15)
+        traces["wrap_train_" + arch] = trace_blob(R, "wrap_train_" + arch, levels, seeds, acts, kw,
+                                                  min_perf_fraction=frac, wrappers=training)
+    # other parameterisations: bonus instead of penalty, real exponent, period 3, reward cells ignored
+    with np.load(os.path.join(REFERENCE, "safelife/levels/benchmarks/v1.0/prune-still.npz")) as d:
+        levels = [normalize_level(d["levels"][60 + i]) for i in range(4)]
+    for l in levels:
+        l["min_performance"] = np.float64(-1)
+    seeds = [700 + i for i in range(4)]
+    games = [seeded(Game.loaddata(l), sd) for l, sd in zip(levels, seeds)]
+    acts = []
+    for g in games:
+        acts += greedy_actions(R, g, rng, 120, p_random=0.25)
+    other = dict(movement=dict(as_penalty=False, movement_bonus=0.25, movement_bonus_power=0.5,
+                               movement_bonus_period=3),
+                 exit_bonus=1.5, side_effect=dict(penalty_coef=0.125, ignore_reward_cells=True))
+    traces["wrap_other_prune-still"] = trace_blob(R, "wrap_other_prune-still", levels, seeds, acts, kw, wrappers=other)
+    only_se = dict(side_effect=dict(penalty_coef=1.0))
+    lv = load_level(R, "benchmarks/v0.1/append-stochastic-1.npz")
+    traces["wrap_se_append-stochastic-1"] = trace_blob(
+        R, "wrap_se_append-stochastic-1", [lv], [5], rng.integers(0, 9, 200),
+        dict(view_shape=(25, 25), output_channels=None, **no_se), wrappers=only_se)
+    only_mv = dict(movement=dict(movement_bonus_period=8, movement_bonus_power=1.0))
+    lv = load_level(R, "patterns/glider.npz")
+    traces["wrap_mv_noagent"] = trace_blob(R, "wrap_mv_noagent", [lv, lv], [0, 1], [0, 3, 5],
+                                           dict(view_shape=(9, 9), output_channels=None, **no_se), wrappers=only_mv)
+    for name, blob in traces.items():
+        np.savez_compressed(os.path.join(out, "trace_%s.npz" % name), **blob)
+
+
 def gen_env_traces(R, out):
     Game = R.game.SafeLifeGame
     rng = np.random.default_rng(77)
     traces = {}
 
     def add(name, level_datas, seeds, actions, env_kw, min_perf_fraction=None):
-        games = [seeded(Game.loaddata(d), s) for d, s in zip(level_datas, seeds)]
-        tr = run_trace(R, games, actions, env_kw, min_perf_fraction=min_perf_fraction)
-        games2 = [seeded(Game.loaddata(d), s) for d, s in zip(level_datas, seeds)]
-        blob = {}
-        for i, g in enumerate(games2):
-            for k, v in level_record(g).items():
-                blob["level%d_%s" % (i, k)] = v
-            blob["level%d_rng" % i] = words(g._rng.bit_generator)
-        blob["n_levels"] = np.array(len(games2))
-        for k, v in tr.items():
-            blob["trace_" + k] = v
-        for k, v in env_kw.items():
-            blob["env_" + k] = np.array(-1 if v is None else v)
-        if min_perf_fraction is not None:
-            blob["min_performance_fraction"] = np.array(min_perf_fraction)
-        traces[name] = blob
-        print("trace %-28s steps=%4d episodes=%d sum_reward=%.1f success=%d" % (
-            name, len(tr["reward"]), len(tr["reset_at"]), tr["reward"].sum(), tr["success"].sum()))
+        traces[name] = trace_blob(R, name, level_datas, seeds, actions, env_kw, min_perf_fraction)
 
     full19 = tuple(range(16)) + (25, 26, 27)
     train15 = (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 25, 26, 27)
@@ -487,13 +579,15 @@ def main():
     args = ap.parse_args()
     R = import_reference()
     out = HERE
-    todo = args.only.split(",") if args.only else ["primitives", "patterns", "traces", "pools", "side"]
+    todo = args.only.split(",") if args.only else ["primitives", "patterns", "traces", "wrappers", "pools", "side"]
     if "primitives" in todo:
         gen_primitives(R, out)
     if "patterns" in todo:
         gen_patterns(R, out)
     if "traces" in todo:
         gen_env_traces(R, out)
+    if "wrappers" in todo:
+        gen_wrapper_traces(R, out)
     if "side" in todo:
         gen_side_effect_inputs(R, out)
     if "pools" in todo:

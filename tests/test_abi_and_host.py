@@ -2,6 +2,7 @@
 (no compute calls without a GPU), and the host-side logic (level files, level pool constants)."""
 import ctypes as C
 import os
+import subprocess
 import re
 
 import numpy as np
@@ -21,32 +22,53 @@ def test_library_exports_every_declared_symbol():
     lib = _hip.lib()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.slhip_abi_version() == 1
+    assert lib.slhip_abi_version() == 2
 
 
-def test_env_struct_layout_matches_header():
-    """ctypes mirror vs the C struct: same fields in the same order, same size."""
+def _ctypes_layout(struct, prefix=""):
+    out = []
+    for name, ctype in struct._fields_:
+        off = getattr(struct, name).offset
+        if isinstance(ctype, type) and issubclass(ctype, C.Structure):
+            out += [(prefix + name + "." + n, off + o, sz) for n, o, sz in _ctypes_layout(ctype)]
+        else:
+            out.append((prefix + name, off, C.sizeof(ctype)))
+    return out
+
+
+def test_env_struct_layout_matches_header(tmp_path):
+    """ctypes mirrors vs the C structs as gcc lays them out: offset and size of every field."""
+    structs = {"sl_env_batch": _hip.EnvBatch, "sl_wrappers": _hip.Wrappers, "sl_wrap_state": _hip.WrapState,
+               "sl_pcg64": _hip.Pcg64}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "safelife_hip.h"', 'int main(void) {']
+    want = []
+    for cname, st in structs.items():
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        want.append("%s %d" % (cname, C.sizeof(st)))
+        for name, off, sz in _ctypes_layout(st):
+            lines.append('printf("%s.%s %%zu %%zu\\n", offsetof(%s, %s), sizeof(((%s *)0)->%s));'
+                         % (cname, name, cname, name, cname, name))
+            want.append("%s.%s %d %d" % (cname, name, off, sz))
+    lines += ['printf("scalars %zu level %zu out %zu\\n", sizeof(sl_env_scalars), sizeof(sl_level_scalars), '
+              'sizeof(sl_step_out));', "return 0; }"]
+    want.append("scalars 64 level 32 out 16")
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = str(tmp_path / "layout")
+    subprocess.check_call(["gcc", "-I", os.path.join(REPO, "include"), str(src), "-o", exe])
+    got = subprocess.check_output([exe]).decode().split("\n")
+    assert [g for g in got if g] == want
+    # every field the header declares in sl_env_batch is mirrored (names, in order)
     header = open(os.path.join(REPO, "include", "safelife_hip.h")).read()
     start = header.index("typedef struct sl_env_batch {") + len("typedef struct sl_env_batch {")
     body = re.sub(r"/\*.*?\*/", "", header[start:header.index("} sl_env_batch;")], flags=re.S)
-    expanded, size = [], 0
+    names = []
     for stmt in body.split(";"):
         stmt = " ".join(stmt.split())
-        if not stmt:
-            continue
-        m = re.match(r"^(const )?(\w+) ?(\*?)(.*)$", stmt)
-        ctype, star, rest = m.group(2), m.group(3), m.group(4)
-        for part in rest.split(","):
-            name = re.sub(r"[\*\s]", "", part)
-            arr = re.search(r"\[(\w+)\]", name)
-            name = re.sub(r"\[\w+\]", "", name)
-            expanded.append(name)
-            if star or "*" in part:
-                size = (size + 7) // 8 * 8 + 8
-            else:
-                size += 4 * (32 if arr else 1)
-    assert expanded == [f[0] for f in _hip.EnvBatch._fields_]
-    assert C.sizeof(_hip.EnvBatch) == (size + 7) // 8 * 8
+        if stmt:
+            rest = re.match(r"^(const )?(\w+) ?(\*?)(.*)$", stmt).group(4)
+            names += [re.sub(r"\[\w+\]|[\*\s]", "", part) for part in rest.split(",")]
+    assert names == [f[0] for f in _hip.EnvBatch._fields_]
 
 
 def test_no_gpu_fails_loudly():

@@ -214,6 +214,63 @@ def test_env_batch_vs_oracle(pool_name, B, T, kw):
     assert n_done > B      # every env went through at least one auto-reset on average
 
 
+TRAINING_WRAPPERS = dict(movement_bonus=0.1, movement_bonus_power=1e-100, movement_bonus_period=4,
+                         as_penalty=True, exit_bonus=0.5, penalty_coef=0.3, ignore_reward_cells=False)
+
+
+@pytest.mark.parametrize("pool_name,B,T,wrappers,kw", [
+    ("prune_still_25", 300, 120, TRAINING_WRAPPERS, dict(time_limit=50)),
+    ("append_spawn_25", 300, 120, TRAINING_WRAPPERS, dict(time_limit=60)),
+    ("append_still_26", 120, 100, dict(movement_bonus=0.25, movement_bonus_power=0.5, movement_bonus_period=3,
+                                       as_penalty=False, exit_bonus=1.5, penalty_coef=0.125,
+                                       ignore_reward_cells=True), dict(time_limit=40)),
+    ("navigation_64", 48, 70, TRAINING_WRAPPERS, dict(time_limit=30)),
+    ("prune_still_25", 64, 60, dict(penalty_coef=1.0, movement_bonus=None, exit_bonus=None), dict(time_limit=25)),
+    ("prune_still_25", 64, 60, dict(movement_bonus=0.1, movement_bonus_period=8, movement_bonus_power=1.0,
+                                    penalty_coef=None, exit_bonus=None), dict(time_limit=25)),
+])
+def test_env_batch_wrappers_vs_oracle(pool_name, B, T, wrappers, kw):
+    """Training-wrapper math fused into the step: float64 shaped reward, bit for bit, every step,
+    across auto-resets; then the same through the T-step rollout."""
+    pool, _ = util.pool_from_fixture(pool_name, _device_counts, min_performance_fraction=0.05)
+    first = (np.arange(B) * 5) % len(pool)
+    common = dict(first_level=first, auto_reset=True, level_stride=3, view_shape=(15, 15), wrappers=wrappers, **kw)
+    dev = util.DeviceBackend(pool, B, **common)
+    cpu = util.OracleBackend(pool, B, **common)
+    assert np.array_equal(dev.reset(), cpu.reset())
+    rng = np.random.default_rng(13)
+    n_done = 0
+    for t in range(T):
+        a = rng.integers(0, 9, B).astype(np.int32)
+        o1, r1, d1 = dev.step(a)
+        o2, r2, d2 = cpu.step(a)
+        assert np.array_equal(r1, r2) and np.array_equal(d1, d2), t
+        assert np.array_equal(dev.get("shaped_reward"), cpu.get("shaped_reward")), t
+        assert np.array_equal(o1, o2), t
+        n_done += int(d1.sum())
+    assert n_done > B // 2
+    assert np.array_equal(dev.get("board"), cpu.get("board"))
+    # rollout: T2 more steps in one launch
+    T2 = 12
+    a = rng.integers(0, 9, (T2, B)).astype(np.int32)
+    dev.env.rollout(a)
+    want = []
+    for t in range(T2):
+        cpu.step(a[t])
+        want.append(cpu.get("shaped_reward"))
+    assert np.array_equal(dev.env.shaped_reward_t.cpu().numpy(), np.stack(want))
+    assert np.array_equal(dev.get("board"), cpu.get("board"))
+
+
+def test_generic_kernels_with_wrappers():
+    """The size-generic kernels carry the same wrapper math: rerun the wrapper traces with the row
+    kernels switched off (the switch is read once per process, hence the subprocess)."""
+    import subprocess, sys
+    env = dict(os.environ, SAFELIFE_HIP_FORCE_GENERIC="1")
+    subprocess.check_call([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu",
+                           "-k", "test_env_trace and wrap"], env=env, cwd=util.REPO)
+
+
 def test_rollout_equals_steps():
     pool, _ = util.pool_from_fixture("append_spawn_25", _device_counts, n=16)
     B, T = 128, 40
@@ -327,3 +384,38 @@ def test_compat_env_trace(name):
                 break
             obs = env.reset()
             assert np.array_equal(obs, tr["trace_reset_obs"][episode]), where
+
+
+@pytest.mark.parametrize("name", ["wrap_train_prune-still", "wrap_train_append-still", "wrap_other_prune-still",
+                                  "wrap_se_append-stochastic-1", "wrap_mv_noagent"])
+def test_compat_wrappers_trace(name):
+    """safelife_amd.env_wrappers stacked over the compat SafeLifeEnv as training/env_factory.py does:
+    the reward the outermost wrapper returns equals the reference's, float64 bit for bit."""
+    from safelife_amd import env_wrappers as W
+    from safelife_amd.env import SafeLifeEnv
+    tr = util.load_trace(name)
+    env = SafeLifeEnv(iter(_compat_games(tr)), **util.env_kwargs_from_trace(tr))
+    if "wrap_movement" in tr:
+        bonus, power, period, as_penalty = tr["wrap_movement"]
+        env = W.MovementBonusWrapper(env, movement_bonus=float(bonus), movement_bonus_power=float(power),
+                                     movement_bonus_period=int(period), as_penalty=bool(as_penalty))
+    if "wrap_exit_bonus" in tr:
+        env = W.ExtraExitBonus(env, bonus=float(tr["wrap_exit_bonus"]))
+    if "wrap_side_effect" in tr:
+        coef, ignore = tr["wrap_side_effect"]
+        env = W.SimpleSideEffectPenalty(env, penalty_coef=float(coef), ignore_reward_cells=bool(ignore))
+    if "min_performance_fraction" in tr:
+        env = W.MinPerformanceScheduler(env, min_performance_fraction=float(tr["min_performance_fraction"]))
+    obs = env.reset()
+    assert np.array_equal(obs, tr["trace_reset_obs"][0])
+    episode = 0
+    for t in range(len(tr["trace_reward"])):
+        obs, reward, done, info = env.step(int(tr["trace_actions"][t]))
+        assert isinstance(reward, np.float64) and reward == tr["trace_shaped_reward"][t], t
+        assert bool(done) == bool(tr["trace_done"][t]), t
+        assert np.array_equal(info["board"], tr["trace_board"][t]), t
+        if done:
+            episode += 1
+            if episode >= len(tr["trace_reset_at"]):
+                break
+            assert np.array_equal(env.reset(), tr["trace_reset_obs"][episode]), t

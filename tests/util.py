@@ -80,6 +80,23 @@ def env_kwargs_from_trace(tr):
     return kw
 
 
+def wrappers_from_trace(tr):
+    """Keyword arguments of the training-wrapper stack a wrap_* trace was recorded with, or None."""
+    if not any(k.startswith("wrap_") for k in tr):
+        return None
+    w = {}
+    if "wrap_movement" in tr:
+        bonus, power, period, as_penalty = tr["wrap_movement"]
+        w.update(movement_bonus=float(bonus), movement_bonus_power=float(power),
+                 movement_bonus_period=int(period), as_penalty=bool(as_penalty))
+    if "wrap_exit_bonus" in tr:
+        w["exit_bonus"] = float(tr["wrap_exit_bonus"])
+    if "wrap_side_effect" in tr:
+        coef, ignore = tr["wrap_side_effect"]
+        w.update(penalty_coef=float(coef), ignore_reward_cells=bool(ignore))
+    return w
+
+
 def pool_from_trace(tr, counts_fn):
     from safelife_amd.levels import LevelPool
     frac = float(tr["min_performance_fraction"]) if "min_performance_fraction" in tr else 1.0
@@ -93,7 +110,10 @@ class OracleBackend(object):
         self.arrays = empty_env_arrays(pool, B)
         self.arrays["level_idx"][:] = first_level
         kw.setdefault("view_shape", (15, 15))
+        wrappers = kw.pop("wrappers", None)
         self.env = oracle.OracleEnv(self.arrays, **kw)
+        if wrappers is not None:
+            self.env.set_wrappers(**wrappers)
 
     def reset(self):
         return self.env.reset().copy()
@@ -103,12 +123,17 @@ class OracleBackend(object):
         return obs.copy(), r.copy(), d.copy()
 
     def get(self, name):
+        if name == "shaped_reward":
+            return self.env.wa[name].copy()
         return self.arrays[name].copy()
 
 
 class DeviceBackend(object):
     def __init__(self, pool, B, first_level=0, **kw):
         from safelife_amd.vector_env import SafeLifeVectorEnv
+        w = kw.get("wrappers")
+        if w is not None:       # the oracle's keyword names are the product's; absent wrappers are None
+            kw["wrappers"] = {k: v for k, v in w.items() if v is not None}
         self.env = SafeLifeVectorEnv(pool, B, first_level=first_level, **kw)
 
     def reset(self):
@@ -132,6 +157,9 @@ def replay_trace(tr, backend_cls, counts_fn):
     """Replay a reference SafeLifeEnv trace (B = 1, auto-reset) and assert every recorded output."""
     pool = pool_from_trace(tr, counts_fn)
     kw = env_kwargs_from_trace(tr)
+    wrappers = wrappers_from_trace(tr)
+    if wrappers is not None:
+        kw["wrappers"] = wrappers
     be = backend_cls(pool, 1, first_level=0, auto_reset=True, level_stride=1, **kw)
     obs = be.reset()
     resets = list(tr["trace_reset_at"])
@@ -146,6 +174,8 @@ def replay_trace(tr, backend_cls, counts_fn):
         obs, reward, done = be.step(np.array([actions[t]], np.int32))
         where = "step %d" % t
         assert reward[0] == tr["trace_reward"][t], where
+        if wrappers is not None:        # float64, bit for bit: same operations in the same order
+            assert be.get("shaped_reward")[0] == tr["trace_shaped_reward"][t], where + " shaped reward"
         assert bool(done[0]) == bool(tr["trace_done"][t]), where
         assert bool(be.get("success")[0]) == bool(tr["trace_success"][t]), where
         assert bool(be.get("times_up")[0]) == bool(tr["trace_times_up"][t]), where
