@@ -200,6 +200,35 @@ def main():
             extra[tag + "_env_steps_per_s"] = B / (us * 1e-6)
             del env2
 
+        def time_steps(env3, n_envs, n=200):
+            acts = torch.randint(0, 9, (n + 20, n_envs), generator=gen, device=dev, dtype=torch.int32)
+            env3.reset()
+            for t in range(20):
+                env3.step(acts[t])
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for t in range(20, 20 + n):
+                env3.step(acts[t])
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / n * 1e3
+
+        # the same step with the training wrappers of env_factory.py:277-283 fused in (float64 shaped reward)
+        us = time_steps(SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25), output_channels=TRAIN_CHANNELS,
+                                          auto_reset=True, with_obs=False,
+                                          wrappers=dict(movement_bonus=0.1, exit_bonus=0.5, penalty_coef=0.3)), B)
+        extra["training_wrappers_us_per_step"] = us
+        # per-GPU shares of the sharded configs of BASELINE.json (C4: append-spawn 25x25, C5: navigation 64x64)
+        for tag, pname, n_envs in (("c4_append_spawn_25", "append_spawn_25", 8192), ("c5_navigation_64", "navigation_64", 4096)):
+            if not os.path.exists(os.path.join(REPO, "tests", "golden", "pool_%s.npz" % pname)):
+                continue
+            p2 = load_pool(pname, _device_counts)
+            us = time_steps(SafeLifeVectorEnv(p2, n_envs, time_limit=1000, view_shape=(25, 25),
+                                              output_channels=TRAIN_CHANNELS, auto_reset=True, with_obs=False), n_envs)
+            extra[tag + "_us_per_step"] = us
+            extra[tag + "_env_steps_per_s_per_gpu"] = n_envs / (us * 1e-6)
+
     if rank == 0:
         obs_bytes = {0: 0, 1: H * Wd * len(TRAIN_CHANNELS), 2: H * Wd * 4}[args.obs]
         bytes_per_step = 3 * H * Wd * 2 + obs_bytes
@@ -219,10 +248,11 @@ def main():
             "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u16", "data": "synthetic (reference-procgen prune-still level pool cycled on device, "
-                                    "uniform random actions)",
-            "config": {"workload": "C3: %d envs/GPU x %dx%d prune-still, fused step()+reward+auto-reset%s" % (
-                           B, H, Wd, {0: ", no observation", 1: " + 25x25x15 u8 obs", 2: " + 25x25 u32 view"}[args.obs]),
+            "dtype": "u16", "data": "synthetic (reference-procgen %s level pool cycled on device, "
+                                    "uniform random actions)" % args.pool.rsplit("_", 1)[0].replace("_", "-"),
+            "config": {"workload": "%s%d envs/GPU x %dx%d %s, fused step()+reward+auto-reset%s" % (
+                           "C3: " if args.pool == "prune_still_25" else "", B, H, Wd, args.pool.rsplit("_", 1)[0].replace("_", "-"),
+                           {0: ", no observation", 1: " + 25x25x15 u8 obs", 2: " + 25x25 u32 view"}[args.obs]),
                        "envs_per_gpu": B, "global_envs": world * B, "board": [H, Wd],
                        "level_pool": len(pool), "parallelism": "envs sharded %d-way, reward/done gathered "
                                                                "to rank 0 every %d steps" % (world, args.gather_every)},
