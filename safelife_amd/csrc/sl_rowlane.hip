@@ -352,21 +352,21 @@ __device__ __forceinline__ void ca_rows(const RowWords<H, W> &b, RowWords<H, W> 
     }
 }
 
-template <int H, int W>
-__device__ __forceinline__ bool flagged_lo(const Elig &elig, int k) { return (elig.lo >> (Geom<H, W>::WS - 1 - k)) & 1u; }
-template <int H, int W>
-__device__ __forceinline__ bool flagged_hi(const Elig &elig, int k) {
-    return Geom<H, W>::WS <= 16 ? (elig.lo >> (16 + Geom<H, W>::WS - 1 - k)) & 1u : (elig.hi >> (Geom<H, W>::WS - 1 - k)) & 1u;
-}
-
 // Resolve the flagged halves with each board's PCG64 stream, row-major (wave-uniform call).
 // rng_lds: this wave's G x {state_hi, state_lo, inc_hi, inc_lo}; advanced by the draws consumed.
+//
+// A lane's flagged cells, in row-major order, are the set bits of `ord` from the top down (low
+// halves = cells 0..WS-1 in the upper 32 bits, high halves = cells WS..W-1 in the lower 32 bits, cell
+// k of a part at bit WS-1-k).  Every lane jumps the board's generator to its own first draw (prefix
+// sum of the flag counts over the board's lanes) and then steps through its cells; the wave iterates
+// as often as its busiest lane has flags -- a handful -- rather than once per cell position.
 template <int H, int W>
 __device__ void resolve_draws(const RowWords<H, W> &b, RowWords<H, W> &n, const Elig &elig, u64 *rng_lds, int g,
                               bool lead, double p, const Jump *__restrict__ jump) {
     using Gm = Geom<H, W>;
     constexpr int WS = Gm::WS;
-    const int mine = __popc(elig.lo) + __popc(elig.hi);
+    const u32 part_lo = WS <= 16 ? (elig.lo & 0xFFFFu) : elig.lo, part_hi = WS <= 16 ? (elig.lo >> 16) : elig.hi;
+    const int mine = __popc(part_lo) + __popc(part_hi);
     const int incl = wave_scan(mine);
     int before = 0, total = 0;
 #pragma unroll
@@ -381,22 +381,22 @@ __device__ void resolve_draws(const RowWords<H, W> &b, RowWords<H, W> &n, const 
     const int excl = incl - mine - before;
     const U128 st = {rng_lds[4 * g + 0], rng_lds[4 * g + 1]}, inc = {rng_lds[4 * g + 2], rng_lds[4 * g + 3]};
     wave_sync();     // every lane has read the old state before a leader replaces it
+    u64 ord = ((u64)part_lo << 32) | part_hi, failed = 0;
     if (mine > 0) {
         U128 cur = pcg_jump(jump, excl, st, inc);
-        // row-major order inside the row: cells 0..WS-1 are the low halves, WS..W-1 the high halves
-#pragma unroll
-        for (int k = 0; k < WS; ++k) {
-            if (flagged_lo<H, W>(elig, k)) {
-                cur = pcg_step(cur, inc);
-                if (!(pcg_output_double(cur) < p)) n[k] = (n[k] & 0xFFFF0000u) | (b[k] & 0x0000FFFFu);
-            }
+        while (ord) {
+            const int pos = 63 - __clzll((long long)ord);
+            cur = pcg_step(cur, inc);
+            if (!(pcg_output_double(cur) < p)) failed |= 1ull << pos;      // advance_board.c:115
+            ord &= ~(1ull << pos);
         }
+    }
+    if (__ballot(failed != 0)) {        // a failed draw keeps the old cell
+        const u32 f_lo = (u32)(failed >> 32), f_hi = (u32)failed;
 #pragma unroll
         for (int k = 0; k < WS; ++k) {
-            if (flagged_hi<H, W>(elig, k)) {
-                cur = pcg_step(cur, inc);
-                if (!(pcg_output_double(cur) < p)) n[k] = (n[k] & 0x0000FFFFu) | (b[k] & 0xFFFF0000u);
-            }
+            const u32 keep = ((f_lo >> (WS - 1 - k)) & 1u) * 0x0000FFFFu | ((f_hi >> (WS - 1 - k)) & 1u) * 0xFFFF0000u;
+            n[k] = (n[k] & ~keep) | (b[k] & keep);
         }
     }
     if (lead && total > 0) {

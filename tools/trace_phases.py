@@ -20,8 +20,9 @@ env.reset()
 acts = torch.randint(0, 9, (64, B), device=env.device, dtype=torch.int32)
 for t in range(20):
     env.step(acts[t])
-grid = B // 8
-nw = grid * 4
+H = pool.shape[0]
+boards_per_wave = 64 // (H + 2) if 64 // (H + 2) == 64 // H else max(1, 64 // H)
+nw = -(-B // (4 * boards_per_wave)) * 4             # 4 waves per workgroup
 trace = torch.zeros((nw, 16), dtype=torch.int64, device=env.device)
 lib = _hip.lib()
 names = ["start", "loads issued", "after barrier", "goal rows ready", "after act", "after CA", "after score",
