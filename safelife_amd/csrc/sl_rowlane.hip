@@ -122,7 +122,10 @@ struct Geom {
     static constexpr int OFF_GOALS = REGION;
     static constexpr int OFF_RNG = 2 * REGION;             // NB x 4 u64
     static constexpr int OFF_GSH = OFF_RNG + NB * 32;      // per lane WS words: goal colours, pre-shifted
-    static constexpr int OFF_LUT = OFF_GSH + WAVES * 64 * WS * 4;   // 4 KiB compact score table
+    // (boards wider than 32 cells keep the goal words in registers in every variant: the region shrinks
+    //  to the few hundred bytes the observation epilogue parks its per-board parameters in)
+    static constexpr int GSH_BYTES = WAVES_PER_SIMD < 4 ? 512 : WAVES * 64 * WS * 4;
+    static constexpr int OFF_LUT = OFF_GSH + GSH_BYTES;             // 4 KiB compact score table
     static constexpr int LDS_BYTES = OFF_LUT + 4096;
     // training wrappers (WRAP variants only): per-board sl_wrap_state, the movement table, and -- when the
     // goal words occupy OFF_GSH -- the baseline rows of the side-effect count
@@ -133,6 +136,18 @@ struct Geom {
     static constexpr int LDS_WRAP_GSHREG = OFF_BASE;                           // baseline rows reuse OFF_GSH
     static constexpr int LDS_WRAP_GSHLDS = OFF_BASE + WAVES * 64 * WS * 4;
     static constexpr int LDS_ADVANCE = OFF_RNG + NB * 32;  // advance_board needs no score state
+    // LDS image of a board: row-major cells, except that for 128-byte rows (W = 64) the 16-byte chunks of
+    // row y are XOR-swizzled with (y >> 1) & 7.  Unswizzled, all 64 row lanes would hit the same two banks
+    // (row pitch = half the bank sweep: measured 95 % of the LDS cycles were bank conflicts); swizzled,
+    // "chunk j of every row" spreads over all 64 banks.  The HBM<->LDS DMA applies the permutation on the
+    // global side (an LDS slot is fixed per lane, the global address is free), so HBM keeps the plain layout.
+    static constexpr bool SWZ = W == 64;
+    static __device__ __forceinline__ int cell(int y, int x) {          // (row, col) -> cell index in the image
+        return SWZ ? y * W + ((((x >> 3) ^ (y >> 1)) & 7) << 3) + (x & 7) : y * W + x;
+    }
+    static __device__ __forceinline__ int flat(int i) {                 // row-major index -> cell index
+        return SWZ ? cell(i / W, i % W) : i;
+    }
     // validity of the halves of word k as a 0x0001-per-half mask
     static constexpr u32 vm1(int k) { return (ODD && k == WS - 1) ? 0x00000001u : 0x00010001u; }
 };
@@ -147,6 +162,24 @@ using RowWords = u32[Geom<H, W>::WS];
 template <int H, int W>
 __device__ __forceinline__ void read_row(const unsigned char *region, int gb, int r, RowWords<H, W> &b) {
     using Gm = Geom<H, W>;
+    if (Gm::SWZ) {      // eight aligned 16-byte reads (chunk j sits at j ^ key), then one v_perm per word
+        typedef const __attribute__((address_space(3))) u32x4 *lds_c128;
+        lds_c128 row = (lds_c128)(region + Gm::PAD) + (gb * Gm::HW + r * W) / 8;
+        const int key = (r >> 1) & 7;
+        u32 d[W / 2];
+#pragma unroll
+        for (int j = 0; j < W / 8; ++j) {
+            const u32x4 v = row[j ^ key];
+            d[4 * j + 0] = v.x;
+            d[4 * j + 1] = v.y;
+            d[4 * j + 2] = v.z;
+            d[4 * j + 3] = v.w;
+        }
+#pragma unroll
+        for (int k = 0; k < Gm::WS; ++k)        // (cell k, cell k + WS): both in the same half of their dwords
+            b[k] = __builtin_amdgcn_perm(d[(k + Gm::WS) >> 1], d[k >> 1], (k & 1) ? 0x07060302u : 0x05040100u);
+        return;
+    }
     typedef const volatile __attribute__((address_space(3))) u16 *lds_cv16;
     lds_cv16 c = (lds_cv16)(region + Gm::PAD) + gb * Gm::HW + r * W;
     u32 lo[Gm::WS], hi[Gm::WS];
@@ -162,6 +195,23 @@ __device__ __forceinline__ void read_row(const unsigned char *region, int gb, in
 template <int H, int W>
 __device__ __forceinline__ void write_row(unsigned char *region, int gb, int r, const RowWords<H, W> &n) {
     using Gm = Geom<H, W>;
+    if (Gm::SWZ) {
+        u32x4 *row = (u32x4 *)(region + Gm::PAD) + (gb * Gm::HW + r * W) / 8;
+        const int key = (r >> 1) & 7;
+#pragma unroll
+        for (int j = 0; j < W / 8; ++j) {       // dword q = (cell 2q, cell 2q+1)
+            u32 q[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c0 = 2 * (4 * j + i);
+                q[i] = c0 < Gm::WS ? __builtin_amdgcn_perm(n[c0 + 1], n[c0], 0x05040100u)
+                                   : __builtin_amdgcn_perm(n[c0 + 1 - Gm::WS], n[c0 - Gm::WS], 0x07060302u);
+            }
+            u32x4 v = {q[0], q[1], q[2], q[3]};
+            row[j ^ key] = v;
+        }
+        return;
+    }
     u16 *c = (u16 *)(region + Gm::PAD) + gb * Gm::HW + r * W;
 #pragma unroll
     for (int k = 0; k < Gm::WS; ++k) {
@@ -493,13 +543,15 @@ __device__ __forceinline__ int row_side_effect(const RowWords<H, W> &b, const u3
 // (advance_board.c:217-300; valid for H, W >= 4 where the four cells are distinct)
 __device__ __forceinline__ int wrap1(int v, int n) { return v < 0 ? v + n : (v >= n ? v - n : v); }
 
-__device__ __forceinline__ void act_gather(u16 *board, int H, int W, int &ly, int &lx, int action) {
+template <int H, int W>
+__device__ __forceinline__ void act_gather(u16 *board, int &ly, int &lx, int action) {
+    using Gm = Geom<H, W>;
     const int dir = (action - 1) & 3;
     const int dy = (dir & 1) ? 0 : dir - 1, dx = (dir & 1) ? 2 - dir : 0;
     const int y1 = wrap1(ly + dy, H), x1 = wrap1(lx + dx, W);
-    const int i0 = ly * W + lx, i1 = y1 * W + x1;
-    const int i2 = wrap1(ly + 2 * dy, H) * W + wrap1(lx + 2 * dx, W);
-    const int i3 = wrap1(ly - dy, H) * W + wrap1(lx - dx, W);
+    const int i0 = Gm::cell(ly, lx), i1 = Gm::cell(y1, x1);
+    const int i2 = Gm::cell(wrap1(ly + 2 * dy, H), wrap1(lx + 2 * dx, W));
+    const int i3 = Gm::cell(wrap1(ly - dy, H), wrap1(lx - dx, W));
     u32 c0 = board[i0], c1 = board[i1], c2 = board[i2], c3 = board[i3];
     if (action == 0 || !(c0 & AGENT)) return;
     c0 = (c0 & ~ORIENT_MASK) | ((u32)dir << ORIENT_SHIFT);
@@ -550,12 +602,14 @@ __device__ __forceinline__ void act_gather(u16 *board, int H, int W, int &ly, in
 }
 
 // update_exit_colors for the board of a leader lane, on the flat LDS image.
-__device__ __forceinline__ bool recolor_exits_lds(u16 *board, int W, int ly, int lx, const int32_t *exits,
+template <int H, int W>
+__device__ __forceinline__ bool recolor_exits_lds(u16 *board, int ly, int lx, const int32_t *exits,
                                                   int exit0, int E, int score, int initial, int required,
                                                   int exit_points, int *n_exits = nullptr) {
+    using Gm = Geom<H, W>;
     bool any_can = false;
     if (ly >= 0) {
-        u16 *cell = board + ly * W + lx;
+        u16 *cell = board + Gm::cell(ly, lx);
         const u32 c = *cell;
         int earned = score - initial + (has_exited(c) ? exit_points : 0);
         if (earned < 0) earned = 0;
@@ -566,13 +620,13 @@ __device__ __forceinline__ bool recolor_exits_lds(u16 *board, int W, int ly, int
     const u16 paint = (u16)(FROZEN | EXIT | (any_can ? COLOR_R : 0u));
     int nx = 0;
     if (exit0 >= 0) {                             // slot 0 was prefetched; the usual level has one exit
-        board[exit0] = paint;
+        board[Gm::flat(exit0)] = paint;
         nx = 1;
     }
     for (int k = 1; k < E; ++k) {
         const int ex = exits[k];
         if (ex >= 0) {
-            board[ex] = paint;
+            board[Gm::flat(ex)] = paint;
             ++nx;
         }
     }
@@ -588,7 +642,10 @@ typedef __attribute__((address_space(3))) void *glds_dst_t;
 // `bytes` of global memory -> LDS with the asynchronous global_load_lds DMA (16 bytes per lane,
 // 1 KiB per wave instruction, no VGPR staging, no ds_write).  Chunk c of 1 KiB is moved by wave
 // c % WAVES.  Completion: the vmcnt(0) the compiler places in front of the next __syncthreads().
-template <int MAX_BYTES>
+// SWZ: LDS slot s (16-byte chunk) receives global chunk swz_chunk(s) -- the board-image swizzle of Geom.
+__device__ __forceinline__ int swz_chunk(int s) { return s ^ ((s >> 4) & 7); }     // 8 chunks per row; key (row>>1)&7
+
+template <int MAX_BYTES, bool SWZ = false>
 __device__ __forceinline__ void dma_to_lds(const unsigned char *__restrict__ src, unsigned char *dst, int bytes,
                                            int lane, int wave) {
     const int nv = bytes >> 4;
@@ -596,9 +653,10 @@ __device__ __forceinline__ void dma_to_lds(const unsigned char *__restrict__ src
 #pragma unroll
     for (int j = 0; j < (NCH + WAVES - 1) / WAVES; ++j) {
         const int c = wave + WAVES * j;
-        if (c * 64 + lane < nv)
-            __builtin_amdgcn_global_load_lds((glds_src_t)(src + c * 1024 + lane * 16), (glds_dst_t)(dst + c * 1024), 16,
-                                             0, 0);
+        const int s = c * 64 + lane;
+        if (s < nv)
+            __builtin_amdgcn_global_load_lds((glds_src_t)(src + (SWZ ? swz_chunk(s) : s) * 16),
+                                             (glds_dst_t)(dst + c * 1024), 16, 0, 0);
     }
 }
 
@@ -606,7 +664,7 @@ template <int H, int W>
 __device__ __forceinline__ void load_span(const u16 *__restrict__ src, unsigned char *region, int nbb, int tid) {
     using Gm = Geom<H, W>;
     const int bytes = nbb * Gm::HW * 2;
-    dma_to_lds<Gm::SPAN>((const unsigned char *)src, region + Gm::PAD, bytes, tid & 63, tid >> 6);
+    dma_to_lds<Gm::SPAN, Gm::SWZ>((const unsigned char *)src, region + Gm::PAD, bytes, tid & 63, tid >> 6);
     const int nv = bytes >> 4, rem = (bytes & 15) >> 1;          // leftover cells: tail workgroup only
     if (tid < rem) ((u16 *)(region + Gm::PAD))[nv * 8 + tid] = src[nv * 8 + tid];
 }
@@ -620,8 +678,10 @@ __device__ __forceinline__ void store_span(u16 *__restrict__ dst, const unsigned
     const u32x4 *s = (const u32x4 *)(region + Gm::PAD);
     constexpr int NVI = (Gm::SPAN / 16 + 64 * WAVES - 1) / (64 * WAVES);
 #pragma unroll
-    for (int i = 0; i < NVI; ++i)
-        if (tid + 64 * WAVES * i < nv) d[tid + 64 * WAVES * i] = s[tid + 64 * WAVES * i];
+    for (int i = 0; i < NVI; ++i) {
+        const int slot = tid + 64 * WAVES * i;
+        if (slot < nv) d[Gm::SWZ ? swz_chunk(slot) : slot] = s[slot];
+    }
     const int rem = (bytes & 15) >> 1;
     if (tid < rem) dst[nv * 8 + tid] = ((const u16 *)s)[nv * 8 + tid];
 }
@@ -745,6 +805,7 @@ __device__ __forceinline__ u32 obs_fetch(const sl_env_batch &env, const unsigned
     int cell = sy * W + sx;
     for (int k = 0; k < n_exits; ++k)             // later exits overwrite earlier ones, as numpy does
         if (pp[2 + k] == cu.v) cell = pp[2 + OBS_MAX_EXITS + k];
+    cell = Gm::flat(cell);
     u32 g = g16[cell] & COLORS;
     if (env.remove_white_goals && g == COLORS) g = 0;
     return (u32)b16[cell] | (g << 16);
@@ -893,7 +954,8 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
     u32 *gsh_lane = GSH_REG ? gsh_reg : (u32 *)(smem + Gm::OFF_GSH) + (wave * 64 + lane) * WS;
     const int8_t *lds_lut = (const int8_t *)(smem + Gm::OFF_LUT);
     // wrappers: this wave's baseline rows, word k of lane l at [k * 64 + l] (the layout the b32 DMA writes)
-    unsigned char *base_rows = smem + (GSH_REG ? Gm::OFF_GSH : Gm::OFF_BASE) + wave * 64 * WS * 4;
+    constexpr bool BASE_IN_GSH = GSH_REG && Gm::GSH_BYTES >= WAVES * 64 * WS * 4;
+    unsigned char *base_rows = smem + (BASE_IN_GSH ? Gm::OFF_GSH : Gm::OFF_BASE) + wave * 64 * WS * 4;
     sl_wrap_state *wst = (sl_wrap_state *)(smem + Gm::OFF_WST);
     const double *mvt = (const double *)(smem + Gm::OFF_MVT);
     const int8_t *__restrict__ lut = env.score_lut + 4096;        // wide form of table t at + t * SCORE_LUT_BYTES
@@ -965,7 +1027,7 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
         // safelife_env.py:151
         if (leader && ly >= 0) {
             if (t > 0) action = actions[(size_t)t * B + e];
-            act_gather(board16, H, W, ly, lx, action);
+            act_gather<H, W>(board16, ly, lx, action);
         }
         wave_sync();
         SL_STAMP(4);
@@ -1021,7 +1083,7 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
         bool w_times_up = false, w_open = false;
         int w_exits = 0;
         if (leader) {
-            w_open = recolor_exits_lds(board16, W, ly, lx, exits, exit0, E, score, initial, required,
+            w_open = recolor_exits_lds<H, W>(board16, ly, lx, exits, exit0, E, score, initial, required,
                                        env.exit_points, WRAP ? &w_exits : nullptr);
             steps += 1;
             const bool times_up = steps >= env.time_limit;
@@ -1029,7 +1091,7 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
             bool success = false;
             done = true;
             if (ly >= 0) {
-                const u32 cell = board16[ly * W + lx];
+                const u32 cell = board16[Gm::cell(ly, lx)];
                 success = has_exited(cell);
                 const int value = score + (success ? env.exit_points : 0);
                 reward = (float)((value - old_value) * (active ? 1 : 0));
@@ -1092,8 +1154,8 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
                 const u16 *pb = env.pool_board + (size_t)level * HW, *pg = env.pool_goals + (size_t)level * HW;
                 u16 *gdst = (u16 *)(goals + Gm::PAD) + gb * HW;
                 for (int i = r; i < HW; i += H) {
-                    board16[i] = pb[i];
-                    gdst[i] = pg[i];
+                    board16[Gm::flat(i)] = pb[i];
+                    gdst[Gm::flat(i)] = pg[i];
                 }
                 lut_base = (u32)env.pool_scalars[level].table_idx * (u32)SCORE_LUT_BYTES;
                 p = (double)env.pool_scalars[level].spawn_prob;
@@ -1121,10 +1183,10 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
                 ly = lv.agent_row;
                 lx = lv.agent_col;
                 initial = lv.initial_points;
-                open0 = recolor_exits_lds(board16, W, ly, lx, exits, exit0, E, s0, initial, lv.required_reset,
+                open0 = recolor_exits_lds<H, W>(board16, ly, lx, exits, exit0, E, s0, initial, lv.required_reset,
                                           env.exit_points) ? 1 : 0;
                 if (WRAP) wrap_reset(wst[gb], ly, lx);
-                const int exited = ly >= 0 ? (has_exited(board16[ly * W + lx]) ? 1 : 0) : 0;
+                const int exited = ly >= 0 ? (has_exited(board16[Gm::cell(ly, lx)]) ? 1 : 0) : 0;
                 old_value = s0 + env.exit_points * exited;
                 required = lv.required_step;
                 steps = 0;
@@ -1288,8 +1350,8 @@ static hipError_t launch_rollout_t(const sl_env_batch &env, const int32_t *actio
         k_env_rollout_rowlane<H, W, false, true, true>,  k_env_rollout_rowlane<H, W, true, true, true>,
         k_env_rollout_rowlane<H, W, false, false, true>,  k_env_rollout_rowlane<H, W, true, false, true>};
     const kernel_t fn = table[variant];
-    const bool spawn = !(variant & 2), gsh_reg = !spawn || Gm::WAVES_PER_SIMD < 4;
-    const int lds = !(variant & 4) ? Gm::LDS_BYTES : (gsh_reg ? Gm::LDS_WRAP_GSHREG : Gm::LDS_WRAP_GSHLDS);
+    const bool spawn = !(variant & 2), base_in_gsh = !spawn && Gm::WAVES_PER_SIMD == 4;
+    const int lds = !(variant & 4) ? Gm::LDS_BYTES : (base_in_gsh ? Gm::LDS_WRAP_GSHREG : Gm::LDS_WRAP_GSHLDS);
     static bool configured[8] = {};               // the attribute is sticky: set it once
     if (!configured[variant]) {
         hipError_t err = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

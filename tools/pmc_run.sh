@@ -9,10 +9,11 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() { # name counters...
   local name=$1; shift
-  rocprofv3 --pmc "$@" -d $OUT/$name -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --cpu-baseline 0 "${BARGS[@]}" > $OUT/$name.log 2>&1
+  rocprofv3 --pmc "$@" -d $OUT/$name -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --cpu-baseline 0 --extras 0 --rollout 0 "${BARGS[@]}" > $OUT/$name.log 2>&1
   local db=$(ls $OUT/$name/*/*_results.db 2>/dev/null | head -1)
   [ -n "$db" ] && python $GRAFT_REPO_ROOT/tools/prof_summary.py $db --pmc | grep -E "counter|rollout|advance" > $OUT/$name.txt
   cat $OUT/$name.txt
+  rm -rf $OUT/$name          # raw databases are large; only the summaries travel back
 }
 BARGS=("$@")
 run sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_WAIT_ANY
