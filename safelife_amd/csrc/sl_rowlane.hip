@@ -440,6 +440,10 @@ __device__ void resolve_draws(const RowWords<H, W> &b, RowWords<H, W> &n, const 
             if (!(pcg_output_double(cur) < p)) failed |= 1ull << pos;      // advance_board.c:115
             ord &= ~(1ull << pos);
         }
+        if (excl + mine == total) {     // the lane that made the board's last draw holds its new state
+            rng_lds[4 * g + 0] = cur.hi;
+            rng_lds[4 * g + 1] = cur.lo;
+        }
     }
     if (__ballot(failed != 0)) {        // a failed draw keeps the old cell
         const u32 f_lo = (u32)(failed >> 32), f_hi = (u32)failed;
@@ -449,11 +453,7 @@ __device__ void resolve_draws(const RowWords<H, W> &b, RowWords<H, W> &n, const 
             n[k] = (n[k] & ~keep) | (b[k] & keep);
         }
     }
-    if (lead && total > 0) {
-        const U128 s2 = pcg_jump(jump, total, st, inc);
-        rng_lds[4 * g + 0] = s2.hi;
-        rng_lds[4 * g + 1] = s2.lo;
-    }
+    (void)lead;
     wave_sync();
 }
 
