@@ -228,6 +228,24 @@ def main():
                                               output_channels=TRAIN_CHANNELS, auto_reset=True, with_obs=False), n_envs)
             extra[tag + "_us_per_step"] = us
             extra[tag + "_env_steps_per_s_per_gpu"] = n_envs / (us * 1e-6)
+            if pname == "navigation_64":
+                # side_effects.py:109-111 runs life_occupancy(board, n_step=1000) twice at every episode end
+                from safelife_amd import speedups
+                nb = 1024
+                boards = env3_boards = torch.from_numpy(
+                    np.ascontiguousarray(p2.arrays()["pool_board"][np.arange(nb) % len(p2)]).view(np.int16)).to(dev)
+                probs = torch.full((nb,), 0.3, dtype=torch.float32, device=dev)
+                rngs = torch.arange(nb * 4, dtype=torch.int64, device=dev).reshape(nb, 4) * 2 + 1
+                speedups.life_occupancy_batch(boards[:8], probs[:8], rngs[:8].clone(), 10)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                speedups.life_occupancy_batch(boards, probs, rngs, 1000)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1)
+                extra["life_occupancy_64x64_1000steps_boards_per_s"] = nb / (ms * 1e-3)
+                extra["life_occupancy_64x64_board_steps_per_s"] = nb * 1000 / (ms * 1e-3)
 
     if rank == 0:
         obs_bytes = {0: 0, 1: H * Wd * len(TRAIN_CHANNELS), 2: H * Wd * 4}[args.obs]
