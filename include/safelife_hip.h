@@ -232,6 +232,14 @@ int slhip_env_rollout(const sl_env_batch *env, const int32_t *actions, int T,
 /* SafeLifeEnv.get_obs() for the current state. */
 int slhip_env_obs(const sl_env_batch *env, void *stream);
 
+/* The raw uint32 view (output_channels=None, safelife_env.py:141) -> the tensor the policy network
+ * convolves: channel-first with the spatial axes swapped, out[b][c][x][y] = (view[b][y][x] >> channels[c]) & 1,
+ * i.e. what training/models.py:100-103 (obs.transpose(-1, -3)) and the float cast of training/ppo.py:64
+ * produce from the (h, w, c) uint8 observation.  dtype: 0 = uint8, 1 = float32.  view: [B,vh,vw],
+ * out: [B,C,vw,vh].  The step then only writes 4 bytes per view cell instead of C. */
+int slhip_obs_to_policy(const uint32_t *view, int B, int vh, int vw, const int32_t *channels, int C,
+                        void *out, int dtype, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

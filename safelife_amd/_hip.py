@@ -21,6 +21,7 @@ EXPORTS = (
     "slhip_abi_version", "slhip_last_error", "slhip_device_count",
     "slhip_advance_board", "slhip_life_occupancy", "slhip_alive_counts", "slhip_execute_actions",
     "slhip_env_prepare", "slhip_env_reset", "slhip_env_step", "slhip_env_rollout", "slhip_env_obs",
+    "slhip_obs_to_policy",
 )
 
 
@@ -113,6 +114,7 @@ def lib():
         L.slhip_env_step.argtypes = [C.POINTER(EnvBatch), _p, _p]
         L.slhip_env_rollout.argtypes = [C.POINTER(EnvBatch), _p, C.c_int, _p, _p, _p]
         L.slhip_env_obs.argtypes = [C.POINTER(EnvBatch), _p]
+        L.slhip_obs_to_policy.argtypes = [_p, C.c_int, C.c_int, C.c_int, _p, C.c_int, _p, C.c_int, _p]
         for name in EXPORTS:
             getattr(L, name)  # AttributeError here means the .so is stale
         _lib = L

@@ -235,4 +235,20 @@ int slhip_env_obs(const sl_env_batch *env, void *stream) {
     return err == hipSuccess ? SL_OK : hip_fail(err, "env_obs launch");
 }
 
+int slhip_obs_to_policy(const uint32_t *view, int B, int vh, int vw, const int32_t *channels, int C, void *out,
+                        int dtype, void *stream) {
+    if (B < 0 || vh < 1 || vw < 1) return fail(SL_E_ARG, "bad view shape");
+    if (C < 1 || C > SL_MAX_CHANNELS || !channels) return fail(SL_E_ARG, "bad channel list");
+    if (dtype != 0 && dtype != 1) return fail(SL_E_ARG, "dtype must be 0 (uint8) or 1 (float32)");
+    if (!view || !out) return fail(SL_E_ARG, "null pointer");
+    sl::sl_channel_list ch;
+    for (int k = 0; k < C; ++k) {
+        if (channels[k] < 0 || channels[k] > 31) return fail(SL_E_ARG, "channel outside 0..31");
+        ch.c[k] = channels[k];
+    }
+    if (B == 0) return SL_OK;
+    hipError_t err = sl::launch_obs_to_policy(view, B, vh, vw, ch, C, out, dtype, (hipStream_t)stream);
+    return err == hipSuccess ? SL_OK : hip_fail(err, "obs_to_policy launch");
+}
+
 }  // extern "C"

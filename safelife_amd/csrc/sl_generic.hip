@@ -492,7 +492,35 @@ __global__ __launch_bounds__(GB) void k_env_obs_generic(sl_env_batch env) {
               env.scalars[e].agent_col, env.exit_locs + (size_t)e * env.E);
 }
 
+// One thread per output element quad along y (contiguous in the output); view reads hit L2.
+template <typename T>
+__global__ __launch_bounds__(256) void k_obs_to_policy(const u32 *__restrict__ view, int vh, int vw, int C,
+                                                       sl_channel_list ch, T *__restrict__ out, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;      // index into out [B,C,vw,vh]
+    if (i >= total) return;
+    const int y = (int)(i % vh);
+    long long q = i / vh;
+    const int x = (int)(q % vw);
+    q /= vw;
+    const int c = (int)(q % C);
+    const long long b = q / C;
+    const u32 word = view[(b * vh + y) * vw + x];
+    out[i] = (T)((word >> ch.c[c]) & 1u);
+}
+
 // ------------------------------------------------------------------------------ launchers
+
+hipError_t launch_obs_to_policy(const u32 *view, int B, int vh, int vw, const sl_channel_list &ch, int C, void *out,
+                                int dtype, hipStream_t stream) {
+    const long long total = (long long)B * C * vw * vh;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (dtype == 0)
+        hipLaunchKernelGGL(k_obs_to_policy<uint8_t>, grid, dim3(256), 0, stream, view, vh, vw, C, ch, (uint8_t *)out, total);
+    else
+        hipLaunchKernelGGL(k_obs_to_policy<float>, grid, dim3(256), 0, stream, view, vh, vw, C, ch, (float *)out, total);
+    return hipGetLastError();
+}
+
 
 static hipError_t set_lds(const void *fn, size_t bytes) {
     return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);

@@ -22,6 +22,11 @@ hipError_t launch_env_rollout_generic(const sl_env_batch &env, const int32_t *ac
                                       hipStream_t stream);
 hipError_t launch_env_reset_generic(const sl_env_batch &env, const uint8_t *mask, hipStream_t stream);
 hipError_t launch_env_obs_generic(const sl_env_batch &env, hipStream_t stream);
+struct sl_channel_list {
+    int32_t c[SL_MAX_CHANNELS];
+};
+hipError_t launch_obs_to_policy(const u32 *view, int B, int vh, int vw, const sl_channel_list &ch, int C, void *out,
+                                int dtype, hipStream_t stream);
 
 // sl_rowlane.hip : row-per-lane SWAR kernels for the shapes listed in SL_ROWLANE_SHAPES
 bool rowlane_supports(int H, int W);

@@ -240,6 +240,27 @@ class SafeLifeVectorEnv(object):
         _hip.check(rc)
         return self.obs
 
+    def policy_obs(self, channels=_DEFAULT_CHANNELS, dtype=None, out=None):
+        """The observation as the policy network takes it (training/models.py:100-103): channel-first,
+        spatial axes swapped, ``[B, C, view_w, view_h]``, uint8 or float32 -- unpacked on the device from
+        the raw uint32 view (needs ``output_channels=None``), so a step writes 4 bytes per view cell and
+        the (h, w, c) byte tensor is never materialised."""
+        torch = self.torch
+        if self.output_channels is not None or self.obs is None:
+            raise ValueError("policy_obs() needs the raw view: construct with output_channels=None")
+        dtype = dtype or torch.float32
+        if dtype not in (torch.uint8, torch.float32):
+            raise ValueError("dtype must be torch.uint8 or torch.float32")
+        vh, vw = self.view_shape
+        chans = np.ascontiguousarray(channels, dtype=np.int32)
+        if out is None:
+            out = torch.empty((self.num_envs, len(chans), vw, vh), dtype=dtype, device=self.device)
+        rc = self._lib.slhip_obs_to_policy(_hip.ptr(self.obs), self.num_envs, vh, vw,
+                                           chans.ctypes.data_as(C.c_void_p), len(chans), _hip.ptr(out),
+                                           0 if dtype == torch.uint8 else 1, _hip.current_stream_ptr())
+        _hip.check(rc)
+        return out
+
     # ------------------------------------------------------------------ host views
 
     def numpy(self, name):

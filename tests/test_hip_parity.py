@@ -419,3 +419,27 @@ def test_compat_wrappers_trace(name):
             if episode >= len(tr["trace_reset_at"]):
                 break
             assert np.array_equal(env.reset(), tr["trace_reset_obs"][episode]), t
+
+
+def test_policy_obs_layout():
+    """policy_obs() == the reference pipeline on the (h, w, c) observation: transpose(-1, -3) and a
+    float cast (training/models.py:100-103, ppo.py:64), for the same state."""
+    import torch
+    pool, _ = util.pool_from_fixture("append_spawn_25", _device_counts, n=16)
+    B = 96
+    chans = (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 25, 26, 27)
+    kw = dict(time_limit=30, view_shape=(13, 21), auto_reset=True)
+    a = util.DeviceBackend(pool, B, first_level=np.arange(B) % 16, output_channels=chans, **kw)
+    b = util.DeviceBackend(pool, B, first_level=np.arange(B) % 16, output_channels=None, **kw)
+    a.reset()
+    b.reset()
+    rng = np.random.default_rng(2)
+    for t in range(25):
+        acts = rng.integers(0, 9, B).astype(np.int32)
+        a.step(acts)
+        b.step(acts)
+    want = torch.from_numpy(a.get("obs")).transpose(-1, -3)
+    for dtype in (torch.uint8, torch.float32):
+        got = b.env.policy_obs(chans, dtype=dtype).cpu()
+        assert got.shape == (B, len(chans), 21, 13) and got.is_contiguous()
+        assert torch.equal(got, want.to(dtype))
