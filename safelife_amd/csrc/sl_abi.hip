@@ -148,8 +148,12 @@ int slhip_life_occupancy(const uint16_t *in, int32_t *counts, int B, int H, int 
     if (B == 0) return SL_OK;
     const sl::Jump *jump;
     if ((rc = jump_table(&jump))) return rc;
-    hipError_t err = sl::launch_advance_generic(in, nullptr, B, H, W, spawn_prob, n_steps, rng, jump, counts,
-                                                (hipStream_t)stream);
+    // 16-bit per-colour counters in LDS: the row kernel covers every step count the reference is called with
+    hipError_t err = (sl::rowlane_supports(H, W) && n_steps <= 65535 && !force_generic())
+                         ? sl::launch_occupancy_rowlane(in, counts, B, H, W, spawn_prob, n_steps, rng, jump,
+                                                        (hipStream_t)stream)
+                         : sl::launch_advance_generic(in, nullptr, B, H, W, spawn_prob, n_steps, rng, jump, counts,
+                                                      (hipStream_t)stream);
     return err == hipSuccess ? SL_OK : hip_fail(err, "life_occupancy launch");
 }
 

@@ -34,6 +34,8 @@ hipError_t launch_build_score_lut(const int32_t *points_table, int n_tables, int
 hipError_t launch_build_baseline(const sl_env_batch &env, hipStream_t stream);
 hipError_t launch_advance_rowlane(const u16 *in, u16 *out, int B, int H, int W, const float *spawn_prob,
                                   int n_steps, sl_pcg64 *rng, const Jump *jump, hipStream_t stream);
+hipError_t launch_occupancy_rowlane(const u16 *in, int32_t *counts, int B, int H, int W, const float *spawn_prob,
+                                    int n_steps, sl_pcg64 *rng, const Jump *jump, hipStream_t stream);
 hipError_t launch_env_rollout_rowlane(const sl_env_batch &env, const int32_t *actions, int T, float *reward_t,
                                       uint8_t *done_t, const Jump *jump, hipStream_t stream);
 

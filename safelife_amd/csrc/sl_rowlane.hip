@@ -738,6 +738,94 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_ad
         ((u64 *)(rng + e0b + wave * Gm::G))[lane] = rng_lds[lane];
 }
 
+// ---- life_occupancy ---------------------------------------------------------------------------------
+// (advance_board.c:153-189)  One wavefront per workgroup, G boards per wavefront, rows in registers for
+// all n steps.  After every step each lane bumps, for each of its cells that is ALIVE and not
+// AGENT|EXIT|FROZEN, a 16-bit counter (cell, colour) in LDS with a fire-and-forget ds_add_u32 (two
+// colours share a dword; n_steps <= 65535 keeps a half from carrying into its neighbour).  A lane's
+// counters are one contiguous run with an odd dword pitch between lanes, so "same cell, every row"
+// spreads over the banks.  The counters become the int32 [H,W,8] output at the end.
+template <int H, int W>
+struct OccGeom {
+    using Gm = Geom<H, W>;
+    static constexpr int PITCH = W * 4 + 1;                             // dwords per lane: W cells x 8 colours x u16
+    static constexpr int OFF_CNT = 0;
+    static constexpr int OFF_RNG = 64 * PITCH * 4;                      // G x 4 u64
+    static constexpr int LDS_BYTES = OFF_RNG + Gm::G * 32;
+};
+
+template <int H, int W>
+__global__ __launch_bounds__(64) void k_occupancy_rowlane(const u16 *__restrict__ in, int32_t *__restrict__ counts,
+                                                          int B, const float *__restrict__ spawn_prob, int n_steps,
+                                                          sl_pcg64 *rng, const Jump *__restrict__ jump) {
+    using Gm = Geom<H, W>;
+    using Oc = OccGeom<H, W>;
+    constexpr int WS = Gm::WS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const int e0b = blockIdx.x * Gm::G;
+    const int nbb = min(Gm::G, B - e0b);
+    const LaneMap<H, W> lm(lane);
+    const int g = lm.g, r = lm.r;
+    const bool rowl = lane < Gm::NL && g < nbb;
+    const bool live = rowl && lm.real;
+    const unsigned e = e0b + (rowl ? g : 0);
+    u32 *cnt = (u32 *)(smem + Oc::OFF_CNT) + lane * Oc::PITCH;
+    u64 *rng_lds = (u64 *)(smem + Oc::OFF_RNG);
+
+    for (int i = 0; i < Oc::PITCH; ++i) cnt[i] = 0;
+    if (lane < 4 * nbb) rng_lds[lane] = ((const u64 *)(rng + e0b))[lane];
+    const double p = rowl ? (double)spawn_prob[e] : 0.0;
+    RowWords<H, W> b, n;
+    Elig elig;
+    {   // the row straight from HBM (once per launch)
+        const u16 *row = in + ((size_t)e * H + r) * W;
+#pragma unroll
+        for (int k = 0; k < WS; ++k) {
+            const u32 lo = rowl ? row[k] : 0u;
+            const u32 hi = (rowl && !(Gm::ODD && k == WS - 1)) ? row[k + WS] : 0u;
+            b[k] = lo | (hi << 16);
+        }
+    }
+    // V_SHIFT: after a step the halo lanes take the new first / last row from the lanes that own them
+    const int partner = !rowl || lm.real ? lane : (r == 0 ? lane - H : lane + H);
+    const Consts cst = make_consts();
+    wave_sync();
+    for (int s = 0; s < n_steps; ++s) {
+        ca_rows<H, W, true>(b, n, elig, lm.up, lm.dn, cst);
+        if (!live) elig.clear();
+        if (__ballot(elig.any())) resolve_draws<H, W>(b, n, elig, rng_lds, rowl ? g : 0, live && r == 0, p, jump);
+#pragma unroll
+        for (int k = 0; k < WS; ++k) b[k] = Gm::VERT == V_SHIFT ? bperm(4 * partner, n[k]) : n[k];
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < WS; ++k) {
+                const u32 c = b[k];
+                const u32 tick = c & ~(c >> 1) & ~(c >> 4) & ~(c >> 8) & 0x00010001u;    // alive, not agent/frozen/exit
+                const u32 lo_col = (c >> 9) & 7u, hi_col = (c >> 25) & 7u;
+                __hip_atomic_fetch_add(cnt + k * 4 + (lo_col >> 1), (tick & 1u) << (16 * (lo_col & 1u)),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                if (!(Gm::ODD && k == WS - 1))
+                    __hip_atomic_fetch_add(cnt + (k + WS) * 4 + (hi_col >> 1), (tick >> 16) << (16 * (hi_col & 1u)),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+        }
+    }
+    wave_sync();
+    if (live) {
+        int32_t *dst = counts + (((size_t)e * H + r) * W) * 8;
+        for (int x = 0; x < W; ++x) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const u32 v = cnt[x * 4 + q];
+                dst[x * 8 + 2 * q] = (int32_t)(v & 0xFFFFu);
+                dst[x * 8 + 2 * q + 1] = (int32_t)(v >> 16);
+            }
+        }
+    }
+    if (lane < 4 * nbb) ((u64 *)(rng + e0b))[lane] = rng_lds[lane];
+}
+
 // ---- observation ------------------------------------------------------------------------------------
 constexpr int OBS_MAX_EXITS = 8;                       // exit slots handled by the fast obs path
 constexpr int OBS_PAR_INTS = 2 + 2 * OBS_MAX_EXITS;
@@ -1339,6 +1427,19 @@ static hipError_t launch_advance_t(const u16 *in, u16 *out, int B, const float *
 }
 
 template <int H, int W>
+static hipError_t launch_occupancy_t(const u16 *in, int32_t *counts, int B, const float *spawn_prob, int n_steps,
+                                     sl_pcg64 *rng, const Jump *jump, hipStream_t stream) {
+    using Gm = Geom<H, W>;
+    using Oc = OccGeom<H, W>;
+    auto fn = k_occupancy_rowlane<H, W>;
+    hipError_t err = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, Oc::LDS_BYTES);
+    if (err != hipSuccess) return err;
+    hipLaunchKernelGGL(fn, dim3((B + Gm::G - 1) / Gm::G), dim3(64), Oc::LDS_BYTES, stream, in, counts, B, spawn_prob,
+                       n_steps, rng, jump);
+    return hipGetLastError();
+}
+
+template <int H, int W>
 static hipError_t launch_rollout_t(const sl_env_batch &env, const int32_t *actions, int T, float *reward_t,
                                    uint8_t *done_t, const Jump *jump, hipStream_t stream) {
     using Gm = Geom<H, W>;
@@ -1389,6 +1490,14 @@ hipError_t launch_build_baseline(const sl_env_batch &env, hipStream_t stream) {
 hipError_t launch_advance_rowlane(const u16 *in, u16 *out, int B, int H, int W, const float *spawn_prob,
                                   int n_steps, sl_pcg64 *rng, const Jump *jump, hipStream_t stream) {
 #define X(h, w) if (H == h && W == w) return rl::launch_advance_t<h, w>(in, out, B, spawn_prob, n_steps, rng, jump, stream);
+    SL_ROWLANE_SHAPES(X)
+#undef X
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_occupancy_rowlane(const u16 *in, int32_t *counts, int B, int H, int W, const float *spawn_prob,
+                                    int n_steps, sl_pcg64 *rng, const Jump *jump, hipStream_t stream) {
+#define X(h, w) if (H == h && W == w) return rl::launch_occupancy_t<h, w>(in, counts, B, spawn_prob, n_steps, rng, jump, stream);
     SL_ROWLANE_SHAPES(X)
 #undef X
     return hipErrorInvalidValue;

@@ -130,6 +130,24 @@ def test_advance_board_vs_oracle(sp, shape, B, kind):
         assert np.array_equal(w_dev, w_cpu)
 
 
+@pytest.mark.parametrize("shape,B,n_step", [((25, 25), 70, 1000), ((26, 26), 33, 300), ((64, 64), 9, 400),
+                                            ((20, 20), 10, 100), ((15, 15), 13, 100), ((10, 10), 25, 100),
+                                            ((9, 31), 6, 60), ((25, 25), 3, 0)])
+@pytest.mark.parametrize("kind", [0, 1])
+def test_life_occupancy_vs_oracle(sp, shape, B, n_step, kind):
+    import torch
+    rng = np.random.default_rng(hash((shape, kind, n_step)) % 2**31)
+    boards = util.random_boards(rng, B, shape[0], shape[1], kind)
+    words = util.random_rng_words(rng, B)
+    p = rng.choice([0.3, 0.05, 1.0], B).astype(np.float32)
+    w_cpu = words.copy()
+    want = oracle.life_occupancy_batch(boards, p, n_step, w_cpu, n_threads=8)
+    d_rng = sp._to_device(words.copy(), np.uint64)
+    got = sp.life_occupancy_batch(sp._to_device(boards, np.uint16), torch.from_numpy(p).to(d_rng.device), d_rng, n_step)
+    assert np.array_equal(got.cpu().numpy(), want)
+    assert np.array_equal(sp._to_host(d_rng, np.uint64), w_cpu)
+
+
 def test_alive_counts_and_actions_vs_oracle(sp):
     import torch
     rng = np.random.default_rng(11)
