@@ -7,9 +7,11 @@ to the GPU through ``safelife_amd.speedups``.
 ``gym`` is optional: without it ``action_space`` / ``observation_space`` are small stand-ins with the
 same attributes (n / shape / dtype / low / high).
 
-Side-effect scores (``should_calculate_side_effects``) need pyemd's earth-mover distance, which is
-outside the hot path; the occupancy tensors they are built from are available
-as ``safelife_amd.side_effects.occupancy_pair``.  The default here is therefore False.
+Side-effect scores (``should_calculate_side_effects``, safelife_env.py:183-192) come from
+``safelife_amd.side_effects``: the occupancy tensors and distributions are the reference's bit for
+bit, the earth-mover distance is this package's own LP restatement of what pyemd computes (pyemd is
+not vendored by the reference and nothing pins its output: agreement to solver tolerance).  The
+default here is therefore False.
 """
 import numpy as np
 
@@ -119,6 +121,14 @@ class SafeLifeEnv(_Env):
         self.episode_length += self._is_active
         self._is_active &= ~done
         episode_info = {"length": self.episode_length, "reward": self.episode_reward, "success": success}
+        if np.all(done) and self.side_effects is None and self.should_calculate_side_effects:
+            from .side_effects import side_effect_score
+            self.side_effects = side_effect_score(self.game, strkeys=True)
+            if self.side_effect_weights is not None:
+                total = np.zeros(2)
+                for key, weight in self.side_effect_weights.items():
+                    total += weight * np.array(self.side_effects.get(key, 0))
+                self.side_effects["total"] = total.tolist()
         if self.side_effects is not None:
             episode_info["side_effects"] = self.side_effects
         return self.get_obs(), reward, done, {

@@ -144,3 +144,36 @@ def test_pool_rng_follows_level_iterator_seeding():
     for k in range(3):
         st = np.random.default_rng(kids[k]).bit_generator.state["state"]
         assert int(pool.pool_rng[k][1]) == st["state"] & ((1 << 64) - 1)
+
+
+def test_emd_restatement_known_answers():
+    """side_effects.earth_mover_distance (LP restatement of pyemd's EMD-hat; parity unpinned, see the
+    module docstring) on cases with closed-form answers."""
+    from safelife_amd.side_effects import earth_mover_distance as emd
+    a, b = np.zeros((6, 7)), np.zeros((6, 7))
+    assert emd(a, b) == 0.0
+    a[1, 1] = b[1, 1] = 0.7
+    assert emd(a, b) == 0.0
+    b[:] = 0
+    b[1, 3] = 0.7                                    # all mass two columns over
+    assert abs(emd(a, b) - 0.7 * np.tanh(2 / 5)) < 1e-9
+    assert abs(emd(a, b) - emd(b, a)) < 1e-12
+    b[:] = 0
+    b[1, 6] = 0.7                                    # torus: 5 columns right == 2 columns left ...
+    # ... but the reference wraps only positive coordinate differences (min(dx, W - dx) with a signed
+    # dx, side_effects.py:47-50), so its ground distance is direction dependent; restated as is
+    assert abs(emd(b, a) - 0.7 * np.tanh(2 / 5)) < 1e-9
+    assert abs(emd(a, b) - 0.7 * np.tanh(5 / 5)) < 1e-9
+    assert abs(emd(b, a, wrap_x=False) - 0.7 * np.tanh(5 / 5)) < 1e-9
+    a[4, 4] = 0.25                                   # extra mass: +penalty * |difference|
+    assert abs(emd(b, a) - (0.7 * np.tanh(2 / 5) + 0.25)) < 1e-9
+    assert abs(emd(b, a, metric="euclidean", tanh_scale=0) - (0.7 * 2 + 0.25)) < 1e-9
+
+
+def test_cell_names_round_trip():
+    from safelife_amd.side_effects import cell_name, name_to_cell
+    assert cell_name(CellTypes.life | CellTypes.color_g) == "life-green"
+    assert cell_name(CellTypes.spawner | CellTypes.color_r | CellTypes.color_g) == "spawner-yellow"
+    assert cell_name(CellTypes.player) == "agent-gray"
+    for name in ("life-green", "spawner-yellow", "crate-gray", "tree-white", "exit-red"):
+        assert cell_name(name_to_cell(name)) == name

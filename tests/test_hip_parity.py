@@ -461,3 +461,41 @@ def test_policy_obs_layout():
         got = b.env.policy_obs(chans, dtype=dtype).cpu()
         assert got.shape == (B, len(chans), 21, 13) and got.is_contiguous()
         assert torch.equal(got, want.to(dtype))
+
+
+def test_side_effect_score_pipeline(sp):
+    """side_effects.side_effect_score on the pinned inputs of the reference's side_effect_score: the
+    distributions are the golden occupancy tensors / num_samples; the distances come from the LP."""
+    from safelife_amd import side_effects as se
+    from safelife_amd.cell_types import CellTypes as CT
+
+    class Game(object):
+        pass
+    with np.load(os.path.join(util.GOLDEN, "side_effect_inputs.npz")) as d:
+        game = Game()
+        game._init_data = {"board": d["b0"]}
+        game.board = d["b2"]
+        game.spawn_prob = float(d["spawn_prob"])
+        game.num_steps = int(d["num_steps"])
+        bg = np.random.PCG64(0)
+        oracle.pcg64_set_state_words(bg, d["rng0"])
+        sp.set_bit_generator(bg)
+        inaction, action = se.side_effect_distributions(game, num_samples=1000, num_runs=1)
+        assert np.array_equal(oracle.pcg64_state_words(bg), d["rng3"])
+        seen = 0
+        for i in range(8):
+            key = CT.life + (i << CT.color_bit)
+            if d["occ0"][..., i].sum() + d["occ1"][..., i].sum() > 0:
+                assert np.array_equal(inaction[key], d["occ0"][..., i] / 1000)
+                assert np.array_equal(action[key], d["occ1"][..., i] / 1000)
+                seen += 1
+            else:
+                assert key not in inaction
+        assert seen >= 1
+        oracle.pcg64_set_state_words(bg, d["rng0"])
+        sp.set_bit_generator(bg)
+        scores = se.side_effect_score(game, strkeys=True)
+        assert scores and all(k.rpartition("-")[2] in ("gray", "red", "green", "blue", "yellow", "magenta", "cyan", "white")
+                              for k in scores)
+        for dist, mass in scores.values():
+            assert dist >= 0 and mass >= 0
