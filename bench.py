@@ -98,7 +98,7 @@ def main():
                     help="1: also write the 25x25x15 uint8 observation; 2: the raw 25x25 uint32 view")
     ap.add_argument("--gather-every", type=int, default=32)
     ap.add_argument("--cpu-baseline", type=int, default=1)
-    ap.add_argument("--cpu-steps", type=int, default=101)
+    ap.add_argument("--cpu-steps", type=int, default=1001)
     ap.add_argument("--rollout", type=int, default=32,
                     help="T>0: additionally time T-step fused rollouts (reported under 'extra')")
     ap.add_argument("--extras", type=int, default=1,
