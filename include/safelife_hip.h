@@ -61,6 +61,11 @@ int slhip_device_count(void);
 int slhip_advance_board(const uint16_t *in, uint16_t *out, int B, int H, int W,
                         const float *spawn_prob, int n_steps, sl_pcg64 *rng, void *stream);
 
+/* The same with one step count per board (n_steps: int32 [B]): side_effect_score rolls every
+ * finished episode's starting board forward by that episode's length (side_effects.py:108). */
+int slhip_advance_board_each(const uint16_t *in, uint16_t *out, int B, int H, int W,
+                             const float *spawn_prob, const int32_t *n_steps, sl_pcg64 *rng, void *stream);
+
 /* life_occupancy (advance_board.h:9-10, module.c:52-81).  counts: int32 [B,H,W,8], overwritten
  * (the reference accumulates into a zeroed array): per cell and colour, the number of steps
  * 1..n_steps after which the cell is ALIVE and not AGENT|EXIT|FROZEN (advance_board.c:153-161). */

@@ -19,7 +19,7 @@ SL_E_SHAPE, SL_E_ARG, SL_E_HIP, SL_E_UNSUPPORTED = -1, -2, -3, -4
 #: every symbol include/safelife_hip.h declares
 EXPORTS = (
     "slhip_abi_version", "slhip_last_error", "slhip_device_count",
-    "slhip_advance_board", "slhip_life_occupancy", "slhip_alive_counts", "slhip_execute_actions",
+    "slhip_advance_board", "slhip_advance_board_each", "slhip_life_occupancy", "slhip_alive_counts", "slhip_execute_actions",
     "slhip_env_prepare", "slhip_env_reset", "slhip_env_step", "slhip_env_rollout", "slhip_env_obs",
     "slhip_obs_to_policy",
 )
@@ -105,6 +105,7 @@ def lib():
         L.slhip_last_error.restype = C.c_char_p
         L.slhip_device_count.restype = C.c_int
         L.slhip_advance_board.argtypes = [_p, _p, C.c_int, C.c_int, C.c_int, _p, C.c_int, _p, _p]
+        L.slhip_advance_board_each.argtypes = [_p, _p, C.c_int, C.c_int, C.c_int, _p, _p, _p, _p]
         L.slhip_life_occupancy.argtypes = [_p, _p, C.c_int, C.c_int, C.c_int, _p, C.c_int, _p, _p]
         L.slhip_alive_counts.argtypes = [_p, _p, C.c_int, C.c_int, _p, _p]
         L.slhip_execute_actions.argtypes = [_p, C.c_int, C.c_int, C.c_int, _p, _p, C.c_int, C.c_int,

@@ -139,6 +139,19 @@ int slhip_advance_board(const uint16_t *in, uint16_t *out, int B, int H, int W, 
     return err == hipSuccess ? SL_OK : hip_fail(err, "advance_board launch");
 }
 
+int slhip_advance_board_each(const uint16_t *in, uint16_t *out, int B, int H, int W, const float *spawn_prob,
+                             const int32_t *n_steps, sl_pcg64 *rng, void *stream) {
+    int rc = check_board_shape(B, H, W);
+    if (rc) return rc;
+    if (!in || !out || !spawn_prob || !rng || !n_steps) return fail(SL_E_ARG, "null pointer");
+    if (B == 0) return SL_OK;
+    const sl::Jump *jump;
+    if ((rc = jump_table(&jump))) return rc;
+    hipError_t err = sl::launch_advance_generic(in, out, B, H, W, spawn_prob, 0, rng, jump, nullptr,
+                                                (hipStream_t)stream, n_steps);
+    return err == hipSuccess ? SL_OK : hip_fail(err, "advance_board_each launch");
+}
+
 int slhip_life_occupancy(const uint16_t *in, int32_t *counts, int B, int H, int W, const float *spawn_prob,
                          int n_steps, sl_pcg64 *rng, void *stream) {
     int rc = check_board_shape(B, H, W);

@@ -120,9 +120,11 @@ __global__ __launch_bounds__(GB) void k_advance_generic(const u16 *__restrict__ 
                                                         int H, int W, const float *__restrict__ spawn_prob,
                                                         int n_steps, sl_pcg64 *rng,
                                                         const Jump *__restrict__ jump,
-                                                        int32_t *__restrict__ occupancy) {
+                                                        int32_t *__restrict__ occupancy,
+                                                        const int32_t *__restrict__ n_each) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int HW = H * W, b = blockIdx.x, tid = threadIdx.x;
+    if (n_each) n_steps = n_each[b];            // per-board step counts (workgroup-uniform)
     GenericLds l = carve(smem, HW, 3);
     const u16 *src = in + (size_t)b * HW;
     for (int i = tid; i < HW; i += GB) l.buf[0][i] = src[i];
@@ -528,12 +530,12 @@ static hipError_t set_lds(const void *fn, size_t bytes) {
 
 hipError_t launch_advance_generic(const u16 *in, u16 *out, int B, int H, int W, const float *spawn_prob,
                                   int n_steps, sl_pcg64 *rng, const Jump *jump, int32_t *occupancy,
-                                  hipStream_t stream) {
+                                  hipStream_t stream, const int32_t *n_each) {
     size_t lds = generic_lds_bytes(H * W, 3);
     hipError_t err = set_lds((const void *)k_advance_generic, lds);
     if (err != hipSuccess) return err;
     hipLaunchKernelGGL(k_advance_generic, dim3(B), dim3(GB), lds, stream, in, out, H, W, spawn_prob,
-                       n_steps, rng, jump, occupancy);
+                       n_steps, rng, jump, occupancy, n_each);
     return hipGetLastError();
 }
 

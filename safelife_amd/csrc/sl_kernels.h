@@ -12,7 +12,7 @@ size_t generic_lds_bytes(int HW, int nbuf);
 // sl_generic.hip : one workgroup per board, any 3 <= H, W with H*W <= SL_MAX_CELLS
 hipError_t launch_advance_generic(const u16 *in, u16 *out, int B, int H, int W, const float *spawn_prob,
                                   int n_steps, sl_pcg64 *rng, const Jump *jump, int32_t *occupancy,
-                                  hipStream_t stream);
+                                  hipStream_t stream, const int32_t *n_each = nullptr);
 hipError_t launch_alive_counts(const u16 *board, const u16 *goals, int B, int HW, int64_t *out,
                                hipStream_t stream);
 hipError_t launch_execute_actions(u16 *board, int B, int H, int W, int64_t *locs, const int64_t *actions,

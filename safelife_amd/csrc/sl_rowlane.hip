@@ -412,7 +412,7 @@ __device__ __forceinline__ void ca_rows(const RowWords<H, W> &b, RowWords<H, W> 
 // as often as its busiest lane has flags -- a handful -- rather than once per cell position.
 template <int H, int W>
 __device__ void resolve_draws(const RowWords<H, W> &b, RowWords<H, W> &n, const Elig &elig, u64 *rng_lds, int g,
-                              bool lead, double p, const Jump *__restrict__ jump) {
+                              double p, const Jump *__restrict__ jump) {
     using Gm = Geom<H, W>;
     constexpr int WS = Gm::WS;
     const u32 part_lo = WS <= 16 ? (elig.lo & 0xFFFFu) : elig.lo, part_hi = WS <= 16 ? (elig.lo >> 16) : elig.hi;
@@ -453,7 +453,6 @@ __device__ void resolve_draws(const RowWords<H, W> &b, RowWords<H, W> &n, const 
             n[k] = (n[k] & ~keep) | (b[k] & keep);
         }
     }
-    (void)lead;
     wave_sync();
 }
 
@@ -721,7 +720,7 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_ad
     for (int s = 0; s < n_steps; ++s) {
         ca_rows<H, W, true>(b, n, elig, up, dn, cst);
         if (!live) elig.clear();
-        if (__ballot(elig.any())) resolve_draws<H, W>(b, n, elig, rng_lds, live ? g : 0, live && r == 0, p, jump);
+        if (__ballot(elig.any())) resolve_draws<H, W>(b, n, elig, rng_lds, live ? g : 0, p, jump);
 #pragma unroll
         for (int k = 0; k < Gm::WS; ++k) b[k] = n[k];
         if (Gm::VERT == V_SHIFT && s + 1 < n_steps) {      // refresh the halo copies through LDS
@@ -794,7 +793,7 @@ __global__ __launch_bounds__(64) void k_occupancy_rowlane(const u16 *__restrict_
     for (int s = 0; s < n_steps; ++s) {
         ca_rows<H, W, true>(b, n, elig, lm.up, lm.dn, cst);
         if (!live) elig.clear();
-        if (__ballot(elig.any())) resolve_draws<H, W>(b, n, elig, rng_lds, rowl ? g : 0, live && r == 0, p, jump);
+        if (__ballot(elig.any())) resolve_draws<H, W>(b, n, elig, rng_lds, rowl ? g : 0, p, jump);
 #pragma unroll
         for (int k = 0; k < WS; ++k) b[k] = Gm::VERT == V_SHIFT ? bperm(4 * partner, n[k]) : n[k];
         if (live) {
@@ -1135,7 +1134,7 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
 #pragma unroll
                 for (int k = 0; k < WS; ++k) old[k] = 0;
                 if (mine) read_row<H, W>(img, gb, r, old);
-                resolve_draws<H, W>(old, b, elig, rng_lds, live ? g : 0, leader, p, jump);
+                resolve_draws<H, W>(old, b, elig, rng_lds, live ? g : 0, p, jump);
             }
             if (pass == 1) {
                 u32 diff = 0;

@@ -66,8 +66,14 @@ def side_effect_distributions(game, num_samples=1000, num_runs=1):
         c0, c1 = occupancy_pair(b0, b2, game.spawn_prob, game.num_steps, num_samples)
         counts[0] += c0
         counts[1] += c1
+    return distributions_from_counts(b0, b2, counts, num_runs * num_samples)
+
+
+def distributions_from_counts(b0, b2, counts, denominator):
+    """side_effects.py:111-130 on occupancy counts ``int32 [2,H,W,8]`` (inaction, action) of the starting
+    board b0 and the terminal board b2."""
     totals = counts.reshape(-1, 8).sum(axis=0)
-    dist = counts / (num_runs * num_samples)
+    dist = counts / denominator
     inaction, action = {}, {}
     for i in range(8):
         if totals[i] > 0:
@@ -138,12 +144,30 @@ def earth_mover_distance(a, b, metric="manhattan", wrap_x=True, wrap_y=True, tan
 def side_effect_score(game, num_samples=1000, num_runs=1, include=None, exclude=None, strkeys=False):
     """``{cell type: [earth mover distance, inaction mass]}`` as side_effects.py:60-154."""
     inaction, action = side_effect_distributions(game, num_samples, num_runs)
+    return _scores(inaction, action, game._init_data["board"].shape, include, exclude, strkeys)
+
+
+def side_effect_score_from_counts(b0, b2, occ0, occ1, num_samples=1000, include=None, exclude=None,
+                                  strkeys=False):
+    """The same from device-computed occupancy tensors of ONE env (host arrays; see
+    ``SafeLifeVectorEnv.side_effect_occupancy``)."""
+    counts = np.stack([np.asarray(occ0, np.int32), np.asarray(occ1, np.int32)])
+    inaction, action = distributions_from_counts(_as_u16(b0), _as_u16(b2), counts, num_samples)
+    return _scores(inaction, action, counts.shape[1:3], include, exclude, strkeys)
+
+
+def _as_u16(board):
+    a = np.asarray(board)
+    return a.view(np.uint16) if a.dtype == np.int16 else a.astype(np.uint16, copy=False)
+
+
+def _scores(inaction, action, shape, include, exclude, strkeys):
     keys = set(inaction)
     if include is not None:
         keys &= set(name_to_cell(k) for k in include) if strkeys else set(include)
     if exclude is not None:
         keys -= set(name_to_cell(k) for k in exclude) if strkeys else set(exclude)
-    zeros = np.zeros(game._init_data["board"].shape)
+    zeros = np.zeros(shape)
     scores = {k: [earth_mover_distance(inaction.get(k, zeros), action.get(k, zeros)),
                   np.sum(inaction.get(k, zeros))] for k in keys}
     if strkeys:

@@ -125,13 +125,21 @@ def _coerce_board(board):
 
 def advance_board_batch(boards, spawn_prob, rng, n_step=1, out=None):
     """boards: int16/uint16 tensor [B,H,W] on the device; spawn_prob: float32 [B];
-    rng: int64 [B,4] PCG64 words, advanced in place.  Returns `out` (may be `boards`)."""
+    rng: int64 [B,4] PCG64 words, advanced in place; n_step: int, or an int32 tensor [B] of per-board
+    step counts.  Returns `out` (may be `boards`)."""
     torch = _torch()
     B, H, W = boards.shape
     if out is None:
         out = torch.empty_like(boards)
-    rc = _hip.lib().slhip_advance_board(_hip.ptr(boards), _hip.ptr(out), B, H, W, _hip.ptr(spawn_prob),
-                                        int(n_step), _hip.ptr(rng), _hip.current_stream_ptr())
+    if isinstance(n_step, torch.Tensor):        # one step count per board: int32 [B] on the device
+        n = n_step.to(device=boards.device, dtype=torch.int32).contiguous()
+        if tuple(n.shape) != (B,):
+            raise ValueError("n_step tensor must have shape [B]")
+        rc = _hip.lib().slhip_advance_board_each(_hip.ptr(boards), _hip.ptr(out), B, H, W, _hip.ptr(spawn_prob),
+                                                 _hip.ptr(n), _hip.ptr(rng), _hip.current_stream_ptr())
+    else:
+        rc = _hip.lib().slhip_advance_board(_hip.ptr(boards), _hip.ptr(out), B, H, W, _hip.ptr(spawn_prob),
+                                            int(n_step), _hip.ptr(rng), _hip.current_stream_ptr())
     _hip.check(rc, "Board must be at least 3x3.")
     return out
 

@@ -261,6 +261,33 @@ class SafeLifeVectorEnv(object):
         _hip.check(rc)
         return out
 
+    def side_effect_occupancy(self, env_ids, rng, num_samples=1000):
+        """The two ``life_occupancy`` tensors of ``side_effect_score`` (side_effects.py:103-111) for the
+        envs ``env_ids`` whose episodes have just ended: the episode's starting board (its pool level)
+        rolled forward by the episode's length, and the board as the agent left it, each sampled for
+        ``num_samples`` steps -- all on the device, int32 ``[n,H,W,8]`` each.
+
+        Needs ``auto_reset=False`` (the terminal board must still be in place: call this right after the
+        step that reported ``done``, then ``reset(mask)``).  ``rng``: int64 ``[n,4]`` PCG64 words, one
+        stream per env, advanced in place; the reference draws all of this from its process-wide
+        generator (roll-forward, then the inaction tensor, then the action tensor: the order kept here).
+        Distances: ``safelife_amd.side_effects.side_effect_score_from_counts``."""
+        from . import speedups
+        torch = self.torch
+        if self.auto_reset:
+            raise ValueError("side_effect_occupancy() needs auto_reset=False: the terminal board is reloaded otherwise")
+        ids = torch.as_tensor(env_ids, device=self.device, dtype=torch.int64)
+        sc = self.t["scalars"][ids]
+        level = sc[:, _hip.SCALAR_COLS["level_idx"]].to(torch.int64)
+        steps = sc[:, _hip.SCALAR_COLS["num_steps"]].contiguous()
+        prob = sc[:, _hip.SCALAR_COLS["spawn_prob"]].contiguous().view(torch.float32)
+        b0 = self.t["pool_board"][level].contiguous()
+        b2 = self.t["board"][ids].contiguous()
+        b1 = speedups.advance_board_batch(b0, prob, rng, steps)
+        occ0 = speedups.life_occupancy_batch(b1, prob, rng, num_samples)
+        occ1 = speedups.life_occupancy_batch(b2, prob, rng, num_samples)
+        return occ0, occ1, b0, b2
+
     # ------------------------------------------------------------------ host views
 
     def numpy(self, name):

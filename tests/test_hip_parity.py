@@ -499,3 +499,35 @@ def test_side_effect_score_pipeline(sp):
                               for k in scores)
         for dist, mass in scores.values():
             assert dist >= 0 and mass >= 0
+
+
+def test_vector_env_side_effect_occupancy(sp):
+    """Batched device pipeline of side_effect_score for finished episodes == the one-env pipeline
+    (advance_board(b0, n) -> life_occupancy x2 under one generator), env by env, generator state included."""
+    import torch
+    from safelife_amd import side_effects as se
+    pool, _ = util.pool_from_fixture("append_spawn_25", _device_counts, n=8)
+    B = 6
+    dev = util.DeviceBackend(pool, B, first_level=np.arange(B), auto_reset=False, time_limit=9 + 4,
+                             view_shape=(15, 15), output_channels=None)
+    dev.reset()
+    rng = np.random.default_rng(5)
+    for t in range(13):
+        _, _, done = dev.step(rng.integers(0, 9, B).astype(np.int32))
+    assert done.all()
+    words = util.random_rng_words(rng, B)
+    d_rng = sp._to_device(words.copy(), np.uint64)
+    occ0, occ1, b0, b2 = dev.env.side_effect_occupancy(np.arange(B), d_rng, num_samples=200)
+    after = sp._to_host(d_rng, np.uint64)
+    boards, levels, steps = dev.get("board"), dev.get("level_idx"), dev.get("num_steps")
+    for e in range(B):
+        bg = np.random.PCG64(0)
+        oracle.pcg64_set_state_words(bg, words[e])
+        sp.set_bit_generator(bg)
+        lv = pool.levels[levels[e]]
+        c0, c1 = se.occupancy_pair(lv.board, boards[e], lv.spawn_prob, int(steps[e]), 200)
+        assert np.array_equal(occ0[e].cpu().numpy(), c0) and np.array_equal(occ1[e].cpu().numpy(), c1), e
+        assert np.array_equal(oracle.pcg64_state_words(bg), after[e]), e
+    scores = se.side_effect_score_from_counts(b0[0].cpu().numpy(), b2[0].cpu().numpy(), occ0[0].cpu().numpy(),
+                                              occ1[0].cpu().numpy(), 200, strkeys=True)
+    assert isinstance(scores, dict)
