@@ -47,6 +47,35 @@ def load_pool(name, counts_fn, n=None):
     return LevelPool(levels, counts_fn=counts_fn)
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def parity_sample(pool, actions, n_envs, device_env):
+    """Checker use of the oracle inside the cpu_baseline leg: replay the first `n_envs` envs of the
+    measured run (same levels, same action stream, every step since reset) on the CPU and compare
+    boards, agent locations, generator states and episode counters with the device's final state."""
+    import oracle
+    from safelife_amd.levels import empty_env_arrays
+    arrays = empty_env_arrays(pool, n_envs)
+    arrays["level_idx"][:] = np.arange(n_envs) % len(pool)
+    env = oracle.OracleEnv(arrays, time_limit=1000, auto_reset=True, level_stride=1, view_shape=(25, 25),
+                           output_channels=TRAIN_CHANNELS, with_obs=False)
+    env.reset()
+    for a in actions:
+        env.step(np.ascontiguousarray(a[:n_envs]), n_threads=4)
+    ok = True
+    for name in ("board", "goals", "agent_loc", "rng", "num_steps", "episode_idx", "episode_length", "level_idx"):
+        ok = ok and bool(np.array_equal(device_env.numpy(name)[:n_envs], arrays[name]))
+    return {"envs": n_envs, "steps": len(actions), "bit_exact": ok}
+
+
 def cpu_baseline(pool, envs, steps, seed):
     """Oracle (CPU checker) timed on the same workload; bounded sample."""
     import oracle
@@ -82,8 +111,8 @@ def cpu_baseline(pool, envs, steps, seed):
     return {
         "value": envs * (steps - 1) / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
         "sample": "%d envs x %d steps of the same 25x25 prune-still workload (oracle/sl_oracle.c, OpenMP "
-                  "over envs, no observation); single thread: %.3g env-steps/s" % (
-                      envs, steps - 1, envs * n1 / dt1),
+                  "over envs, no observation) on %s; single thread: %.3g env-steps/s" % (
+                      envs, steps - 1, cpu_model(), envs * n1 / dt1),
     }
 
 
@@ -162,6 +191,11 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    parity = None
+    if args.cpu_baseline and world == 1:
+        # the state the timed launches left behind against a CPU replay of the same envs and actions
+        parity = parity_sample(pool, actions[:W + K].cpu().numpy(), min(B, 64), env)
+
     extra = {}
     if args.rollout > 0:
         T = args.rollout
@@ -213,6 +247,28 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) / n * 1e3
+
+        # C2 (BASELINE configs[1]): advance_board alone on 1024 random 25x25 boards (SURVEY 8d palette-like)
+        from safelife_amd import speedups
+        c2 = np.random.default_rng(1234)
+        pal = np.array([0] * 10 + [9] * 4 + [1, 16, 17, 32788, 152, 152 | 0x200, 144, 48, 53, 85, 32884, 272, 9 | 0x200,
+                                      9 | 0x400, 9 | 0x800, 122], np.uint16)
+        c2_boards = torch.from_numpy(pal[c2.integers(0, len(pal), (1024, 25, 25))].view(np.int16)).to(dev)
+        c2_prob = torch.full((1024,), 0.3, dtype=torch.float32, device=dev)
+        c2_rng = torch.arange(4096, dtype=torch.int64, device=dev).reshape(1024, 4) * 2 + 1
+        c2_out = torch.empty_like(c2_boards)
+        for _ in range(10):
+            speedups.advance_board_batch(c2_boards, c2_prob, c2_rng, 1, out=c2_out)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(200):
+            speedups.advance_board_batch(c2_boards, c2_prob, c2_rng, 1, out=c2_out)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 200 * 1e3
+        extra["c2_advance_board_1024x25x25_us_per_launch"] = us
+        extra["c2_advance_board_board_steps_per_s"] = 1024 / (us * 1e-6)
 
         # the same step with the training wrappers of env_factory.py:277-283 fused in (float64 shaped reward)
         us = time_steps(SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25), output_channels=TRAIN_CHANNELS,
@@ -287,6 +343,7 @@ def main():
             def cpu_counts(b, g):
                 return oracle.alive_counts_batch(b, g)
             out["cpu_baseline"] = cpu_baseline(load_pool(args.pool, cpu_counts), B, args.cpu_steps, 7)
+            out["cpu_baseline"]["parity_check"] = parity
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()
