@@ -1,26 +1,31 @@
 // sl_rowlane.hip -- the fast gfx950 path: one board ROW per lane, two cells per 32-bit register.
 //
-// Mapping (template on the board shape H x W, H <= 64):
-//   * a 256-thread workgroup owns NB = 4*G consecutive boards (G = floor(64/H) per wavefront); lane
-//     l = g*H + r of a wave holds row r of its board g entirely in VGPRs as WP = (W+3)/2 words of two
-//     uint16 cells each, with one halo cell on either side ("ext" index e = x+1; word k holds
-//     e = 2k in its low half and e = 2k+1 in its high half);
-//   * HBM <-> LDS: the workgroup's boards are one contiguous, 16-byte aligned span that is moved with
-//     lane-linear 16-byte vectors (fully coalesced); LDS <-> registers converts between that flat
-//     image and the row-per-lane layout (funnel shifts absorb odd row starts);
-//   * the 3x3 neighbourhood reduction is the commutative merge of sl_device.h in SWAR form:
-//     horizontal neighbours are funnel shifts of adjacent registers, vertical neighbours come from
-//     the lanes above/below through ds_bpermute (wrap inside the board's lane group);
-//   * random draws (spawners) are rare: eligible cells are flagged in the fast pass and resolved in
-//     a wave-uniform slow path with a segmented prefix count + PCG64 jump, preserving the
-//     reference's row-major draw order (advance_board.c:115);
-//   * the score sum(points_table * alive_counts) is a per-cell gather from a 2048-entry table
-//     indexed by the cell's relevant bits and the goal colour (slhip_env_prepare builds it);
+// Mapping (template on the board shape H x W, H, W <= 64; see struct Geom / LaneMap):
+//   * a 256-thread workgroup owns NB = 4*G consecutive boards, each wavefront G of them; a lane holds
+//     one row of one board entirely in VGPRs as WS = ceil(W/2) words in the "split halves" layout:
+//     word k = (cell k, cell k+WS), so the horizontal neighbours of both cells of a word are the two
+//     cells of the adjacent word and only the row seam needs byte permutes;
+//   * vertical neighbours: a DPP wave shift when the board can afford two halo lanes (25, 26 rows), a
+//     DPP wave rotate for 64 rows, ds_bpermute otherwise;
+//   * HBM -> LDS: the workgroup's boards are one contiguous, 16-byte aligned span moved by the
+//     global_load_lds DMA (no VGPR staging); LDS -> HBM by lane-linear 16-byte stores.  The flat LDS
+//     image is what the agent's action, the exit repaint, the on-device reset and the observation
+//     epilogue work on; rows wider than 32 cells are stored bank-swizzled (Geom::cell);
+//   * the 3x3 neighbourhood reduction is the commutative merge of sl_device.h in SWAR form: OR ("seen
+//     once"), majority ("seen twice") and integer add (alive count) on whole registers, bitop3 for every
+//     three-input function;
+//   * random draws (spawners) are rare: eligible cells are flagged in the fast pass and resolved in a
+//     wave-uniform slow path (DPP prefix count per board, PCG64 jump to the lane's first draw, the lane
+//     then steps through its own flagged cells), preserving the reference's row-major draw order
+//     (advance_board.c:115); kernels for spawner-free batches drop all of it;
+//   * the score sum(points_table * alive_counts) is a per-cell byte gather from a table indexed by the
+//     cell's relevant bits and the goal colour (slhip_env_prepare builds it);
+//   * the training wrappers of env_wrappers.py run in the WRAP variants (leader lane, float64);
 //   * the only workgroup barriers are the two around the HBM <-> LDS moves.
 //
-// Reference behaviour restated: advance_board.c:34-125 (CA step), :217-300 (actions),
-// safelife_env.py:148-218 + safelife_game.py:505-552,684-719,746-761 (step / reset glue),
-// safelife_env.py:105-146 + helper_utils.py:42-75 (observation).
+// Reference behaviour restated: advance_board.c:34-125 (CA step), :153-189 (occupancy), :217-300
+// (actions), safelife_env.py:148-218 + safelife_game.py:505-552,684-719,746-761 (step / reset glue),
+// safelife_env.py:105-146 + helper_utils.py:42-75 (observation), env_wrappers.py:32-213 (wrappers).
 #include "sl_device.h"
 #include "sl_kernels.h"
 
