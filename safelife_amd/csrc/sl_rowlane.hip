@@ -1092,6 +1092,8 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
     double p = (double)rec.spawn_prob;
     u32 lut_base = (u32)rec.table_idx * (u32)SCORE_LUT_BYTES;
     int open0 = rec.exit_open_at_reset;                 // exit paint of the side-effect baseline
+    volatile int *dirty_flag = (volatile int *)(smem + Gm::OFF_GOALS);     // in the region's leading pad
+    if (tid == 0) *dirty_flag = 0;
     SL_STAMP(1);
     __syncthreads();
     SL_STAMP(2);
@@ -1314,7 +1316,11 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
         asm volatile("" : "+v"(e2));          // a 64-bit pointer alive (and spilled) across the kernel
         env.scalars[e2] = rec;
     }
-    const int dirty = __syncthreads_or(goals_dirty);
+    // one barrier (the library's __syncthreads_or costs three): any wave that changed its goals raises the
+    // flag, which was cleared before the load barrier
+    if (goals_dirty) *dirty_flag = 1;
+    __syncthreads();
+    const int dirty = *dirty_flag;
     SL_STAMP(8);
     store_span<H, W>(env.board + (size_t)e0b * HW, board, nbb, tid);
     if (dirty) store_span<H, W>(env.goals + (size_t)e0b * HW, goals, nbb, tid);
