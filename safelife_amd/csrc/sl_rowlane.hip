@@ -1016,17 +1016,20 @@ __device__ __forceinline__ void write_obs_block(const sl_env_batch &env, const u
 // ---- fused env step / rollout ---------------------------------------------------------------------
 
 template <int H, int W, bool LDS_LUT, bool SPAWN, bool WRAP>
-__global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_env_rollout_rowlane(sl_env_batch env,
-                                                                       const int32_t *__restrict__ actions, int T,
-                                                                       float *__restrict__ reward_t,
-                                                                       uint8_t *__restrict__ done_t,
-                                                                       const Jump *__restrict__ jump) {
+__global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_env_rollout_rowlane(
+    // the eight arguments the prologue needs before anything else come first: with
+    // -amdgpu-kernarg-preload-count=8 they arrive in SGPRs with the wave instead of behind an s_load
+    const u16 *__restrict__ hot_board, const u16 *__restrict__ hot_goals, const sl_pcg64 *__restrict__ hot_rng,
+    sl_env_scalars *__restrict__ hot_scalars, const int8_t *__restrict__ hot_lut,
+    const int32_t *__restrict__ actions, int hot_B, int hot_E,
+    sl_env_batch env, int T, float *__restrict__ reward_t, uint8_t *__restrict__ done_t,
+    const Jump *__restrict__ jump) {
     using Gm = Geom<H, W>;
     constexpr int WS = Gm::WS, HW = Gm::HW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned B = env.B;
-    const int E = env.E;
+    const unsigned B = hot_B;
+    const int E = hot_E;
     const int e0b = blockIdx.x * Gm::NB;
     const int nbb = min(Gm::NB, (int)B - e0b);
     const LaneMap<H, W> lm(lane);
@@ -1061,10 +1064,10 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
     //  * the per-board record is loaded by EVERY lane, unconditionally (a load inside `if (leader)`
     //    is waited for at the end of that block, in front of the DMA issue).  Only the leader lane's
     //    copy of the per-episode fields is ever used or updated.
-    const u16 *k_board = env.board, *k_goals = env.goals;
-    const sl_pcg64 *k_rng = env.rng;
-    const int8_t *k_lut = env.score_lut;
-    sl_env_scalars *const sc = env.scalars + e;
+    const u16 *k_board = hot_board, *k_goals = hot_goals;
+    const sl_pcg64 *k_rng = hot_rng;
+    const int8_t *k_lut = hot_lut;
+    sl_env_scalars *const sc = hot_scalars + e;
     const int32_t *exits = env.exit_locs + (size_t)e * E;
     const int32_t *k_act = actions + e;
     asm volatile("" ::"s"(k_board), "s"(k_goals), "s"(k_rng), "s"(k_lut));
@@ -1454,7 +1457,8 @@ static hipError_t launch_rollout_t(const sl_env_batch &env, const int32_t *actio
                                    uint8_t *done_t, const Jump *jump, hipStream_t stream) {
     using Gm = Geom<H, W>;
     const int variant = (env.n_tables == 1 ? 1 : 0) | (env.spawner_free ? 2 : 0) | (env.wrap.flags ? 4 : 0);
-    typedef void (*kernel_t)(sl_env_batch, const int32_t *, int, float *, uint8_t *, const Jump *);
+    typedef void (*kernel_t)(const u16 *, const u16 *, const sl_pcg64 *, sl_env_scalars *, const int8_t *,
+                             const int32_t *, int, int, sl_env_batch, int, float *, uint8_t *, const Jump *);
     static const kernel_t table[8] = {
         k_env_rollout_rowlane<H, W, false, true, false>, k_env_rollout_rowlane<H, W, true, true, false>,
         k_env_rollout_rowlane<H, W, false, false, false>, k_env_rollout_rowlane<H, W, true, false, false>,
@@ -1469,8 +1473,8 @@ static hipError_t launch_rollout_t(const sl_env_batch &env, const int32_t *actio
         if (err != hipSuccess) return err;
         configured[variant] = true;
     }
-    hipLaunchKernelGGL(fn, dim3((env.B + Gm::NB - 1) / Gm::NB), dim3(64 * WAVES), lds, stream, env, actions, T,
-                       reward_t, done_t, jump);
+    hipLaunchKernelGGL(fn, dim3((env.B + Gm::NB - 1) / Gm::NB), dim3(64 * WAVES), lds, stream, env.board, env.goals,
+                       env.rng, env.scalars, env.score_lut, actions, env.B, env.E, env, T, reward_t, done_t, jump);
     return hipGetLastError();
 }
 
