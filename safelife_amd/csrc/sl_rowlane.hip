@@ -1095,7 +1095,8 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
     double p = (double)rec.spawn_prob;
     u32 lut_base = (u32)rec.table_idx * (u32)SCORE_LUT_BYTES;
     int open0 = rec.exit_open_at_reset;                 // exit paint of the side-effect baseline
-    volatile int *dirty_flag = (volatile int *)(smem + Gm::OFF_GOALS);     // in the region's leading pad
+    typedef __attribute__((address_space(3))) int *lds_int;       // (a generic volatile pointer would go through FLAT)
+    lds_int dirty_flag = (lds_int)(smem + Gm::OFF_GOALS);              // in the region's leading pad
     if (tid == 0) *dirty_flag = 0;
     SL_STAMP(1);
     __syncthreads();
