@@ -1073,7 +1073,6 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
     asm volatile("" ::"s"(k_board), "s"(k_goals), "s"(k_rng), "s"(k_lut));
     const sl_env_scalars rec = *sc;     // one 64-byte record (same address within a board: broadcast)
     int action = *k_act;
-    int exit0 = exits[0];
     // everything bulky goes through the LDS DMA
     dma_to_lds<Gm::NB * 32>((const unsigned char *)(k_rng + e0b), smem + Gm::OFF_RNG, nbb * 32, lane, wave);
     if (LDS_LUT) dma_to_lds<4096>((const unsigned char *)k_lut, smem + Gm::OFF_LUT, 4096, lane, wave);
@@ -1087,6 +1086,7 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
             dma_to_lds<Gm::MVT_N * 8>((const unsigned char *)env.wrap.move_table, smem + Gm::OFF_MVT,
                                       min(env.wrap.move_table_len & ~1, Gm::MVT_N) * 8, lane, wave);
     }
+    int exit0 = exits[0];       // (its pointer is not among the preloaded arguments: after the DMA issue)
     int ly = rec.agent_row, lx = rec.agent_col, steps = rec.num_steps, old_value = rec.old_value;
     int required = rec.required_points, initial = rec.initial_points, ep_len = rec.episode_length;
     int gstatic = rec.goals_static, level = rec.level_idx, episodes = rec.episode_idx;
