@@ -1095,6 +1095,15 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
     double p = (double)rec.spawn_prob;
     u32 lut_base = (u32)rec.table_idx * (u32)SCORE_LUT_BYTES;
     int open0 = rec.exit_open_at_reset;                 // exit paint of the side-effect baseline
+    // the step loop's invariant arguments: fetched in one batch here, in the shadow of the bulk loads
+    // (left alone the compiler fetches them in four dependent groups right after the barrier)
+    {
+        const int a0 = env.time_limit, a1 = env.exit_points, a2 = env.auto_reset, a3 = env.L, a4 = env.level_stride;
+        const void *p0 = env.out, *p1 = env.pool_board, *p2 = env.pool_goals, *p3 = env.pool_exit_locs;
+        const void *p4 = env.pool_rng, *p5 = env.pool_scalars, *p6 = env.exit_locs;
+        asm volatile("" ::"s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(T), "s"(p0), "s"(p1), "s"(p2), "s"(p3),
+                     "s"(p4), "s"(p5), "s"(p6), "s"(reward_t), "s"(done_t));
+    }
     typedef __attribute__((address_space(3))) int *lds_int;       // (a generic volatile pointer would go through FLAT)
     lds_int dirty_flag = (lds_int)(smem + Gm::OFF_GOALS);              // in the region's leading pad
     if (tid == 0) *dirty_flag = 0;
