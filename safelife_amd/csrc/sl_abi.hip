@@ -225,7 +225,8 @@ int slhip_env_rollout(const sl_env_batch *env, const int32_t *actions, int T, fl
     if (env->B == 0 || T == 0) return SL_OK;
     const sl::Jump *jump;
     if ((rc = jump_table(&jump))) return rc;
-    const bool aligned = (((uintptr_t)env->board | (uintptr_t)env->goals) & 15) == 0;
+    const bool aligned = (((uintptr_t)env->board | (uintptr_t)env->goals | (uintptr_t)env->rng |
+                           (uintptr_t)env->score_lut) & 15) == 0;       // sources of the 16-byte LDS DMA
     // the row kernels take the wrapper math when its workspace is there (side-effect baseline)
     const bool wrap_ok =
         !env->wrap.flags ||
