@@ -125,9 +125,9 @@ int slhip_advance_board(const uint16_t *in, uint16_t *out, int B, int H, int W, 
                         int n_steps, sl_pcg64 *rng, void *stream) {
     int rc = check_board_shape(B, H, W);
     if (rc) return rc;
-    if (!in || !out || !spawn_prob || !rng) return fail(SL_E_ARG, "null pointer");
     if (n_steps < 0) return fail(SL_E_ARG, "negative n_steps");
-    if (B == 0) return SL_OK;
+    if (B == 0) return SL_OK;            // (an empty tensor has no storage: checked before the pointers)
+    if (!in || !out || !spawn_prob || !rng) return fail(SL_E_ARG, "null pointer");
     const sl::Jump *jump;
     if ((rc = jump_table(&jump))) return rc;
     const bool aligned = (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
@@ -143,8 +143,8 @@ int slhip_advance_board_each(const uint16_t *in, uint16_t *out, int B, int H, in
                              const int32_t *n_steps, sl_pcg64 *rng, void *stream) {
     int rc = check_board_shape(B, H, W);
     if (rc) return rc;
-    if (!in || !out || !spawn_prob || !rng || !n_steps) return fail(SL_E_ARG, "null pointer");
     if (B == 0) return SL_OK;
+    if (!in || !out || !spawn_prob || !rng || !n_steps) return fail(SL_E_ARG, "null pointer");
     const sl::Jump *jump;
     if ((rc = jump_table(&jump))) return rc;
     hipError_t err = sl::launch_advance_generic(in, out, B, H, W, spawn_prob, 0, rng, jump, nullptr,
@@ -156,9 +156,9 @@ int slhip_life_occupancy(const uint16_t *in, int32_t *counts, int B, int H, int 
                          int n_steps, sl_pcg64 *rng, void *stream) {
     int rc = check_board_shape(B, H, W);
     if (rc) return rc;
-    if (!in || !counts || !spawn_prob || !rng) return fail(SL_E_ARG, "null pointer");
     if (n_steps < 0) return fail(SL_E_ARG, "negative n_steps");
     if (B == 0) return SL_OK;
+    if (!in || !counts || !spawn_prob || !rng) return fail(SL_E_ARG, "null pointer");
     const sl::Jump *jump;
     if ((rc = jump_table(&jump))) return rc;
     // 16-bit per-colour counters in LDS: the row kernel covers every step count the reference is called with
@@ -173,8 +173,8 @@ int slhip_life_occupancy(const uint16_t *in, int32_t *counts, int B, int H, int 
 int slhip_alive_counts(const uint16_t *board, const uint16_t *goals, int B, int HW, int64_t *out,
                        void *stream) {
     if (B < 0 || HW < 0) return fail(SL_E_ARG, "negative size");
-    if (!board || !goals || !out) return fail(SL_E_ARG, "null pointer");
     if (B == 0) return SL_OK;
+    if (!board || !goals || !out) return fail(SL_E_ARG, "null pointer");
     hipError_t err = sl::launch_alive_counts(board, goals, B, HW, out, (hipStream_t)stream);
     return err == hipSuccess ? SL_OK : hip_fail(err, "alive_counts launch");
 }
@@ -184,8 +184,8 @@ int slhip_execute_actions(uint16_t *board, int B, int H, int W, int64_t *locs, c
     int rc = check_board_shape(B, H, W);
     if (rc) return rc;
     if (A < 0) return fail(SL_E_ARG, "negative agent count");
-    if (!board || (A > 0 && (!locs || !actions))) return fail(SL_E_ARG, "null pointer");
     if (B == 0 || A == 0) return SL_OK;
+    if (!board || !locs || !actions) return fail(SL_E_ARG, "null pointer");
     hipError_t err = sl::launch_execute_actions(board, B, H, W, locs, actions, A, action_stride,
                                                 action_batch_stride, (hipStream_t)stream);
     return err == hipSuccess ? SL_OK : hip_fail(err, "execute_actions launch");

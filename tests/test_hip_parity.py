@@ -531,3 +531,75 @@ def test_vector_env_side_effect_occupancy(sp):
     scores = se.side_effect_score_from_counts(b0[0].cpu().numpy(), b2[0].cpu().numpy(), occ0[0].cpu().numpy(),
                                               occ1[0].cpu().numpy(), 200, strkeys=True)
     assert isinstance(scores, dict)
+
+
+# ------------------------------------------------------------------ edges: empty, maximal, ragged
+
+def test_empty_batches_and_size_limits(sp):
+    """B = 0 is a no-op for every primitive; H*W = 16384 is the largest board; beyond it, and below
+    3x3, the C-ABI reports SL_E_SHAPE, which the Python layer turns into the reference's ValueError."""
+    import torch
+    from safelife_amd import _hip
+    dev = _hip.device()
+    z16 = torch.zeros((0, 25, 25), dtype=torch.int16, device=dev)
+    zf = torch.zeros((0,), dtype=torch.float32, device=dev)
+    zr = torch.zeros((0, 4), dtype=torch.int64, device=dev)
+    assert sp.advance_board_batch(z16, zf, zr, 3).shape == (0, 25, 25)
+    assert sp.life_occupancy_batch(z16, zf, zr, 5).shape == (0, 25, 25, 8)
+    assert sp.alive_counts_batch(z16, z16).shape == (0, 8, 9)
+    rng = np.random.default_rng(3)
+    big = util.random_boards(rng, 2, 128, 128, 1)                      # 16384 cells
+    words = util.random_rng_words(rng, 2)
+    w_cpu = words.copy()
+    want = oracle.advance_board_batch(big, 0.3, 2, w_cpu, n_threads=2)
+    got, w_dev = _dev_advance(sp, big, 0.3, 2, words)
+    assert np.array_equal(got, want) and np.array_equal(w_dev, w_cpu)
+    too_big = torch.zeros((1, 128, 129), dtype=torch.int16, device=dev)
+    one = torch.full((1,), 0.3, dtype=torch.float32, device=dev)
+    r1 = torch.zeros((1, 4), dtype=torch.int64, device=dev)
+    with pytest.raises(ValueError):
+        sp.advance_board_batch(too_big, one, r1, 1)
+    with pytest.raises(ValueError):
+        sp.advance_board_batch(torch.zeros((1, 2, 9), dtype=torch.int16, device=dev), one, r1, 1)
+    with pytest.raises(ValueError):
+        sp.advance_board(np.zeros((2, 2), np.uint16))
+
+
+def test_ragged_tail_workgroups_and_many_exits():
+    """Batch sizes that leave partly filled workgroups / waves in the row kernels (8 boards per
+    workgroup, 2 per wave), and a level with more exit cells than the row kernels take (E > 8 runs the
+    size-generic kernels): both against the oracle."""
+    from safelife_amd.levels import Level, LevelPool
+    from safelife_amd.cell_types import CellTypes as CT
+    pool, _ = util.pool_from_fixture("append_spawn_25", _device_counts, n=12)
+    for B in (1, 2, 7, 9, 15, 17):
+        kw = dict(first_level=np.arange(B) % 12, auto_reset=True, time_limit=9, view_shape=(25, 25),
+                  output_channels=None, level_stride=5)
+        dev, cpu = util.DeviceBackend(pool, B, **kw), util.OracleBackend(pool, B, **kw)
+        assert np.array_equal(dev.reset(), cpu.reset())
+        rng = np.random.default_rng(B)
+        for t in range(25):
+            a = rng.integers(0, 9, B).astype(np.int32)
+            o1, r1, d1 = dev.step(a)
+            o2, r2, d2 = cpu.step(a)
+            assert np.array_equal(r1, r2) and np.array_equal(d1, d2) and np.array_equal(o1, o2), (B, t)
+        for name in ENV_STATE:
+            assert np.array_equal(dev.get(name), cpu.get(name)), (B, name)
+    board = np.zeros((25, 25), np.uint16)
+    board[12, 12] = CT.player
+    for k in range(11):
+        board[3, 2 * k + 1] = CT.level_exit
+    board[8:10, 8:10] = CT.life
+    many = LevelPool([Level(board, np.zeros_like(board), np.array([[12, 12]]), min_performance=-1)],
+                     counts_fn=_device_counts)
+    assert many.exit_slots == 11
+    kw = dict(first_level=0, auto_reset=True, time_limit=30, view_shape=(9, 9), output_channels=None)
+    dev, cpu = util.DeviceBackend(many, 5, **kw), util.OracleBackend(many, 5, **kw)
+    assert np.array_equal(dev.reset(), cpu.reset())
+    rng = np.random.default_rng(1)
+    for t in range(60):
+        a = rng.integers(0, 9, 5).astype(np.int32)
+        o1, r1, d1 = dev.step(a)
+        o2, r2, d2 = cpu.step(a)
+        assert np.array_equal(r1, r2) and np.array_equal(d1, d2) and np.array_equal(o1, o2), t
+    assert np.array_equal(dev.get("board"), cpu.get("board"))
