@@ -15,7 +15,9 @@ from safelife_amd.vector_env import SafeLifeVectorEnv
 
 pool = bench.load_pool(os.environ.get("SL_TRACE_POOL", "prune_still_25"), _device_counts)
 B = int(os.environ.get("SL_TRACE_ENVS", "8192"))
-env = SafeLifeVectorEnv(pool, B, view_shape=(25, 25), output_channels=bench.TRAIN_CHANNELS, with_obs=False)
+wrappers = dict(movement_bonus=0.1, exit_bonus=0.5, penalty_coef=0.3) if os.environ.get("SL_TRACE_WRAP") == "1" else None
+env = SafeLifeVectorEnv(pool, B, view_shape=(25, 25), output_channels=bench.TRAIN_CHANNELS, with_obs=False,
+                        wrappers=wrappers)
 env.reset()
 acts = torch.randint(0, 9, (64, B), device=env.device, dtype=torch.int32)
 for t in range(20):
