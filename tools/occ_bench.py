@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""life_occupancy throughput: python tools/occ_bench.py [pool] [boards] [n_steps]  (SAFELIFE_HIP_OCC_LDS=1: LDS counters)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench
+from safelife_amd import speedups, _hip
+from safelife_amd.levels import _device_counts
+name = sys.argv[1] if len(sys.argv) > 1 else "navigation_64"
+nb = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
+pool = bench.load_pool(name, _device_counts)
+dev = _hip.device()
+boards = torch.from_numpy(np.ascontiguousarray(pool.arrays()["pool_board"][np.arange(nb) % len(pool)]).view(np.int16)).to(dev)
+probs = torch.full((nb,), 0.3, dtype=torch.float32, device=dev)
+rngs = torch.arange(nb * 4, dtype=torch.int64, device=dev).reshape(nb, 4) * 2 + 1
+speedups.life_occupancy_batch(boards[:16], probs[:16], rngs[:16].clone(), 10)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+speedups.life_occupancy_batch(boards, probs, rngs, n)
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1)
+print("%s %d boards x %d steps: %.2f ms, %.3g board-steps/s (%s counters)" % (
+    name, nb, n, ms, nb * n / (ms * 1e-3), "LDS" if os.environ.get("SAFELIFE_HIP_OCC_LDS") == "1" else "global"))
