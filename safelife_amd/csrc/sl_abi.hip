@@ -161,7 +161,8 @@ int slhip_life_occupancy(const uint16_t *in, int32_t *counts, int B, int H, int 
     if (!in || !counts || !spawn_prob || !rng) return fail(SL_E_ARG, "null pointer");
     const sl::Jump *jump;
     if ((rc = jump_table(&jump))) return rc;
-    // 16-bit per-colour counters in LDS: the row kernel covers every step count the reference is called with
+    // 16-bit (or drained 8-bit) per-colour counters in LDS: the row kernel covers every step count the
+    // reference is called with
     hipError_t err = (sl::rowlane_supports(H, W) && n_steps <= 65535 && !force_generic())
                          ? sl::launch_occupancy_rowlane(in, counts, B, H, W, spawn_prob, n_steps, rng, jump,
                                                         (hipStream_t)stream)

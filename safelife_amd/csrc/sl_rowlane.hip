@@ -745,18 +745,45 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_ad
 // ---- life_occupancy ---------------------------------------------------------------------------------
 // (advance_board.c:153-189)  One wavefront per workgroup, G boards per wavefront, rows in registers for
 // all n steps.  After every step each lane bumps, for each of its cells that is ALIVE and not
-// AGENT|EXIT|FROZEN, a 16-bit counter (cell, colour) in LDS with a fire-and-forget ds_add_u32 (two
-// colours share a dword; n_steps <= 65535 keeps a half from carrying into its neighbour).  A lane's
+// AGENT|EXIT|FROZEN, a small counter (cell, colour) in LDS with a fire-and-forget ds_add_u32.  A lane's
 // counters are one contiguous run with an odd dword pitch between lanes, so "same cell, every row"
-// spreads over the banks.  The counters become the int32 [H,W,8] output at the end.
+// spreads over the banks.  CB = bits per counter:
+//   16  two colours per dword; n_steps <= 65535 keeps a half from carrying into its neighbour; the
+//       counters become the int32 [H,W,8] output at the end (boards up to 32 cells wide);
+//   8   four colours per dword, drained into the zeroed output every 255 steps: half the LDS, twice the
+//       wavefronts per CU -- what 64-wide boards need (a 16-bit set is 64 KiB per board).
 template <int H, int W>
 struct OccGeom {
     using Gm = Geom<H, W>;
-    static constexpr int PITCH = W * 4 + 1;                             // dwords per lane: W cells x 8 colours x u16
+    static constexpr int CB = W > 32 ? 8 : 16;
+    static constexpr int PER_DWORD = 32 / CB;                           // colours per dword
+    static constexpr int CELL_DWORDS = 8 / PER_DWORD;
+    static constexpr int PITCH = W * CELL_DWORDS + 1;                   // dwords per lane
     static constexpr int OFF_CNT = 0;
     static constexpr int OFF_RNG = 64 * PITCH * 4;                      // G x 4 u64
     static constexpr int LDS_BYTES = OFF_RNG + Gm::G * 32;
+    static constexpr int FLUSH_EVERY = CB == 8 ? 255 : 0x7FFFFFFF;
 };
+
+// counters of one lane's row -> its slice of the output (add: the output was zeroed), counters cleared
+template <int H, int W>
+__device__ __forceinline__ void occ_drain(u32 *cnt, int32_t *dst) {
+    using Oc = OccGeom<H, W>;
+    for (int x = 0; x < W; ++x) {
+#pragma unroll
+        for (int q = 0; q < Oc::CELL_DWORDS; ++q) {
+            const u32 v = cnt[x * Oc::CELL_DWORDS + q];
+            if (v) {
+#pragma unroll
+                for (int j = 0; j < Oc::PER_DWORD; ++j) {
+                    const int c = (v >> (Oc::CB * j)) & ((1u << Oc::CB) - 1u);
+                    if (c) dst[x * 8 + q * Oc::PER_DWORD + j] += c;
+                }
+                cnt[x * Oc::CELL_DWORDS + q] = 0;
+            }
+        }
+    }
+}
 
 template <int H, int W>
 __global__ __launch_bounds__(64) void k_occupancy_rowlane(const u16 *__restrict__ in, int32_t *__restrict__ counts,
@@ -776,6 +803,7 @@ __global__ __launch_bounds__(64) void k_occupancy_rowlane(const u16 *__restrict_
     const unsigned e = e0b + (rowl ? g : 0);
     u32 *cnt = (u32 *)(smem + Oc::OFF_CNT) + lane * Oc::PITCH;
     u64 *rng_lds = (u64 *)(smem + Oc::OFF_RNG);
+    int32_t *dst = counts + (((size_t)e * H + r) * W) * 8;          // this lane's row of the output
 
     for (int i = 0; i < Oc::PITCH; ++i) cnt[i] = 0;
     if (lane < 4 * nbb) rng_lds[lane] = ((const u64 *)(rng + e0b))[lane];
@@ -795,6 +823,7 @@ __global__ __launch_bounds__(64) void k_occupancy_rowlane(const u16 *__restrict_
     const int partner = !rowl || lm.real ? lane : (r == 0 ? lane - H : lane + H);
     const Consts cst = make_consts();
     wave_sync();
+    int since_drain = 0;
     for (int s = 0; s < n_steps; ++s) {
         ca_rows<H, W, true>(b, n, elig, lm.up, lm.dn, cst);
         if (!live) elig.clear();
@@ -807,23 +836,34 @@ __global__ __launch_bounds__(64) void k_occupancy_rowlane(const u16 *__restrict_
                 const u32 c = b[k];
                 const u32 tick = c & ~(c >> 1) & ~(c >> 4) & ~(c >> 8) & 0x00010001u;    // alive, not agent/frozen/exit
                 const u32 lo_col = (c >> 9) & 7u, hi_col = (c >> 25) & 7u;
-                __hip_atomic_fetch_add(cnt + k * 4 + (lo_col >> 1), (tick & 1u) << (16 * (lo_col & 1u)),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_fetch_add(cnt + k * Oc::CELL_DWORDS + lo_col / Oc::PER_DWORD,
+                                       (tick & 1u) << (Oc::CB * (lo_col % Oc::PER_DWORD)), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WAVEFRONT);
                 if (!(Gm::ODD && k == WS - 1))
-                    __hip_atomic_fetch_add(cnt + (k + WS) * 4 + (hi_col >> 1), (tick >> 16) << (16 * (hi_col & 1u)),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __hip_atomic_fetch_add(cnt + (k + WS) * Oc::CELL_DWORDS + hi_col / Oc::PER_DWORD,
+                                           (tick >> 16) << (Oc::CB * (hi_col % Oc::PER_DWORD)), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
+        }
+        if (++since_drain == Oc::FLUSH_EVERY) {         // (wave-uniform) 8-bit counters are about to wrap
+            since_drain = 0;
+            wave_sync();
+            if (live) occ_drain<H, W>(cnt, dst);
+            wave_sync();
         }
     }
     wave_sync();
     if (live) {
-        int32_t *dst = counts + (((size_t)e * H + r) * W) * 8;
-        for (int x = 0; x < W; ++x) {
+        if (Oc::CB == 8) {
+            occ_drain<H, W>(cnt, dst);
+        } else {            // nothing was drained on the way: plain stores, the output need not be zeroed
+            for (int x = 0; x < W; ++x) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const u32 v = cnt[x * 4 + q];
-                dst[x * 8 + 2 * q] = (int32_t)(v & 0xFFFFu);
-                dst[x * 8 + 2 * q + 1] = (int32_t)(v >> 16);
+                for (int q = 0; q < 4; ++q) {
+                    const u32 v = cnt[x * 4 + q];
+                    dst[x * 8 + 2 * q] = (int32_t)(v & 0xFFFFu);
+                    dst[x * 8 + 2 * q + 1] = (int32_t)(v >> 16);
+                }
             }
         }
     }
@@ -1457,6 +1497,10 @@ static hipError_t launch_occupancy_t(const u16 *in, int32_t *counts, int B, cons
     auto fn = k_occupancy_rowlane<H, W>;
     hipError_t err = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, Oc::LDS_BYTES);
     if (err != hipSuccess) return err;
+    if (Oc::CB == 8) {      // the drained counters are added into the output
+        err = hipMemsetAsync(counts, 0, (size_t)B * H * W * 8 * sizeof(int32_t), stream);
+        if (err != hipSuccess) return err;
+    }
     hipLaunchKernelGGL(fn, dim3((B + Gm::G - 1) / Gm::G), dim3(64), Oc::LDS_BYTES, stream, in, counts, B, spawn_prob,
                        n_steps, rng, jump);
     return hipGetLastError();

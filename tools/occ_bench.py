@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""life_occupancy throughput: python tools/occ_bench.py [pool] [boards] [n_steps]  (SAFELIFE_HIP_OCC_LDS=1: LDS counters)"""
+"""life_occupancy throughput: python tools/occ_bench.py [pool] [boards] [n_steps]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -22,5 +22,4 @@ speedups.life_occupancy_batch(boards, probs, rngs, n)
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1)
-print("%s %d boards x %d steps: %.2f ms, %.3g board-steps/s (%s counters)" % (
-    name, nb, n, ms, nb * n / (ms * 1e-3), "LDS" if os.environ.get("SAFELIFE_HIP_OCC_LDS") == "1" else "global"))
+print("%s %d boards x %d steps: %.2f ms, %.3g board-steps/s" % (name, nb, n, ms, nb * n / (ms * 1e-3)))
