@@ -603,3 +603,28 @@ def test_ragged_tail_workgroups_and_many_exits():
         o2, r2, d2 = cpu.step(a)
         assert np.array_equal(r1, r2) and np.array_equal(d1, d2) and np.array_equal(o1, o2), t
     assert np.array_equal(dev.get("board"), cpu.get("board"))
+
+
+def test_sharded_equals_unsharded():
+    """env e behaves the same whichever rank owns it -- two half-size envs with
+    env_offset 0 / B/2 (what ranks 0 and 1 of a 2-GPU run hold) against one env of size B."""
+    from safelife_amd.vector_env import SafeLifeVectorEnv
+    pool, _ = util.pool_from_fixture("append_spawn_25", _device_counts, n=24)
+    B, T = 96, 60
+    kw = dict(time_limit=25, view_shape=(15, 15), output_channels=None, auto_reset=True, level_stride=7)
+    whole = SafeLifeVectorEnv(pool, B, **kw)
+    parts = [SafeLifeVectorEnv(pool, B // 2, env_offset=k * (B // 2), **kw) for k in range(2)]
+    whole.reset()
+    for p_ in parts:
+        p_.reset()
+    rng = np.random.default_rng(17)
+    for t in range(T):
+        a = rng.integers(0, 9, B).astype(np.int32)
+        whole.step(a)
+        for k, p_ in enumerate(parts):
+            p_.step(a[k * (B // 2):(k + 1) * (B // 2)])
+        for name in ("reward", "done", "obs"):
+            joined = np.concatenate([p_.numpy(name) for p_ in parts])
+            assert np.array_equal(whole.numpy(name), joined), (t, name)
+    for name in ("board", "goals", "rng", "agent_loc", "episode_idx", "level_idx"):
+        assert np.array_equal(whole.numpy(name), np.concatenate([p_.numpy(name) for p_ in parts])), name
