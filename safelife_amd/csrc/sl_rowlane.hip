@@ -1380,8 +1380,9 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
     if (dirty) store_span<H, W>(env.goals + (size_t)e0b * HW, goals, nbb, tid);
     if (lane < 4 * Gm::G && wave * Gm::G + (lane >> 2) < nbb)
         ((u64 *)(env.rng + e0b + wave * Gm::G))[lane] = rng_lds[lane];
-    if (WRAP && tid < nbb * (int)(sizeof(sl_wrap_state) / 4))
-        ((u32 *)(env.wrap.state + e0b))[tid] = ((const u32 *)wst)[tid];
+    if (WRAP)       // (10-row boards: 24 per workgroup, more state words than threads)
+        for (int i = tid; i < nbb * (int)(sizeof(sl_wrap_state) / 4); i += 64 * WAVES)
+            ((u32 *)(env.wrap.state + e0b))[i] = ((const u32 *)wst)[i];
 
     SL_STAMP(9);
 #ifdef SL_TRACE

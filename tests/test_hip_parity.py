@@ -628,3 +628,15 @@ def test_sharded_equals_unsharded():
             assert np.array_equal(whole.numpy(name), joined), (t, name)
     for name in ("board", "goals", "rng", "agent_loc", "episode_idx", "level_idx"):
         assert np.array_equal(whole.numpy(name), np.concatenate([p_.numpy(name) for p_ in parts])), name
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_randomised_soak(seed):
+    """tools/soak.py for a few seconds: random synthetic pools (shapes incl. 10x10 with 24 boards per
+    workgroup, 0..8 exits, spawners, evolving goals, agent-less levels), random env options and wrapper
+    settings, odd batch sizes -- device vs oracle on everything.  (Seed 1 is the run that caught the
+    wrapper-state write-back of workgroups holding more than 21 boards.)"""
+    import subprocess, sys
+    out = subprocess.check_output([sys.executable, os.path.join(util.REPO, "tools", "soak.py"), "6", str(seed)],
+                                  cwd=util.REPO, stderr=subprocess.STDOUT).decode()
+    assert "soak ok" in out, out[-2000:]

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Randomised differential soak: SafeLifeVectorEnv (HIP) vs the CPU oracle over synthetic level pools
+that mix shapes, exits (0..8), spawners, dynamic goals, missing agents, wrappers and odd batch sizes.
+    python tools/soak.py [seconds] [seed]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from tests import util
+from safelife_amd.levels import Level, LevelPool, _device_counts
+from safelife_amd.cell_types import CellTypes as CT
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(seed)
+PAL = np.array([0] * 14 + [9] * 5 + [1, 16, 17, 32788, 48, 53, 85, 32884, 9 | 0x200, 9 | 0x400, 9 | 0x800, 9 | 0xE00,
+                              4 | 8, 32, 64], np.uint16)
+SPAWN = np.array([152, 152 | 0x200, 152 | 0x600, 144 | 0x800], np.uint16)
+
+
+def random_level(H, W, spawners, n_exits, dynamic_goals, agent):
+    b = PAL[rng.integers(0, len(PAL), (H, W))]
+    for _ in range(spawners):
+        b[rng.integers(0, H), rng.integers(0, W)] = rng.choice(SPAWN)
+    for _ in range(n_exits):
+        b[rng.integers(0, H), rng.integers(0, W)] = CT.level_exit
+    g = (rng.integers(0, 8, (H, W)) << 9).astype(np.uint16) * (rng.random((H, W)) < 0.3)
+    g = g.astype(np.uint16)
+    if dynamic_goals:
+        g[rng.integers(0, H, 12), rng.integers(0, W, 12)] |= np.uint16(9)          # living goal cells evolve
+        if rng.random() < 0.5:
+            g[rng.integers(0, H), rng.integers(0, W)] = rng.choice(SPAWN)
+    locs = np.zeros((0, 2), int)
+    if agent:
+        y, x = int(rng.integers(0, H)), int(rng.integers(0, W))
+        b[y, x] = CT.player | (int(rng.integers(0, 4)) << 12)
+        locs = np.array([[y, x]])
+    return Level(b, g, locs, spawn_prob=float(rng.choice([0.3, 0.05, 0.9])),
+                 min_performance=float(rng.choice([-1, 0.0, 0.3, 1.0])))
+
+
+t_end, n_cfg, n_steps = time.time() + budget, 0, 0
+while time.time() < t_end:
+    H, W = [(25, 25), (26, 26), (64, 64), (15, 15), (20, 20), (10, 10), (9, 13), (12, 12)][rng.integers(0, 8)]
+    spawners = int(rng.choice([0, 0, 3, 12]))
+    L = int(rng.integers(1, 7))
+    levels = [random_level(H, W, spawners, int(rng.integers(0, 9)), rng.random() < 0.3, rng.random() < 0.9)
+              for _ in range(L)]
+    pool = LevelPool(levels, counts_fn=_device_counts, min_performance_fraction=float(rng.choice([1.0, 0.1])))
+    B = int(rng.choice([1, 3, 8, 9, 17, 40]))
+    wrappers = None
+    if rng.random() < 0.5:
+        wrappers = dict(movement_bonus=float(rng.choice([0.1, 0.3])), movement_bonus_period=int(rng.integers(1, 9)),
+                        movement_bonus_power=float(rng.choice([1e-100, 0.5, 1.0])), as_penalty=bool(rng.random() < 0.5),
+                        exit_bonus=float(rng.choice([0.5, 2.0])), penalty_coef=float(rng.choice([0.0, 0.3, 1.0])),
+                        ignore_reward_cells=bool(rng.random() < 0.5))
+    chans = [None, (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 25, 26, 27), tuple(range(16)) + (25, 26, 27)][rng.integers(0, 3)]
+    kw = dict(first_level=rng.integers(0, L, B), auto_reset=True, level_stride=int(rng.integers(1, 4)),
+              time_limit=int(rng.choice([1, 7, 30])), view_shape=(int(rng.integers(1, 30)), int(rng.integers(1, 30))),
+              output_channels=chans, remove_white_goals=bool(rng.random() < 0.5), wrappers=wrappers)
+    dev, cpu = util.DeviceBackend(pool, B, **kw), util.OracleBackend(pool, B, **kw)
+    desc = dict(shape=(H, W), B=B, L=L, spawners=spawners, wrappers=wrappers, kw={k: v for k, v in kw.items() if k != "first_level"})
+    assert np.array_equal(dev.reset(), cpu.reset()), ("reset obs", desc)
+    T = int(rng.integers(5, 40))
+    for t in range(T):
+        a = rng.integers(0, 9, B).astype(np.int32)
+        o1, r1, d1 = dev.step(a)
+        o2, r2, d2 = cpu.step(a)
+        assert np.array_equal(r1, r2) and np.array_equal(d1, d2), ("reward/done", t, desc)
+        assert np.array_equal(o1, o2), ("obs", t, desc)
+        if wrappers:
+            s1, s2 = dev.get("shaped_reward"), cpu.get("shaped_reward")
+            if not np.array_equal(s1, s2):
+                bad = np.nonzero(s1 != s2)[0]
+                ws = dev.env.t["wrap_state"].cpu().numpy()
+                for e in bad[:4]:
+                    print("env", e, "dev", s1[e], "cpu", s2[e], "reward", r1[e], "done", d1[e], "dev state", ws[e][:2],
+                          "cpu last", cpu.env.wa["last_side_effect"][e], "cpu n_prior", cpu.env.wa["n_prior"][e],
+                          "level", dev.get("level_idx")[e], "loc", dev.get("agent_loc")[e], "exits", dev.get("exit_locs")[e],
+                          "open", dev.get("exit_open_at_reset")[e])
+                raise AssertionError(("shaped", t, desc))
+    for name in ("board", "goals", "agent_loc", "rng", "num_steps", "episode_idx", "goals_static", "exit_locs"):
+        assert np.array_equal(dev.get(name), cpu.get(name)), (name, desc)
+    n_cfg += 1
+    n_steps += T * B
+print("soak ok: %d configurations, %d env-steps compared, seed %d" % (n_cfg, n_steps, seed))
