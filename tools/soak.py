@@ -80,6 +80,24 @@ while time.time() < t_end:
                 raise AssertionError(("shaped", t, desc))
     for name in ("board", "goals", "agent_loc", "rng", "num_steps", "episode_idx", "goals_static", "exit_locs"):
         assert np.array_equal(dev.get(name), cpu.get(name)), (name, desc)
+    if rng.random() < 0.5:          # the same through the T-step launch
+        T2 = int(rng.integers(2, 12))
+        a = rng.integers(0, 9, (T2, B)).astype(np.int32)
+        r_t, d_t = dev.env.rollout(a)
+        want_r, want_d, want_s = [], [], []
+        for t in range(T2):
+            _, r2, d2 = cpu.step(a[t])
+            want_r.append(r2)
+            want_d.append(d2)
+            if wrappers:
+                want_s.append(cpu.get("shaped_reward"))
+        assert np.array_equal(r_t.cpu().numpy(), np.stack(want_r)) and np.array_equal(d_t.cpu().numpy(), np.stack(want_d)), ("rollout", desc)
+        if wrappers:
+            assert np.array_equal(dev.env.shaped_reward_t.cpu().numpy(), np.stack(want_s)), ("rollout shaped", desc)
+        assert np.array_equal(dev.get("obs"), cpu.env.obs), ("rollout obs", desc)
+        for name in ("board", "goals", "agent_loc", "rng", "num_steps", "episode_idx"):
+            assert np.array_equal(dev.get(name), cpu.get(name)), ("rollout " + name, desc)
+        T += T2
     n_cfg += 1
     n_steps += T * B
 print("soak ok: %d configurations, %d env-steps compared, seed %d" % (n_cfg, n_steps, seed))
