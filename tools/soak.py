@@ -34,8 +34,14 @@ def random_level(H, W, spawners, n_exits, dynamic_goals, agent):
         y, x = int(rng.integers(0, H)), int(rng.integers(0, W))
         b[y, x] = CT.player | (int(rng.integers(0, 4)) << 12)
         locs = np.array([[y, x]])
+    table = None
+    u = rng.random()
+    if u < 0.25:        # its own points table: batches with several tables gather scores from global memory
+        table = rng.integers(-3, 4, (1, 8, 9))
+    elif u < 0.30:      # entries beyond int8: no score table at all, the size-generic kernels take over
+        table = rng.integers(-300, 300, (1, 8, 9))
     return Level(b, g, locs, spawn_prob=float(rng.choice([0.3, 0.05, 0.9])),
-                 min_performance=float(rng.choice([-1, 0.0, 0.3, 1.0])))
+                 min_performance=float(rng.choice([-1, 0.0, 0.3, 1.0])), points_table=table)
 
 
 t_end, n_cfg, n_steps = time.time() + budget, 0, 0
