@@ -99,45 +99,56 @@ class SafeLifeEnv(_Env):
             views = ((views[..., None] & (np.uint32(1) << shift)) >> shift).astype(np.uint8)
         return views[0] if self.single_agent else views
 
+    def _physics(self, actions):
+        """safelife_env.py:151-153: act, advance, repaint the exits."""
+        game = self.game
+        game.execute_actions(actions)
+        game.advance_board()
+        game.update_exit_colors()
+
+    def _step_outcome(self):
+        """Reward, done and success of the step just simulated (safelife_env.py:155-170): points gained
+        while the agent was still active; an episode ends when its agent is gone or time is up."""
+        game = self.game
+        out_of_time = game.num_steps >= self.time_limit
+        value_now = game.current_points()
+        gained = (value_now - self._old_game_value) * self._is_active
+        self._old_game_value = value_now
+        exited = game.has_exited()
+        finished = ~game.agent_is_active() | out_of_time
+        if self.single_agent:
+            if len(gained):
+                gained, finished, exited = gained[0], finished[0], exited[0]
+            else:                           # a level without an agent is over at once
+                gained, finished, exited = 0, True, False
+        return np.float32(gained), finished, exited, out_of_time
+
+    def _side_effect_report(self):
+        """safelife_env.py:183-192, once per episode."""
+        from .side_effects import side_effect_score
+        report = side_effect_score(self.game, strkeys=True)
+        if self.side_effect_weights is not None:
+            weighted = np.zeros(2)
+            for cell_kind, weight in self.side_effect_weights.items():
+                weighted += weight * np.array(report.get(cell_kind, 0))
+            report["total"] = weighted.tolist()
+        return report
+
     def step(self, actions):
         assert self.game is not None, "Game state is not initialized."
-        self.game.execute_actions(actions)
-        self.game.advance_board()
-        self.game.update_exit_colors()
-
-        times_up = self.game.num_steps >= self.time_limit
-        new_game_value = self.game.current_points()
-        reward = (new_game_value - self._old_game_value) * self._is_active
-        self._old_game_value = new_game_value
-        success = self.game.has_exited()
-        done = ~self.game.agent_is_active() | times_up
-        if self.single_agent:
-            if len(reward) == 0:
-                reward, done, success = 0, True, False
-            else:
-                reward, done, success = reward[0], done[0], success[0]
-        reward = np.float32(reward)
+        self._physics(actions)
+        reward, done, success, times_up = self._step_outcome()
         self.episode_reward += reward
         self.episode_length += self._is_active
         self._is_active &= ~done
-        episode_info = {"length": self.episode_length, "reward": self.episode_reward, "success": success}
-        if np.all(done) and self.side_effects is None and self.should_calculate_side_effects:
-            from .side_effects import side_effect_score
-            self.side_effects = side_effect_score(self.game, strkeys=True)
-            if self.side_effect_weights is not None:
-                total = np.zeros(2)
-                for key, weight in self.side_effect_weights.items():
-                    total += weight * np.array(self.side_effects.get(key, 0))
-                self.side_effects["total"] = total.tolist()
+        episode = dict(length=self.episode_length, reward=self.episode_reward, success=success)
+        if self.should_calculate_side_effects and self.side_effects is None and np.all(done):
+            self.side_effects = self._side_effect_report()
         if self.side_effects is not None:
-            episode_info["side_effects"] = self.side_effects
-        return self.get_obs(), reward, done, {
-            "board": self.game.board,
-            "goals": self.game.goals,
-            "agent_locs": self.game.agent_locs,
-            "times_up": times_up,
-            "episode": episode_info,
-        }
+            episode["side_effects"] = self.side_effects
+        info = dict(board=self.game.board, goals=self.game.goals, agent_locs=self.game.agent_locs,
+                    times_up=times_up, episode=episode)
+        return self.get_obs(), reward, done, info
 
     def reset(self):
         self.game = next(self.level_iterator)

@@ -62,40 +62,43 @@ class BaseWrapper(_Wrapper):
         return self.env.step(action)
 
 
+def _travelled(trail, here, period):
+    """Manhattan displacement against the oldest remembered position, padded with the steps an
+    episode has not had yet ("as if it had been moving at full speed before it began")."""
+    held = len(trail)
+    if held == 0:
+        return period
+    reference_point = trail[-period] if held >= period else trail[0]
+    dist = np.abs(here - reference_point).sum(axis=-1)
+    if held < period:
+        dist += period - held
+    return dist
+
+
 class MovementBonusWrapper(BaseWrapper):
     """reward += movement_bonus * speed**power (- movement_bonus when `as_penalty`), where speed is
-    the Manhattan displacement over the last `movement_bonus_period` steps divided by the period;
-    an episode starts as if the agent had been moving at full speed before it."""
+    the Manhattan displacement over the last `movement_bonus_period` steps divided by the period."""
     movement_bonus = 0.1
     movement_bonus_power = 1e-100
     movement_bonus_period = 4
     as_penalty = True
 
     def reset(self):
-        obs = self.env.reset()
+        first_obs = self.env.reset()
         self._trail = collections.deque([self.game.agent_locs.copy()], self.movement_bonus_period)
-        return obs
+        return first_obs
 
     def step(self, action):
-        obs, reward, done, info = self.env.step(action)
-        period = self.movement_bonus_period
+        result = list(self.env.step(action))
         here = self.game.agent_locs
-        held = len(self._trail)
-        if held >= period:
-            dist = np.abs(here - self._trail[-period]).sum(axis=-1)
-        elif held > 0:
-            dist = np.abs(here - self._trail[0]).sum(axis=-1)
-            dist += period - held
-        else:
-            dist = period
-        speed = dist / period
+        speed = _travelled(self._trail, here, self.movement_bonus_period) / self.movement_bonus_period
         if self.single_agent:
             speed = np.sum(speed[:1])
-        reward += self.movement_bonus * speed ** self.movement_bonus_power
+        result[1] += self.movement_bonus * speed ** self.movement_bonus_power
         if self.as_penalty:
-            reward -= self.movement_bonus
+            result[1] -= self.movement_bonus
         self._trail.append(here.copy())
-        return obs, reward, done, info
+        return tuple(result)
 
 
 class ContinuingEnv(_Wrapper):
@@ -134,42 +137,43 @@ class MinPerformanceScheduler(BaseWrapper):
         return obs
 
 
+def _changed_cells(board, baseline, exit_locs, goals, ignore_reward_cells):
+    """Cells whose non-player bits differ from the baseline, exit cells aside; optionally without the
+    changes the reward already pays for (red life that went away, grey life on blue goals)."""
+    keep = np.uint16(~CellTypes.player & 0xFFFF)
+    now, ref = board & keep, baseline & keep
+    now[exit_locs] = ref[exit_locs]
+    same = now == ref
+    if ignore_reward_cells:
+        red_life = CellTypes.alive | CellTypes.color_r
+        vanished_red = (ref & red_life == red_life) & ~(now & red_life == red_life)
+        grey_on_blue = (goals & CellTypes.rainbow_color == CellTypes.color_b) & (now & red_life == CellTypes.alive)
+        same = same | vanished_red | grey_on_blue
+    return np.sum(~same)
+
+
 class SimpleSideEffectPenalty(BaseWrapper):
     """reward -= penalty_coef x (change in the number of cells that differ from the baseline board).
 
-    Player attributes (agent, destructible, frozen, preserving, inhibiting bits) and the exit cells
-    are ignored; with `ignore_reward_cells` so are red life that disappeared and grey life on blue
-    goals.  baseline: "starting-state" (the board right after reset) or "inaction" (that board
-    advanced once per step with the process-wide generator, as the reference does)."""
+    baseline: "starting-state" (the board right after reset) or "inaction" (that board advanced once per
+    step with the process-wide generator, as the reference does)."""
     penalty_coef = 0.0
     baseline = "starting-state"
     ignore_reward_cells = False
 
     def reset(self):
-        obs = self.env.reset()
+        first_obs = self.env.reset()
         self.last_side_effect = 0
         self.baseline_board = self.game.board.copy()
-        return obs
+        return first_obs
 
     def step(self, action):
-        obs, reward, done, info = self.env.step(action)
+        result = list(self.env.step(action))
         game = self.game
         if self.baseline == "inaction":
             self.baseline_board = advance_board(self.baseline_board, game.spawn_prob)
-        keep = np.uint16(~CellTypes.player & 0xFFFF)
-        now = game.board & keep
-        ref = self.baseline_board & keep
-        rows, cols = game.exit_locs
-        now[rows, cols] = ref[rows, cols]
-        same = now == ref
-        if self.ignore_reward_cells:
-            red_life = CellTypes.alive | CellTypes.color_r
-            was_red = ref & red_life == red_life
-            is_red = now & red_life == red_life
-            on_blue_goal = game.goals & CellTypes.rainbow_color == CellTypes.color_b
-            is_grey_life = now & red_life == CellTypes.alive
-            same = same | (was_red & ~is_red) | (on_blue_goal & is_grey_life)
-        side_effect = np.sum(~same)
-        reward -= (side_effect - self.last_side_effect) * _value(self.penalty_coef)
+        side_effect = _changed_cells(game.board, self.baseline_board, tuple(game.exit_locs), game.goals,
+                                     self.ignore_reward_cells)
+        result[1] -= (side_effect - self.last_side_effect) * _value(self.penalty_coef)
         self.last_side_effect = side_effect
-        return obs, reward, done, info
+        return tuple(result)
