@@ -640,3 +640,27 @@ def test_randomised_soak(seed):
     out = subprocess.check_output([sys.executable, os.path.join(util.REPO, "tools", "soak.py"), "6", str(seed)],
                                   cwd=util.REPO, stderr=subprocess.STDOUT).decode()
     assert "soak ok" in out, out[-2000:]
+
+
+@pytest.mark.parametrize("shape", [(25, 25), (64, 64), (7, 11)])
+def test_advance_board_per_board_step_counts(sp, shape):
+    """slhip_advance_board_each: every board advanced by its own number of steps (what
+    side_effect_score needs for a batch of finished episodes), generator states included."""
+    import torch
+    rng = np.random.default_rng(shape[0])
+    B = 37
+    boards = util.random_boards(rng, B, shape[0], shape[1], 1)
+    words = util.random_rng_words(rng, B)
+    p = rng.choice([0.3, 0.05], B).astype(np.float32)
+    steps = rng.integers(0, 40, B).astype(np.int32)
+    steps[0] = 0
+    want, w_cpu = np.zeros_like(boards), words.copy()
+    for b in range(B):
+        wb = w_cpu[b:b + 1].copy()
+        want[b] = oracle.advance_board_batch(boards[b:b + 1], p[b:b + 1], int(steps[b]), wb)[0]
+        w_cpu[b] = wb[0]
+    d_rng = sp._to_device(words.copy(), np.uint64)
+    d_b = sp._to_device(boards, np.uint16)
+    got = sp.advance_board_batch(d_b, torch.from_numpy(p).to(d_b.device), d_rng, torch.from_numpy(steps).to(d_b.device))
+    assert np.array_equal(sp._to_host(got, np.uint16), want)
+    assert np.array_equal(sp._to_host(d_rng, np.uint64), w_cpu)
