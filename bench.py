@@ -28,6 +28,9 @@ import time
 
 import numpy as np
 
+# kernel arguments in device memory: read by the runtime when it loads, i.e. before torch is imported
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
