@@ -1016,17 +1016,25 @@ __device__ __forceinline__ void write_obs_block(const sl_env_batch &env, const u
         }
     } else {
         using Sel = ObsSel<C>;
+        using Gm = Geom<H, W>;
         constexpr int P = Sel::P;
+        // staging space: the goal-word and score-table regions are dead by now (the first KiB holds the
+        // per-board view parameters)
+        constexpr int STAGE_OFF = 1024, STAGE_BYTES = WAVES * 64 * 4 * C;
+        constexpr bool STAGED = Gm::GSH_BYTES + 4096 >= STAGE_OFF + STAGE_BYTES;
+        u32 *stage = (u32 *)(const_cast<unsigned char *>(smem) + Gm::OFF_GSH + STAGE_OFF) + (tid >> 6) * 64 * C;
         u32 *dst = (u32 *)(env.obs + (size_t)e0b * nv * C);      // e0b is a multiple of 8: dword aligned
         const int ngroup = ncell / 4;
         constexpr int STEP = 4 * 64 * WAVES - 4;              // after the 4 next() calls of a group
         const int qy = STEP / vw, qx = STEP - qy * vw;
         cu.init(4 * tid, nv, vw, inv_nv, inv_vw);
-        for (int u = tid; u < ngroup; u += 64 * WAVES, cu.advance(STEP, qy, qx, nv, vw, env.view_h)) {
+        // (whole waves iterate together -- the staged write-back below is a wave-wide job -- and lanes
+        //  past the last group just skip the gather)
+        for (int u = tid; u - (tid & 63) < ngroup; u += 64 * WAVES, cu.advance(STEP, qy, qx, nv, vw, env.view_h)) {
             u32 pad[4 * P];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const u32 word = obs_fetch<H, W>(env, smem, cu, n_exits);
+                const u32 word = u < ngroup ? obs_fetch<H, W>(env, smem, cu, n_exits) : 0u;
 #pragma unroll
                 for (int g = 0; g < P; ++g) pad[q * P + g] = obs_bytes<C>(env, word, g);
                 cu.next(nv, vw);
@@ -1037,13 +1045,37 @@ __device__ __forceinline__ void write_obs_block(const sl_env_batch &env, const u
                 static_assert(Sel::ok(), "obs packing needs at most two source dwords per output dword");
                 out[j] = __builtin_amdgcn_perm(pad[Sel::second(j)], pad[Sel::first(j)], Sel::selector(j));
             }
-            u32 *o = dst + (size_t)u * C;
-            int j = 0;
+            if (!STAGED && u >= ngroup) continue;
+            if constexpr (STAGED) {
+                // a thread's 4C bytes are contiguous, but a store instruction would write 16 of every 4C bytes
+                // of the wave's run (partial lines from four instructions).  Each wave parks its 64 x 4C bytes
+                // in LDS and writes them back lane-linear: every store instruction covers 1 KiB contiguously.
+                u32 *mine = stage + (tid & 63) * C;
 #pragma unroll
-            for (; j + 4 <= C; j += 4) *(u32x4_a4 *)(o + j) = u32x4_a4{out[j], out[j + 1], out[j + 2], out[j + 3]};
-            if constexpr (C % 4 == 3) *(u32x3_a4 *)(o + C - 3) = u32x3_a4{out[C - 3], out[C - 2], out[C - 1]};
-            if constexpr (C % 4 == 2) *(u32x2_a4 *)(o + C - 2) = u32x2_a4{out[C - 2], out[C - 1]};
-            if constexpr (C % 4 == 1) o[C - 1] = out[C - 1];
+                for (int j = 0; j < C; ++j) mine[j] = out[j];
+                wave_sync();
+                const int first = u - (tid & 63);                       // first group of this wave's run
+                const int run_dwords = min(64, ngroup - first) * C;     // dwords the wave really produced
+                u32 *o = dst + (size_t)first * C;
+#pragma unroll
+                for (int j = 0; j < (64 * C + 255) / 256; ++j) {
+                    const int d = 4 * ((tid & 63) + 64 * j);
+                    if (d + 4 <= run_dwords) {
+                        *(u32x4_a4 *)(o + d) = *(const u32x4 *)(stage + d);
+                    } else {
+                        for (int q = d; q < run_dwords; ++q) o[q] = stage[q];
+                    }
+                }
+                wave_sync();
+            } else {
+                u32 *o = dst + (size_t)u * C;
+                int j = 0;
+#pragma unroll
+                for (; j + 4 <= C; j += 4) *(u32x4_a4 *)(o + j) = u32x4_a4{out[j], out[j + 1], out[j + 2], out[j + 3]};
+                if constexpr (C % 4 == 3) *(u32x3_a4 *)(o + C - 3) = u32x3_a4{out[C - 3], out[C - 2], out[C - 1]};
+                if constexpr (C % 4 == 2) *(u32x2_a4 *)(o + C - 2) = u32x2_a4{out[C - 2], out[C - 1]};
+                if constexpr (C % 4 == 1) o[C - 1] = out[C - 1];
+            }
         }
         for (int c = 4 * ngroup + tid; c < ncell; c += 64 * WAVES) {      // tail workgroup leftovers
             cu.init(c, nv, vw, inv_nv, inv_vw);
