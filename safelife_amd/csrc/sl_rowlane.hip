@@ -934,7 +934,8 @@ __device__ __forceinline__ u32 obs_fetch(const sl_env_batch &env, const unsigned
     const int *pp = (const int *)(smem + Gm::OFF_GSH) + cu.bq * OBS_PAR_INTS;
     const u16 *b16 = (const u16 *)(smem + Gm::OFF_BOARD + Gm::PAD) + cu.bq * Gm::HW;
     const u16 *g16 = (const u16 *)(smem + Gm::OFF_GOALS + Gm::PAD) + cu.bq * Gm::HW;
-    const int sy = pos_mod(pp[0] - vh / 2 + cu.vy, H), sx = pos_mod(pp[1] - vw / 2 + cu.vx, W);
+    // pp[0], pp[1]: the board cell under the view's top-left corner, already reduced to [0,H) x [0,W)
+    const int sy = (int)((unsigned)(pp[0] + cu.vy) % (unsigned)H), sx = (int)((unsigned)(pp[1] + cu.vx) % (unsigned)W);
     int cell = sy * W + sx;
     for (int k = 0; k < n_exits; ++k)             // later exits overwrite earlier ones, as numpy does
         if (pp[2 + k] == cu.v) cell = pp[2 + OBS_MAX_EXITS + k];
@@ -1434,8 +1435,8 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
             int *pp = par + gb * OBS_PAR_INTS;
             const int y0 = ly >= 0 ? ly : 0, x0 = ly >= 0 ? lx : 0;
             const int vh = env.view_h, vw = env.view_w;
-            pp[0] = y0;
-            pp[1] = x0;
+            pp[0] = pos_mod(y0 - vh / 2, H);
+            pp[1] = pos_mod(x0 - vw / 2, W);
             for (int k = 0; k < OBS_MAX_EXITS; ++k) {
                 int tv = -1, xk = -1;
                 if (k < E) xk = k == 0 ? exit0 : exits[k];
