@@ -1019,11 +1019,15 @@ __device__ __forceinline__ void write_obs_block(const sl_env_batch &env, const u
         using Sel = ObsSel<C>;
         using Gm = Geom<H, W>;
         constexpr int P = Sel::P;
-        // staging space: the goal-word and score-table regions are dead by now (the first KiB holds the
+        // staging space: the goal-word and score-table regions are dead by now (their first bytes hold the
         // per-board view parameters)
-        constexpr int STAGE_OFF = 1024, STAGE_BYTES = WAVES * 64 * 4 * C;
-        constexpr bool STAGED = Gm::GSH_BYTES + 4096 >= STAGE_OFF + STAGE_BYTES;
-        u32 *stage = (u32 *)(const_cast<unsigned char *>(smem) + Gm::OFF_GSH + STAGE_OFF) + (tid >> 6) * 64 * C;
+        constexpr int STAGE_OFF = (Gm::NB * OBS_PAR_INTS * 4 + 15) & ~15;     // behind the per-board view parameters
+        constexpr int STAGE_ROOM = Gm::GSH_BYTES + 4096 - STAGE_OFF;
+        // when a whole wave's run does not fit, it goes out in SUB rounds of LPS lanes each
+        constexpr int SUB = WAVES * 64 * 4 * C <= STAGE_ROOM ? 1 : (WAVES * 32 * 4 * C <= STAGE_ROOM ? 2 : 0);
+        constexpr bool STAGED = SUB != 0;
+        constexpr int LPS = STAGED ? 64 / SUB : 64;
+        u32 *stage = (u32 *)(const_cast<unsigned char *>(smem) + Gm::OFF_GSH + STAGE_OFF) + (tid >> 6) * LPS * C;
         u32 *dst = (u32 *)(env.obs + (size_t)e0b * nv * C);      // e0b is a multiple of 8: dword aligned
         const int ngroup = ncell / 4;
         constexpr int STEP = 4 * 64 * WAVES - 4;              // after the 4 next() calls of a group
@@ -1051,23 +1055,29 @@ __device__ __forceinline__ void write_obs_block(const sl_env_batch &env, const u
                 // a thread's 4C bytes are contiguous, but a store instruction would write 16 of every 4C bytes
                 // of the wave's run (partial lines from four instructions).  Each wave parks its 64 x 4C bytes
                 // in LDS and writes them back lane-linear: every store instruction covers 1 KiB contiguously.
-                u32 *mine = stage + (tid & 63) * C;
+                const int ln = tid & 63;
 #pragma unroll
-                for (int j = 0; j < C; ++j) mine[j] = out[j];
-                wave_sync();
-                const int first = u - (tid & 63);                       // first group of this wave's run
-                const int run_dwords = min(64, ngroup - first) * C;     // dwords the wave really produced
-                u32 *o = dst + (size_t)first * C;
+                for (int sub = 0; sub < SUB; ++sub) {
+                    if (ln / LPS == sub) {
+                        u32 *mine = stage + (ln % LPS) * C;
 #pragma unroll
-                for (int j = 0; j < (64 * C + 255) / 256; ++j) {
-                    const int d = 4 * ((tid & 63) + 64 * j);
-                    if (d + 4 <= run_dwords) {
-                        *(u32x4_a4 *)(o + d) = *(const u32x4 *)(stage + d);
-                    } else {
-                        for (int q = d; q < run_dwords; ++q) o[q] = stage[q];
+                        for (int j = 0; j < C; ++j) mine[j] = out[j];
                     }
+                    wave_sync();
+                    const int first = u - ln + sub * LPS;                              // first group of this round
+                    const int run_dwords = max(0, min(LPS, ngroup - first)) * C;       // dwords really produced
+                    u32 *o = dst + (size_t)first * C;
+#pragma unroll
+                    for (int j = 0; j < (LPS * C + 255) / 256; ++j) {
+                        const int d = 4 * (ln + 64 * j);
+                        if (d + 4 <= run_dwords) {
+                            *(u32x4_a4 *)(o + d) = *(const u32x4 *)(stage + d);
+                        } else {
+                            for (int q = d; q < run_dwords; ++q) o[q] = stage[q];
+                        }
+                    }
+                    wave_sync();
                 }
-                wave_sync();
             } else {
                 u32 *o = dst + (size_t)u * C;
                 int j = 0;
