@@ -1002,6 +1002,29 @@ __device__ __forceinline__ void write_obs_block(const sl_env_batch &env, const u
     const int ncell = nbb * nv;
     const int n_exits = min(env.E, OBS_MAX_EXITS);
     ObsCursor cu;
+    if (C == 0 && env.n_channels == 0) {
+        // raw uint32 view: four consecutive cells per thread, one aligned 16-byte store each (the view
+        // of a workgroup's first board starts on a 32-byte boundary: e0b is a multiple of 8)
+        u32x4 *dst = (u32x4 *)((u32 *)env.obs + (size_t)e0b * nv);
+        const int ngroup = ncell / 4;
+        constexpr int STEP = 4 * 64 * WAVES - 4;
+        const int qy = STEP / vw, qx = STEP - qy * vw;
+        cu.init(4 * tid, nv, vw, inv_nv, inv_vw);
+        for (int u = tid; u < ngroup; u += 64 * WAVES, cu.advance(STEP, qy, qx, nv, vw, env.view_h)) {
+            u32 w4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                w4[q] = obs_fetch<H, W>(env, smem, cu, n_exits);
+                cu.next(nv, vw);
+            }
+            dst[u] = u32x4{w4[0], w4[1], w4[2], w4[3]};
+        }
+        for (int c = 4 * ngroup + tid; c < ncell; c += 64 * WAVES) {      // tail workgroup leftovers
+            cu.init(c, nv, vw, inv_nv, inv_vw);
+            ((u32 *)env.obs)[(size_t)e0b * nv + c] = obs_fetch<H, W>(env, smem, cu, n_exits);
+        }
+        return;
+    }
     if constexpr (C == 0) {
         const int nc = env.n_channels;
         const int qy = (64 * WAVES) / vw, qx = (64 * WAVES) - qy * vw;
