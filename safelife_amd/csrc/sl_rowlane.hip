@@ -925,20 +925,69 @@ struct ObsCursor {
     }
 };
 
+// The cursor plus the board cell it looks at, kept incrementally: per-board view parameters (origin,
+// first exit) are read from LDS when the board changes, the source cell is reduced modulo the board
+// once per jump and then only stepped.
+template <int H, int W>
+struct ObsSource : ObsCursor {
+    int oy, ox, tv0, xk0;       // board cell under the view's top-left corner; first exit: view cell, board cell
+    int sy, sx;                 // board cell under the cursor
+    __device__ __forceinline__ void load(const unsigned char *smem) {
+        const int *pp = (const int *)(smem + Geom<H, W>::OFF_GSH) + bq * OBS_PAR_INTS;
+        oy = pp[0];
+        ox = pp[1];
+        tv0 = pp[2];
+        xk0 = pp[2 + OBS_MAX_EXITS];
+    }
+    __device__ __forceinline__ void locate() {
+        sy = (int)((unsigned)(oy + vy) % (unsigned)H);
+        sx = (int)((unsigned)(ox + vx) % (unsigned)W);
+    }
+    __device__ __forceinline__ void start(const unsigned char *smem, int c, int nv, int vw, float inv_nv, float inv_vw) {
+        init(c, nv, vw, inv_nv, inv_vw);
+        load(smem);
+        locate();
+    }
+    __device__ __forceinline__ void jump(const unsigned char *smem, int step, int qy, int qx, int nv, int vw, int vh) {
+        const int b0 = bq;
+        advance(step, qy, qx, nv, vw, vh);
+        if (bq != b0) load(smem);
+        locate();
+    }
+    __device__ __forceinline__ void step(const unsigned char *smem, int nv, int vw) {
+        ++v;
+        ++vx;
+        sx = sx + 1 == W ? 0 : sx + 1;
+        if (vx == vw) {
+            vx = 0;
+            ++vy;
+            sx = ox;
+            sy = sy + 1 == H ? 0 : sy + 1;
+        }
+        if (v == nv) {
+            v = vy = vx = 0;
+            ++bq;
+            load(smem);
+            sy = oy;
+            sx = ox;
+        }
+    }
+};
+
 // Observation word (board | goal colour << 16) at a cursor position.
 template <int H, int W>
-__device__ __forceinline__ u32 obs_fetch(const sl_env_batch &env, const unsigned char *smem, const ObsCursor &cu,
+__device__ __forceinline__ u32 obs_fetch(const sl_env_batch &env, const unsigned char *smem, const ObsSource<H, W> &cu,
                                          int n_exits) {
     using Gm = Geom<H, W>;
-    const int vw = env.view_w, vh = env.view_h;
-    const int *pp = (const int *)(smem + Gm::OFF_GSH) + cu.bq * OBS_PAR_INTS;
     const u16 *b16 = (const u16 *)(smem + Gm::OFF_BOARD + Gm::PAD) + cu.bq * Gm::HW;
     const u16 *g16 = (const u16 *)(smem + Gm::OFF_GOALS + Gm::PAD) + cu.bq * Gm::HW;
-    // pp[0], pp[1]: the board cell under the view's top-left corner, already reduced to [0,H) x [0,W)
-    const int sy = (int)((unsigned)(pp[0] + cu.vy) % (unsigned)H), sx = (int)((unsigned)(pp[1] + cu.vx) % (unsigned)W);
-    int cell = sy * W + sx;
-    for (int k = 0; k < n_exits; ++k)             // later exits overwrite earlier ones, as numpy does
-        if (pp[2 + k] == cu.v) cell = pp[2 + OBS_MAX_EXITS + k];
+    int cell = __mul24(cu.sy, W) + cu.sx;
+    if (n_exits > 0 && cu.tv0 == cu.v) cell = cu.xk0;
+    if (n_exits > 1) {                            // later exits overwrite earlier ones, as numpy does
+        const int *pp = (const int *)(smem + Gm::OFF_GSH) + cu.bq * OBS_PAR_INTS;
+        for (int k = 1; k < n_exits; ++k)
+            if (pp[2 + k] == cu.v) cell = pp[2 + OBS_MAX_EXITS + k];
+    }
     cell = Gm::flat(cell);
     u32 g = g16[cell] & COLORS;
     if (env.remove_white_goals && g == COLORS) g = 0;
@@ -1001,7 +1050,7 @@ __device__ __forceinline__ void write_obs_block(const sl_env_batch &env, const u
     const float inv_nv = 1.0f / (float)nv, inv_vw = 1.0f / (float)vw;
     const int ncell = nbb * nv;
     const int n_exits = min(env.E, OBS_MAX_EXITS);
-    ObsCursor cu;
+    ObsSource<H, W> cu;
     if (C == 0 && env.n_channels == 0) {
         // raw uint32 view: four consecutive cells per thread, one aligned 16-byte store each (the view
         // of a workgroup's first board starts on a 32-byte boundary: e0b is a multiple of 8)
@@ -1009,18 +1058,18 @@ __device__ __forceinline__ void write_obs_block(const sl_env_batch &env, const u
         const int ngroup = ncell / 4;
         constexpr int STEP = 4 * 64 * WAVES - 4;
         const int qy = STEP / vw, qx = STEP - qy * vw;
-        cu.init(4 * tid, nv, vw, inv_nv, inv_vw);
-        for (int u = tid; u < ngroup; u += 64 * WAVES, cu.advance(STEP, qy, qx, nv, vw, env.view_h)) {
+        cu.start(smem, 4 * tid, nv, vw, inv_nv, inv_vw);
+        for (int u = tid; u < ngroup; u += 64 * WAVES, cu.jump(smem, STEP, qy, qx, nv, vw, env.view_h)) {
             u32 w4[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 w4[q] = obs_fetch<H, W>(env, smem, cu, n_exits);
-                cu.next(nv, vw);
+                cu.step(smem, nv, vw);
             }
             dst[u] = u32x4{w4[0], w4[1], w4[2], w4[3]};
         }
         for (int c = 4 * ngroup + tid; c < ncell; c += 64 * WAVES) {      // tail workgroup leftovers
-            cu.init(c, nv, vw, inv_nv, inv_vw);
+            cu.start(smem, c, nv, vw, inv_nv, inv_vw);
             ((u32 *)env.obs)[(size_t)e0b * nv + c] = obs_fetch<H, W>(env, smem, cu, n_exits);
         }
         return;
@@ -1028,8 +1077,8 @@ __device__ __forceinline__ void write_obs_block(const sl_env_batch &env, const u
     if constexpr (C == 0) {
         const int nc = env.n_channels;
         const int qy = (64 * WAVES) / vw, qx = (64 * WAVES) - qy * vw;
-        cu.init(tid, nv, vw, inv_nv, inv_vw);
-        for (int c = tid; c < ncell; c += 64 * WAVES, cu.advance(64 * WAVES, qy, qx, nv, vw, env.view_h)) {
+        cu.start(smem, tid, nv, vw, inv_nv, inv_vw);
+        for (int c = tid; c < ncell; c += 64 * WAVES, cu.jump(smem, 64 * WAVES, qy, qx, nv, vw, env.view_h)) {
             const u32 word = obs_fetch<H, W>(env, smem, cu, n_exits);
             if (nc == 0) {
                 ((u32 *)env.obs)[(size_t)e0b * nv + c] = word;
@@ -1055,17 +1104,17 @@ __device__ __forceinline__ void write_obs_block(const sl_env_batch &env, const u
         const int ngroup = ncell / 4;
         constexpr int STEP = 4 * 64 * WAVES - 4;              // after the 4 next() calls of a group
         const int qy = STEP / vw, qx = STEP - qy * vw;
-        cu.init(4 * tid, nv, vw, inv_nv, inv_vw);
+        cu.start(smem, 4 * tid, nv, vw, inv_nv, inv_vw);
         // (whole waves iterate together -- the staged write-back below is a wave-wide job -- and lanes
         //  past the last group just skip the gather)
-        for (int u = tid; u - (tid & 63) < ngroup; u += 64 * WAVES, cu.advance(STEP, qy, qx, nv, vw, env.view_h)) {
+        for (int u = tid; u - (tid & 63) < ngroup; u += 64 * WAVES, cu.jump(smem, STEP, qy, qx, nv, vw, env.view_h)) {
             u32 pad[4 * P];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const u32 word = u < ngroup ? obs_fetch<H, W>(env, smem, cu, n_exits) : 0u;
 #pragma unroll
                 for (int g = 0; g < P; ++g) pad[q * P + g] = obs_bytes<C>(env, word, g);
-                cu.next(nv, vw);
+                cu.step(smem, nv, vw);
             }
             u32 out[C];
 #pragma unroll
@@ -1112,7 +1161,7 @@ __device__ __forceinline__ void write_obs_block(const sl_env_batch &env, const u
             }
         }
         for (int c = 4 * ngroup + tid; c < ncell; c += 64 * WAVES) {      // tail workgroup leftovers
-            cu.init(c, nv, vw, inv_nv, inv_vw);
+            cu.start(smem, c, nv, vw, inv_nv, inv_vw);
             const u32 word = obs_fetch<H, W>(env, smem, cu, n_exits);
             uint8_t *o = env.obs + ((size_t)e0b * nv + c) * C;
             for (int k = 0; k < C; ++k) o[k] = (word >> env.channels[k]) & 1u;
