@@ -235,6 +235,8 @@ def main():
             us = e0.elapsed_time(e1) / n * 1e3
             extra[tag + "_us_per_step"] = us
             extra[tag + "_env_steps_per_s"] = B / (us * 1e-6)
+            obs_b = H * Wd * (len(chans) if chans else 4)           # step bytes + observation bytes
+            extra[tag + "_roofline_frac"] = (3 * H * Wd * 2 + obs_b) * B / (us * 1e-6) / (HBM_PEAK_GBS * 1e9)
             del env2
 
         def time_steps(env3, n_envs, n=200):
