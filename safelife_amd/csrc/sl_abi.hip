@@ -271,3 +271,51 @@ int slhip_obs_to_policy(const uint32_t *view, int B, int vh, int vw, const int32
 }
 
 }  // extern "C"
+
+// ---- experiment (not part of the ABI yet): n slices of one batch, each on its own stream -------------
+#include <chrono>
+#include <thread>
+#include <atomic>
+extern "C" int slhip_exp_pipeline(const sl_env_batch *envs, int n, const int32_t *const *actions, int K, int stride,
+                                  int threaded, double *us_out) {
+    const sl::Jump *jump;
+    int rc;
+    if ((rc = jump_table(&jump))) return rc;
+    std::vector<hipStream_t> streams(n);
+    for (int i = 0; i < n; ++i)
+        if (hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking) != hipSuccess) return fail(SL_E_HIP, "stream");
+    auto run_slice = [&](int i, int k0, int k1) {
+        for (int t = k0; t < k1; ++t)
+            sl::launch_env_rollout_rowlane(envs[i], actions[i] + (size_t)t * stride, 1, nullptr, nullptr, jump, streams[i]);
+    };
+    // warm-up
+    for (int i = 0; i < n; ++i) run_slice(i, 0, 5);
+    (void)hipDeviceSynchronize();
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const auto t0 = std::chrono::steady_clock::now();
+    if (threaded & 1) {
+        std::vector<std::thread> th;
+        for (int i = 0; i < n; ++i)
+            th.emplace_back([&, i] {
+                (void)hipSetDevice(dev);
+                run_slice(i, 5, 5 + K);
+            });
+        for (auto &t : th) t.join();
+    } else {
+        for (int t = 5; t < 5 + K; ++t)
+            for (int i = 0; i < n; ++i)
+                sl::launch_env_rollout_rowlane(envs[i], actions[i] + (size_t)t * stride, 1, nullptr, nullptr, jump, streams[i]);
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    if (threaded & 2) {                       // spin on hipStreamQuery instead of a blocking wait
+        for (int i = 0; i < n; ++i)
+            while (hipStreamQuery(streams[i]) == hipErrorNotReady) {}
+    }
+    for (int i = 0; i < n; ++i) (void)hipStreamSynchronize(streams[i]);
+    const auto t2 = std::chrono::steady_clock::now();
+    us_out[0] = std::chrono::duration<double, std::micro>(t1 - t0).count();     // host enqueue time
+    us_out[1] = std::chrono::duration<double, std::micro>(t2 - t0).count();     // until everything finished
+    for (int i = 0; i < n; ++i) (void)hipStreamDestroy(streams[i]);
+    return hipGetLastError() == hipSuccess ? SL_OK : fail(SL_E_HIP, "pipeline");
+}

@@ -29,6 +29,14 @@
 #include "sl_device.h"
 #include "sl_kernels.h"
 
+// A/B knobs of the span moves (cache policy of the LDS DMA loads, flavour of the span stores)
+#ifndef SL_LOAD_AUX
+#define SL_LOAD_AUX 0
+#endif
+#ifndef SL_STORE
+#define SL_STORE 0
+#endif
+
 namespace sl {
 namespace rl {
 
@@ -661,7 +669,7 @@ __device__ __forceinline__ void dma_to_lds(const unsigned char *__restrict__ src
         const int s = c * 64 + lane;
         if (s < nv)
             __builtin_amdgcn_global_load_lds((glds_src_t)(src + (SWZ ? swz_chunk(s) : s) * 16),
-                                             (glds_dst_t)(dst + c * 1024), 16, 0, 0);
+                                             (glds_dst_t)(dst + c * 1024), 16, 0, SL_LOAD_AUX);
     }
 }
 
@@ -672,6 +680,18 @@ __device__ __forceinline__ void load_span(const u16 *__restrict__ src, unsigned 
     dma_to_lds<Gm::SPAN, Gm::SWZ>((const unsigned char *)src, region + Gm::PAD, bytes, tid & 63, tid >> 6);
     const int nv = bytes >> 4, rem = (bytes & 15) >> 1;          // leftover cells: tail workgroup only
     if (tid < rem) ((u16 *)(region + Gm::PAD))[nv * 8 + tid] = src[nv * 8 + tid];
+}
+
+__device__ __forceinline__ void store16(u32x4 *p, u32x4 v) {
+#if SL_STORE == 1
+    __builtin_nontemporal_store(v, p);
+#elif SL_STORE == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#elif SL_STORE == 3
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+#else
+    *p = v;
+#endif
 }
 
 template <int H, int W>
@@ -685,7 +705,7 @@ __device__ __forceinline__ void store_span(u16 *__restrict__ dst, const unsigned
 #pragma unroll
     for (int i = 0; i < NVI; ++i) {
         const int slot = tid + 64 * WAVES * i;
-        if (slot < nv) d[Gm::SWZ ? swz_chunk(slot) : slot] = s[slot];
+        if (slot < nv) store16(d + (Gm::SWZ ? swz_chunk(slot) : slot), s[slot]);
     }
     const int rem = (bytes & 15) >> 1;
     if (tid < rem) dst[nv * 8 + tid] = ((const u16 *)s)[nv * 8 + tid];
