@@ -129,6 +129,9 @@ def main():
     ap.add_argument("--obs", type=int, default=0,
                     help="1: also write the 25x25x15 uint8 observation; 2: the raw 25x25 uint32 view")
     ap.add_argument("--gather-every", type=int, default=32)
+    ap.add_argument("--slices", type=int, default=2,
+                    help="slices of the per-GPU batch, each stepped by its own launch on its own stream "
+                         "(1 = one launch per step on one stream)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-steps", type=int, default=1001)
     ap.add_argument("--rollout", type=int, default=32,
@@ -158,18 +161,24 @@ def main():
     H, Wd = pool.shape
     env = SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25),
                             output_channels=None if args.obs == 2 else TRAIN_CHANNELS,
-                            auto_reset=True, level_stride=1, env_offset=rank * B, with_obs=bool(args.obs))
+                            auto_reset=True, level_stride=1, env_offset=rank * B, with_obs=bool(args.obs),
+                            slices=args.slices)
     env.reset()
     gen = torch.Generator(device=dev)
     gen.manual_seed(7 + rank)
     actions = torch.randint(0, 9, (K + W, B), generator=gen, device=dev, dtype=torch.int32)
     gather = RewardGather(env, every=args.gather_every, world=world, rank=rank)
 
+    # one step = every env stepped once = one launch per slice, each on the slice's own stream; the action
+    # tensor is complete before the loop starts, so nothing has to be fenced per step (step_async)
+    act_ptr = [actions[t].data_ptr() for t in range(K + W)]
+    before, after, step = gather.before_step, gather.after_step, env.step_async
+
     def run(t0, n):
         for t in range(t0, t0 + n):
-            gather.before_step(t)
-            env.step(actions[t])
-            gather.after_step(t)
+            before(t)
+            step(act_ptr[t])
+            after(t)
 
     run(0, W)
     gather.flush()
@@ -177,18 +186,25 @@ def main():
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # HIP events on the streams the kernels are launched on (one pair per slice stream)
+    streams = env._slice_streams or [torch.cuda.current_stream()]
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in streams]
     t_start = time.perf_counter()
-    ev0.record()
+    for st, (e0, _) in zip(streams, evs):
+        e0.record(st)
     run(W, K)
-    ev1.record()
+    t_enqueued = time.perf_counter()
+    for st, (_, e1) in zip(streams, evs):
+        e1.record(st)
     gather.flush()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
-    kernel_ms = ev0.elapsed_time(ev1) / K          # average launch-to-launch duration on the stream
+    # device time per step: every slice stream runs its K launches back to back, all streams concurrently
+    slice_ms = [e0.elapsed_time(e1) / K for e0, e1 in evs]
+    kernel_ms = max(slice_ms)
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -334,11 +350,19 @@ def main():
                            {0: ", no observation", 1: " + 25x25x15 u8 obs", 2: " + 25x25 u32 view"}[args.obs]),
                        "envs_per_gpu": B, "global_envs": world * B, "board": [H, Wd],
                        "level_pool": len(pool), "parallelism": "envs sharded %d-way, reward/done gathered "
-                                                               "to rank 0 every %d steps" % (world, args.gather_every)},
+                                                               "to rank 0 every %d steps; %d slice(s) per GPU, one launch "
+                                                               "and one stream each" % (world, args.gather_every, env.slices)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "fused env step", "bytes_per_env_step": bytes_per_step,
-                         "launch_ms": kernel_ms},
+                         # device time of one step (HIP events): all slice launches of a step run concurrently,
+                         # so a step costs the slowest slice stream's launch-to-launch time
+                         "launch_ms": kernel_ms, "launches_per_step": len(slice_ms),
+                         "slice_launch_ms": slice_ms,
+                         "host_enqueue_ms_per_step": (t_enqueued - t_start) / K * 1e3,
+                         # the same fraction from the wall clock of the timed region (ms_per_step: includes the
+                         # first launch from an idle GPU and the final synchronize)
+                         "frac_wall": bytes_per_step * B / (elapsed / K) / 1e9 / HBM_PEAK_GBS},
         }
         if extra:
             out["extra"] = extra

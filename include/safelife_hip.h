@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SL_ABI_VERSION 2
+#define SL_ABI_VERSION 3
 #define SL_MAX_CELLS 16384        /* H*W limit of one board */
 #define SL_MAX_CHANNELS 32
 
@@ -233,6 +233,17 @@ int slhip_env_step(const sl_env_batch *env, const int32_t *actions, void *stream
  * env->reward/done are kept).  Observations are produced for the final state only. */
 int slhip_env_rollout(const sl_env_batch *env, const int32_t *actions, int T,
                       float *reward_t, uint8_t *done_t, void *stream);
+
+/* One step for every env, issued as n_slices launches: slice i = envs [bounds[i], bounds[i+1]) on
+ * streams[i] (bounds: HOST int32 [n_slices+1], bounds[0] = 0, bounds[n_slices] = B; streams: HOST array of
+ * hipStream_t).  Envs are independent, so the slices need no ordering among themselves: on distinct
+ * streams the load / compute / store phases and the launch boundaries of one slice overlap those of the
+ * others, step after step (a single launch per step leaves the chip idle at both ends of every launch).
+ * The caller orders each stream against whoever produces `actions` and consumes the outputs.
+ * actions: int32 [B].  Slice bounds should be multiples of 64
+ * envs so that every slice keeps the 16-byte alignment the row kernels' DMA needs. */
+int slhip_env_step_slices(const sl_env_batch *env, int n_slices, const int32_t *bounds, const int32_t *actions,
+                          void *const *streams);
 
 /* SafeLifeEnv.get_obs() for the current state. */
 int slhip_env_obs(const sl_env_batch *env, void *stream);

@@ -20,7 +20,8 @@ SL_E_SHAPE, SL_E_ARG, SL_E_HIP, SL_E_UNSUPPORTED = -1, -2, -3, -4
 EXPORTS = (
     "slhip_abi_version", "slhip_last_error", "slhip_device_count",
     "slhip_advance_board", "slhip_advance_board_each", "slhip_life_occupancy", "slhip_alive_counts", "slhip_execute_actions",
-    "slhip_env_prepare", "slhip_env_reset", "slhip_env_step", "slhip_env_rollout", "slhip_env_obs",
+    "slhip_env_prepare", "slhip_env_reset", "slhip_env_step", "slhip_env_step_slices", "slhip_env_rollout",
+    "slhip_env_obs",
     "slhip_obs_to_policy",
 )
 
@@ -42,6 +43,7 @@ ENV_SCALARS_HEAD = ("B", "H", "W", "E", "time_limit", "exit_points", "n_tables",
 ENV_STATE_PTRS = ("board", "goals", "exit_locs", "rng", "scalars", "points_table")
 ENV_POOL_PTRS = ("pool_board", "pool_goals", "pool_exit_locs", "pool_rng", "pool_scalars")
 ENV_OUT_PTRS = ("out", "obs", "score_lut")
+SL_ABI_VERSION = 3
 
 #: int32 column of each field inside `struct sl_env_scalars` (64 bytes = 16 columns)
 SCALAR_COLS = {"agent_row": 0, "agent_col": 1, "num_steps": 2, "old_value": 3, "required_points": 4,
@@ -113,11 +115,15 @@ def lib():
         L.slhip_env_prepare.argtypes = [C.POINTER(EnvBatch), _p]
         L.slhip_env_reset.argtypes = [C.POINTER(EnvBatch), _p, _p]
         L.slhip_env_step.argtypes = [C.POINTER(EnvBatch), _p, _p]
+        L.slhip_env_step_slices.argtypes = [C.POINTER(EnvBatch), C.c_int, _p, _p, _p]
         L.slhip_env_rollout.argtypes = [C.POINTER(EnvBatch), _p, C.c_int, _p, _p, _p]
         L.slhip_env_obs.argtypes = [C.POINTER(EnvBatch), _p]
         L.slhip_obs_to_policy.argtypes = [_p, C.c_int, C.c_int, C.c_int, _p, C.c_int, _p, C.c_int, _p]
         for name in EXPORTS:
             getattr(L, name)  # AttributeError here means the .so is stale
+        if L.slhip_abi_version() != SL_ABI_VERSION:
+            raise SafeLifeHipError("%s has ABI version %d, this package needs %d: rebuild it"
+                                   % (LIB_PATH, L.slhip_abi_version(), SL_ABI_VERSION))
         _lib = L
     return _lib
 

@@ -1,6 +1,8 @@
 // sl_abi.hip -- the extern "C" boundary declared in include/safelife_hip.h: argument validation,
 // the per-device PCG64 jump table, and dispatch to the gfx950 kernels.
 #include <cstdint>
+#include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <string>
@@ -25,6 +27,7 @@ int hip_fail(hipError_t err, const char *what) {
 constexpr int kMaxDevices = 64;
 std::mutex g_jump_mutex;
 sl::Jump *g_jump[kMaxDevices] = {nullptr};
+std::atomic<const sl::Jump *> g_jump_ready[kMaxDevices];
 
 typedef unsigned __int128 u128;
 
@@ -33,6 +36,10 @@ int jump_table(const sl::Jump **out) {
     hipError_t err = hipGetDevice(&dev);
     if (err != hipSuccess) return hip_fail(err, "hipGetDevice");
     if (dev < 0 || dev >= kMaxDevices) return fail(SL_E_UNSUPPORTED, "device index out of range");
+    if (const sl::Jump *ready = g_jump_ready[dev].load(std::memory_order_acquire)) {      // (every launch comes through here)
+        *out = ready;
+        return SL_OK;
+    }
     std::lock_guard<std::mutex> lock(g_jump_mutex);
     if (!g_jump[dev]) {
         const u128 mult = (((u128)0x2360ED051FC65DA4ull) << 64) | (u128)0x4385DF649FCCF645ull;
@@ -55,6 +62,7 @@ int jump_table(const sl::Jump **out) {
             return hip_fail(err, "hipMemcpy(jump table)");
         }
         g_jump[dev] = d;
+        g_jump_ready[dev].store(d, std::memory_order_release);
     }
     *out = g_jump[dev];
     return SL_OK;
@@ -104,6 +112,29 @@ int check_env(const sl_env_batch *env) {
         }
     }
     return SL_OK;
+}
+
+// A contiguous sub-range of the batch as a batch of its own (pointer arithmetic only; the level pool, tables
+// and workspaces are shared): what the size-generic kernels take for a slice.
+sl_env_batch env_slice(const sl_env_batch &env, int e0, int n) {
+    sl_env_batch s = env;
+    const size_t hw = (size_t)env.H * env.W;
+    s.B = n;
+    s.board = env.board + (size_t)e0 * hw;
+    s.goals = env.goals + (size_t)e0 * hw;
+    s.exit_locs = env.exit_locs + (size_t)e0 * env.E;
+    s.rng = env.rng + e0;
+    s.scalars = env.scalars + e0;
+    s.out = env.out + e0;
+    if (env.obs) {
+        const size_t cell = env.n_channels > 0 ? (size_t)env.n_channels : 4;     // uint8 channels, or the raw uint32 view
+        s.obs = env.obs + (size_t)e0 * env.view_h * env.view_w * cell;
+    }
+    if (env.wrap.flags) {
+        s.wrap.state = env.wrap.state + e0;
+        s.wrap.shaped_reward = env.wrap.shaped_reward + e0;
+    }
+    return s;
 }
 
 }  // namespace
@@ -217,6 +248,49 @@ int slhip_env_reset(const sl_env_batch *env, const uint8_t *mask, void *stream) 
     return err == hipSuccess ? SL_OK : hip_fail(err, "env_reset launch");
 }
 
+// Row kernels or size-generic kernels for this batch?  (The generic family is a complete, slower HIP
+// implementation: one workgroup per board.  Falling to it is legitimate but ~5x slower at C3, so the first
+// time it happens for a reason other than an explicit request the library says so once on stderr.)
+static bool use_rowlane(const sl_env_batch *env, int e_first) {
+    if (force_generic()) return false;
+    const char *why = nullptr;
+    const size_t slice_bytes = (size_t)e_first * env->H * env->W * sizeof(uint16_t);
+    if (!sl::rowlane_supports(env->H, env->W)) why = "no row-lane kernel for this board shape";
+    else if (!env->score_lut) why = "points_table entries outside int8";
+    else if ((((uintptr_t)env->board | (uintptr_t)env->goals | (uintptr_t)env->rng | (uintptr_t)env->score_lut) & 15) ||
+             (slice_bytes & 15))
+        why = "board / goals / rng / score_lut (or the slice start) not 16-byte aligned";
+    else if (env->E > 8) why = "more than 8 exit slots";
+    else if (env->wrap.flags && (((env->wrap.flags & SL_WRAP_SIDE_EFFECT) && !env->wrap.pool_baseline) ||
+                                 (((uintptr_t)env->wrap.state | (uintptr_t)env->wrap.move_table) & 15)))
+        why = "wrapper workspace missing or unaligned";
+    if (!why) return true;
+    static std::atomic<bool> warned{false};
+    if (!warned.exchange(true))
+        fprintf(stderr, "libsafelife_hip: %dx%d batch runs on the size-generic kernels (%s)\n", env->H, env->W, why);
+    return false;
+}
+
+// One launch over envs [e_first, e_first + e_count).  actions / reward_t / done_t are indexed
+// [t * tstride + (env index in the whole batch)].
+static int rollout_range(const sl_env_batch *env, int e_first, int e_count, const int32_t *actions, int T, int tstride,
+                         float *reward_t, uint8_t *done_t, void *stream) {
+    const sl::Jump *jump;
+    int rc;
+    if ((rc = jump_table(&jump))) return rc;
+    hipError_t err;
+    if (use_rowlane(env, e_first)) {
+        err = sl::launch_env_rollout_rowlane(*env, e_first, e_count, actions, T, tstride, reward_t, done_t, jump,
+                                             (hipStream_t)stream);
+    } else {
+        if (T > 1 && e_count != env->B) return fail(SL_E_UNSUPPORTED, "T-step launches of a slice need the row kernels");
+        const sl_env_batch s = env_slice(*env, e_first, e_count);
+        err = sl::launch_env_rollout_generic(s, actions + e_first, T, reward_t ? reward_t + e_first : nullptr,
+                                             done_t ? done_t + e_first : nullptr, jump, (hipStream_t)stream);
+    }
+    return err == hipSuccess ? SL_OK : hip_fail(err, "env_step launch");
+}
+
 int slhip_env_rollout(const sl_env_batch *env, const int32_t *actions, int T, float *reward_t,
                       uint8_t *done_t, void *stream) {
     int rc = check_env(env);
@@ -224,26 +298,27 @@ int slhip_env_rollout(const sl_env_batch *env, const int32_t *actions, int T, fl
     if (!actions) return fail(SL_E_ARG, "null actions");
     if (T < 0) return fail(SL_E_ARG, "negative T");
     if (env->B == 0 || T == 0) return SL_OK;
-    const sl::Jump *jump;
-    if ((rc = jump_table(&jump))) return rc;
-    const bool aligned = (((uintptr_t)env->board | (uintptr_t)env->goals | (uintptr_t)env->rng |
-                           (uintptr_t)env->score_lut) & 15) == 0;       // sources of the 16-byte LDS DMA
-    // the row kernels take the wrapper math when its workspace is there (side-effect baseline)
-    const bool wrap_ok =
-        !env->wrap.flags ||
-        ((!(env->wrap.flags & SL_WRAP_SIDE_EFFECT) || env->wrap.pool_baseline) &&
-         (((uintptr_t)env->wrap.state | (uintptr_t)env->wrap.move_table) & 15) == 0);
-    hipError_t err = (sl::rowlane_supports(env->H, env->W) && env->score_lut && aligned && env->E <= 8 &&
-                      wrap_ok && !force_generic())
-                         ? sl::launch_env_rollout_rowlane(*env, actions, T, reward_t, done_t, jump,
-                                                          (hipStream_t)stream)
-                         : sl::launch_env_rollout_generic(*env, actions, T, reward_t, done_t, jump,
-                                                          (hipStream_t)stream);
-    return err == hipSuccess ? SL_OK : hip_fail(err, "env_step launch");
+    return rollout_range(env, 0, env->B, actions, T, env->B, reward_t, done_t, stream);
 }
 
 int slhip_env_step(const sl_env_batch *env, const int32_t *actions, void *stream) {
     return slhip_env_rollout(env, actions, 1, nullptr, nullptr, stream);
+}
+
+int slhip_env_step_slices(const sl_env_batch *env, int n_slices, const int32_t *bounds, const int32_t *actions,
+                          void *const *streams) {
+    int rc = check_env(env);
+    if (rc) return rc;
+    if (n_slices < 1 || !bounds || !streams || !actions) return fail(SL_E_ARG, "bad slice arguments");
+    if (bounds[0] != 0 || bounds[n_slices] != env->B) return fail(SL_E_ARG, "slice bounds must run from 0 to B");
+    for (int i = 0; i < n_slices; ++i) {
+        if (bounds[i + 1] < bounds[i]) return fail(SL_E_ARG, "slice bounds must not decrease");
+        const int n = bounds[i + 1] - bounds[i];
+        if (n == 0) continue;
+        rc = rollout_range(env, bounds[i], n, actions, 1, env->B, nullptr, nullptr, streams[i]);
+        if (rc) return rc;
+    }
+    return SL_OK;
 }
 
 int slhip_env_obs(const sl_env_batch *env, void *stream) {
@@ -286,7 +361,7 @@ extern "C" int slhip_exp_pipeline(const sl_env_batch *envs, int n, const int32_t
         if (hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking) != hipSuccess) return fail(SL_E_HIP, "stream");
     auto run_slice = [&](int i, int k0, int k1) {
         for (int t = k0; t < k1; ++t)
-            sl::launch_env_rollout_rowlane(envs[i], actions[i] + (size_t)t * stride, 1, nullptr, nullptr, jump, streams[i]);
+            (void)sl::launch_env_rollout_rowlane(envs[i], 0, envs[i].B, actions[i] + (size_t)t * stride, 1, envs[i].B, nullptr, nullptr, jump, streams[i]);
     };
     // warm-up
     for (int i = 0; i < n; ++i) run_slice(i, 0, 5);
@@ -305,7 +380,7 @@ extern "C" int slhip_exp_pipeline(const sl_env_batch *envs, int n, const int32_t
     } else {
         for (int t = 5; t < 5 + K; ++t)
             for (int i = 0; i < n; ++i)
-                sl::launch_env_rollout_rowlane(envs[i], actions[i] + (size_t)t * stride, 1, nullptr, nullptr, jump, streams[i]);
+                (void)sl::launch_env_rollout_rowlane(envs[i], 0, envs[i].B, actions[i] + (size_t)t * stride, 1, envs[i].B, nullptr, nullptr, jump, streams[i]);
     }
     const auto t1 = std::chrono::steady_clock::now();
     if (threaded & 2) {                       // spin on hipStreamQuery instead of a blocking wait

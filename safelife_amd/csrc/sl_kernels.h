@@ -36,7 +36,10 @@ hipError_t launch_advance_rowlane(const u16 *in, u16 *out, int B, int H, int W, 
                                   int n_steps, sl_pcg64 *rng, const Jump *jump, hipStream_t stream);
 hipError_t launch_occupancy_rowlane(const u16 *in, int32_t *counts, int B, int H, int W, const float *spawn_prob,
                                     int n_steps, sl_pcg64 *rng, const Jump *jump, hipStream_t stream);
-hipError_t launch_env_rollout_rowlane(const sl_env_batch &env, const int32_t *actions, int T, float *reward_t,
-                                      uint8_t *done_t, const Jump *jump, hipStream_t stream);
+// envs [e_first, e_first + e_count) of the batch; actions / reward_t / done_t are indexed [t * tstride + e]
+// with the env's index in the whole batch
+hipError_t launch_env_rollout_rowlane(const sl_env_batch &env, int e_first, int e_count, const int32_t *actions,
+                                      int T, int tstride, float *reward_t, uint8_t *done_t, const Jump *jump,
+                                      hipStream_t stream);
 
 }  // namespace sl

@@ -27,6 +27,8 @@
 // (actions), safelife_env.py:148-218 + safelife_game.py:505-552,684-719,746-761 (step / reset glue),
 // safelife_env.py:105-146 + helper_utils.py:42-75 (observation), env_wrappers.py:32-213 (wrappers).
 #include "sl_device.h"
+#include <atomic>
+
 #include "sl_kernels.h"
 
 // A/B knobs of the span moves (cache policy of the LDS DMA loads, flavour of the span stores)
@@ -34,7 +36,8 @@
 #define SL_LOAD_AUX 0
 #endif
 #ifndef SL_STORE
-#define SL_STORE 0
+#define SL_STORE 2   /* write-through (sc1): the board bytes leave L2 while other workgroups still compute, instead of in the
+                        end-of-kernel write-back (10.7 vs 11.55 us per C3 step, one launch per step) */
 #endif
 
 namespace sl {
@@ -1197,17 +1200,24 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
     // -amdgpu-kernarg-preload-count=8 they arrive in SGPRs with the wave instead of behind an s_load
     const u16 *__restrict__ hot_board, const u16 *__restrict__ hot_goals, const sl_pcg64 *__restrict__ hot_rng,
     sl_env_scalars *__restrict__ hot_scalars, const int8_t *__restrict__ hot_lut,
-    const int32_t *__restrict__ actions, int hot_B, int hot_E,
-    sl_env_batch env, int T, float *__restrict__ reward_t, uint8_t *__restrict__ done_t,
+    const int32_t *__restrict__ actions, int hot_first, int hot_end,
+    // The batch constants travel by value.  (Measured alternative: the struct resident in device memory behind
+    // a pointer -- ~100 bytes of arguments instead of ~700 -- is SLOWER, 12.1 vs 11.5 us per C3 step and 16.6 vs
+    // 13.8 in the first steps after a reset: loads through a global pointer are not invariant for the compiler,
+    // which re-fetches fields after every store with a scalar-cache round trip each time, on the leader's
+    // critical path; kernel-argument loads are.)
+    sl_env_batch env, int hot_E, int tstride, int T, sl_step_out *__restrict__ out_rec,
+    float *__restrict__ reward_t, uint8_t *__restrict__ done_t, double *__restrict__ shaped_t,
     const Jump *__restrict__ jump) {
     using Gm = Geom<H, W>;
     constexpr int WS = Gm::WS, HW = Gm::HW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned B = hot_B;
+    // envs [hot_first, hot_end) of the batch: one slice (slhip_env_step_slices) or all of it
+    const unsigned B = tstride;                        // row pitch of the [T, B] per-step arrays
     const int E = hot_E;
-    const int e0b = blockIdx.x * Gm::NB;
-    const int nbb = min(Gm::NB, (int)B - e0b);
+    const int e0b = hot_first + blockIdx.x * Gm::NB;
+    const int nbb = min(Gm::NB, hot_end - e0b);
     const LaneMap<H, W> lm(lane);
     const int g = lm.g, r = lm.r, up = lm.up, dn = lm.dn;
     const int gb = wave * Gm::G + g;
@@ -1275,7 +1285,7 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
     // (left alone the compiler fetches them in four dependent groups right after the barrier)
     {
         const int a0 = env.time_limit, a1 = env.exit_points, a2 = env.auto_reset, a3 = env.L, a4 = env.level_stride;
-        const void *p0 = env.out, *p1 = env.pool_board, *p2 = env.pool_goals, *p3 = env.pool_exit_locs;
+        const void *p0 = out_rec, *p1 = env.pool_board, *p2 = env.pool_goals, *p3 = env.pool_exit_locs;
         const void *p4 = env.pool_rng, *p5 = env.pool_scalars, *p6 = env.exit_locs;
         asm volatile("" ::"s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(T), "s"(p0), "s"(p1), "s"(p2), "s"(p3),
                      "s"(p4), "s"(p5), "s"(p6), "s"(reward_t), "s"(done_t));
@@ -1396,7 +1406,7 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
             o.episode_length = ep_len;
             unsigned e3 = e;
             asm volatile("" : "+v"(e3));
-            env.out[e3] = o;
+            out_rec[e3] = o;
 #ifndef SL_TRACE
             if (reward_t) reward_t[(size_t)t * B + e] = reward;
             if (done_t) done_t[(size_t)t * B + e] = done;
@@ -1424,7 +1434,7 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
                 unsigned e4 = e;
                 asm volatile("" : "+v"(e4));
                 env.wrap.shaped_reward[e4] = shaped;
-                if (env.wrap.shaped_reward_t) env.wrap.shaped_reward_t[(size_t)t * B + e4] = shaped;
+                if (shaped_t) shaped_t[(size_t)t * B + e4] = shaped;
             }
         }
         // on-device auto-reset (training/base_algo.py:231-236 calls env.reset() after a done step)
@@ -1644,12 +1654,14 @@ static hipError_t launch_occupancy_t(const u16 *in, int32_t *counts, int B, cons
 }
 
 template <int H, int W>
-static hipError_t launch_rollout_t(const sl_env_batch &env, const int32_t *actions, int T, float *reward_t,
-                                   uint8_t *done_t, const Jump *jump, hipStream_t stream) {
+static hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, const int32_t *actions, int T,
+                                   int tstride, float *reward_t, uint8_t *done_t, const Jump *jump,
+                                   hipStream_t stream) {
     using Gm = Geom<H, W>;
     const int variant = (env.n_tables == 1 ? 1 : 0) | (env.spawner_free ? 2 : 0) | (env.wrap.flags ? 4 : 0);
     typedef void (*kernel_t)(const u16 *, const u16 *, const sl_pcg64 *, sl_env_scalars *, const int8_t *,
-                             const int32_t *, int, int, sl_env_batch, int, float *, uint8_t *, const Jump *);
+                             const int32_t *, int, int, sl_env_batch, int, int, int, sl_step_out *, float *,
+                             uint8_t *, double *, const Jump *);
     static const kernel_t table[8] = {
         k_env_rollout_rowlane<H, W, false, true, false>, k_env_rollout_rowlane<H, W, true, true, false>,
         k_env_rollout_rowlane<H, W, false, false, false>, k_env_rollout_rowlane<H, W, true, false, false>,
@@ -1658,14 +1670,20 @@ static hipError_t launch_rollout_t(const sl_env_batch &env, const int32_t *actio
     const kernel_t fn = table[variant];
     const bool spawn = !(variant & 2), base_in_gsh = !spawn && Gm::WAVES_PER_SIMD == 4;
     const int lds = !(variant & 4) ? Gm::LDS_BYTES : (base_in_gsh ? Gm::LDS_WRAP_GSHREG : Gm::LDS_WRAP_GSHLDS);
-    static bool configured[8] = {};               // the attribute is sticky: set it once
-    if (!configured[variant]) {
-        hipError_t err = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    // the attribute is per device: set once per (device, variant)
+    static std::atomic<uint64_t> configured[8];
+    int dev = 0;
+    hipError_t err = hipGetDevice(&dev);
+    if (err != hipSuccess) return err;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(configured[variant].load(std::memory_order_acquire) & bit)) {
+        err = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (err != hipSuccess) return err;
-        configured[variant] = true;
+        configured[variant].fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL(fn, dim3((env.B + Gm::NB - 1) / Gm::NB), dim3(64 * WAVES), lds, stream, env.board, env.goals,
-                       env.rng, env.scalars, env.score_lut, actions, env.B, env.E, env, T, reward_t, done_t, jump);
+    hipLaunchKernelGGL(fn, dim3((e_count + Gm::NB - 1) / Gm::NB), dim3(64 * WAVES), lds, stream, env.board, env.goals,
+                       env.rng, env.scalars, env.score_lut, actions, e_first, e_first + e_count, env, env.E, tstride, T,
+                       env.out, reward_t, done_t, env.wrap.shaped_reward_t, jump);
     return hipGetLastError();
 }
 
@@ -1708,9 +1726,10 @@ hipError_t launch_occupancy_rowlane(const u16 *in, int32_t *counts, int B, int H
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_env_rollout_rowlane(const sl_env_batch &env, const int32_t *actions, int T, float *reward_t,
-                                      uint8_t *done_t, const Jump *jump, hipStream_t stream) {
-#define X(h, w) if (env.H == h && env.W == w) return rl::launch_rollout_t<h, w>(env, actions, T, reward_t, done_t, jump, stream);
+hipError_t launch_env_rollout_rowlane(const sl_env_batch &env, int e_first, int e_count, const int32_t *actions,
+                                      int T, int tstride, float *reward_t, uint8_t *done_t, const Jump *jump,
+                                      hipStream_t stream) {
+#define X(h, w) if (env.H == h && env.W == w) return rl::launch_rollout_t<h, w>(env, e_first, e_count, actions, T, tstride, reward_t, done_t, jump, stream);
     SL_ROWLANE_SHAPES(X)
 #undef X
     return hipErrorInvalidValue;

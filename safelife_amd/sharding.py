@@ -48,25 +48,36 @@ class RewardGather(object):
                          for _ in range(2)]
         self.work = [None, None]
         self.last = None
+        self._slot_ptr = [[b.data_ptr() + self.RECORD_BYTES * slot * B for slot in range(self.every)]
+                          for b in self.buf]
 
     def before_step(self, t):
         slot, which = t % self.every, (t // self.every) % 2
         if slot == 0 and self.work[which] is not None:
             self.work[which].wait()          # stream-level wait: buffer is free again
             self.work[which] = None
-        self.env.set_step_outputs(self.buf[which].data_ptr() + self.RECORD_BYTES * slot * self.B)
+            if getattr(self.env, "slices", 1) > 1:
+                self.env.fence()             # ... for the slice streams too
+        self.env.set_step_outputs(self._slot_ptr[which][slot])
 
     def after_step(self, t):
         if t % self.every != self.every - 1:
             return
         which = (t // self.every) % 2
         self.last = which
+        if getattr(self.env, "slices", 1) > 1:
+            self.env.join()                  # the window was written on the slice streams
         if self.world > 1 or self.force:
             import torch.distributed as dist
             self.work[which] = dist.gather(self.buf[which], self.recv[which] if self.rank == 0 else None,
                                            dst=0, group=self.group, async_op=True)
 
     def flush(self):
+        """Wait (stream-level) for outstanding gathers and hand the step outputs back to the env's own
+        tensor.  While a gather is active, ``env.reward`` / ``env.done`` / ``env.info`` are NOT written --
+        the records go to the window buffers; read them through ``latest()``."""
+        if getattr(self.env, "slices", 1) > 1:
+            self.env.join()
         for k in (0, 1):
             if self.work[k] is not None:
                 self.work[k].wait()
@@ -74,10 +85,15 @@ class RewardGather(object):
         self.env.set_step_outputs(None)
 
     def latest_records(self):
+        """Records of the last COMPLETED window, int32 [world, every, B, 4] (the gather that filled it is
+        waited for on the current stream first)."""
         if self.last is None:
             return None
+        if self.work[self.last] is not None:
+            self.work[self.last].wait()
+            self.work[self.last] = None
         bufs = self.recv[self.last] if self.recv is not None else [self.buf[self.last]]
-        return self.torch.stack(bufs)                 # int32 [world, every, B, 4]
+        return self.torch.stack(bufs)
 
     def latest(self):
         rec = self.latest_records()

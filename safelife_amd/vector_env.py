@@ -37,6 +37,14 @@ class SafeLifeVectorEnv(object):
     level_stride : int             an env's next level is ``(level + level_stride) % len(pool)``
     env_offset : int               global index of this process's env 0 (multi-GPU sharding)
     with_obs : bool                False skips observation writes entirely
+    slices : int                   >1: the batch is cut into this many contiguous slices, each stepped by its
+                                   own launch on its own HIP stream (``slhip_env_step_slices``).  Envs are
+                                   independent, so consecutive steps of different slices overlap on the chip
+                                   (the load / store phases and the launch boundary of one slice hide under
+                                   the compute phase of the other).  ``step()`` keeps the one-stream
+                                   semantics (it fences the slice streams against the caller's stream on
+                                   both sides); ``step_async()`` + ``join()`` leave the fences to the caller
+                                   and are what a pipelined driver uses.
     wrappers : dict or None        training-wrapper math of the reference's env_wrappers.py, fused into the
                                    step (stacked as training/env_factory.py:277-283 does); keys, all
                                    optional: ``movement_bonus``, ``movement_bonus_power``,
@@ -51,7 +59,7 @@ class SafeLifeVectorEnv(object):
     def __init__(self, pool, num_envs, *, time_limit=1000, remove_white_goals=True,
                  view_shape=(15, 15), output_channels=_DEFAULT_CHANNELS, auto_reset=True,
                  first_level=None, level_stride=1, env_offset=0, with_obs=True,
-                 points_on_level_exit=1, wrappers=None):
+                 points_on_level_exit=1, wrappers=None, slices=1):
         import torch
         self.torch = torch
         if not isinstance(pool, LevelPool):
@@ -133,6 +141,16 @@ class SafeLifeVectorEnv(object):
             self._setup_wrappers(dict(wrappers))
         self._lib = _hip.lib()
         self._sref = C.byref(s)
+        # slices: boundaries at multiples of 64 envs (keeps every slice 16-byte aligned for the row kernels)
+        n_sl = max(1, min(int(slices), (B + 63) // 64))
+        per = -(-B // n_sl)
+        per = -(-per // 64) * 64
+        bounds = [min(B, i * per) for i in range(n_sl)] + [B]
+        self.slices = n_sl
+        self.slice_bounds = tuple(bounds)
+        self._bounds = (C.c_int32 * (n_sl + 1))(*bounds)
+        self._slice_streams = [torch.cuda.Stream(device=dev) for _ in range(n_sl)] if n_sl > 1 else []
+        self._stream_ptrs = (C.c_void_p * max(1, n_sl))(*[st.cuda_stream for st in self._slice_streams])
         rc = self._lib.slhip_env_prepare(self._sref, _hip.current_stream_ptr())
         if rc == _hip.SL_E_UNSUPPORTED:
             s.score_lut = None          # points outside int8: every shape runs the size-generic kernels
@@ -189,8 +207,12 @@ class SafeLifeVectorEnv(object):
         m = None
         if mask is not None:
             m = self.torch.as_tensor(mask, device=self.device).to(self.torch.uint8).contiguous()
+        if self.slices > 1:
+            self.join()
         rc = self._lib.slhip_env_reset(self._sref, _hip.ptr(m), _hip.current_stream_ptr())
         _hip.check(rc)
+        if self.slices > 1:
+            self.fence()
         return self.obs
 
     def _actions(self, actions, shape):
@@ -204,12 +226,44 @@ class SafeLifeVectorEnv(object):
 
     def step(self, actions):
         """actions: int [B] in 0..8.  Returns (obs, reward, done, info) as device tensors that are
-        overwritten by the next call."""
+        overwritten by the next call.  Ordered on the caller's current stream, sliced or not."""
         a = self._actions(actions, (self.num_envs,))
-        rc = self._lib.slhip_env_step(self._sref, _hip.ptr(a), _hip.current_stream_ptr())
-        _hip.check(rc)
-        t = self.t
+        if self.slices > 1:
+            self.fence()
+            self.step_async(a)
+            self.join()
+        else:
+            rc = self._lib.slhip_env_step(self._sref, _hip.ptr(a), _hip.current_stream_ptr())
+            _hip.check(rc)
         return self.obs, self.reward, self.done, self.info
+
+    # ---- sliced stepping (slices > 1): no implicit ordering against the caller's stream
+
+    def fence(self):
+        """Slice streams wait for everything enqueued so far on the caller's current stream (call after
+        producing actions, resetting, or touching env state there)."""
+        cur = self.torch.cuda.current_stream()
+        for st in self._slice_streams:
+            st.wait_stream(cur)
+
+    def join(self):
+        """The caller's current stream waits for every slice's enqueued steps (call before consuming
+        reward / done / obs / state there)."""
+        cur = self.torch.cuda.current_stream()
+        for st in self._slice_streams:
+            cur.wait_stream(st)
+
+    def step_async(self, actions):
+        """One step per env, one launch per slice on the slice's own stream; nothing is fenced.  `actions`:
+        a contiguous int32 device tensor [B] that is already complete (or ordered by ``fence()``), or its
+        device address as an int.  Outputs are valid on the caller's stream after ``join()``."""
+        ptr = actions if isinstance(actions, int) else actions.data_ptr()
+        if self.slices > 1:
+            rc = self._lib.slhip_env_step_slices(self._sref, self.slices, self._bounds, ptr, self._stream_ptrs)
+        else:
+            rc = self._lib.slhip_env_step(self._sref, ptr, _hip.current_stream_ptr())
+        if rc:
+            _hip.check(rc)
 
     def rollout(self, actions, reward_out=None, done_out=None):
         """T steps in one launch.  actions: int [T,B].  Returns (reward[T,B], done[T,B])."""
@@ -223,10 +277,14 @@ class SafeLifeVectorEnv(object):
         if self.shaped_reward is not None:      # wrapped reward of every step: env.shaped_reward_t [T,B]
             self.shaped_reward_t = torch.empty((T, self.num_envs), dtype=torch.float64, device=self.device)
             self.struct.wrap.shaped_reward_t = self.shaped_reward_t.data_ptr()
+        if self.slices > 1:
+            self.join()
         rc = self._lib.slhip_env_rollout(self._sref, _hip.ptr(a), T, _hip.ptr(reward_out),
                                          _hip.ptr(done_out), _hip.current_stream_ptr())
         self.struct.wrap.shaped_reward_t = None
         _hip.check(rc)
+        if self.slices > 1:
+            self.fence()
         return reward_out, done_out
 
     def set_step_outputs(self, out_ptr):
@@ -235,7 +293,10 @@ class SafeLifeVectorEnv(object):
         the kernel fill a send buffer directly."""
         self.struct.out = self.t["out"].data_ptr() if out_ptr is None else int(out_ptr)
 
+
     def get_obs(self):
+        if self.slices > 1:
+            self.join()
         rc = self._lib.slhip_env_obs(self._sref, _hip.current_stream_ptr())
         _hip.check(rc)
         return self.obs
@@ -292,6 +353,8 @@ class SafeLifeVectorEnv(object):
 
     def numpy(self, name):
         """Host copy of a state array under the reference's / oracle's name and dtype."""
+        if self.slices > 1:
+            self.join()
         if name == "obs":
             a = self.obs.cpu().numpy()
             return a.view(np.uint32) if self.output_channels is None else a

@@ -605,6 +605,47 @@ def test_ragged_tail_workgroups_and_many_exits():
     assert np.array_equal(dev.get("board"), cpu.get("board"))
 
 
+@pytest.mark.parametrize("pool_name,B,slices,kw", [
+    ("prune_still_25", 1000, 3, dict(time_limit=40, view_shape=(25, 25),
+                                     output_channels=(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 25, 26, 27))),
+    ("append_spawn_25", 700, 2, dict(time_limit=50, view_shape=(15, 15), output_channels=None,
+                                     wrappers=TRAINING_WRAPPERS)),
+    ("navigation_64", 200, 4, dict(time_limit=30, view_shape=(25, 25))),
+    ("append_still_26", 130, 8, dict(time_limit=30, view_shape=(9, 9))),       # more slices asked than 64-env blocks
+])
+def test_sliced_stepping_vs_oracle(pool_name, B, slices, kw):
+    """slhip_env_step_slices: the batch cut into slices, one launch per slice on its own stream -- the
+    drop-in step() (fenced on both sides) every step against the oracle, then a run of step_async() calls
+    (nothing fenced until join()) against the same oracle steps."""
+    import torch
+    pool, _ = util.pool_from_fixture(pool_name, _device_counts, min_performance_fraction=0.05)
+    first = (np.arange(B) * 3) % len(pool)
+    common = dict(first_level=first, auto_reset=True, level_stride=5, **kw)
+    dev = util.DeviceBackend(pool, B, slices=slices, **common)
+    cpu = util.OracleBackend(pool, B, **common)
+    env = dev.env
+    assert env.slices == min(slices, (B + 63) // 64) and env.slice_bounds[-1] == B
+    assert np.array_equal(dev.reset(), cpu.reset())
+    rng = np.random.default_rng(23)
+    for t in range(45):
+        a = rng.integers(0, 9, B).astype(np.int32)
+        o1, r1, d1 = dev.step(a)
+        o2, r2, d2 = cpu.step(a)
+        assert np.array_equal(r1, r2) and np.array_equal(d1, d2) and np.array_equal(o1, o2), t
+    acts = rng.integers(0, 9, (40, B)).astype(np.int32)
+    d_acts = torch.from_numpy(acts).to(env.device)
+    torch.cuda.synchronize()                    # the actions are complete: nothing to fence per step
+    for t in range(40):
+        env.step_async(d_acts[t])
+        cpu.step(acts[t])
+    env.join()
+    for name in ENV_STATE:
+        assert np.array_equal(dev.get(name), cpu.get(name)), name
+    assert np.array_equal(env.numpy("obs"), cpu.env.obs)
+    if "wrappers" in kw:
+        assert np.array_equal(env.shaped_reward.cpu().numpy(), cpu.env.wa["shaped_reward"])
+
+
 def test_sharded_equals_unsharded():
     """env e behaves the same whichever rank owns it -- two half-size envs with
     env_offset 0 / B/2 (what ranks 0 and 1 of a 2-GPU run hold) against one env of size B."""
