@@ -1446,9 +1446,27 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
                 level = (level + env.level_stride) % env.L;
                 const u16 *pb = env.pool_board + (size_t)level * HW, *pg = env.pool_goals + (size_t)level * HW;
                 u16 *gdst = (u16 *)(goals + Gm::PAD) + gb * HW;
-                for (int i = r; i < HW; i += H) {
-                    board16[Gm::flat(i)] = pb[i];
-                    gdst[Gm::flat(i)] = pg[i];
+                // lane r moves cells r, r + H, ... (consecutive lanes touch consecutive cells); the loads of a
+                // batch are all issued before the first is used -- one memory round trip per batch instead of
+                // one per cell (a wave that resets holds up its whole workgroup at the end barrier)
+                constexpr int CH = WRAP ? 4 : (W <= 32 ? (W + 3) / 4 : 8);      // (more cells per batch spill registers)
+#pragma unroll 1
+                for (int q0 = 0; q0 < W; q0 += CH) {
+                    u16 tb[CH], tg[CH];
+#pragma unroll
+                    for (int q = 0; q < CH; ++q) {
+                        const int i = r + (q0 + q) * H;
+                        tb[q] = q0 + q < W ? pb[i] : (u16)0;
+                        tg[q] = q0 + q < W ? pg[i] : (u16)0;
+                    }
+#pragma unroll
+                    for (int q = 0; q < CH; ++q) {
+                        const int i = r + (q0 + q) * H;
+                        if (q0 + q < W) {
+                            board16[Gm::flat(i)] = tb[q];
+                            gdst[Gm::flat(i)] = tg[q];
+                        }
+                    }
                 }
                 lut_base = (u32)env.pool_scalars[level].table_idx * (u32)SCORE_LUT_BYTES;
                 p = (double)env.pool_scalars[level].spawn_prob;
@@ -1670,20 +1688,54 @@ static hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_c
     const kernel_t fn = table[variant];
     const bool spawn = !(variant & 2), base_in_gsh = !spawn && Gm::WAVES_PER_SIMD == 4;
     const int lds = !(variant & 4) ? Gm::LDS_BYTES : (base_in_gsh ? Gm::LDS_WRAP_GSHREG : Gm::LDS_WRAP_GSHLDS);
-    // the attribute is per device: set once per (device, variant)
-    static std::atomic<uint64_t> configured[8];
+    // per (device, variant), once: raise the dynamic LDS limit and look up the module-level handle of the kernel
+    struct Entry {
+        std::atomic<hipFunction_t> fn{nullptr};
+        std::atomic<bool> ready{false};
+    };
+    static Entry cache[8][16];
     int dev = 0;
     hipError_t err = hipGetDevice(&dev);
     if (err != hipSuccess) return err;
-    const uint64_t bit = 1ull << (dev & 63);
-    if (!(configured[variant].load(std::memory_order_acquire) & bit)) {
+    Entry &ce = cache[variant][dev & 15];
+    if (!ce.ready.load(std::memory_order_acquire)) {
         err = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (err != hipSuccess) return err;
-        configured[variant].fetch_or(bit, std::memory_order_release);
+        hipFunction_t f = nullptr;
+        if (hipGetFuncBySymbol(&f, (const void *)fn) != hipSuccess) f = nullptr;
+        (void)hipGetLastError();
+        ce.fn.store(f, std::memory_order_relaxed);
+        ce.ready.store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL(fn, dim3((e_count + Gm::NB - 1) / Gm::NB), dim3(64 * WAVES), lds, stream, env.board, env.goals,
-                       env.rng, env.scalars, env.score_lut, actions, e_first, e_first + e_count, env, env.E, tstride, T,
-                       env.out, reward_t, done_t, env.wrap.shaped_reward_t, jump);
+    const unsigned grid = (unsigned)((e_count + Gm::NB - 1) / Gm::NB);
+    if (hipFunction_t f = ce.fn.load(std::memory_order_relaxed)) {
+        // Launch through the module API with the argument block already packed: the runtime copies ONE buffer
+        // instead of walking eighteen arguments (a step is two ~2.5 us launches; the host must keep ahead of a
+        // ~8 us device step).  The struct mirrors the kernel's parameter list (natural alignment == the
+        // kernel-argument layout).
+        struct Args {
+            const u16 *board, *goals;
+            const sl_pcg64 *rng;
+            sl_env_scalars *scalars;
+            const int8_t *lut;
+            const int32_t *actions;
+            int first, end;
+            sl_env_batch env;
+            int E, tstride, T;
+            sl_step_out *out;
+            float *reward_t;
+            uint8_t *done_t;
+            double *shaped_t;
+            const Jump *jump;
+        } args = {env.board, env.goals, env.rng, env.scalars, env.score_lut, actions, e_first, e_first + e_count, env,
+                  env.E, tstride, T, env.out, reward_t, done_t, env.wrap.shaped_reward_t, jump};
+        size_t size = sizeof(args);
+        void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+        return hipModuleLaunchKernel(f, grid, 1, 1, 64 * WAVES, 1, 1, (unsigned)lds, stream, nullptr, extra);
+    }
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * WAVES), lds, stream, env.board, env.goals, env.rng, env.scalars,
+                       env.score_lut, actions, e_first, e_first + e_count, env, env.E, tstride, T, env.out, reward_t,
+                       done_t, env.wrap.shaped_reward_t, jump);
     return hipGetLastError();
 }
 
