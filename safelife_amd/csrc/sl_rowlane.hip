@@ -36,8 +36,12 @@
 #define SL_LOAD_AUX 0
 #endif
 #ifndef SL_STORE
-#define SL_STORE 2   /* write-through (sc1): the board bytes leave L2 while other workgroups still compute, instead of in the
-                        end-of-kernel write-back (10.7 vs 11.55 us per C3 step, one launch per step) */
+#define SL_STORE 0   /* plain stores.  Write-through (sc1) stores are 0.8 us per step faster with ONE launch per step
+                        (10.7 vs 11.5 us: the board bytes leave L2 while other workgroups still compute instead of
+                        in the end-of-kernel write-back) and make no difference with two overlapping launches -- but
+                        with concurrent launches they produced WRONG boards now and then (an env whose workgroup
+                        lands on another XCD than last step reads a stale line; 64x64 spawner levels, ~1 run in 3),
+                        so they stay an experiment knob */
 #endif
 
 namespace sl {
@@ -1254,7 +1258,6 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
     const sl_pcg64 *k_rng = hot_rng;
     const int8_t *k_lut = hot_lut;
     sl_env_scalars *const sc = hot_scalars + e;
-    const int32_t *exits = env.exit_locs + (size_t)e * E;
     const int32_t *k_act = actions + e;
     asm volatile("" ::"s"(k_board), "s"(k_goals), "s"(k_rng), "s"(k_lut));
     const sl_env_scalars rec = *sc;     // one 64-byte record (same address within a board: broadcast)
@@ -1272,7 +1275,19 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
             dma_to_lds<Gm::MVT_N * 8>((const unsigned char *)env.wrap.move_table, smem + Gm::OFF_MVT,
                                       min(env.wrap.move_table_len & ~1, Gm::MVT_N) * 8, lane, wave);
     }
-    int exit0 = exits[0];       // (its pointer is not among the preloaded arguments: after the DMA issue)
+    // Every kernel argument the rest of the kernel needs that did not arrive preloaded: fetched in ONE batch
+    // here, in the shadow of the bulk loads.  (Left alone the compiler fetches them in dependent groups: each
+    // is a scalar-cache miss on a kernel-argument segment the host has just rewritten, ~0.35 us apiece --
+    // the exit table's pointer used to be waited for on its own ahead of this batch.)
+    {
+        const int a0 = env.time_limit, a1 = env.exit_points, a2 = env.auto_reset, a3 = env.L, a4 = env.level_stride;
+        const void *p0 = out_rec, *p1 = env.pool_board, *p2 = env.pool_goals, *p3 = env.pool_exit_locs;
+        const void *p4 = env.pool_rng, *p5 = env.pool_scalars, *p6 = env.exit_locs;
+        asm volatile("" ::"s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(T), "s"(p0), "s"(p1), "s"(p2), "s"(p3),
+                     "s"(p4), "s"(p5), "s"(p6), "s"(reward_t), "s"(done_t));
+    }
+    const int32_t *exits = env.exit_locs + (size_t)e * E;
+    int exit0 = exits[0];
     int ly = rec.agent_row, lx = rec.agent_col, steps = rec.num_steps, old_value = rec.old_value;
     int required = rec.required_points, initial = rec.initial_points, ep_len = rec.episode_length;
     int gstatic = rec.goals_static, level = rec.level_idx, episodes = rec.episode_idx;
@@ -1281,15 +1296,6 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
     double p = (double)rec.spawn_prob;
     u32 lut_base = (u32)rec.table_idx * (u32)SCORE_LUT_BYTES;
     int open0 = rec.exit_open_at_reset;                 // exit paint of the side-effect baseline
-    // the step loop's invariant arguments: fetched in one batch here, in the shadow of the bulk loads
-    // (left alone the compiler fetches them in four dependent groups right after the barrier)
-    {
-        const int a0 = env.time_limit, a1 = env.exit_points, a2 = env.auto_reset, a3 = env.L, a4 = env.level_stride;
-        const void *p0 = out_rec, *p1 = env.pool_board, *p2 = env.pool_goals, *p3 = env.pool_exit_locs;
-        const void *p4 = env.pool_rng, *p5 = env.pool_scalars, *p6 = env.exit_locs;
-        asm volatile("" ::"s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(T), "s"(p0), "s"(p1), "s"(p2), "s"(p3),
-                     "s"(p4), "s"(p5), "s"(p6), "s"(reward_t), "s"(done_t));
-    }
     typedef __attribute__((address_space(3))) int *lds_int;       // (a generic volatile pointer would go through FLAT)
     lds_int dirty_flag = (lds_int)(smem + Gm::OFF_GOALS);              // in the region's leading pad
     if (tid == 0) *dirty_flag = 0;
@@ -1301,10 +1307,14 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
     Elig elig;
 #pragma unroll
     for (int k = 0; k < WS; ++k) b[k] = 0;
+    u32 goal_bits = 0;
     if (live) {
         read_row<H, W>(goals, gb, r, b);
 #pragma unroll
-        for (int k = 0; k < WS; ++k) gsh_lane[k] = goal_shift(b[k]);
+        for (int k = 0; k < WS; ++k) {
+            gsh_lane[k] = goal_shift(b[k]);
+            goal_bits |= b[k];
+        }
     }
     bool goals_dirty = false;
     SL_STAMP(3);
@@ -1324,7 +1334,16 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
         }
         wave_sync();
         SL_STAMP(4);
-        // safelife_env.py:152 : board first, then goals unless they are static (safelife_game.py:746-761)
+        // safelife_env.py:152 : board first, then goals unless they are static (safelife_game.py:746-761).
+        // Goals still undecided (first step after a reset; the reference finds out by advancing them once,
+        // :753-760): a goal array without a single ALIVE or SPAWNING cell cannot change and draws nothing, so it
+        // IS static and the second CA pass of this step is skipped -- the usual case for every level a reset loads.
+#ifndef SL_NO_SHORTCUT1
+        if (__ballot(rowl && gstatic == 0)) {
+            const int restless = group_total<H, W>(live && (goal_bits & 0x00810081u) ? 1 : 0, rowl ? g : 0);
+            if (rowl && gstatic == 0 && restless == 0) gstatic = 1;
+        }
+#endif
         const bool dyn = rowl && gstatic != 1;
         const int passes = __ballot(dyn) ? 2 : 1;
 #pragma nounroll
@@ -1446,27 +1465,25 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
                 level = (level + env.level_stride) % env.L;
                 const u16 *pb = env.pool_board + (size_t)level * HW, *pg = env.pool_goals + (size_t)level * HW;
                 u16 *gdst = (u16 *)(goals + Gm::PAD) + gb * HW;
-                // lane r moves cells r, r + H, ... (consecutive lanes touch consecutive cells); the loads of a
-                // batch are all issued before the first is used -- one memory round trip per batch instead of
-                // one per cell (a wave that resets holds up its whole workgroup at the end barrier)
-                constexpr int CH = WRAP ? 4 : (W <= 32 ? (W + 3) / 4 : 8);      // (more cells per batch spill registers)
-#pragma unroll 1
-                for (int q0 = 0; q0 < W; q0 += CH) {
-                    u16 tb[CH], tg[CH];
+                // each lane copies its OWN row of the new level: W cells = one contiguous run, fetched as 4-byte
+                // pairs (2-byte aligned: the hardware splits what it must) all issued before the first is used --
+                // one memory round trip for the board and one for the goals, not one per cell (a wave that resets
+                // holds up its whole workgroup at the end barrier, and the launch behind it)
+                typedef u32 u32_a2 __attribute__((aligned(2)));
+                const u16 *rows[2] = {pb + r * W, pg + r * W};
+                u16 *imgs[2] = {board16, gdst};
 #pragma unroll
-                    for (int q = 0; q < CH; ++q) {
-                        const int i = r + (q0 + q) * H;
-                        tb[q] = q0 + q < W ? pb[i] : (u16)0;
-                        tg[q] = q0 + q < W ? pg[i] : (u16)0;
-                    }
+                for (int a = 0; a < 2; ++a) {
+                    u32 tw[WS];
 #pragma unroll
-                    for (int q = 0; q < CH; ++q) {
-                        const int i = r + (q0 + q) * H;
-                        if (q0 + q < W) {
-                            board16[Gm::flat(i)] = tb[q];
-                            gdst[Gm::flat(i)] = tg[q];
-                        }
+                    for (int j = 0; j < W / 2; ++j) tw[j] = *(const u32_a2 *)(rows[a] + 2 * j);
+                    if (Gm::ODD) tw[WS - 1] = rows[a][W - 1];
+#pragma unroll
+                    for (int j = 0; j < W / 2; ++j) {
+                        imgs[a][Gm::cell(r, 2 * j)] = (u16)tw[j];
+                        imgs[a][Gm::cell(r, 2 * j + 1)] = (u16)(tw[j] >> 16);
                     }
+                    if (Gm::ODD) imgs[a][Gm::cell(r, W - 1)] = (u16)tw[WS - 1];
                 }
                 lut_base = (u32)env.pool_scalars[level].table_idx * (u32)SCORE_LUT_BYTES;
                 p = (double)env.pool_scalars[level].spawn_prob;
@@ -1477,12 +1494,17 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
                 goals_dirty = true;
             }
             wave_sync();
+            u32 new_goal_bits = 0;
             if (mine) {
                 read_row<H, W>(goals, gb, r, b);
 #pragma unroll
-                for (int k = 0; k < WS; ++k) gsh_lane[k] = goal_shift(b[k]);
+                for (int k = 0; k < WS; ++k) {
+                    gsh_lane[k] = goal_shift(b[k]);
+                    new_goal_bits |= b[k];
+                }
                 read_row<H, W>(board, gb, r, b);
             }
+            if (mine) goal_bits = new_goal_bits;
             const int s0 = group_total<H, W>(
                 mine ? row_score<H, W, LDS_LUT>(b, gsh_lane, lut, lut_base, lds_lut, cell_mask, c100) : 0,
                 live ? g : 0);

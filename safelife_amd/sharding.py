@@ -65,10 +65,10 @@ class RewardGather(object):
             return
         which = (t // self.every) % 2
         self.last = which
-        if getattr(self.env, "slices", 1) > 1:
-            self.env.join()                  # the window was written on the slice streams
         if self.world > 1 or self.force:
             import torch.distributed as dist
+            if getattr(self.env, "slices", 1) > 1:
+                self.env.join()              # the window was written on the slice streams
             self.work[which] = dist.gather(self.buf[which], self.recv[which] if self.rank == 0 else None,
                                            dst=0, group=self.group, async_op=True)
 
@@ -89,6 +89,8 @@ class RewardGather(object):
         waited for on the current stream first)."""
         if self.last is None:
             return None
+        if getattr(self.env, "slices", 1) > 1:
+            self.env.join()
         if self.work[self.last] is not None:
             self.work[self.last].wait()
             self.work[self.last] = None

@@ -646,6 +646,37 @@ def test_sliced_stepping_vs_oracle(pool_name, B, slices, kw):
         assert np.array_equal(env.shaped_reward.cpu().numpy(), cpu.env.wa["shaped_reward"])
 
 
+@pytest.mark.parametrize("pool_name,B", [("navigation_64", 200), ("append_spawn_25", 1500)])
+def test_sliced_stepping_soak(pool_name, B):
+    """Slices of one batch run as concurrent launches, so from step to step an env's workgroup may land on
+    another XCD (with one launch per step the placement never changes): repeated unfenced runs of 2, 3 and 4
+    slices against the one-launch env on the same actions -- boards, generators and episode state.
+    (Write-through board stores failed exactly this on 64x64 spawner levels.)"""
+    import torch
+    from safelife_amd.vector_env import SafeLifeVectorEnv
+    pool, _ = util.pool_from_fixture(pool_name, _device_counts, min_performance_fraction=0.05)
+    first = (np.arange(B) * 3) % len(pool)
+    kw = dict(first_level=first, auto_reset=True, level_stride=5, time_limit=30, view_shape=(15, 15), with_obs=False)
+    T = 50
+    acts = torch.from_numpy(np.random.default_rng(5).integers(0, 9, (T, B)).astype(np.int32)).to("cuda")
+    whole = SafeLifeVectorEnv(pool, B, **kw)
+    whole.reset()
+    for t in range(T):
+        whole.step_async(acts[t])
+    want = {name: whole.numpy(name) for name in ("board", "goals", "rng", "agent_loc", "episode_idx", "level_idx",
+                                                 "episode_reward", "num_steps")}
+    for trial in range(3):
+        for n in (2, 3, 4):
+            env = SafeLifeVectorEnv(pool, B, slices=n, **kw)
+            env.reset()
+            torch.cuda.synchronize()
+            for t in range(T):
+                env.step_async(acts[t])
+            env.join()
+            for name, ref in want.items():
+                assert np.array_equal(env.numpy(name), ref), (trial, n, name)
+
+
 def test_sharded_equals_unsharded():
     """env e behaves the same whichever rank owns it -- two half-size envs with
     env_offset 0 / B/2 (what ranks 0 and 1 of a 2-GPU run hold) against one env of size B."""
