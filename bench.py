@@ -172,13 +172,14 @@ def main():
     # one step = every env stepped once = one launch per slice, each on the slice's own stream; the action
     # tensor is complete before the loop starts, so nothing has to be fenced per step (step_async)
     act_ptr = [actions[t].data_ptr() for t in range(K + W)]
-    before, after, step = gather.before_step, gather.after_step, env.step_async
+    before, after, step, every = gather.before_step, gather.after_step, env.step_async, gather.every
 
     def run(t0, n):
         for t in range(t0, t0 + n):
             before(t)
             step(act_ptr[t])
-            after(t)
+            if t % every == every - 1:
+                after(t)
 
     run(0, W)
     gather.flush()
@@ -186,22 +187,34 @@ def main():
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
-    # HIP events on the streams the kernels are launched on (one pair per slice stream)
+    # HIP events on the stream the kernels are launched on.  With slices, every slice stream runs the same K
+    # launches concurrently; the pair sits on slice 0's stream only: an event record as the LAST command of a
+    # stream makes the closing synchronize ~15 us slower for that stream (ROCm retires a trailing marker
+    # through its blocking path even when the GPU is long done), and one such stream is enough
     streams = env._slice_streams or [torch.cuda.current_stream()]
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in streams]
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))]
+    dbg = os.environ.get("SL_BENCH_DEBUG") == "1"
+    # (the start event is enqueued on the idle stream just ahead of the wall clock: the event interval then
+    #  covers the whole timed region, and its ~3 us of host time stays out of it)
+    evs[0][0].record(streams[0])
     t_start = time.perf_counter()
-    for st, (e0, _) in zip(streams, evs):
-        e0.record(st)
     run(W, K)
     t_enqueued = time.perf_counter()
-    for st, (_, e1) in zip(streams, evs):
-        e1.record(st)
+    evs[0][1].record(streams[0])
+    # (completion is left to the synchronize below: polling hipStreamQuery / hipEventQuery first was measured
+    #  10-25 us slower over the region -- the polls contend with the runtime's own completion handling)
+    t_b = time.perf_counter()
     gather.flush()
+    t_c = time.perf_counter()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
+    if dbg:
+        print("timeline us: enqueue loop %.1f | e1 record %.1f | flush %.1f | synchronize %.1f | total %.1f"
+              % ((t_enqueued - t_start) * 1e6, (t_b - t_enqueued) * 1e6, (t_c - t_b) * 1e6,
+                 (t_start + elapsed - t_c) * 1e6, elapsed * 1e6), file=sys.stderr)
     # device time per step: every slice stream runs its K launches back to back, all streams concurrently
     slice_ms = [e0.elapsed_time(e1) / K for e0, e1 in evs]
     kernel_ms = max(slice_ms)
@@ -355,10 +368,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "fused env step", "bytes_per_env_step": bytes_per_step,
-                         # device time of one step (HIP events): all slice launches of a step run concurrently,
-                         # so a step costs the slowest slice stream's launch-to-launch time
-                         "launch_ms": kernel_ms, "launches_per_step": len(slice_ms),
-                         "slice_launch_ms": slice_ms,
+                         # device time of one step (HIP events on slice 0's stream): the slice launches of a step
+                         # run concurrently, each stream back to back, so a step costs one stream's
+                         # launch-to-launch time
+                         "launch_ms": kernel_ms, "launches_per_step": env.slices,
                          "host_enqueue_ms_per_step": (t_enqueued - t_start) / K * 1e3,
                          # the same fraction from the wall clock of the timed region (ms_per_step: includes the
                          # first launch from an idle GPU and the final synchronize)

@@ -58,7 +58,7 @@ class RewardGather(object):
             self.work[which] = None
             if getattr(self.env, "slices", 1) > 1:
                 self.env.fence()             # ... for the slice streams too
-        self.env.set_step_outputs(self._slot_ptr[which][slot])
+        self.env.struct.out = self._slot_ptr[which][slot]
 
     def after_step(self, t):
         if t % self.every != self.every - 1:
@@ -76,12 +76,12 @@ class RewardGather(object):
         """Wait (stream-level) for outstanding gathers and hand the step outputs back to the env's own
         tensor.  While a gather is active, ``env.reward`` / ``env.done`` / ``env.info`` are NOT written --
         the records go to the window buffers; read them through ``latest()``."""
-        if getattr(self.env, "slices", 1) > 1:
+        pending = [k for k in (0, 1) if self.work[k] is not None]
+        if pending and getattr(self.env, "slices", 1) > 1:
             self.env.join()
-        for k in (0, 1):
-            if self.work[k] is not None:
-                self.work[k].wait()
-                self.work[k] = None
+        for k in pending:
+            self.work[k].wait()
+            self.work[k] = None
         self.env.set_step_outputs(None)
 
     def latest_records(self):

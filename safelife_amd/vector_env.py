@@ -38,7 +38,8 @@ class SafeLifeVectorEnv(object):
     env_offset : int               global index of this process's env 0 (multi-GPU sharding)
     with_obs : bool                False skips observation writes entirely
     slices : int                   >1: the batch is cut into this many contiguous slices, each stepped by its
-                                   own launch on its own HIP stream (``slhip_env_step_slices``).  Envs are
+                                   own launch on its own HIP stream (``slhip_env_step_slices``; slice 0 on the
+                                   stream that is current at construction, the others on side streams).  Envs are
                                    independent, so consecutive steps of different slices overlap on the chip
                                    (the load / store phases and the launch boundary of one slice hide under
                                    the compute phase of the other).  ``step()`` keeps the one-stream
@@ -149,8 +150,13 @@ class SafeLifeVectorEnv(object):
         self.slices = n_sl
         self.slice_bounds = tuple(bounds)
         self._bounds = (C.c_int32 * (n_sl + 1))(*bounds)
-        self._slice_streams = [torch.cuda.Stream(device=dev) for _ in range(n_sl)] if n_sl > 1 else []
+        # slice 0 runs on the stream that is current now (the caller's), the others on side streams: one stream
+        # fewer to fence, join and synchronize (a device-wide synchronize costs ~10 us per stream it has to visit)
+        self._primary = torch.cuda.current_stream(dev)
+        self._side_streams = [torch.cuda.Stream(device=dev) for _ in range(n_sl - 1)]
+        self._slice_streams = ([self._primary] + self._side_streams) if n_sl > 1 else []
         self._stream_ptrs = (C.c_void_p * max(1, n_sl))(*[st.cuda_stream for st in self._slice_streams])
+        self._primary_ptr = C.c_void_p(self._primary.cuda_stream)
         rc = self._lib.slhip_env_prepare(self._sref, _hip.current_stream_ptr())
         if rc == _hip.SL_E_UNSUPPORTED:
             s.score_lut = None          # points outside int8: every shape runs the size-generic kernels
@@ -244,14 +250,16 @@ class SafeLifeVectorEnv(object):
         producing actions, resetting, or touching env state there)."""
         cur = self.torch.cuda.current_stream()
         for st in self._slice_streams:
-            st.wait_stream(cur)
+            if st != cur:
+                st.wait_stream(cur)
 
     def join(self):
         """The caller's current stream waits for every slice's enqueued steps (call before consuming
         reward / done / obs / state there)."""
         cur = self.torch.cuda.current_stream()
         for st in self._slice_streams:
-            cur.wait_stream(st)
+            if st != cur:
+                cur.wait_stream(st)
 
     def step_async(self, actions):
         """One step per env, one launch per slice on the slice's own stream; nothing is fenced.  `actions`:
