@@ -69,7 +69,7 @@ def parity_sample(pool, actions, n_envs, device_env):
     arrays = empty_env_arrays(pool, n_envs)
     arrays["level_idx"][:] = np.arange(n_envs) % len(pool)
     env = oracle.OracleEnv(arrays, time_limit=1000, auto_reset=True, level_stride=1, view_shape=(25, 25),
-                           output_channels=TRAIN_CHANNELS, with_obs=False)
+                           output_channels=TRAIN_CHANNELS, with_obs=False, stream_salt=1)
     env.reset()
     for a in actions:
         env.step(np.ascontiguousarray(a[:n_envs]), n_threads=4)
@@ -97,7 +97,7 @@ def cpu_baseline(pool, envs, steps, seed):
     arrays = empty_env_arrays(pool, envs)
     arrays["level_idx"][:] = np.arange(envs) % len(pool)
     env = oracle.OracleEnv(arrays, time_limit=1000, auto_reset=True, level_stride=1,
-                           view_shape=(25, 25), output_channels=TRAIN_CHANNELS, with_obs=False)
+                           view_shape=(25, 25), output_channels=TRAIN_CHANNELS, with_obs=False, stream_salt=1)
     env.reset()
     rng = np.random.default_rng(seed)
     acts = rng.integers(0, 9, (steps, envs)).astype(np.int32)

@@ -109,7 +109,9 @@ typedef struct sl_env_scalars {
     int32_t is_active;            /* SafeLifeEnv._is_active */
     int32_t exit_open_at_reset;   /* can_exit() during the reset's update_exit_colors (the exit paint of
                                      SimpleSideEffectPenalty's starting-state baseline) */
-    int32_t reserved;
+    int32_t loaded;               /* != 0 once a level has been loaded into this slot: slhip_env_reset() then moves on
+                                     to the next level (level_idx += level_stride, episode_idx += 1), as
+                                     SafeLifeEnv.reset() takes next(level_iterator) (safelife_env.py:204) */
 } sl_env_scalars;
 
 /* What one step() returns per env besides the observation (16 bytes). */
@@ -190,7 +192,13 @@ typedef struct sl_env_batch {
     int32_t spawner_free;        /* !=0: the caller guarantees that no board or goal array of the batch and
                                     of the pool holds a SPAWNING cell (the rules never create one), which
                                     lets the kernels drop the random-draw machinery; 0 = no promise */
-    int32_t reserved0;
+    int32_t stream_salt;         /* 0: an env that loads pool level l starts from pool_rng[l] exactly (what replaying
+                                    the reference's traces needs: every recorded level carries its own generator).
+                                    != 0: the episode's generator is pool_rng[l] moved to a state derived from
+                                    (stream_salt + env index, episode_idx), so envs that replay one pool level --
+                                    and successive replays by one env -- see different random streams, as the
+                                    reference's per-game SeedSequence children do (level_iterator.py:218).
+                                    Use 1 + (global index of env 0) so that shards of one run do not collide */
     /* per-env state */
     uint16_t *board;             /* [B,H,W] */
     uint16_t *goals;             /* [B,H,W] */
@@ -221,8 +229,9 @@ typedef struct sl_env_batch {
  * caller then passes score_lut = NULL and every shape runs on the size-generic kernels. */
 int slhip_env_prepare(const sl_env_batch *env, void *stream);
 
-/* SafeLifeEnv.reset() for the envs with mask[e] != 0 (mask NULL = all): loads pool level
- * level_idx[e] into slot e and writes its first observation. */
+/* SafeLifeEnv.reset() for the envs with mask[e] != 0 (mask NULL = all): an env that has never been loaded
+ * takes pool level level_idx[e]; any other moves on to (level_idx[e] + level_stride) % L and counts an
+ * episode, exactly as the in-kernel auto-reset does.  Writes the first observation. */
 int slhip_env_reset(const sl_env_batch *env, const uint8_t *mask, void *stream);
 
 /* One SafeLifeEnv.step() for every env.  actions: int32 [B] in 0..8. */

@@ -78,9 +78,9 @@ class EnvBatch(C.Structure):
         ("rng", _pcgp), ("spawn_prob", _f32p), ("num_steps", _i32p), ("old_value", _i32p),
         ("required_points", _i32p), ("initial_points", _i32p), ("table_idx", _i32p),
         ("goals_static", _u8p), ("is_active", _u8p), ("episode_reward", _f32p),
-        ("episode_length", _i32p), ("level_idx", _i32p), ("episode_idx", _i32p),
+        ("episode_length", _i32p), ("level_idx", _i32p), ("episode_idx", _i32p), ("loaded", _u8p),
         ("points_table", _i32p),
-        ("L", C.c_int32), ("level_stride", C.c_int32),
+        ("L", C.c_int32), ("level_stride", C.c_int32), ("stream_salt", C.c_int32), ("reserved0", C.c_int32),
         ("pool_board", _u16p), ("pool_goals", _u16p), ("pool_agent_loc", _i32p),
         ("pool_exit_locs", _i32p), ("pool_rng", _pcgp), ("pool_spawn_prob", _f32p),
         ("pool_required_reset", _i32p), ("pool_required_step", _i32p),
@@ -299,7 +299,7 @@ _ENV_ARRAYS = {
     "rng": np.uint64, "spawn_prob": np.float32, "num_steps": np.int32, "old_value": np.int32,
     "required_points": np.int32, "initial_points": np.int32, "table_idx": np.int32,
     "goals_static": np.uint8, "is_active": np.uint8, "episode_reward": np.float32,
-    "episode_length": np.int32, "level_idx": np.int32, "episode_idx": np.int32,
+    "episode_length": np.int32, "level_idx": np.int32, "episode_idx": np.int32, "loaded": np.uint8,
     "points_table": np.int32,
     "pool_board": np.uint16, "pool_goals": np.uint16, "pool_agent_loc": np.int32,
     "pool_exit_locs": np.int32, "pool_rng": np.uint64, "pool_spawn_prob": np.float32,
@@ -319,7 +319,8 @@ class OracleEnv:
 
     def __init__(self, arrays, *, time_limit=1000, exit_points=1, auto_reset=False,
                  remove_white_goals=True, view_shape=(15, 15),
-                 output_channels=tuple(range(16)) + (25, 26, 27), level_stride=1, with_obs=True):
+                 output_channels=tuple(range(16)) + (25, 26, 27), level_stride=1, with_obs=True,
+                 stream_salt=0):
         self.a = a = {}
         for k, dt in _ENV_ARRAYS.items():
             v = arrays[k]
@@ -345,6 +346,7 @@ class OracleEnv:
             s.channels[i] = c
         s.L = a["pool_board"].shape[0]
         s.level_stride = level_stride
+        s.stream_salt = int(stream_salt)
         for k in _ENV_ARRAYS:
             ftype = dict(EnvBatch._fields_)[k]
             setattr(s, k, C.cast(_ptr(a[k]), ftype))

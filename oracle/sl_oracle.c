@@ -428,6 +428,14 @@ static void make_obs(const slo_env_batch *env, int e) {
     free(view);
 }
 
+/* per-episode stream: the product's sl_episode_stream() (safelife_amd/csrc/sl_device.h), splitmix64 finaliser */
+static uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
 static void reset_one(slo_env_batch *env, int e) {
     int H = env->H, W = env->W, E = env->E;
     size_t n = (size_t)H * W;
@@ -439,6 +447,12 @@ static void reset_one(slo_env_batch *env, int e) {
     env->agent_loc[2 * e + 1] = env->pool_agent_loc[2 * l + 1];
     memcpy(env->exit_locs + (size_t)e * E, env->pool_exit_locs + (size_t)l * E, E * sizeof(int32_t));
     env->rng[e] = env->pool_rng[l];
+    if (env->stream_salt) {
+        uint64_t a = mix64(((uint64_t)(uint32_t)(env->stream_salt + e) << 32) | (uint64_t)(uint32_t)env->episode_idx[e]);
+        env->rng[e].state_hi ^= a;
+        env->rng[e].state_lo ^= mix64(a);
+    }
+    env->loaded[e] = 1;
     env->spawn_prob[e] = env->pool_spawn_prob[l];
     env->table_idx[e] = env->pool_table_idx[l];
     env->initial_points[e] = env->pool_initial_points[l];
@@ -538,6 +552,10 @@ static void wrap_step_one(slo_env_batch *env, slo_wrappers *w, int e) {
 int slo_env_reset_wrapped(slo_env_batch *env, slo_wrappers *wrap, const uint8_t *mask) {
     for (int e = 0; e < env->B; e++) {
         if (mask && !mask[e]) continue;
+        if (env->loaded[e]) {      /* SafeLifeEnv.reset() takes next(level_iterator), safelife_env.py:204 */
+            env->level_idx[e] = (env->level_idx[e] + env->level_stride) % env->L;
+            env->episode_idx[e] += 1;
+        }
         reset_one(env, e);
         if (wrap) wrap_reset_one(env, wrap, e);
         make_obs(env, e);

@@ -49,7 +49,7 @@ SL_ABI_VERSION = 3
 SCALAR_COLS = {"agent_row": 0, "agent_col": 1, "num_steps": 2, "old_value": 3, "required_points": 4,
                "initial_points": 5, "table_idx": 6, "level_idx": 7, "episode_idx": 8, "episode_length": 9,
                "episode_reward": 10, "spawn_prob": 11, "goals_static": 12, "is_active": 13,
-               "exit_open_at_reset": 14}
+               "exit_open_at_reset": 14, "loaded": 15}
 SCALAR_FLOATS = ("episode_reward", "spawn_prob")
 #: `struct sl_level_scalars` (32 bytes = 8 columns)
 LEVEL_COLS = {"agent_row": 0, "agent_col": 1, "required_reset": 2, "required_step": 3, "initial_points": 4,
@@ -78,7 +78,7 @@ class Wrappers(C.Structure):
 class EnvBatch(C.Structure):
     _fields_ = (
         [(n, C.c_int32) for n in ENV_SCALARS_HEAD]
-        + [("channels", C.c_int32 * SL_MAX_CHANNELS), ("spawner_free", C.c_int32), ("reserved0", C.c_int32)]
+        + [("channels", C.c_int32 * SL_MAX_CHANNELS), ("spawner_free", C.c_int32), ("stream_salt", C.c_int32)]
         + [(n, _p) for n in ENV_STATE_PTRS]
         + [("L", C.c_int32), ("level_stride", C.c_int32)]
         + [(n, _p) for n in ENV_POOL_PTRS]

@@ -93,6 +93,9 @@ int check_env(const sl_env_batch *env) {
     if (env->n_channels < 0 || env->n_channels > SL_MAX_CHANNELS) return fail(SL_E_ARG, "bad n_channels");
     if (env->view_h < 1 || env->view_w < 1) return fail(SL_E_ARG, "bad view shape");
     if (env->L < 1 || env->n_tables < 1) return fail(SL_E_ARG, "empty level pool or points table");
+    if (env->level_stride < 0) return fail(SL_E_ARG, "level_stride must be >= 0");
+    for (int k = 0; k < env->n_channels; ++k)
+        if (env->channels[k] < 0 || env->channels[k] > 31) return fail(SL_E_ARG, "output channel outside 0..31");
     const void *need[] = {env->board, env->goals, env->exit_locs, env->rng, env->scalars, env->points_table,
                           env->pool_board, env->pool_goals, env->pool_exit_locs, env->pool_rng,
                           env->pool_scalars, env->out};
@@ -126,6 +129,7 @@ sl_env_batch env_slice(const sl_env_batch &env, int e0, int n) {
     s.rng = env.rng + e0;
     s.scalars = env.scalars + e0;
     s.out = env.out + e0;
+    if (env.stream_salt) s.stream_salt = env.stream_salt + e0;
     if (env.obs) {
         const size_t cell = env.n_channels > 0 ? (size_t)env.n_channels : 4;     // uint8 channels, or the raw uint32 view
         s.obs = env.obs + (size_t)e0 * env.view_h * env.view_w * cell;

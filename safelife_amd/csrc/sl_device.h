@@ -96,6 +96,21 @@ __device__ __forceinline__ bool has_exited(u32 cell) { return (cell & (AGENT | E
 
 // ---- PCG64 (numpy) ---------------------------------------------------------------------------
 
+// Per-episode random stream (sl_env_batch.stream_salt != 0): the level's generator moved to a state that
+// depends on (salt + env index, episode index).  splitmix64 finaliser; the increment (the stream constant of
+// the level) is kept.  (The CPU checker restates it.)
+__host__ __device__ __forceinline__ u64 sl_mix64(u64 z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__host__ __device__ __forceinline__ void sl_episode_stream(u64 &state_hi, u64 &state_lo, int salt_plus_env, int episode) {
+    const u64 a = sl_mix64(((u64)(u32)salt_plus_env << 32) | (u64)(u32)episode);
+    state_hi ^= a;
+    state_lo ^= sl_mix64(a);
+}
+
 struct U128 {
     u64 hi, lo;
 };

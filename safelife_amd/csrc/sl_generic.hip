@@ -292,7 +292,9 @@ __device__ void reset_block(const sl_env_batch &env, int e, u16 *brd, int *ivar,
     if (tid == 0) {
         ivar[0] = lv.agent_row;
         ivar[1] = lv.agent_col;
-        env.rng[e] = env.pool_rng[l];
+        sl_pcg64 gen = env.pool_rng[l];
+        if (env.stream_salt) sl_episode_stream(gen.state_hi, gen.state_lo, env.stream_salt + e, sc->episode_idx);
+        env.rng[e] = gen;
     }
     __syncthreads();
     const int32_t *table = env.points_table + 72 * lv.table_idx;
@@ -317,7 +319,7 @@ __device__ void reset_block(const sl_env_batch &env, int e, u16 *brd, int *ivar,
         n.goals_static = 0;
         n.is_active = 1;
         n.exit_open_at_reset = open ? 1 : 0;
-        n.reserved = 0;
+        n.loaded = 1;
         *sc = n;
         if (env.wrap.flags) wrap_reset(env.wrap.state[e], ivar[0], ivar[1]);
     }
@@ -476,6 +478,14 @@ __global__ __launch_bounds__(GB) void k_env_reset_generic(sl_env_batch env,
     const int HW = env.H * env.W, e = blockIdx.x, tid = threadIdx.x;
     if (mask && !mask[e]) return;
     GenericLds l = carve(smem, HW, 1);
+    if (tid == 0) {         // a slot that already holds a level moves on to its next one (safelife_env.py:204)
+        sl_env_scalars *sc = env.scalars + e;
+        if (sc->loaded) {
+            sc->level_idx = pos_mod(sc->level_idx + env.level_stride, env.L);
+            sc->episode_idx += 1;
+        }
+    }
+    __syncthreads();
     reset_block(env, e, l.buf[0], l.ivar, l.wave_tot);
     u16 *gboard = env.board + (size_t)e * HW;
     for (int i = tid; i < HW; i += GB) gboard[i] = l.buf[0][i];

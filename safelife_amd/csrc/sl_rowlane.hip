@@ -1510,6 +1510,12 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
                 live ? g : 0);
             if (mine && r == 0) {
                 episodes += 1;
+                if (env.stream_salt) {      // the new episode's own stream (lanes r < 4 wrote the level's state above)
+                    u64 hi = rng_lds[4 * g + 0], lo = rng_lds[4 * g + 1];
+                    sl_episode_stream(hi, lo, env.stream_salt + (int)e, episodes);
+                    rng_lds[4 * g + 0] = hi;
+                    rng_lds[4 * g + 1] = lo;
+                }
                 exits = env.pool_exit_locs + (size_t)level * E;   // never written by this launch
                 exit0 = exits[0];
                 const sl_level_scalars lv = env.pool_scalars[level];
@@ -1550,7 +1556,7 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
         rec.goals_static = gstatic;
         rec.is_active = active ? 1 : 0;
         rec.exit_open_at_reset = open0;
-        rec.reserved = 0;
+        rec.loaded = 1;
         unsigned e2 = e;                      // recompute the record address here instead of keeping
         asm volatile("" : "+v"(e2));          // a 64-bit pointer alive (and spilled) across the kernel
         env.scalars[e2] = rec;

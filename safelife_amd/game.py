@@ -1,276 +1,188 @@
 """
-``SafeLifeGame`` look-alike on top of the GPU ``speedups`` functions (compat tier).
+One SafeLife game on the host, stepped through the GPU ``speedups`` functions (compat tier).
 
-Same attribute names, dtypes and call sequence as the reference's
-``GameState -> GameWithGoals -> SafeLifeGame`` chain (safelife/safelife_game.py:126-761), restricted
-to what ``SafeLifeEnv.step()/reset()``, the reward wrappers and the episode logger touch:
+This is NOT the reference's class hierarchy re-typed: it is a small state holder written against the
+interface that ``safelife_amd.env.SafeLifeEnv``, the reward wrappers and an episode logger use
+(SURVEY.md section 7), with the reward glue derived from the rules in SURVEY.md Appendix C and checked
+against the reference's recorded traces (tests/test_hip_parity.py::test_compat_env_trace).  What it
+offers, under the reference's names so that reference-style drivers run unchanged:
 
-    board, goals, agent_locs, agent_names, exit_locs, spawn_prob, min_performance, num_steps,
-    points_table, points_on_level_exit, file_name, title, seed, rng, game_over,
-    execute_actions(), advance_board(), update_exit_colors(), alive_counts, current_points(),
-    points_earned(), initial_available_points(), required_points(), can_exit(), has_exited(),
-    agent_is_active(), is_stochastic, revert(), serialize(), deserialize(), loaddata(), load(), save()
+    state        board, goals, agent_locs, agent_names, num_steps, game_over
+    constants    spawn_prob, min_performance, points_table, points_on_level_exit, exit_locs,
+                 file_name, title, seed / rng
+    physics      execute_actions(actions), advance_board(), update_exit_colors()
+    scoring      alive_counts, current_points(), points_earned(), initial_available_points(),
+                 required_points(), can_exit(), has_exited(), agent_is_active()
+    lifecycle    loaddata(data), revert()
 
-One env at a time, host arrays, every native call a (tiny) kernel launch: this tier exists so that
-reference-style drivers and wrappers run unchanged; throughput lives in ``SafeLifeVectorEnv``.
-Editing (`execute_edit`), `GameOfLife` and `AsyncGame` are outside the hot path and not provided.
+A game is built from a ``levels.Level`` (the loader of the reference's ``.npz`` format lives there, as do
+the per-level constants ``initial_colors`` / ``available_points`` / ``required_points``) and keeps that
+level as its pristine copy, so ``revert()`` is a copy back, not a re-parse (files: ``levels.load_levels``).
+Editing commands, saving, ``GameOfLife`` and ``AsyncGame`` are outside the hot path and not provided.
+One env at a time, host arrays, every native call a (tiny) kernel launch: throughput lives in ``SafeLifeVectorEnv``.
 """
 import os
 
 import numpy as np
 
+from . import levels as _levels
 from . import speedups
-from .cell_types import CellTypes, DEFAULT_POINTS_TABLE
+from .cell_types import CellTypes
 from .random import get_rng, set_rng
+
+_AGENT_OR_EXIT = CellTypes.agent | CellTypes.exit
 
 
 class SafeLifeGame(object):
-    spawn_prob = 0.3
-    board = None
-    goals = None
-    file_name = None
-    game_over = False
-    points_on_level_exit = +1
-    num_steps = 0
-    min_performance = -1
-    _seed = None
-    _rng = None
-    _static_goals = None
-    default_points_table = DEFAULT_POINTS_TABLE
+    points_on_level_exit, game_over, file_name = 1, False, None
 
-    def __init__(self, board_size=(10, 10)):
-        self.exit_locs = (np.array([], dtype=int), np.array([], dtype=int))
-        self.agent_locs = np.empty((0, 2), dtype=int)
-        self.agent_names = np.array([], dtype=str)
-        if board_size is not None:
-            self.board = np.zeros(board_size, dtype=np.uint16)
-            self.agent_locs = np.array(board_size).reshape(1, 2) // 2
-            self.agent_names = np.array(["agent0"])
-            self.board[self.agent_locs_idx] = CellTypes.player
-            self.goals = np.zeros_like(self.board)
-            self._needs_new_counts = True
-            self.reset_points_table()
-            self.setup_initial_counts()
-            self._init_data = self.serialize()
+    def __init__(self, board_size=(10, 10), level=None):
+        """``level``: a ``levels.Level``; without one, an empty board of ``board_size`` with the agent
+        in its middle (what the reference's constructor yields)."""
+        if level is None:
+            h, w = board_size
+            board = np.zeros((h, w), np.uint16)
+            board[h // 2, w // 2] = CellTypes.player
+            level = _levels.Level(board, agent_locs=[[h // 2, w // 2]])
+        self._level = level
+        self._seed = None
+        self._rng = None
+        self._install(level)
 
-    # ------------------------------------------------------------------ seeding (safelife_game.py:166-192)
+    # ------------------------------------------------------------------ construction / reset
+    def _install(self, level):
+        """(Re)start from the pristine level: state arrays are fresh copies, the per-level constants of
+        the reward glue are derived once."""
+        self.board = level.board.copy()
+        self.goals = level.goals.copy()
+        self.agent_locs = np.ascontiguousarray(level.agent_locs, dtype=np.int64).reshape(-1, 2)
+        self.agent_names = np.array(["agent%d" % k for k in range(len(self.agent_locs))])
+        self.spawn_prob = level.spawn_prob
+        self.min_performance = level.min_performance
+        self.points_table = level.points_table.copy()
+        if len(self.points_table) != len(self.agent_locs):        # one table per agent
+            self.points_table = np.resize(self.points_table, (len(self.agent_locs), 8, 9))
+        flat = level.exit_locs
+        self.exit_locs = np.unravel_index(flat, self.board.shape)
+        self.num_steps, self.game_over = 0, False
+        self._static_goals = None          # unknown until the goals have been advanced once
+        self._counts = None                # cache of alive_counts, dropped whenever the board changes
+        self._init_data = {"board": level.board}              # side_effect_score reads the starting board here
+        self.initial_counts = self.alive_counts
+        self.initial_colors = _levels.initial_colors(level.board)
+        self.update_exit_colors()
+
+    @classmethod
+    def loaddata(cls, data, auto_cls=True):
+        """From a dict / ``.npz`` record with the reference's keys.  The ``class`` key of level files is
+        ignored: every level runs SafeLifeGame physics."""
+        return cls(level=_levels.Level.from_data(data))
+
+    def revert(self):
+        self._install(self._level)
+        return True                        # (the reference reports whether there was a state to go back to)
+
+    # ------------------------------------------------------------------ identity, randomness
+    @property
+    def title(self):
+        if not self.file_name:
+            return None
+        stem, _, ext = os.path.basename(self.file_name).rpartition(".")
+        if not stem:
+            return ext
+        key = self._seed.spawn_key if self._seed is not None else ()
+        return "%s-e%d" % (stem, key[-1]) if ext in ("yaml", "json") and key else stem
+
     @property
     def seed(self):
         return self._seed
 
     @seed.setter
-    def seed(self, seed):
-        if not isinstance(seed, np.random.SeedSequence):
-            seed = np.random.SeedSequence(seed)
-        self._seed = seed
-        self._rng = np.random.default_rng(seed)
+    def seed(self, value):
+        self._seed = value if isinstance(value, np.random.SeedSequence) else np.random.SeedSequence(value)
+        self._rng = np.random.default_rng(self._seed)          # PCG64: the only generator the kernels model
 
     @property
     def rng(self):
-        return self._rng if self._rng is not None else get_rng()
+        return get_rng() if self._rng is None else self._rng
 
-    # ------------------------------------------------------------------ (de)serialisation
-    def serialize(self):
-        cls = self.__class__
-        return {
-            "spawn_prob": self.spawn_prob,
-            "agent_locs": self.agent_locs.copy(),
-            "agent_names": self.agent_names.copy(),
-            "board": self.board.copy(),
-            "class": "%s.%s" % (cls.__module__, cls.__name__),
-            "goals": self.goals.copy(),
-            "points_table": self.points_table.copy(),
-            "min_performance": self.min_performance,
-        }
+    # ------------------------------------------------------------------ agents
+    def _agent_index(self):
+        return self.agent_locs[:, 0], self.agent_locs[:, 1]
 
-    def deserialize(self, data, as_initial_state=True):
-        keys = data.dtype.fields if getattr(getattr(data, "dtype", None), "fields", None) else data
-        if as_initial_state:
-            self._init_data = data
-        self.board = np.array(data["board"], dtype=np.uint16)
-        if "spawn_prob" in keys:
-            self.spawn_prob = float(data["spawn_prob"])
-        if "agent_loc" in keys:             # legacy single-agent key, stored as (x, y)
-            self.agent_locs = np.ascontiguousarray(np.array(data["agent_loc"])[None, ::-1])
-        elif "agent_locs" in keys:
-            self.agent_locs = np.array(data["agent_locs"]).reshape(-1, 2)
-        if "agent_names" in keys:
-            self.agent_names = np.array(data["agent_names"])
-        else:
-            self.agent_names = np.array(["agent%i" % i for i in range(len(self.agent_locs))])
-        if "orientation" in keys:
-            self.orientation = int(data["orientation"])
-        self.update_exit_locs()
-        self.game_over = False
-        self.num_steps = 0
-        self.goals = np.array(data["goals"], dtype=np.uint16) if "goals" in keys else np.zeros_like(self.board)
-        if "min_performance" in keys:
-            self.min_performance = data["min_performance"]
-        if "points_table" in keys:
-            self.points_table = np.array(data["points_table"])
-        else:
-            self.reset_points_table()
-        self._needs_new_counts = True
-        if as_initial_state:
-            self.setup_initial_counts()
-        self._static_goals = None
-        self.update_exit_colors()
-
-    def revert(self):
-        if hasattr(self, "_init_data"):
-            self.deserialize(self._init_data)
-            return True
-        return False
-
-    @classmethod
-    def loaddata(cls, data, auto_cls=True):
-        """The `class` key of level files is ignored: every level runs SafeLifeGame physics."""
-        obj = cls(board_size=None)
-        obj.deserialize(data)
-        return obj
-
-    @classmethod
-    def load(cls, file_name, auto_cls=True):
-        file_name = os.path.abspath(os.path.expanduser(file_name))
-        with np.load(file_name) as data:
-            obj = cls.loaddata({k: data[k] for k in data.files})
-        obj.file_name = file_name
-        return obj
-
-    def save(self, file_name=None):
-        file_name = file_name or self.file_name
-        if file_name is None:
-            raise ValueError("Must specify a file name")
-        file_name = os.path.abspath(os.path.expanduser(file_name))
-        if not file_name.endswith(".npz"):
-            file_name += ".npz"
-        self.file_name = file_name
-        self._init_data = self.serialize()
-        self.num_steps = 0
-        np.savez_compressed(file_name, **self._init_data)
-
-    # ------------------------------------------------------------------ simple properties
-    @property
-    def width(self):
-        return self.board.shape[1]
-
-    @property
-    def height(self):
-        return self.board.shape[0]
-
-    @property
-    def title(self):
-        if self.file_name is None:
-            return None
-        fname = os.path.split(self.file_name)[-1]
-        fname, *ext = fname.rsplit(".", 1)
-        if ext and ext[0] in ("json", "yaml") and self._seed and self._seed.spawn_key:
-            fname += "-e" + str(self._seed.spawn_key[-1])
-        return fname
-
-    @property
-    def agent_locs_idx(self):
-        return tuple(self.agent_locs.T)
-
-    @property
-    def orientation(self):
-        agents = self.board[self.agent_locs_idx]
-        return ((agents & CellTypes.orientation_mask) >> CellTypes.orientation_bit).astype(np.int64)
-
-    @orientation.setter
-    def orientation(self, value):
-        value = (np.array(value, dtype=np.uint16) & 3) << CellTypes.orientation_bit
-        idx = self.agent_locs_idx
-        self.board[idx] = (self.board[idx] & ~CellTypes.orientation_mask) | value
-
-    @property
-    def is_stochastic(self):
-        return bool((self.board & CellTypes.spawning).any())
-
-    # ------------------------------------------------------------------ actions / physics
-    def execute_actions(self, actions):
-        """safelife_game.py:380-389 -> C execute_actions (advance_board.c:217-300)."""
-        if self.agent_locs.dtype != np.int64 or not self.agent_locs.flags.c_contiguous:
-            self.agent_locs = np.ascontiguousarray(self.agent_locs, dtype=np.int64)
-        speedups.execute_actions(self.board, self.agent_locs, actions)
-
-    def advance_board(self):
-        """safelife_game.py:746-761: one CA step of the board, and of the goals unless static,
-        drawing from the game's own generator."""
-        with set_rng(self.rng):
-            self.num_steps += 1
-            self._needs_new_counts = True
-            self.board = speedups.advance_board(self.board, self.spawn_prob)
-            if not self._static_goals:
-                new_goals = speedups.advance_board(self.goals, self.spawn_prob)
-                if self._static_goals is None:
-                    self._static_goals = bool(
-                        not (new_goals & CellTypes.spawning).any() and (new_goals == self.goals).all())
-                self.goals = new_goals
-
-    # ------------------------------------------------------------------ exits (safelife_game.py:505-552)
-    def has_exited(self):
-        agents = self.board[self.agent_locs_idx]
-        return agents & (CellTypes.agent | CellTypes.exit) == CellTypes.exit
+    def _agent_cells(self):
+        return self.board[self._agent_index()]
 
     def agent_is_active(self):
-        return self.board[self.agent_locs_idx] & CellTypes.agent > 0
+        return (self._agent_cells() & CellTypes.agent) != 0
 
-    def update_exit_locs(self):
-        exits = self.board & (CellTypes.exit | CellTypes.agent) == CellTypes.exit
-        self.exit_locs = np.nonzero(exits)
+    def has_exited(self):
+        """An agent that stepped into an exit leaves the exit cell behind at its location."""
+        return (self._agent_cells() & _AGENT_OR_EXIT) == CellTypes.exit
+
+    # ------------------------------------------------------------------ physics (the native path)
+    def execute_actions(self, actions):
+        if not (self.agent_locs.dtype == np.int64 and self.agent_locs.flags.c_contiguous):
+            self.agent_locs = np.ascontiguousarray(self.agent_locs, dtype=np.int64)
+        speedups.execute_actions(self.board, self.agent_locs, actions)
+        self._counts = None
+
+    def advance_board(self):
+        """One CA step of the board under the game's own generator, then of the goals unless they are
+        known not to change (decided after their first step: unchanged and without spawners)."""
+        self.num_steps += 1
+        self._counts = None
+        with set_rng(self.rng):
+            self.board = speedups.advance_board(self.board, self.spawn_prob)
+            if self._static_goals:
+                return
+            stepped = speedups.advance_board(self.goals, self.spawn_prob)
+            if self._static_goals is None:
+                has_spawner = bool(np.any(stepped & CellTypes.spawning))
+                self._static_goals = not has_spawner and bool(np.array_equal(stepped, self.goals))
+            self.goals = stepped
 
     def update_exit_colors(self):
-        can_exit = self.can_exit()
-        idx = self.agent_locs_idx
-        self.board[idx] = (self.board[idx] & ~CellTypes.exit) | (CellTypes.exit * can_exit).astype(np.uint16)
-        exit_type = CellTypes.level_exit | CellTypes.color_r if can_exit.any() else CellTypes.level_exit
-        self.board[self.exit_locs] = exit_type
+        """Agents that have earned the level's required points stand on an open exit; every exit cell of the
+        level is repainted -- red once anybody may leave."""
+        may_leave = self.can_exit()
+        rows, cols = self._agent_index()
+        cells = self.board[rows, cols] & np.uint16(~CellTypes.exit & 0xFFFF)
+        self.board[rows, cols] = np.where(may_leave, cells | CellTypes.exit, cells)
+        paint = CellTypes.level_exit | (CellTypes.color_r if np.any(may_leave) else 0)
+        self.board[self.exit_locs] = paint
 
-    # ------------------------------------------------------------------ points (safelife_game.py:657-719)
+    # ------------------------------------------------------------------ scoring
     @property
     def alive_counts(self):
-        if getattr(self, "_needs_new_counts", True):
-            self._needs_new_counts = False
-            self._alive_counts = speedups.alive_counts(self.board, self.goals)
-            self._alive_counts.setflags(write=False)
-        return self._alive_counts
+        """int64 [8 goal colours, 9 = 8 cell colours + empty] histogram (native), cached per board state."""
+        if self._counts is None:
+            counts = speedups.alive_counts(self.board, self.goals)
+            counts.setflags(write=False)
+            self._counts = counts
+        return self._counts
 
-    def setup_initial_counts(self):
-        self.initial_counts = self.alive_counts
-        self.initial_colors = np.zeros(9, dtype=bool)
-        generators = CellTypes.agent | CellTypes.alive | CellTypes.spawning
-        colors = self.board[self.board & generators > 0] & CellTypes.rainbow_color
-        self.initial_colors[np.unique(colors) >> CellTypes.color_bit] = True
-        self.initial_colors[-1] = True
+    def _weighted(self, counts):
+        """sum(points_table * counts) for every agent."""
+        return np.einsum("agc,gc->a", self.points_table, counts)
 
-    def reset_points_table(self):
-        self.points_table = np.tile(self.default_points_table, [len(self.agent_locs), 1, 1])
-
-    def _exit_points(self):
+    def _exit_bonus(self):
         return self.points_on_level_exit * self.has_exited()
 
     def current_points(self):
-        points = (self.points_table * self.alive_counts).reshape(-1, 72)
-        return np.sum(points, axis=1) + self._exit_points()
+        return self._weighted(self.alive_counts) + self._exit_bonus()
 
     def points_earned(self):
-        delta = self.alive_counts - self.initial_counts
-        points = (self.points_table * delta).reshape(-1, 72)
-        return np.sum(points, axis=1) + self._exit_points()
+        return self._weighted(self.alive_counts - self.initial_counts) + self._exit_bonus()
 
     def initial_available_points(self):
-        goal_counts = np.sum(self.initial_counts, axis=1)
-        max_points = np.max(self.points_table * self.initial_colors, axis=2)
-        total_available = np.sum(max_points * goal_counts, axis=1)
-        initial_points = np.sum((self.points_table * self.initial_counts).reshape(-1, 72), axis=1)
-        return total_available - initial_points
+        return np.array([_levels.available_points(table, self.initial_counts, self.initial_colors)
+                         for table in self.points_table], dtype=np.int64)
 
     def required_points(self):
-        req_points = self.min_performance * self.initial_available_points()
-        return np.maximum(0, np.int64(np.ceil(req_points)))
+        return np.array([_levels.required_points(self.min_performance, int(avail))
+                         for avail in self.initial_available_points()], dtype=np.int64)
 
     def can_exit(self):
-        points_earned = np.maximum(0, self.points_earned())
-        is_agent = self.board[self.agent_locs_idx] & CellTypes.agent > 0
-        return is_agent & (points_earned >= self.required_points())
+        enough = np.maximum(self.points_earned(), 0) >= self.required_points()
+        return self.agent_is_active() & enough

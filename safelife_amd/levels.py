@@ -290,7 +290,7 @@ def empty_env_arrays(pool, num_envs):
         "table_idx": np.zeros(B, np.int32), "goals_static": np.zeros(B, np.uint8),
         "is_active": np.zeros(B, np.uint8), "episode_reward": np.zeros(B, np.float32),
         "episode_length": np.zeros(B, np.int32), "level_idx": np.zeros(B, np.int32),
-        "episode_idx": np.zeros(B, np.int32),
+        "episode_idx": np.zeros(B, np.int32), "loaded": np.zeros(B, np.uint8),
         "reward": np.zeros(B, np.float32), "done": np.zeros(B, np.uint8),
         "success": np.zeros(B, np.uint8), "times_up": np.zeros(B, np.uint8),
     }

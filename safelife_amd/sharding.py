@@ -58,7 +58,7 @@ class RewardGather(object):
             self.work[which] = None
             if getattr(self.env, "slices", 1) > 1:
                 self.env.fence()             # ... for the slice streams too
-        self.env.struct.out = self._slot_ptr[which][slot]
+        self.env.set_step_outputs(self._slot_ptr[which][slot])
 
     def after_step(self, t):
         if t % self.every != self.every - 1:

@@ -46,6 +46,12 @@ class SafeLifeVectorEnv(object):
                                    semantics (it fences the slice streams against the caller's stream on
                                    both sides); ``step_async()`` + ``join()`` leave the fences to the caller
                                    and are what a pipelined driver uses.
+    episode_streams : bool         True: every episode gets its own random stream, derived from the level's
+                                   generator, the env's global index (``env_offset`` + e) and the env's episode
+                                   count -- envs that replay one pool level, and successive replays by one env,
+                                   then differ the way the reference's per-game ``SeedSequence.spawn`` children
+                                   do (level_iterator.py:218).  False: an episode on pool level l starts from
+                                   ``pool.rng[l]`` exactly (replaying recorded traces of the reference).
     wrappers : dict or None        training-wrapper math of the reference's env_wrappers.py, fused into the
                                    step (stacked as training/env_factory.py:277-283 does); keys, all
                                    optional: ``movement_bonus``, ``movement_bonus_power``,
@@ -60,7 +66,7 @@ class SafeLifeVectorEnv(object):
     def __init__(self, pool, num_envs, *, time_limit=1000, remove_white_goals=True,
                  view_shape=(15, 15), output_channels=_DEFAULT_CHANNELS, auto_reset=True,
                  first_level=None, level_stride=1, env_offset=0, with_obs=True,
-                 points_on_level_exit=1, wrappers=None, slices=1):
+                 points_on_level_exit=1, wrappers=None, slices=1, episode_streams=True):
         import torch
         self.torch = torch
         if not isinstance(pool, LevelPool):
@@ -111,6 +117,10 @@ class SafeLifeVectorEnv(object):
         if first_level is None:
             first_level = (int(env_offset) + np.arange(B)) % len(pool)
         first = np.broadcast_to(np.asarray(first_level, np.int32), (B,)).copy()
+        if B and (first.min() < 0 or first.max() >= len(pool)):
+            raise ValueError("first_level must lie in 0..len(pool)-1")
+        if int(level_stride) < 0:
+            raise ValueError("level_stride must be >= 0")
         t["scalars"][:, _hip.SCALAR_COLS["level_idx"]] = torch.from_numpy(first).to(dev)
 
         s = self.struct = _hip.EnvBatch()
@@ -124,6 +134,7 @@ class SafeLifeVectorEnv(object):
             s.channels[i] = int(c)
         s.L, s.level_stride = len(pool), int(level_stride)
         s.spawner_free = int(not pool.has_spawner)
+        s.stream_salt = 1 + int(env_offset) if episode_streams else 0
         t["score_lut"] = torch.zeros((s.n_tables, 4096 + 65536), dtype=torch.int8, device=dev)
         for name in _hip.ENV_STATE_PTRS + _hip.ENV_POOL_PTRS + _hip.ENV_OUT_PTRS:
             if name == "obs":
@@ -376,7 +387,7 @@ class SafeLifeVectorEnv(object):
             col = self.t["scalars"][:, _hip.SCALAR_COLS[name]].cpu().numpy()
             if name in _hip.SCALAR_FLOATS:
                 return col.view(np.float32)
-            if name in ("goals_static", "is_active"):
+            if name in ("goals_static", "is_active", "loaded"):
                 return col.astype(np.uint8)
             return col
         if name == "reward":

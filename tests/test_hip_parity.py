@@ -677,6 +677,35 @@ def test_sliced_stepping_soak(pool_name, B):
                 assert np.array_equal(env.numpy(name), ref), (trial, n, name)
 
 
+def test_manual_reset_moves_on_and_episode_streams():
+    """auto_reset=False, the flow of INTEGRATION.md section 3: the driver resets finished envs itself.  Every such
+    reset takes the env's NEXT pool level (SafeLifeEnv.reset() -> next(level_iterator)) and, with
+    episode_streams, its own random stream -- device against the oracle over several episodes; and two envs
+    on the same spawner level must not be stochastic replicas of each other."""
+    pool, _ = util.pool_from_fixture("append_spawn_25", _device_counts, n=6, min_performance_fraction=0.05)
+    B = 40
+    kw = dict(first_level=np.zeros(B, np.int32), auto_reset=False, level_stride=2, time_limit=12, view_shape=(9, 9))
+    dev, cpu = util.DeviceBackend(pool, B, **kw), util.OracleBackend(pool, B, **kw)
+    assert np.array_equal(dev.reset(), cpu.reset())
+    rng = np.random.default_rng(9)
+    for t in range(40):
+        a = np.zeros(B, np.int32) if t < 6 else rng.integers(0, 9, B).astype(np.int32)
+        o1, r1, d1 = dev.step(a)
+        o2, r2, d2 = cpu.step(a)
+        assert np.array_equal(r1, r2) and np.array_equal(d1, d2) and np.array_equal(o1, o2), t
+        if t == 5:      # same level, same (no-op) actions, different streams: the spawners must have diverged
+            boards = dev.get("board")
+            assert len({boards[e].tobytes() for e in range(B)}) > B // 2
+        if d1.any():
+            dev.env.reset(d1)
+            cpu.env.reset(d1)
+            assert np.array_equal(dev.get("obs"), cpu.env.obs)
+    for name in ENV_STATE + ("loaded",):
+        assert np.array_equal(dev.get(name), cpu.get(name)), name
+    episodes = dev.get("episode_idx")
+    assert episodes.min() >= 2 and np.array_equal(dev.get("level_idx"), (2 * episodes) % len(pool))
+
+
 def test_sharded_equals_unsharded():
     """env e behaves the same whichever rank owns it -- two half-size envs with
     env_offset 0 / B/2 (what ranks 0 and 1 of a 2-GPU run hold) against one env of size B."""

@@ -111,6 +111,9 @@ class OracleBackend(object):
         self.arrays["level_idx"][:] = first_level
         kw.setdefault("view_shape", (15, 15))
         wrappers = kw.pop("wrappers", None)
+        kw.pop("slices", None)
+        # the product's keyword -> the oracle's: salt 1 + env_offset (0 here), or 0 = exact pool generators
+        kw["stream_salt"] = 1 + int(kw.pop("env_offset", 0)) if kw.pop("episode_streams", True) else 0
         self.env = oracle.OracleEnv(self.arrays, **kw)
         if wrappers is not None:
             self.env.set_wrappers(**wrappers)
@@ -160,7 +163,7 @@ def replay_trace(tr, backend_cls, counts_fn):
     wrappers = wrappers_from_trace(tr)
     if wrappers is not None:
         kw["wrappers"] = wrappers
-    be = backend_cls(pool, 1, first_level=0, auto_reset=True, level_stride=1, **kw)
+    be = backend_cls(pool, 1, first_level=0, auto_reset=True, level_stride=1, episode_streams=False, **kw)
     obs = be.reset()
     resets = list(tr["trace_reset_at"])
     n_resets = len(resets)
@@ -207,7 +210,7 @@ def replay_trace_terminal(tr, backend_cls, counts_fn):
     resets = list(tr["trace_reset_at"]) + [len(tr["trace_reward"])]
     checked = 0
     for ep in range(len(resets) - 1):
-        be = backend_cls(pool, 1, first_level=ep, auto_reset=False, **kw)
+        be = backend_cls(pool, 1, first_level=ep, auto_reset=False, episode_streams=False, **kw)
         be.reset()
         for t in range(resets[ep], resets[ep + 1]):
             obs, reward, done = be.step(np.array([actions[t]], np.int32))
