@@ -179,6 +179,32 @@ typedef struct sl_wrappers {
                                      filled by slhip_env_prepare() (needed with SL_WRAP_SIDE_EFFECT) */
 } sl_wrappers;
 
+/* Finished episodes, queued on the device by the step kernels for the side-effect pass (safelife_env.py:183-192
+ * runs side_effect_score() inside the step that ends an episode; with thousands of envs the episode-end work
+ * is batched instead).  The step that ends an env's episode -- done while the env was still active -- takes
+ * slot = atomic_add(count, 1) and, if slot < capacity, writes a record and a copy of the board as the agent
+ * left it (after update_exit_colors, before any auto-reset reloads the slot).  capacity == 0 switches the
+ * queue off.  The consumer (slhip_side_effects) reads min(*count, capacity) entries; it never resets *count:
+ * the caller alternates two queues and clears the idle one (hipMemsetAsync) before handing it back. */
+typedef struct sl_episode_record {    /* 32 bytes */
+    int32_t env;                  /* index of the env in the batch */
+    int32_t level;                /* pool level the episode was played on: its starting board */
+    int32_t num_steps;            /* GameState.num_steps when it ended */
+    int32_t episode_idx;          /* the env's episode counter during that episode */
+    float spawn_prob;
+    float episode_reward;
+    int32_t episode_length;
+    uint8_t success, times_up, reserved[2];
+} sl_episode_record;
+
+typedef struct sl_episode_queue {
+    int32_t capacity;             /* slots; 0 = no queue */
+    int32_t env_base;             /* added to the env index written into records (slices of a batch) */
+    int32_t *count;               /* device int32: episodes pushed so far (beyond capacity: dropped) */
+    sl_episode_record *records;   /* [capacity] */
+    uint16_t *boards;             /* [capacity,H,W] */
+} sl_episode_queue;
+
 typedef struct sl_env_batch {
     int32_t B, H, W, E;          /* envs; board dims; exit slots per env (>= 1) */
     int32_t time_limit;          /* SafeLifeEnv.time_limit (safelife_env.py:65) */
@@ -221,6 +247,7 @@ typedef struct sl_env_batch {
     int8_t *score_lut;           /* [n_tables,4096+65536] per-cell score tables derived from points_table by
                                     slhip_env_prepare(); NULL => the size-generic kernels are used */
     sl_wrappers wrap;            /* training wrappers; wrap.flags == 0 => none */
+    sl_episode_queue finished;   /* episodes that ended, for the side-effect pass; finished.capacity == 0 => none */
 } sl_env_batch;
 
 /* Derive env->score_lut from env->points_table, and env->wrap.pool_baseline from the level pool
@@ -253,6 +280,33 @@ int slhip_env_rollout(const sl_env_batch *env, const int32_t *actions, int T,
  * envs so that every slice keeps the 16-byte alignment the row kernels' DMA needs. */
 int slhip_env_step_slices(const sl_env_batch *env, int n_slices, const int32_t *bounds, const int32_t *actions,
                           void *const *streams);
+
+/* The episode-end pass of side_effect_score() (side_effects.py:103-130) for every episode in `queue` (what
+ * safelife_env.py:183-192 runs inside the step that ends an episode), all on the device and without a host
+ * read: every stage is launched over queue->capacity entries and stops at min(*queue->count, capacity).
+ *   1. b0 = pool_board[record.level]; b1 = advance_board(b0, spawn_prob, record.num_steps)       (:108)
+ *   2. counts[:,0] = life_occupancy(b1, p, num_samples); counts[:,1] = life_occupancy(queue board, ...)  (:109-110)
+ *   3. the distributions of :111-130: keys / life_dist / type_masks below.
+ * Random draws: the reference takes them from its process-wide generator (side_effects.py runs outside
+ * use_rng), so there is nothing to be stream-compatible with; every entry gets its own PCG64 stream derived
+ * from its level's generator, env index and episode index, consumed in the reference's order (roll-forward,
+ * inaction tensor, action tensor); derive_streams == 0 takes the caller's work_rng [C] as they are instead (how
+ * the reference's recorded generator states are replayed).  The earth-mover distances stay on the host (pyemd:
+ * parity unpinned).
+ * All buffers are caller-owned device memory sized by the queue's capacity C:
+ *   work_boards  uint16 [C,H,W]      b0, rolled forward in place
+ *   work_prob    float  [C],  work_steps int32 [C],  work_rng sl_pcg64 [C]
+ *   counts       int32  [C,2,H,W,8]  out: the two occupancy tensors of every entry (inaction, action)
+ *   keys         uint16 [C,SL_SE_MAX_KEYS] out: slots 0-7 = CellTypes.life | colour i where total_counts[i] > 0,
+ *                else 0xFFFF; slots 8.. = the frozen, movable-or-destructible, non-agent cell values of b0 in
+ *                ascending order (np.unique), 0xFFFF-padded (more than SL_SE_MAX_KEYS-8 of them: the rest are cut)
+ *   life_dist    double [C,2,8,H,W]  out: counts / num_samples as float64 (num_runs = 1), colour-major
+ *   type_masks   uint8  [C,2,SL_SE_MAX_KEYS-8,H,W] out: (b0 == key), (final board == key) for slots 8..
+ * Supported for the board shapes of the row kernels (elsewhere SL_E_UNSUPPORTED: use the primitives). */
+#define SL_SE_MAX_KEYS 24
+int slhip_side_effects(const sl_env_batch *env, const sl_episode_queue *queue, int num_samples, int derive_streams,
+                       uint16_t *work_boards, float *work_prob, int32_t *work_steps, sl_pcg64 *work_rng,
+                       int32_t *counts, uint16_t *keys, double *life_dist, uint8_t *type_masks, void *stream);
 
 /* SafeLifeEnv.get_obs() for the current state. */
 int slhip_env_obs(const sl_env_batch *env, void *stream);

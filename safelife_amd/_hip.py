@@ -22,8 +22,9 @@ EXPORTS = (
     "slhip_advance_board", "slhip_advance_board_each", "slhip_life_occupancy", "slhip_alive_counts", "slhip_execute_actions",
     "slhip_env_prepare", "slhip_env_reset", "slhip_env_step", "slhip_env_step_slices", "slhip_env_rollout",
     "slhip_env_obs",
-    "slhip_obs_to_policy",
+    "slhip_obs_to_policy", "slhip_side_effects",
 )
+SL_SE_MAX_KEYS = 24
 
 
 class SafeLifeHipError(RuntimeError):
@@ -75,6 +76,18 @@ class Wrappers(C.Structure):
                 ("pool_baseline", _p)]
 
 
+class EpisodeRecord(C.Structure):
+    """`struct sl_episode_record` (32 bytes)."""
+    _fields_ = [("env", C.c_int32), ("level", C.c_int32), ("num_steps", C.c_int32), ("episode_idx", C.c_int32),
+                ("spawn_prob", C.c_float), ("episode_reward", C.c_float), ("episode_length", C.c_int32),
+                ("success", C.c_uint8), ("times_up", C.c_uint8), ("reserved", C.c_uint8 * 2)]
+
+
+class EpisodeQueue(C.Structure):
+    """`struct sl_episode_queue`."""
+    _fields_ = [("capacity", C.c_int32), ("env_base", C.c_int32), ("count", _p), ("records", _p), ("boards", _p)]
+
+
 class EnvBatch(C.Structure):
     _fields_ = (
         [(n, C.c_int32) for n in ENV_SCALARS_HEAD]
@@ -83,7 +96,7 @@ class EnvBatch(C.Structure):
         + [("L", C.c_int32), ("level_stride", C.c_int32)]
         + [(n, _p) for n in ENV_POOL_PTRS]
         + [(n, _p) for n in ENV_OUT_PTRS]
-        + [("wrap", Wrappers)]
+        + [("wrap", Wrappers), ("finished", EpisodeQueue)]
     )
 
 
@@ -118,6 +131,7 @@ def lib():
         L.slhip_env_step_slices.argtypes = [C.POINTER(EnvBatch), C.c_int, _p, _p, _p]
         L.slhip_env_rollout.argtypes = [C.POINTER(EnvBatch), _p, C.c_int, _p, _p, _p]
         L.slhip_env_obs.argtypes = [C.POINTER(EnvBatch), _p]
+        L.slhip_side_effects.argtypes = [C.POINTER(EnvBatch), C.POINTER(EpisodeQueue), C.c_int, C.c_int] + [_p] * 9
         L.slhip_obs_to_policy.argtypes = [_p, C.c_int, C.c_int, C.c_int, _p, C.c_int, _p, C.c_int, _p]
         for name in EXPORTS:
             getattr(L, name)  # AttributeError here means the .so is stale

@@ -101,6 +101,9 @@ int check_env(const sl_env_batch *env) {
                           env->pool_scalars, env->out};
     for (const void *p : need)
         if (!p) return fail(SL_E_ARG, "null pointer in sl_env_batch");
+    const sl_episode_queue &q = env->finished;
+    if (q.capacity < 0 || (q.capacity > 0 && (!q.count || !q.records || !q.boards)))
+        return fail(SL_E_ARG, "finished-episode queue: negative capacity or null buffers");
     const sl_wrappers &w = env->wrap;
     if (w.flags) {
         if (w.flags & ~(SL_WRAP_MOVEMENT | SL_WRAP_AS_PENALTY | SL_WRAP_EXIT_BONUS | SL_WRAP_SIDE_EFFECT |
@@ -130,6 +133,7 @@ sl_env_batch env_slice(const sl_env_batch &env, int e0, int n) {
     s.scalars = env.scalars + e0;
     s.out = env.out + e0;
     if (env.stream_salt) s.stream_salt = env.stream_salt + e0;
+    s.finished.env_base = env.finished.env_base + e0;
     if (env.obs) {
         const size_t cell = env.n_channels > 0 ? (size_t)env.n_channels : 4;     // uint8 channels, or the raw uint32 view
         s.obs = env.obs + (size_t)e0 * env.view_h * env.view_w * cell;
@@ -167,7 +171,7 @@ int slhip_advance_board(const uint16_t *in, uint16_t *out, int B, int H, int W, 
     if ((rc = jump_table(&jump))) return rc;
     const bool aligned = (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
     hipError_t err = (sl::rowlane_supports(H, W) && aligned && !force_generic())
-                         ? sl::launch_advance_rowlane(in, out, B, H, W, spawn_prob, n_steps, rng, jump,
+                         ? sl::launch_advance_rowlane(in, out, B, H, W, spawn_prob, n_steps, nullptr, nullptr, rng, jump,
                                                       (hipStream_t)stream)
                          : sl::launch_advance_generic(in, out, B, H, W, spawn_prob, n_steps, rng, jump, nullptr,
                                                       (hipStream_t)stream);
@@ -182,8 +186,12 @@ int slhip_advance_board_each(const uint16_t *in, uint16_t *out, int B, int H, in
     if (!in || !out || !spawn_prob || !rng || !n_steps) return fail(SL_E_ARG, "null pointer");
     const sl::Jump *jump;
     if ((rc = jump_table(&jump))) return rc;
-    hipError_t err = sl::launch_advance_generic(in, out, B, H, W, spawn_prob, 0, rng, jump, nullptr,
-                                                (hipStream_t)stream, n_steps);
+    const bool aligned = (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
+    hipError_t err = (sl::rowlane_supports(H, W) && aligned && !force_generic())
+                         ? sl::launch_advance_rowlane(in, out, B, H, W, spawn_prob, 0, n_steps, nullptr, rng, jump,
+                                                      (hipStream_t)stream)
+                         : sl::launch_advance_generic(in, out, B, H, W, spawn_prob, 0, rng, jump, nullptr,
+                                                      (hipStream_t)stream, n_steps);
     return err == hipSuccess ? SL_OK : hip_fail(err, "advance_board_each launch");
 }
 
@@ -199,8 +207,8 @@ int slhip_life_occupancy(const uint16_t *in, int32_t *counts, int B, int H, int 
     // 16-bit (or drained 8-bit) per-colour counters in LDS: the row kernel covers every step count the
     // reference is called with
     hipError_t err = (sl::rowlane_supports(H, W) && n_steps <= 65535 && !force_generic())
-                         ? sl::launch_occupancy_rowlane(in, counts, B, H, W, spawn_prob, n_steps, rng, jump,
-                                                        (hipStream_t)stream)
+                         ? sl::launch_occupancy_rowlane(in, counts, (size_t)H * W * 8, B, nullptr, H, W, spawn_prob, n_steps,
+                                                        rng, jump, (hipStream_t)stream)
                          : sl::launch_advance_generic(in, nullptr, B, H, W, spawn_prob, n_steps, rng, jump, counts,
                                                       (hipStream_t)stream);
     return err == hipSuccess ? SL_OK : hip_fail(err, "life_occupancy launch");
@@ -323,6 +331,41 @@ int slhip_env_step_slices(const sl_env_batch *env, int n_slices, const int32_t *
         if (rc) return rc;
     }
     return SL_OK;
+}
+
+int slhip_side_effects(const sl_env_batch *env, const sl_episode_queue *queue, int num_samples, int derive_streams,
+                       uint16_t *work_boards,
+                       float *work_prob, int32_t *work_steps, sl_pcg64 *work_rng, int32_t *counts, uint16_t *keys,
+                       double *life_dist, uint8_t *type_masks, void *stream) {
+    int rc = check_env(env);
+    if (rc) return rc;
+    if (!queue || queue->capacity < 0) return fail(SL_E_ARG, "bad queue");
+    if (num_samples < 1 || num_samples > 65535) return fail(SL_E_ARG, "num_samples outside 1..65535");
+    if (queue->capacity == 0) return SL_OK;
+    if (!queue->count || !queue->records || !queue->boards || !work_boards || !work_prob || !work_steps || !work_rng ||
+        !counts || !keys || !life_dist || !type_masks)
+        return fail(SL_E_ARG, "null pointer");
+    const int H = env->H, W = env->W, C = queue->capacity;
+    if (!sl::rowlane_supports(H, W) || force_generic() || (((uintptr_t)work_boards | (uintptr_t)queue->boards) & 15))
+        return fail(SL_E_UNSUPPORTED, "side-effect pass: board shape without row kernels (or unaligned boards)");
+    const sl::Jump *jump;
+    if ((rc = jump_table(&jump))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t stride = (size_t)2 * H * W * 8;
+    hipError_t err = sl::launch_se_gather(*env, *queue, work_boards, work_prob, work_steps,
+                                          derive_streams ? work_rng : nullptr, st);
+    if (err == hipSuccess)
+        err = sl::launch_advance_rowlane(work_boards, work_boards, C, H, W, work_prob, 0, work_steps, queue->count,
+                                         work_rng, jump, st);
+    if (err == hipSuccess)
+        err = sl::launch_occupancy_rowlane(work_boards, counts, stride, C, queue->count, H, W, work_prob, num_samples,
+                                           work_rng, jump, st);
+    if (err == hipSuccess)
+        err = sl::launch_occupancy_rowlane(queue->boards, counts + (size_t)H * W * 8, stride, C, queue->count, H, W,
+                                           work_prob, num_samples, work_rng, jump, st);
+    if (err == hipSuccess)
+        err = sl::launch_se_distributions(*env, *queue, counts, (double)num_samples, keys, life_dist, type_masks, st);
+    return err == hipSuccess ? SL_OK : hip_fail(err, "side_effects launch");
 }
 
 int slhip_env_obs(const sl_env_batch *env, void *stream) {

@@ -417,8 +417,34 @@ __global__ __launch_bounds__(GB) void k_env_rollout_generic(sl_env_batch env,
             ivar[3] = __float_as_int(reward);
             ivar[4] = times_up;
             ivar[5] = __float_as_int(ep_r);
+            // the step that ends the episode queues it for the side-effect pass (include/safelife_hip.h)
+            int slot = -1;
+            if (env.finished.capacity > 0 && done && active) {
+                slot = atomicAdd(env.finished.count, 1);
+                if (slot < env.finished.capacity) {
+                    sl_episode_record rec;
+                    rec.env = e + env.finished.env_base;
+                    rec.level = sc->level_idx;
+                    rec.num_steps = steps;
+                    rec.episode_idx = sc->episode_idx;
+                    rec.spawn_prob = sc->spawn_prob;
+                    rec.episode_reward = ep_r;
+                    rec.episode_length = ep_l;
+                    rec.success = success;
+                    rec.times_up = times_up;
+                    rec.reserved[0] = rec.reserved[1] = 0;
+                    env.finished.records[slot] = rec;
+                } else {
+                    slot = -1;
+                }
+            }
+            ivar[6] = slot;
         }
         __syncthreads();
+        if (ivar[6] >= 0) {
+            u16 *dst = env.finished.boards + (size_t)ivar[6] * HW;
+            for (int i = tid; i < HW; i += GB) dst[i] = nxt[i];
+        }
         if (env.wrap.flags) {       // env_wrappers.py: movement bonus, exit bonus, side-effect penalty
             int side = 0;
             if (env.wrap.flags & SL_WRAP_SIDE_EFFECT) {

@@ -32,10 +32,22 @@ hipError_t launch_obs_to_policy(const u32 *view, int B, int vh, int vw, const sl
 bool rowlane_supports(int H, int W);
 hipError_t launch_build_score_lut(const int32_t *points_table, int n_tables, int8_t *lut, hipStream_t stream);
 hipError_t launch_build_baseline(const sl_env_batch &env, hipStream_t stream);
+// n_each (device, optional): one step count per board instead of n_steps; n_valid (device, optional): only
+// the first *n_valid boards exist
 hipError_t launch_advance_rowlane(const u16 *in, u16 *out, int B, int H, int W, const float *spawn_prob,
-                                  int n_steps, sl_pcg64 *rng, const Jump *jump, hipStream_t stream);
-hipError_t launch_occupancy_rowlane(const u16 *in, int32_t *counts, int B, int H, int W, const float *spawn_prob,
-                                    int n_steps, sl_pcg64 *rng, const Jump *jump, hipStream_t stream);
+                                  int n_steps, const int32_t *n_each, const int32_t *n_valid, sl_pcg64 *rng,
+                                  const Jump *jump, hipStream_t stream);
+// counts_stride: int32 elements between the outputs of consecutive boards (H*W*8 when dense)
+hipError_t launch_occupancy_rowlane(const u16 *in, int32_t *counts, size_t counts_stride, int B, const int32_t *n_valid,
+                                    int H, int W, const float *spawn_prob, int n_steps, sl_pcg64 *rng, const Jump *jump,
+                                    hipStream_t stream);
+
+// sl_side_effects.hip : the episode-end pass of side_effect_score for queued episodes
+hipError_t launch_se_gather(const sl_env_batch &env, const sl_episode_queue &q, u16 *start_boards, float *spawn_prob,
+                            int32_t *num_steps, sl_pcg64 *rng, hipStream_t stream);
+hipError_t launch_se_distributions(const sl_env_batch &env, const sl_episode_queue &q, const int32_t *counts,
+                                   double denominator, uint16_t *keys, double *life_dist, uint8_t *type_masks,
+                                   hipStream_t stream);
 // envs [e_first, e_first + e_count) of the batch; actions / reward_t / done_t are indexed [t * tstride + e]
 // with the env's index in the whole batch
 hipError_t launch_env_rollout_rowlane(const sl_env_batch &env, int e_first, int e_count, const int32_t *actions,

@@ -723,19 +723,24 @@ __device__ __forceinline__ void store_span(u16 *__restrict__ dst, const unsigned
 template <int H, int W>
 __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_advance_rowlane(const u16 *__restrict__ in, u16 *__restrict__ out,
                                                                 int B, const float *__restrict__ spawn_prob,
-                                                                int n_steps, sl_pcg64 *rng,
-                                                                const Jump *__restrict__ jump) {
+                                                                int n_steps, const int32_t *__restrict__ n_each,
+                                                                const int32_t *__restrict__ n_valid,
+                                                                sl_pcg64 *rng, const Jump *__restrict__ jump) {
     using Gm = Geom<H, W>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // n_valid (device): only the first *n_valid boards exist -- the side-effect pass sizes its launches by the
+    // queue's capacity and lets the device decide how many entries there are
+    if (n_valid) B = min(B, *n_valid);
     const int e0b = blockIdx.x * Gm::NB;
+    if (e0b >= B) return;
     const int nbb = min(Gm::NB, B - e0b);
     const LaneMap<H, W> lm(lane);
     const int g = lm.g, r = lm.r, up = lm.up, dn = lm.dn;
     const int gb = wave * Gm::G + g;
     const bool rowl = lane < Gm::NL && gb < nbb;       // holds a row (its own or a halo copy)
     const bool live = rowl && lm.real;
-    const unsigned e = e0b + (live ? gb : 0);
+    const unsigned e = e0b + (rowl ? gb : 0);
     unsigned char *board = smem + Gm::OFF_BOARD;
     u64 *rng_lds = (u64 *)(smem + Gm::OFF_RNG) + 4 * Gm::G * wave;
 
@@ -743,6 +748,14 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_ad
     if (lane < 4 * Gm::G && wave * Gm::G + (lane >> 2) < nbb)
         rng_lds[lane] = ((const u64 *)(rng + e0b + wave * Gm::G))[lane];
     const double p = live ? (double)spawn_prob[e] : 0.0;
+    // one step count per board (advance_board_each): the wave runs as long as its busiest board, lanes of
+    // boards that are through keep their rows
+    const int my_n = n_each ? (rowl ? max(0, n_each[e]) : 0) : n_steps;
+    int wave_n = my_n;
+    if (n_each) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) wave_n = max(wave_n, __shfl_xor(wave_n, off));
+    }
     __syncthreads();
     const Consts cst = make_consts();
     RowWords<H, W> b, n;
@@ -750,13 +763,16 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_ad
 #pragma unroll
     for (int k = 0; k < Gm::WS; ++k) b[k] = 0;
     if (rowl) read_row<H, W>(board, gb, r, b);
-    for (int s = 0; s < n_steps; ++s) {
+    for (int s = 0; s < wave_n; ++s) {
+        const bool going = s < my_n;
         ca_rows<H, W, true>(b, n, elig, up, dn, cst);
-        if (!live) elig.clear();
+        if (!live || !going) elig.clear();
         if (__ballot(elig.any())) resolve_draws<H, W>(b, n, elig, rng_lds, live ? g : 0, p, jump);
+        if (going) {
 #pragma unroll
-        for (int k = 0; k < Gm::WS; ++k) b[k] = n[k];
-        if (Gm::VERT == V_SHIFT && s + 1 < n_steps) {      // refresh the halo copies through LDS
+            for (int k = 0; k < Gm::WS; ++k) b[k] = n[k];
+        }
+        if (Gm::VERT == V_SHIFT && s + 1 < wave_n) {      // refresh the halo copies through LDS
             if (live) write_row<H, W>(board, gb, r, b);
             wave_sync();
             if (rowl && !lm.real) read_row<H, W>(board, gb, r, b);
@@ -815,14 +831,17 @@ __device__ __forceinline__ void occ_drain(u32 *cnt, int32_t *dst) {
 
 template <int H, int W>
 __global__ __launch_bounds__(64) void k_occupancy_rowlane(const u16 *__restrict__ in, int32_t *__restrict__ counts,
-                                                          int B, const float *__restrict__ spawn_prob, int n_steps,
+                                                          size_t counts_stride, int B, const int32_t *__restrict__ n_valid,
+                                                          const float *__restrict__ spawn_prob, int n_steps,
                                                           sl_pcg64 *rng, const Jump *__restrict__ jump) {
     using Gm = Geom<H, W>;
     using Oc = OccGeom<H, W>;
     constexpr int WS = Gm::WS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
+    if (n_valid) B = min(B, *n_valid);          // (device-side entry count of the side-effect pass)
     const int e0b = blockIdx.x * Gm::G;
+    if (e0b >= B) return;
     const int nbb = min(Gm::G, B - e0b);
     const LaneMap<H, W> lm(lane);
     const int g = lm.g, r = lm.r;
@@ -831,7 +850,7 @@ __global__ __launch_bounds__(64) void k_occupancy_rowlane(const u16 *__restrict_
     const unsigned e = e0b + (rowl ? g : 0);
     u32 *cnt = (u32 *)(smem + Oc::OFF_CNT) + lane * Oc::PITCH;
     u64 *rng_lds = (u64 *)(smem + Oc::OFF_RNG);
-    int32_t *dst = counts + (((size_t)e * H + r) * W) * 8;          // this lane's row of the output
+    int32_t *dst = counts + (size_t)e * counts_stride + ((size_t)r * W) * 8;    // this lane's row of the output
 
     for (int i = 0; i < Oc::PITCH; ++i) cnt[i] = 0;
     if (lane < 4 * nbb) rng_lds[lane] = ((const u64 *)(rng + e0b))[lane];
@@ -1390,7 +1409,7 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
             live ? row_score<H, W, LDS_LUT>(b, gsh_lane, lut, lut_base, lds_lut, cell_mask, c100) : 0, live ? g : 0);
         wave_sync();
         SL_STAMP(6);
-        bool done = false;
+        bool done = false, ended = false, q_success = false;
         float w_reward = 0.0f;          // WRAP: this step's outputs, kept for the wrapper stage below
         bool w_times_up = false, w_open = false;
         int w_exits = 0;
@@ -1412,6 +1431,8 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
             }
             ep_rew += reward;
             ep_len += active ? 1 : 0;
+            ended = done && active;             // this step ends the episode
+            q_success = success;
             active = active && !done;
             w_reward = reward;
             w_times_up = times_up;
@@ -1454,6 +1475,36 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
                 asm volatile("" : "+v"(e4));
                 env.wrap.shaped_reward[e4] = shaped;
                 if (shaped_t) shaped_t[(size_t)t * B + e4] = shaped;
+            }
+        }
+        // the step that ends an episode queues it for the side-effect pass (include/safelife_hip.h): a record and
+        // the board as the agent left it, taken from the LDS image before any auto-reset reloads the slot
+        if (env.finished.capacity > 0 && __ballot(ended)) {
+            int slot = -1;
+            if (ended) {
+                slot = atomicAdd(env.finished.count, 1);
+                if (slot < env.finished.capacity) {
+                    sl_episode_record qr;
+                    qr.env = (int)e + env.finished.env_base;
+                    qr.level = level;
+                    qr.num_steps = steps;
+                    qr.episode_idx = episodes;
+                    qr.spawn_prob = (float)p;
+                    qr.episode_reward = ep_rew;
+                    qr.episode_length = ep_len;
+                    qr.success = q_success;
+                    qr.times_up = steps >= env.time_limit;
+                    qr.reserved[0] = qr.reserved[1] = 0;
+                    env.finished.records[slot] = qr;
+                } else {
+                    slot = -1;
+                }
+            }
+            wave_sync();                         // the leader's exit repaint is in the LDS image
+            const int mine_slot = group_total<H, W>(slot + 1, rowl ? g : 0) - 1;     // only leaders contribute
+            if (live && mine_slot >= 0) {
+                u16 *dst = env.finished.boards + (size_t)mine_slot * HW + r * W;
+                for (int x = 0; x < W; ++x) dst[x] = board16[Gm::cell(r, x)];
             }
         }
         // on-device auto-reset (training/base_algo.py:231-236 calls env.reset() after a done step)
@@ -1672,30 +1723,37 @@ __global__ void k_build_baseline(sl_env_batch env) {
 
 template <int H, int W>
 static hipError_t launch_advance_t(const u16 *in, u16 *out, int B, const float *spawn_prob, int n_steps,
-                                   sl_pcg64 *rng, const Jump *jump, hipStream_t stream) {
+                                   const int32_t *n_each, const int32_t *n_valid, sl_pcg64 *rng, const Jump *jump,
+                                   hipStream_t stream) {
     using Gm = Geom<H, W>;
     auto fn = k_advance_rowlane<H, W>;
     hipError_t err = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, Gm::LDS_ADVANCE);
     if (err != hipSuccess) return err;
     hipLaunchKernelGGL(fn, dim3((B + Gm::NB - 1) / Gm::NB), dim3(64 * WAVES), Gm::LDS_ADVANCE, stream, in, out, B,
-                       spawn_prob, n_steps, rng, jump);
+                       spawn_prob, n_steps, n_each, n_valid, rng, jump);
     return hipGetLastError();
 }
 
 template <int H, int W>
-static hipError_t launch_occupancy_t(const u16 *in, int32_t *counts, int B, const float *spawn_prob, int n_steps,
-                                     sl_pcg64 *rng, const Jump *jump, hipStream_t stream) {
+static hipError_t launch_occupancy_t(const u16 *in, int32_t *counts, size_t counts_stride, int B, const int32_t *n_valid,
+                                     const float *spawn_prob, int n_steps, sl_pcg64 *rng, const Jump *jump,
+                                     hipStream_t stream) {
     using Gm = Geom<H, W>;
     using Oc = OccGeom<H, W>;
     auto fn = k_occupancy_rowlane<H, W>;
     hipError_t err = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, Oc::LDS_BYTES);
     if (err != hipSuccess) return err;
     if (Oc::CB == 8) {      // the drained counters are added into the output
-        err = hipMemsetAsync(counts, 0, (size_t)B * H * W * 8 * sizeof(int32_t), stream);
+        if (counts_stride == (size_t)H * W * 8) {
+            err = hipMemsetAsync(counts, 0, (size_t)B * H * W * 8 * sizeof(int32_t), stream);
+        } else {
+            err = hipMemset2DAsync(counts, counts_stride * sizeof(int32_t), 0, (size_t)H * W * 8 * sizeof(int32_t),
+                                   (size_t)B, stream);
+        }
         if (err != hipSuccess) return err;
     }
-    hipLaunchKernelGGL(fn, dim3((B + Gm::G - 1) / Gm::G), dim3(64), Oc::LDS_BYTES, stream, in, counts, B, spawn_prob,
-                       n_steps, rng, jump);
+    hipLaunchKernelGGL(fn, dim3((B + Gm::G - 1) / Gm::G), dim3(64), Oc::LDS_BYTES, stream, in, counts, counts_stride, B,
+                       n_valid, spawn_prob, n_steps, rng, jump);
     return hipGetLastError();
 }
 
@@ -1791,16 +1849,18 @@ hipError_t launch_build_baseline(const sl_env_batch &env, hipStream_t stream) {
 }
 
 hipError_t launch_advance_rowlane(const u16 *in, u16 *out, int B, int H, int W, const float *spawn_prob,
-                                  int n_steps, sl_pcg64 *rng, const Jump *jump, hipStream_t stream) {
-#define X(h, w) if (H == h && W == w) return rl::launch_advance_t<h, w>(in, out, B, spawn_prob, n_steps, rng, jump, stream);
+                                  int n_steps, const int32_t *n_each, const int32_t *n_valid, sl_pcg64 *rng,
+                                  const Jump *jump, hipStream_t stream) {
+#define X(h, w) if (H == h && W == w) return rl::launch_advance_t<h, w>(in, out, B, spawn_prob, n_steps, n_each, n_valid, rng, jump, stream);
     SL_ROWLANE_SHAPES(X)
 #undef X
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_occupancy_rowlane(const u16 *in, int32_t *counts, int B, int H, int W, const float *spawn_prob,
-                                    int n_steps, sl_pcg64 *rng, const Jump *jump, hipStream_t stream) {
-#define X(h, w) if (H == h && W == w) return rl::launch_occupancy_t<h, w>(in, counts, B, spawn_prob, n_steps, rng, jump, stream);
+hipError_t launch_occupancy_rowlane(const u16 *in, int32_t *counts, size_t counts_stride, int B, const int32_t *n_valid,
+                                    int H, int W, const float *spawn_prob, int n_steps, sl_pcg64 *rng, const Jump *jump,
+                                    hipStream_t stream) {
+#define X(h, w) if (H == h && W == w) return rl::launch_occupancy_t<h, w>(in, counts, counts_stride, B, n_valid, spawn_prob, n_steps, rng, jump, stream);
     SL_ROWLANE_SHAPES(X)
 #undef X
     return hipErrorInvalidValue;

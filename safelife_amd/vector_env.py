@@ -23,6 +23,66 @@ from .levels import LevelPool
 _DEFAULT_CHANNELS = tuple(range(16)) + (25, 26, 27)      # safelife_env.py:71
 
 
+class SideEffectBatch(object):
+    """What one ``side_effects_flush()`` produced, still on the device.
+
+    ``count``      int32 [1]   episodes that ended since the previous flush (beyond ``capacity``: dropped)
+    ``records``    int32 [C,8] ``struct sl_episode_record`` rows (env, level, num_steps, episode_idx, ...)
+    ``boards``     the boards as the agents left them, uint16 payload [C,H,W]
+    ``counts``     int32 [C,2,H,W,8]: the two ``life_occupancy`` tensors (inaction, action) of side_effects.py:109-110
+    ``keys`` / ``life_dist`` / ``type_masks``: the distributions of :111-130 (include/safelife_hip.h)
+    """
+
+    def __init__(self, env, queue_bufs, out, num_samples):
+        self.env, self.num_samples = env, num_samples
+        self.count, self.rec_tensor, self.boards = queue_bufs["count"], queue_bufs["records"], queue_bufs["boards"]
+        self.counts, self.keys = out["counts"], out["keys"]
+        self.life_dist, self.type_masks = out["life_dist"], out["type_masks"]
+        self._keep = out
+
+    def __len__(self):
+        """Valid entries (synchronises)."""
+        return min(int(self.count.item()), self.rec_tensor.shape[0])
+
+    def records(self):
+        """Host view of the valid records: dict of arrays (env, level, num_steps, episode_idx, spawn_prob,
+        episode_reward, episode_length, success, times_up)."""
+        n = len(self)
+        raw = self.rec_tensor[:n].cpu().numpy()
+        flags = raw[:, 7:8].copy().view(np.uint8)
+        return dict(env=raw[:, 0], level=raw[:, 1], num_steps=raw[:, 2], episode_idx=raw[:, 3],
+                    spawn_prob=raw[:, 4].copy().view(np.float32), episode_reward=raw[:, 5].copy().view(np.float32),
+                    episode_length=raw[:, 6], success=flags[:, 0], times_up=flags[:, 1])
+
+    def distributions(self, i):
+        """(inaction, action): ``{cell type: float64 [H,W]}`` of entry i, as side_effects.py:113-130 builds them."""
+        keys = self.keys[i].cpu().numpy().view(np.uint16)
+        life = self.life_dist[i].cpu().numpy()
+        masks = self.type_masks[i].cpu().numpy()
+        inaction, action = {}, {}
+        for k, key in enumerate(keys):
+            if key == 0xFFFF:
+                continue
+            if k < 8:
+                inaction[int(key)], action[int(key)] = life[0, k], life[1, k]
+            else:
+                inaction[int(key)], action[int(key)] = 1.0 * masks[0, k - 8], 1.0 * masks[1, k - 8]
+        return inaction, action
+
+    def scores(self, i, include=None, exclude=None, strkeys=True, weights=None):
+        """``side_effect_score`` of entry i (earth-mover distances on the host; safelife_env.py:185-192 for
+        ``weights``)."""
+        from . import side_effects as se
+        inaction, action = self.distributions(i)
+        out = se._scores(inaction, action, tuple(self.boards.shape[1:]), include, exclude, strkeys)
+        if weights is not None:
+            total = np.zeros(2)
+            for key, weight in weights.items():
+                total += weight * np.array(out.get(key, 0))
+            out["total"] = total.tolist()
+        return out
+
+
 class SafeLifeVectorEnv(object):
     """
     Parameters
@@ -52,6 +112,11 @@ class SafeLifeVectorEnv(object):
                                    then differ the way the reference's per-game ``SeedSequence.spawn`` children
                                    do (level_iterator.py:218).  False: an episode on pool level l starts from
                                    ``pool.rng[l]`` exactly (replaying recorded traces of the reference).
+    side_effects : dict or None    ``dict(capacity=N, num_samples=1000)``: the step kernels queue every episode that
+                                   ends (record + the board as the agent left it, taken before an auto-reset
+                                   reloads the slot) and ``side_effects_flush()`` runs the episode-end pass of the
+                                   reference's ``side_effect_score`` over the queue on the device -- see
+                                   ``SideEffectBatch``.  ``capacity``: episodes held between two flushes.
     wrappers : dict or None        training-wrapper math of the reference's env_wrappers.py, fused into the
                                    step (stacked as training/env_factory.py:277-283 does); keys, all
                                    optional: ``movement_bonus``, ``movement_bonus_power``,
@@ -66,7 +131,7 @@ class SafeLifeVectorEnv(object):
     def __init__(self, pool, num_envs, *, time_limit=1000, remove_white_goals=True,
                  view_shape=(15, 15), output_channels=_DEFAULT_CHANNELS, auto_reset=True,
                  first_level=None, level_stride=1, env_offset=0, with_obs=True,
-                 points_on_level_exit=1, wrappers=None, slices=1, episode_streams=True):
+                 points_on_level_exit=1, wrappers=None, slices=1, episode_streams=True, side_effects=None):
         import torch
         self.torch = torch
         if not isinstance(pool, LevelPool):
@@ -151,6 +216,12 @@ class SafeLifeVectorEnv(object):
         self.shaped_reward = None
         if wrappers:
             self._setup_wrappers(dict(wrappers))
+        self._se = None
+        if side_effects:
+            self._se = dict(capacity=int(side_effects.get("capacity", 1024)),
+                            num_samples=int(side_effects.get("num_samples", 1000)))
+            self._se["queue"] = self._new_queue()
+            s.finished = self._se["queue"][0]
         self._lib = _hip.lib()
         self._sref = C.byref(s)
         # slices: boundaries at multiples of 64 envs (keeps every slice 16-byte aligned for the row kernels)
@@ -340,6 +411,50 @@ class SafeLifeVectorEnv(object):
                                            0 if dtype == torch.uint8 else 1, _hip.current_stream_ptr())
         _hip.check(rc)
         return out
+
+    def _new_queue(self):
+        torch, cap = self.torch, self._se["capacity"]
+        H, W = self.pool.shape
+        bufs = dict(count=torch.zeros(1, dtype=torch.int32, device=self.device),
+                    records=torch.zeros((cap, 8), dtype=torch.int32, device=self.device),
+                    boards=torch.zeros((cap, H, W), dtype=torch.int16, device=self.device))
+        q = _hip.EpisodeQueue()
+        q.capacity, q.env_base = cap, 0
+        q.count, q.records, q.boards = (bufs[k].data_ptr() for k in ("count", "records", "boards"))
+        return q, bufs
+
+    def side_effects_flush(self):
+        """Run the episode-end pass (``slhip_side_effects``) over the episodes queued since the last flush, on the
+        caller's current stream, and switch the step kernels to the other queue.  Nothing is read back: the
+        returned ``SideEffectBatch`` takes the queue's buffers along (a fresh queue replaces it) next to the pass's
+        outputs, all device tensors sized by the capacity, plus the device-side entry count; its ``records()`` / ``scores()`` synchronise when (and only when) the host wants the numbers."""
+        if self._se is None:
+            raise ValueError("construct the env with side_effects=dict(capacity=...) first")
+        torch, se = self.torch, self._se
+        if self.slices > 1:
+            self.join()                               # the queue was filled on the slice streams
+        q, bufs = se["queue"]
+        se["queue"] = self._new_queue()               # the step kernels fill a fresh queue from here on
+        self.struct.finished = se["queue"][0]
+        if self.slices > 1:
+            self.fence()
+        H, W = self.pool.shape
+        cap, K = se["capacity"], _hip.SL_SE_MAX_KEYS
+        dev = self.device
+        out = dict(work_boards=torch.empty((cap, H, W), dtype=torch.int16, device=dev),
+                   work_prob=torch.empty(cap, dtype=torch.float32, device=dev),
+                   work_steps=torch.empty(cap, dtype=torch.int32, device=dev),
+                   work_rng=torch.empty((cap, 4), dtype=torch.int64, device=dev),
+                   counts=torch.empty((cap, 2, H, W, 8), dtype=torch.int32, device=dev),
+                   keys=torch.empty((cap, K), dtype=torch.int16, device=dev),
+                   life_dist=torch.empty((cap, 2, 8, H, W), dtype=torch.float64, device=dev),
+                   type_masks=torch.zeros((cap, 2, K - 8, H, W), dtype=torch.uint8, device=dev))
+        rc = self._lib.slhip_side_effects(self._sref, C.byref(q), se["num_samples"], 1,
+                                          *[_hip.ptr(out[k]) for k in ("work_boards", "work_prob", "work_steps", "work_rng",
+                                                                       "counts", "keys", "life_dist", "type_masks")],
+                                          _hip.current_stream_ptr())
+        _hip.check(rc)
+        return SideEffectBatch(self, bufs, out, se["num_samples"])
 
     def side_effect_occupancy(self, env_ids, rng, num_samples=1000):
         """The two ``life_occupancy`` tensors of ``side_effect_score`` (side_effects.py:103-111) for the

@@ -501,6 +501,141 @@ def test_side_effect_score_pipeline(sp):
             assert dist >= 0 and mass >= 0
 
 
+def test_side_effect_pass_reproduces_reference_inputs(sp):
+    """slhip_side_effects (the batched episode-end pass) on a queue of 80 entries that all replay the pinned case
+    of the reference's side_effect_score (tests/golden/side_effect_inputs.npz: starting board, final board,
+    episode length, generator state): roll-forward, both occupancy tensors and the distributions of
+    side_effects.py:111-130, every entry -- with a device-side entry count below the capacity."""
+    import ctypes as C
+    import torch
+    from safelife_amd import _hip, side_effects as se
+    from safelife_amd.levels import Level, LevelPool
+    from safelife_amd.vector_env import SafeLifeVectorEnv
+    with np.load(os.path.join(util.GOLDEN, "side_effect_inputs.npz")) as d:
+        d = {k: d[k] for k in d.files}
+    p, n_steps = float(d["spawn_prob"]), int(d["num_steps"])
+    filler = Level(np.zeros_like(d["b0"]), agent_locs=np.zeros((0, 2), int))
+    start = Level(d["b0"], agent_locs=np.zeros((0, 2), int), spawn_prob=p)
+    pool = LevelPool([filler, start], counts_fn=_device_counts)
+    env = SafeLifeVectorEnv(pool, 8, with_obs=False)
+    dev, cap, n = env.device, 96, 80
+    H, W = d["b0"].shape
+    rec = np.zeros((cap, 8), np.int32)
+    rec[:n, 0] = np.arange(n)
+    rec[:n, 1] = 1
+    rec[:n, 2] = n_steps
+    rec[:n, 4] = np.float32(p).view(np.int32)
+    bufs = dict(count=torch.tensor([n], dtype=torch.int32, device=dev), records=torch.from_numpy(rec).to(dev),
+                boards=torch.from_numpy(np.broadcast_to(d["b2"], (cap, H, W)).copy().view(np.int16)).to(dev))
+    q = _hip.EpisodeQueue()
+    q.capacity, q.env_base = cap, 0
+    q.count, q.records, q.boards = (bufs[k].data_ptr() for k in ("count", "records", "boards"))
+    K = _hip.SL_SE_MAX_KEYS
+    out = dict(work_boards=torch.zeros((cap, H, W), dtype=torch.int16, device=dev),
+               work_prob=torch.zeros(cap, dtype=torch.float32, device=dev),
+               work_steps=torch.zeros(cap, dtype=torch.int32, device=dev),
+               work_rng=sp._to_device(np.broadcast_to(d["rng0"], (cap, 4)).copy(), np.uint64),
+               counts=torch.zeros((cap, 2, H, W, 8), dtype=torch.int32, device=dev),
+               keys=torch.zeros((cap, K), dtype=torch.int16, device=dev),
+               life_dist=torch.zeros((cap, 2, 8, H, W), dtype=torch.float64, device=dev),
+               type_masks=torch.zeros((cap, 2, K - 8, H, W), dtype=torch.uint8, device=dev))
+    rc = _hip.lib().slhip_side_effects(env._sref, C.byref(q), 1000, 0,
+                                       *[_hip.ptr(out[k]) for k in ("work_boards", "work_prob", "work_steps", "work_rng",
+                                                                    "counts", "keys", "life_dist", "type_masks")],
+                                       _hip.current_stream_ptr())
+    _hip.check(rc)
+    b1 = out["work_boards"].cpu().numpy().view(np.uint16)
+    counts = out["counts"].cpu().numpy()
+    after = sp._to_host(out["work_rng"], np.uint64)
+    assert np.array_equal(b1[:n], np.broadcast_to(d["b1"], (n, H, W)))
+    assert np.array_equal(counts[:n, 0], np.broadcast_to(d["occ0"], (n, H, W, 8)))
+    assert np.array_equal(counts[:n, 1], np.broadcast_to(d["occ1"], (n, H, W, 8)))
+    assert np.array_equal(after[:n], np.broadcast_to(d["rng3"], (n, 4)))
+    assert np.array_equal(after[n:], np.broadcast_to(d["rng0"], (cap - n, 4)))         # entries past the count: untouched
+    # the distributions against the host restatement of side_effects.py:111-130 on the golden tensors
+    want_in, want_act = se.distributions_from_counts(d["b0"], d["b2"], np.stack([d["occ0"], d["occ1"]]), 1000)
+    batch = type("B", (), {})()
+    from safelife_amd.vector_env import SideEffectBatch
+    batch = SideEffectBatch(env, bufs, out, 1000)
+    assert len(batch) == n
+    for i in (0, 37, n - 1):
+        got_in, got_act = batch.distributions(i)
+        assert set(got_in) == set(int(k) for k in want_in)
+        for k in want_in:
+            assert np.array_equal(got_in[int(k)], want_in[k]) and np.array_equal(got_act[int(k)], want_act[k]), (i, k)
+    assert (out["keys"].cpu().numpy().view(np.uint16)[n:] == 0xFFFF).all()
+    assert isinstance(batch.scores(0), dict)
+
+
+def test_side_effect_queue_end_to_end(sp):
+    """auto_reset=True, 128 envs, short episodes: the step kernels queue every finished episode (record + the
+    board as the agent left it, before the reset reloads the slot); side_effects_flush() runs the pass without
+    any host read.  Checked: the queue against a replay on the oracle (which episode ended when, with which
+    board), and every entry's occupancy tensors against the one-board primitives under the entry's own stream."""
+    from safelife_amd import side_effects as se
+    pool, _ = util.pool_from_fixture("append_spawn_25", _device_counts, n=12, min_performance_fraction=0.05)
+    B, T = 128, 34
+    first = np.arange(B) % len(pool)
+    kw = dict(first_level=first, auto_reset=True, level_stride=1, time_limit=11, view_shape=(9, 9))
+    dev = util.DeviceBackend(pool, B, slices=2, side_effects=dict(capacity=600, num_samples=60), **kw)
+    cpu = util.OracleBackend(pool, B, **kw)
+    dev.reset(), cpu.reset()
+    rng = np.random.default_rng(31)
+    want = {}                      # (env, episode_idx) -> (level, num_steps, final board)
+    for t in range(T):
+        a = rng.integers(0, 9, B).astype(np.int32)
+        before = {k: cpu.get(k) for k in ("level_idx", "episode_idx", "is_active")}
+        boards_before_reset = None
+        cpu.env.s.auto_reset = 0           # look at the terminal boards, then let the oracle reset
+        _, _, d2 = cpu.step(a)
+        boards_before_reset = cpu.get("board")
+        steps_now = cpu.get("num_steps")
+        for e in np.nonzero(d2 & (before["is_active"] != 0))[0]:
+            want[(int(e), int(before["episode_idx"][e]))] = (int(before["level_idx"][e]), int(steps_now[e]),
+                                                            boards_before_reset[e].copy())
+        cpu.env.s.auto_reset = 1
+        for e in np.nonzero(d2)[0]:        # the oracle's auto-reset, by hand
+            cpu.arrays["level_idx"][e] = (cpu.arrays["level_idx"][e] + 1) % len(pool)
+            cpu.arrays["episode_idx"][e] += 1
+        if d2.any():
+            m = d2.astype(np.uint8)
+            cpu.arrays["loaded"][m != 0] = 0
+            cpu.env.reset(m)
+        _, _, d1 = dev.step(a)
+        assert np.array_equal(d1, d2), t
+    batch = dev.env.side_effects_flush()
+    recs = batch.records()
+    assert len(batch) == len(want) and len(want) >= 3 * B
+    boards = batch.boards.cpu().numpy().view(np.uint16)
+    counts = batch.counts.cpu().numpy()
+    pool_rng = pool.arrays()["pool_rng"]
+
+    def mix64(z):
+        m = (1 << 64) - 1
+        z = (z + 0x9E3779B97F4A7C15) & m
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+        return z ^ (z >> 31)
+    for i in range(len(batch)):
+        key = (int(recs["env"][i]), int(recs["episode_idx"][i]))
+        level, steps, board = want.pop(key)
+        assert (int(recs["level"][i]), int(recs["num_steps"][i])) == (level, steps), key
+        assert np.array_equal(boards[i], board), key
+        if i % 9 == 0:             # the pass itself, entry by entry, under the entry's derived stream
+            words = pool_rng[level].copy()
+            a_ = mix64((((0x5EFFEC75 ^ key[0]) & 0xFFFFFFFF) << 32) | key[1])
+            words[0] ^= np.uint64(a_)
+            words[1] ^= np.uint64(mix64(a_))
+            bg = np.random.PCG64(0)
+            oracle.pcg64_set_state_words(bg, words)
+            sp.set_bit_generator(bg)
+            lv = pool.levels[level]
+            c0, c1 = se.occupancy_pair(lv.board, board, lv.spawn_prob, steps, 60)
+            assert np.array_equal(counts[i, 0], c0) and np.array_equal(counts[i, 1], c1), key
+    assert not want
+    assert len(dev.env.side_effects_flush()) == 0          # the fresh queue starts empty
+
+
 def test_vector_env_side_effect_occupancy(sp):
     """Batched device pipeline of side_effect_score for finished episodes == the one-env pipeline
     (advance_board(b0, n) -> life_occupancy x2 under one generator), env by env, generator state included."""
