@@ -303,6 +303,25 @@ def main():
         us = e0.elapsed_time(e1) / 200 * 1e3
         extra["c2_advance_board_1024x25x25_us_per_launch"] = us
         extra["c2_advance_board_board_steps_per_s"] = 1024 / (us * 1e-6)
+        # ... and the reference's own C advance_board (oracle/_ref: its sources compiled by oracle/Makefile) on the
+        # same 1024 boards, one host core, next to it (cpu_baseline kind "reference" for C2)
+        if args.cpu_baseline:
+            import oracle
+            ref = oracle.load_ref()
+            if ref is not None:
+                host_boards = pal[np.random.default_rng(1234).integers(0, len(pal), (1024, 25, 25))]
+                c2_bg = np.random.PCG64(1234)          # (kept alive: the module holds a borrowed pointer)
+                ref.set_bit_generator(c2_bg)
+                t0 = time.perf_counter()
+                reps = 0
+                while time.perf_counter() - t0 < 1.0:
+                    for b in host_boards:
+                        ref.advance_board(b, 0.3)
+                    reps += 1
+                dt = time.perf_counter() - t0
+                extra["c2_cpu_reference_board_steps_per_s"] = 1024 * reps / dt
+                extra["c2_cpu_reference_note"] = ("safelife/speedups_src advance_board compiled with gcc -O3 (oracle/_ref), "
+                                                  "1 core of %s, called per board through its CPython wrapper" % cpu_model())
 
         # the same step with the training wrappers of env_factory.py:277-283 fused in (float64 shaped reward)
         us = time_steps(SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25), output_channels=TRAIN_CHANNELS,
@@ -336,6 +355,43 @@ def main():
                 ms = e0.elapsed_time(e1)
                 extra["life_occupancy_64x64_1000steps_boards_per_s"] = nb / (ms * 1e-3)
                 extra["life_occupancy_64x64_board_steps_per_s"] = nb * 1000 / (ms * 1e-3)
+                # C5 as BASELINE.json states it: navigation WITH the side-effect score.  Episode ends are spread
+                # evenly (every env starts at a different point of its 1000-step episode), the step kernels queue
+                # the finished episodes, and every `flush_every` steps the episode-end pass of side_effect_score
+                # (roll-forward by the episode's length + 2 x 1000-step occupancy + distributions) runs on the
+                # device for whatever the queue holds -- all inside the timed region; the earth-mover distances
+                # (host, pyemd: parity unpinned) are not.
+                n_c5, flush_every, n_meas = n_envs, 128, 384
+                env5 = SafeLifeVectorEnv(p2, n_c5, time_limit=1000, view_shape=(25, 25), output_channels=TRAIN_CHANNELS,
+                                         auto_reset=True, with_obs=False,
+                                         side_effects=dict(capacity=2 * (n_c5 * flush_every // 1000 + 64), num_samples=1000))
+                env5.reset()
+                env5.t["scalars"][:, _hip.SCALAR_COLS["num_steps"]] = (
+                    torch.arange(n_c5, device=dev, dtype=torch.int32) * 997) % 1000
+                acts5 = torch.randint(0, 9, (n_meas + 20, n_c5), generator=gen, device=dev, dtype=torch.int32)
+                for t in range(20):
+                    env5.step(acts5[t])
+                env5.side_effects_flush()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                batches = []
+                e0.record()
+                for t in range(20, 20 + n_meas):
+                    env5.step(acts5[t])
+                    if (t - 19) % flush_every == 0:
+                        batches.append(env5.side_effects_flush())
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1)
+                n_eps = sum(len(b) for b in batches)
+                extra["c5_with_side_effects_us_per_step"] = ms * 1e3 / n_meas
+                extra["c5_with_side_effects_env_steps_per_s_per_gpu"] = n_c5 * n_meas / (ms * 1e-3)
+                extra["c5_with_side_effects_episodes_scored"] = n_eps
+                extra["c5_with_side_effects_note"] = ("%d envs x 64x64 navigation, %d steps, episode-end pass every %d steps "
+                                                      "on the device (%d episodes: roll-forward + 2 x 1000-step "
+                                                      "life_occupancy + distributions); EMD on the host not included"
+                                                      % (n_c5, n_meas, flush_every, n_eps))
+                del env5, batches
 
     if rank == 0:
         obs_bytes = {0: 0, 1: H * Wd * len(TRAIN_CHANNELS), 2: H * Wd * 4}[args.obs]

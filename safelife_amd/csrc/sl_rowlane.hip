@@ -796,12 +796,19 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_ad
 //       counters become the int32 [H,W,8] output at the end (boards up to 32 cells wide);
 //   8   four colours per dword, drained into the zeroed output every 255 steps: half the LDS, twice the
 //       wavefronts per CU -- what 64-wide boards need (a 16-bit set is 64 KiB per board).
-template <int H, int W>
+// SLOTS = counters per cell.  A new cell's colour is made of colour bits of its live neighbours and of
+// spawners (advance_board.c:12-32), so a board whose live and spawner cells use only two of the three colour
+// bits can ever show four colours: SLOTS = 4 (colour -> slot by compressing the two bits) halves the LDS per
+// wavefront, which is what bounds the wavefronts per CU of this kernel (64x64: 33 KiB -> 16.6 KiB, 1 -> 2 per
+// SIMD; 25x25: 25.8 -> 13 KiB).  Boards that use all three bits take the SLOTS = 8 instantiation; both are
+// launched over the whole batch and every wavefront decides from its boards which of the two it belongs to.
+template <int H, int W, int SLOTS>
 struct OccGeom {
     using Gm = Geom<H, W>;
     static constexpr int CB = W > 32 ? 8 : 16;
-    static constexpr int PER_DWORD = 32 / CB;                           // colours per dword
-    static constexpr int CELL_DWORDS = 8 / PER_DWORD;
+    static constexpr int PER_DWORD = 32 / CB;                           // counters per dword
+    static constexpr int CELL_DWORDS = SLOTS / PER_DWORD;
+    static_assert(CELL_DWORDS >= 1, "at least one dword of counters per cell");
     static constexpr int PITCH = W * CELL_DWORDS + 1;                   // dwords per lane
     static constexpr int OFF_CNT = 0;
     static constexpr int OFF_RNG = 64 * PITCH * 4;                      // G x 4 u64
@@ -809,10 +816,11 @@ struct OccGeom {
     static constexpr int FLUSH_EVERY = CB == 8 ? 255 : 0x7FFFFFFF;
 };
 
-// counters of one lane's row -> its slice of the output (add: the output was zeroed), counters cleared
-template <int H, int W>
-__device__ __forceinline__ void occ_drain(u32 *cnt, int32_t *dst) {
-    using Oc = OccGeom<H, W>;
+// counters of one lane's row -> its slice of the output (add: the output was zeroed), counters cleared.
+// inv: colour of slot s at bits [3s, 3s+3).
+template <int H, int W, int SLOTS>
+__device__ __forceinline__ void occ_drain(u32 *cnt, int32_t *dst, u32 inv) {
+    using Oc = OccGeom<H, W, SLOTS>;
     for (int x = 0; x < W; ++x) {
 #pragma unroll
         for (int q = 0; q < Oc::CELL_DWORDS; ++q) {
@@ -821,7 +829,8 @@ __device__ __forceinline__ void occ_drain(u32 *cnt, int32_t *dst) {
 #pragma unroll
                 for (int j = 0; j < Oc::PER_DWORD; ++j) {
                     const int c = (v >> (Oc::CB * j)) & ((1u << Oc::CB) - 1u);
-                    if (c) dst[x * 8 + q * Oc::PER_DWORD + j] += c;
+                    const int slot = q * Oc::PER_DWORD + j;
+                    if (c) dst[x * 8 + ((inv >> (3 * slot)) & 7u)] += c;
                 }
                 cnt[x * Oc::CELL_DWORDS + q] = 0;
             }
@@ -829,13 +838,13 @@ __device__ __forceinline__ void occ_drain(u32 *cnt, int32_t *dst) {
     }
 }
 
-template <int H, int W>
+template <int H, int W, int SLOTS>
 __global__ __launch_bounds__(64) void k_occupancy_rowlane(const u16 *__restrict__ in, int32_t *__restrict__ counts,
                                                           size_t counts_stride, int B, const int32_t *__restrict__ n_valid,
                                                           const float *__restrict__ spawn_prob, int n_steps,
                                                           sl_pcg64 *rng, const Jump *__restrict__ jump) {
     using Gm = Geom<H, W>;
-    using Oc = OccGeom<H, W>;
+    using Oc = OccGeom<H, W, SLOTS>;
     constexpr int WS = Gm::WS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -848,13 +857,6 @@ __global__ __launch_bounds__(64) void k_occupancy_rowlane(const u16 *__restrict_
     const bool rowl = lane < Gm::NL && g < nbb;
     const bool live = rowl && lm.real;
     const unsigned e = e0b + (rowl ? g : 0);
-    u32 *cnt = (u32 *)(smem + Oc::OFF_CNT) + lane * Oc::PITCH;
-    u64 *rng_lds = (u64 *)(smem + Oc::OFF_RNG);
-    int32_t *dst = counts + (size_t)e * counts_stride + ((size_t)r * W) * 8;    // this lane's row of the output
-
-    for (int i = 0; i < Oc::PITCH; ++i) cnt[i] = 0;
-    if (lane < 4 * nbb) rng_lds[lane] = ((const u64 *)(rng + e0b))[lane];
-    const double p = rowl ? (double)spawn_prob[e] : 0.0;
     RowWords<H, W> b, n;
     Elig elig;
     {   // the row straight from HBM (once per launch)
@@ -866,6 +868,51 @@ __global__ __launch_bounds__(64) void k_occupancy_rowlane(const u16 *__restrict_
             b[k] = lo | (hi << 16);
         }
     }
+    // colour bits in use on each board: those of its live cells and of its spawners
+    u32 used = 0;
+#pragma unroll
+    for (int k = 0; k < WS; ++k) {
+        const u32 c = b[k];
+        const u32 src = (c | (c >> 7)) & 0x00010001u;                   // ALIVE or SPAWNING, per half
+        used |= c & (src * 0x0E00u);
+    }
+    used = (used | (used >> 16)) & 0x0E00u;
+    u32 bits = 0;                                                       // of the lane's own board, bit i = colour bit i
+    bool wave_compact = Oc::CB == 8;            // (only 64-wide boards are LDS-bound: see launch_occupancy_t)
+#pragma unroll
+    for (int q = 0; q < Gm::G; ++q) {
+        const unsigned long long in_board = ((Gm::GL == 64 ? ~0ull : ((1ull << Gm::GL) - 1ull)) << (q * Gm::GL % 64));
+        u32 bq = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (__ballot(rowl && (used & (0x0200u << i))) & in_board) bq |= 1u << i;
+        if (q < nbb && __popc(bq) > 2) wave_compact = false;
+        if (g == q) bits = bq;
+    }
+    if (wave_compact != (SLOTS == 4)) return;       // the other instantiation takes this wavefront's boards
+    // colour -> slot (2 bits each) and slot -> colour (3 bits each) for the board's two colour bits
+    u32 lut = 0, inv = 0;
+    if (SLOTS == 4) {
+        int next = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if ((c & ~bits) == 0) {                 // colour c only uses bits the board has
+                lut |= (u32)next << (2 * c);
+                inv |= (u32)c << (3 * next);
+                ++next;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) inv |= (u32)c << (3 * c);
+    }
+    u32 *cnt = (u32 *)(smem + Oc::OFF_CNT) + lane * Oc::PITCH;
+    u64 *rng_lds = (u64 *)(smem + Oc::OFF_RNG);
+    int32_t *dst = counts + (size_t)e * counts_stride + ((size_t)r * W) * 8;    // this lane's row of the output
+
+    for (int i = 0; i < Oc::PITCH; ++i) cnt[i] = 0;
+    if (lane < 4 * nbb) rng_lds[lane] = ((const u64 *)(rng + e0b))[lane];
+    const double p = rowl ? (double)spawn_prob[e] : 0.0;
     // V_SHIFT: after a step the halo lanes take the new first / last row from the lanes that own them
     const int partner = !rowl || lm.real ? lane : (r == 0 ? lane - H : lane + H);
     const Consts cst = make_consts();
@@ -877,40 +924,52 @@ __global__ __launch_bounds__(64) void k_occupancy_rowlane(const u16 *__restrict_
         if (__ballot(elig.any())) resolve_draws<H, W>(b, n, elig, rng_lds, rowl ? g : 0, p, jump);
 #pragma unroll
         for (int k = 0; k < WS; ++k) b[k] = Gm::VERT == V_SHIFT ? bperm(4 * partner, n[k]) : n[k];
+#ifndef SL_OCC_NOCOUNT
         if (live) {
 #pragma unroll
             for (int k = 0; k < WS; ++k) {
                 const u32 c = b[k];
                 const u32 tick = c & ~(c >> 1) & ~(c >> 4) & ~(c >> 8) & 0x00010001u;    // alive, not agent/frozen/exit
-                const u32 lo_col = (c >> 9) & 7u, hi_col = (c >> 25) & 7u;
-                __hip_atomic_fetch_add(cnt + k * Oc::CELL_DWORDS + lo_col / Oc::PER_DWORD,
-                                       (tick & 1u) << (Oc::CB * (lo_col % Oc::PER_DWORD)), __ATOMIC_RELAXED,
+                u32 lo_slot = (c >> 9) & 7u, hi_slot = (c >> 25) & 7u;
+                if (SLOTS == 4) {
+                    lo_slot = (lut >> (2 * lo_slot)) & 3u;
+                    hi_slot = (lut >> (2 * hi_slot)) & 3u;
+                }
+                __hip_atomic_fetch_add(cnt + k * Oc::CELL_DWORDS + lo_slot / Oc::PER_DWORD,
+                                       (tick & 1u) << (Oc::CB * (lo_slot % Oc::PER_DWORD)), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WAVEFRONT);
                 if (!(Gm::ODD && k == WS - 1))
-                    __hip_atomic_fetch_add(cnt + (k + WS) * Oc::CELL_DWORDS + hi_col / Oc::PER_DWORD,
-                                           (tick >> 16) << (Oc::CB * (hi_col % Oc::PER_DWORD)), __ATOMIC_RELAXED,
+                    __hip_atomic_fetch_add(cnt + (k + WS) * Oc::CELL_DWORDS + hi_slot / Oc::PER_DWORD,
+                                           (tick >> 16) << (Oc::CB * (hi_slot % Oc::PER_DWORD)), __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
         }
+#endif
         if (++since_drain == Oc::FLUSH_EVERY) {         // (wave-uniform) 8-bit counters are about to wrap
             since_drain = 0;
             wave_sync();
-            if (live) occ_drain<H, W>(cnt, dst);
+            if (live) occ_drain<H, W, SLOTS>(cnt, dst, inv);
             wave_sync();
         }
     }
     wave_sync();
     if (live) {
         if (Oc::CB == 8) {
-            occ_drain<H, W>(cnt, dst);
+            occ_drain<H, W, SLOTS>(cnt, dst, inv);
         } else {            // nothing was drained on the way: plain stores, the output need not be zeroed
             for (int x = 0; x < W; ++x) {
+                int32_t cell[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const u32 v = cnt[x * 4 + q];
-                    dst[x * 8 + 2 * q] = (int32_t)(v & 0xFFFFu);
-                    dst[x * 8 + 2 * q + 1] = (int32_t)(v >> 16);
+                for (int q = 0; q < Oc::CELL_DWORDS; ++q) {
+                    const u32 v = cnt[x * Oc::CELL_DWORDS + q];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {               // (static register indices: no scratch array)
+                        if (((inv >> (3 * (2 * q))) & 7u) == (u32)c && 2 * q < SLOTS) cell[c] += (int32_t)(v & 0xFFFFu);
+                        if (((inv >> (3 * (2 * q + 1))) & 7u) == (u32)c && 2 * q + 1 < SLOTS) cell[c] += (int32_t)(v >> 16);
+                    }
                 }
+#pragma unroll
+                for (int c = 0; c < 8; ++c) dst[x * 8 + c] = cell[c];
             }
         }
     }
@@ -1484,18 +1543,12 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
             if (ended) {
                 slot = atomicAdd(env.finished.count, 1);
                 if (slot < env.finished.capacity) {
-                    sl_episode_record qr;
-                    qr.env = (int)e + env.finished.env_base;
-                    qr.level = level;
-                    qr.num_steps = steps;
-                    qr.episode_idx = episodes;
-                    qr.spawn_prob = (float)p;
-                    qr.episode_reward = ep_rew;
-                    qr.episode_length = ep_len;
-                    qr.success = q_success;
-                    qr.times_up = steps >= env.time_limit;
-                    qr.reserved[0] = qr.reserved[1] = 0;
-                    env.finished.records[slot] = qr;
+                    // (the 32-byte record as two vector stores assembled in registers: a struct temporary ends
+                    //  up in scratch memory here)
+                    const u32 flags = (q_success ? 1u : 0u) | ((steps >= env.time_limit ? 1u : 0u) << 8);
+                    u32x4 *qdst = (u32x4 *)(env.finished.records + slot);
+                    qdst[0] = u32x4{(u32)((int)e + env.finished.env_base), (u32)level, (u32)steps, (u32)episodes};
+                    qdst[1] = u32x4{__float_as_uint((float)p), __float_as_uint(ep_rew), (u32)ep_len, flags};
                 } else {
                     slot = -1;
                 }
@@ -1504,7 +1557,8 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
             const int mine_slot = group_total<H, W>(slot + 1, rowl ? g : 0) - 1;     // only leaders contribute
             if (live && mine_slot >= 0) {
                 u16 *dst = env.finished.boards + (size_t)mine_slot * HW + r * W;
-                for (int x = 0; x < W; ++x) dst[x] = board16[Gm::cell(r, x)];
+#pragma unroll 1
+                for (int x = 0; x < W; ++x) dst[x] = board16[Gm::cell(r, x)];      // (rare: kept out of the register budget)
             }
         }
         // on-device auto-reset (training/base_algo.py:231-236 calls env.reset() after a done step)
@@ -1739,11 +1793,14 @@ static hipError_t launch_occupancy_t(const u16 *in, int32_t *counts, size_t coun
                                      const float *spawn_prob, int n_steps, sl_pcg64 *rng, const Jump *jump,
                                      hipStream_t stream) {
     using Gm = Geom<H, W>;
-    using Oc = OccGeom<H, W>;
-    auto fn = k_occupancy_rowlane<H, W>;
-    hipError_t err = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, Oc::LDS_BYTES);
+    // four-slot counters only where the LDS bounds the wavefronts per CU (64-wide boards: +42 %); boards up to 32
+    // wide are issue-bound and the slot lookup only costs them (measured 10.3 vs 9.3 ms on 8192 25x25 boards)
+    constexpr bool COMPACT = OccGeom<H, W, 8>::CB == 8;
+    constexpr int lds4 = OccGeom<H, W, 4>::LDS_BYTES, lds8 = OccGeom<H, W, 8>::LDS_BYTES;
+    auto fn8 = k_occupancy_rowlane<H, W, 8>;
+    hipError_t err = hipFuncSetAttribute((const void *)fn8, hipFuncAttributeMaxDynamicSharedMemorySize, lds8);
     if (err != hipSuccess) return err;
-    if (Oc::CB == 8) {      // the drained counters are added into the output
+    if (OccGeom<H, W, 8>::CB == 8) {      // the drained counters are added into the output
         if (counts_stride == (size_t)H * W * 8) {
             err = hipMemsetAsync(counts, 0, (size_t)B * H * W * 8 * sizeof(int32_t), stream);
         } else {
@@ -1752,8 +1809,17 @@ static hipError_t launch_occupancy_t(const u16 *in, int32_t *counts, size_t coun
         }
         if (err != hipSuccess) return err;
     }
-    hipLaunchKernelGGL(fn, dim3((B + Gm::G - 1) / Gm::G), dim3(64), Oc::LDS_BYTES, stream, in, counts, counts_stride, B,
-                       n_valid, spawn_prob, n_steps, rng, jump);
+    // both instantiations cover the batch; a wavefront whose boards belong to the other one exits at once
+    const dim3 grid((B + Gm::G - 1) / Gm::G);
+    if constexpr (COMPACT) {
+        auto fn4 = k_occupancy_rowlane<H, W, 4>;
+        err = hipFuncSetAttribute((const void *)fn4, hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
+        if (err != hipSuccess) return err;
+        hipLaunchKernelGGL(fn4, grid, dim3(64), lds4, stream, in, counts, counts_stride, B, n_valid, spawn_prob, n_steps,
+                           rng, jump);
+    }
+    hipLaunchKernelGGL(fn8, grid, dim3(64), lds8, stream, in, counts, counts_stride, B, n_valid, spawn_prob, n_steps, rng,
+                       jump);
     return hipGetLastError();
 }
 

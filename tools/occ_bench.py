@@ -23,3 +23,13 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1)
 print("%s %d boards x %d steps: %.2f ms, %.3g board-steps/s" % (name, nb, n, ms, nb * n / (ms * 1e-3)))
+# the roll-forward alone (advance_board, same boards, same step count): what the CA + draws cost without counting
+out = torch.empty_like(boards)
+speedups.advance_board_batch(boards[:16], probs[:16], rngs[:16].clone(), 10)
+torch.cuda.synchronize()
+e0.record()
+speedups.advance_board_batch(boards, probs, rngs, n, out=out)
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1)
+print("%s advance_board %d boards x %d steps: %.2f ms, %.3g board-steps/s" % (name, nb, n, ms, nb * n / (ms * 1e-3)))
