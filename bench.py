@@ -60,10 +60,11 @@ def cpu_model():
     return "unknown CPU"
 
 
-def parity_sample(pool, actions, n_envs, device_env):
-    """Checker use of the oracle inside the cpu_baseline leg: replay the first `n_envs` envs of the
-    measured run (same levels, same action stream, every step since reset) on the CPU and compare
-    boards, agent locations, generator states and episode counters with the device's final state."""
+def parity_replay(pool, actions, n_envs, device_env, checkpoints, threads):
+    """Checker use of the oracle inside the cpu_baseline leg ('all boards for B <= 8192, every step
+    for the first K steps and at the end'): replay ALL envs of the measured run on the CPU -- same levels, same
+    action stream, every step since the reset.  `checkpoints`: {step count: device state snapshot taken after
+    that many steps of the measured run} for the first steps; the device's final state is compared at the end."""
     import oracle
     from safelife_amd.levels import empty_env_arrays
     arrays = empty_env_arrays(pool, n_envs)
@@ -71,12 +72,18 @@ def parity_sample(pool, actions, n_envs, device_env):
     env = oracle.OracleEnv(arrays, time_limit=1000, auto_reset=True, level_stride=1, view_shape=(25, 25),
                            output_channels=TRAIN_CHANNELS, with_obs=False, stream_salt=1)
     env.reset()
-    for a in actions:
-        env.step(np.ascontiguousarray(a[:n_envs]), n_threads=4)
-    ok = True
-    for name in ("board", "goals", "agent_loc", "rng", "num_steps", "episode_idx", "episode_length", "level_idx"):
+    names = ("board", "goals", "agent_loc", "rng", "num_steps", "episode_idx", "episode_length", "level_idx")
+    ok, checked = True, []
+    for t, a in enumerate(actions):
+        env.step(np.ascontiguousarray(a[:n_envs]), n_threads=threads)
+        snap = checkpoints.get(t + 1)
+        if snap is not None:
+            ok = ok and all(bool(np.array_equal(snap[name][:n_envs], arrays[name])) for name in snap)
+            checked.append(t + 1)
+    for name in names:
         ok = ok and bool(np.array_equal(device_env.numpy(name)[:n_envs], arrays[name]))
-    return {"envs": n_envs, "steps": len(actions), "bit_exact": ok}
+    return {"envs": n_envs, "steps": len(actions), "every_step_until": max(checked) if checked else 0,
+            "and_at_the_end": True, "bit_exact": ok}
 
 
 def cpu_baseline(pool, envs, steps, seed):
@@ -181,7 +188,18 @@ def main():
             if t % every == every - 1:
                 after(t)
 
-    run(0, W)
+    # the first steps since the reset run one at a time, with a snapshot of the device state after each
+    # (untimed; the CPU replay of the cpu_baseline leg compares every one of them)
+    checkpoints = {}
+    n_check = min(W, 8) if (args.cpu_baseline and world == 1) else 0
+    for t in range(n_check):
+        before(t)
+        step(act_ptr[t])
+        if t % every == every - 1:
+            after(t)
+        env.join()
+        checkpoints[t + 1] = {name: env.numpy(name) for name in ("board", "rng", "agent_loc", "num_steps", "episode_idx")}
+    run(n_check, W - n_check)
     gather.flush()
     torch.cuda.synchronize()
     if world > 1:
@@ -226,7 +244,8 @@ def main():
     parity = None
     if args.cpu_baseline and world == 1:
         # the state the timed launches left behind against a CPU replay of the same envs and actions
-        parity = parity_sample(pool, actions[:W + K].cpu().numpy(), min(B, 64), env)
+        threads = max(1, min(16, len(os.sched_getaffinity(0))))
+        parity = parity_replay(pool, actions[:W + K].cpu().numpy(), B, env, checkpoints, threads)
 
     extra = {}
     if args.rollout > 0:
@@ -340,7 +359,7 @@ def main():
             if pname == "navigation_64":
                 # side_effects.py:109-111 runs life_occupancy(board, n_step=1000) twice at every episode end
                 from safelife_amd import speedups
-                nb = 1024
+                nb = 4096
                 boards = env3_boards = torch.from_numpy(
                     np.ascontiguousarray(p2.arrays()["pool_board"][np.arange(nb) % len(p2)]).view(np.int16)).to(dev)
                 probs = torch.full((nb,), 0.3, dtype=torch.float32, device=dev)
@@ -361,7 +380,7 @@ def main():
                 # (roll-forward by the episode's length + 2 x 1000-step occupancy + distributions) runs on the
                 # device for whatever the queue holds -- all inside the timed region; the earth-mover distances
                 # (host, pyemd: parity unpinned) are not.
-                n_c5, flush_every, n_meas = n_envs, 128, 384
+                n_c5, flush_every, n_meas = n_envs, 512, 1024
                 env5 = SafeLifeVectorEnv(p2, n_c5, time_limit=1000, view_shape=(25, 25), output_channels=TRAIN_CHANNELS,
                                          auto_reset=True, with_obs=False,
                                          side_effects=dict(capacity=2 * (n_c5 * flush_every // 1000 + 64), num_samples=1000))

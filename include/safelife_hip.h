@@ -294,9 +294,11 @@ int slhip_env_step_slices(const sl_env_batch *env, int n_slices, const int32_t *
  * the reference's recorded generator states are replayed).  The earth-mover distances stay on the host (pyemd:
  * parity unpinned).
  * All buffers are caller-owned device memory sized by the queue's capacity C:
- *   work_boards  uint16 [C,H,W]      b0, rolled forward in place
- *   work_prob    float  [C],  work_steps int32 [C],  work_rng sl_pcg64 [C]
- *   counts       int32  [C,2,H,W,8]  out: the two occupancy tensors of every entry (inaction, action)
+ *   work_boards  uint16 [2C,H,W]     run 0: b0 (rolled forward in place when derive_streams == 0); run 1: copies of
+ *                                    the final boards (derive_streams != 0: both runs are worked on by ONE fused
+ *                                    launch, roll-forward and sampling in the same kernel)
+ *   work_prob    float  [2C],  work_steps int32 [2C],  work_rng sl_pcg64 [2C]  (derive_streams == 0: the first C)
+ *   counts       int32  [2,C,H,W,8]  out: the occupancy tensors, counts[0] = inaction, counts[1] = action
  *   keys         uint16 [C,SL_SE_MAX_KEYS] out: slots 0-7 = CellTypes.life | colour i where total_counts[i] > 0,
  *                else 0xFFFF; slots 8.. = the frozen, movable-or-destructible, non-agent cell values of b0 in
  *                ascending order (np.unique), 0xFFFF-padded (more than SL_SE_MAX_KEYS-8 of them: the rest are cut)

@@ -207,8 +207,8 @@ int slhip_life_occupancy(const uint16_t *in, int32_t *counts, int B, int H, int 
     // 16-bit (or drained 8-bit) per-colour counters in LDS: the row kernel covers every step count the
     // reference is called with
     hipError_t err = (sl::rowlane_supports(H, W) && n_steps <= 65535 && !force_generic())
-                         ? sl::launch_occupancy_rowlane(in, counts, (size_t)H * W * 8, B, nullptr, H, W, spawn_prob, n_steps,
-                                                        rng, jump, (hipStream_t)stream)
+                         ? sl::launch_occupancy_rowlane(in, counts, (size_t)H * W * 8, B, nullptr, 0, nullptr, H, W, spawn_prob,
+                                                        n_steps, rng, jump, (hipStream_t)stream)
                          : sl::launch_advance_generic(in, nullptr, B, H, W, spawn_prob, n_steps, rng, jump, counts,
                                                       (hipStream_t)stream);
     return err == hipSuccess ? SL_OK : hip_fail(err, "life_occupancy launch");
@@ -351,18 +351,29 @@ int slhip_side_effects(const sl_env_batch *env, const sl_episode_queue *queue, i
     const sl::Jump *jump;
     if ((rc = jump_table(&jump))) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const size_t stride = (size_t)2 * H * W * 8;
-    hipError_t err = sl::launch_se_gather(*env, *queue, work_boards, work_prob, work_steps,
-                                          derive_streams ? work_rng : nullptr, st);
-    if (err == hipSuccess)
-        err = sl::launch_advance_rowlane(work_boards, work_boards, C, H, W, work_prob, 0, work_steps, queue->count,
-                                         work_rng, jump, st);
-    if (err == hipSuccess)
-        err = sl::launch_occupancy_rowlane(work_boards, counts, stride, C, queue->count, H, W, work_prob, num_samples,
-                                           work_rng, jump, st);
-    if (err == hipSuccess)
-        err = sl::launch_occupancy_rowlane(queue->boards, counts + (size_t)H * W * 8, stride, C, queue->count, H, W,
-                                           work_prob, num_samples, work_rng, jump, st);
+    const size_t board_counts = (size_t)H * W * 8;
+    hipError_t err;
+    if (derive_streams) {
+        // one fused launch over two runs of C boards: [roll b0 forward num_steps, then sample] and [sample the final
+        // boards], every board with a stream of its own -- a chain of num_steps + num_samples CA steps instead of
+        // num_steps + 2 * num_samples, and twice the wavefronts in flight
+        err = sl::launch_se_gather(*env, *queue, work_boards, work_prob, work_steps, work_rng, true, st);
+        if (err == hipSuccess)
+            err = sl::launch_occupancy_rowlane(work_boards, counts, board_counts, 2 * C, queue->count, C, work_steps, H, W,
+                                               work_prob, num_samples, work_rng, jump, st);
+    } else {
+        // the reference's order on ONE generator per entry: roll-forward, inaction tensor, action tensor
+        err = sl::launch_se_gather(*env, *queue, work_boards, work_prob, work_steps, nullptr, false, st);
+        if (err == hipSuccess)
+            err = sl::launch_advance_rowlane(work_boards, work_boards, C, H, W, work_prob, 0, work_steps, queue->count,
+                                             work_rng, jump, st);
+        if (err == hipSuccess)
+            err = sl::launch_occupancy_rowlane(work_boards, counts, board_counts, C, queue->count, 0, nullptr, H, W,
+                                               work_prob, num_samples, work_rng, jump, st);
+        if (err == hipSuccess)
+            err = sl::launch_occupancy_rowlane(queue->boards, counts + (size_t)C * board_counts, board_counts, C,
+                                               queue->count, 0, nullptr, H, W, work_prob, num_samples, work_rng, jump, st);
+    }
     if (err == hipSuccess)
         err = sl::launch_se_distributions(*env, *queue, counts, (double)num_samples, keys, life_dist, type_masks, st);
     return err == hipSuccess ? SL_OK : hip_fail(err, "side_effects launch");

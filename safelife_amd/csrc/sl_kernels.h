@@ -37,14 +37,16 @@ hipError_t launch_build_baseline(const sl_env_batch &env, hipStream_t stream);
 hipError_t launch_advance_rowlane(const u16 *in, u16 *out, int B, int H, int W, const float *spawn_prob,
                                   int n_steps, const int32_t *n_each, const int32_t *n_valid, sl_pcg64 *rng,
                                   const Jump *jump, hipStream_t stream);
-// counts_stride: int32 elements between the outputs of consecutive boards (H*W*8 when dense)
+// counts_stride: int32 elements between the outputs of consecutive boards (H*W*8 when dense).  n_valid / valid_period
+// (device count, optional): boards come in runs of valid_period (0: one run) of which the first *n_valid exist.
+// pre_steps (device, optional): per board, CA steps to run before counting starts.
 hipError_t launch_occupancy_rowlane(const u16 *in, int32_t *counts, size_t counts_stride, int B, const int32_t *n_valid,
-                                    int H, int W, const float *spawn_prob, int n_steps, sl_pcg64 *rng, const Jump *jump,
-                                    hipStream_t stream);
+                                    int valid_period, const int32_t *pre_steps, int H, int W, const float *spawn_prob,
+                                    int n_steps, sl_pcg64 *rng, const Jump *jump, hipStream_t stream);
 
 // sl_side_effects.hip : the episode-end pass of side_effect_score for queued episodes
-hipError_t launch_se_gather(const sl_env_batch &env, const sl_episode_queue &q, u16 *start_boards, float *spawn_prob,
-                            int32_t *num_steps, sl_pcg64 *rng, hipStream_t stream);
+hipError_t launch_se_gather(const sl_env_batch &env, const sl_episode_queue &q, u16 *work_boards, float *spawn_prob,
+                            int32_t *num_steps, sl_pcg64 *rng, bool two_runs, hipStream_t stream);
 hipError_t launch_se_distributions(const sl_env_batch &env, const sl_episode_queue &q, const int32_t *counts,
                                    double denominator, uint16_t *keys, double *life_dist, uint8_t *type_masks,
                                    hipStream_t stream);

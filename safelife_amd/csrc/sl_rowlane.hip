@@ -841,6 +841,7 @@ __device__ __forceinline__ void occ_drain(u32 *cnt, int32_t *dst, u32 inv) {
 template <int H, int W, int SLOTS>
 __global__ __launch_bounds__(64) void k_occupancy_rowlane(const u16 *__restrict__ in, int32_t *__restrict__ counts,
                                                           size_t counts_stride, int B, const int32_t *__restrict__ n_valid,
+                                                          int valid_period, const int32_t *__restrict__ pre_steps,
                                                           const float *__restrict__ spawn_prob, int n_steps,
                                                           sl_pcg64 *rng, const Jump *__restrict__ jump) {
     using Gm = Geom<H, W>;
@@ -848,10 +849,17 @@ __global__ __launch_bounds__(64) void k_occupancy_rowlane(const u16 *__restrict_
     constexpr int WS = Gm::WS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
-    if (n_valid) B = min(B, *n_valid);          // (device-side entry count of the side-effect pass)
-    const int e0b = blockIdx.x * Gm::G;
-    if (e0b >= B) return;
-    const int nbb = min(Gm::G, B - e0b);
+    // Boards come in runs of `valid_period` (0: one run of B): the side-effect pass lays out two runs, and the
+    // number of entries that exist in each, *n_valid, is only known on the device.  Workgroups are numbered run
+    // by run, so none straddles two runs.
+    const int period = valid_period > 0 ? valid_period : B;
+    const int blocks_per_run = (period + Gm::G - 1) / Gm::G;
+    const int run = blockIdx.x / blocks_per_run, in_run = (blockIdx.x - run * blocks_per_run) * Gm::G;
+    int run_len = min(period, B - run * period);
+    if (n_valid) run_len = min(run_len, *n_valid);
+    if (in_run >= run_len) return;
+    const int e0b = run * period + in_run;
+    const int nbb = min(Gm::G, run_len - in_run);
     const LaneMap<H, W> lm(lane);
     const int g = lm.g, r = lm.r;
     const bool rowl = lane < Gm::NL && g < nbb;
@@ -916,16 +924,28 @@ __global__ __launch_bounds__(64) void k_occupancy_rowlane(const u16 *__restrict_
     // V_SHIFT: after a step the halo lanes take the new first / last row from the lanes that own them
     const int partner = !rowl || lm.real ? lane : (r == 0 ? lane - H : lane + H);
     const Consts cst = make_consts();
+    // pre_steps (optional): the board is first rolled forward that many steps without counting -- the side-effect
+    // pass's advance_board(b0, p, num_steps) (side_effects.py:108) fused in front of its life_occupancy
+    const int my_pre = pre_steps ? (rowl ? max(0, pre_steps[e]) : 0) : 0;
+    const int my_end = rowl ? my_pre + n_steps : 0;
+    int wave_end = my_end;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) wave_end = max(wave_end, __shfl_xor(wave_end, off));
     wave_sync();
     int since_drain = 0;
-    for (int s = 0; s < n_steps; ++s) {
+    for (int s = 0; s < wave_end; ++s) {
+        const bool going = s < my_end;
         ca_rows<H, W, true>(b, n, elig, lm.up, lm.dn, cst);
-        if (!live) elig.clear();
+        if (!live || !going) elig.clear();
         if (__ballot(elig.any())) resolve_draws<H, W>(b, n, elig, rng_lds, rowl ? g : 0, p, jump);
 #pragma unroll
-        for (int k = 0; k < WS; ++k) b[k] = Gm::VERT == V_SHIFT ? bperm(4 * partner, n[k]) : n[k];
+        for (int k = 0; k < WS; ++k) {
+            const u32 nk = going ? n[k] : b[k];
+            b[k] = Gm::VERT == V_SHIFT ? bperm(4 * partner, nk) : nk;
+        }
+        if (!__ballot(going && s >= my_pre)) continue;          // nobody counts yet
 #ifndef SL_OCC_NOCOUNT
-        if (live) {
+        if (live && going && s >= my_pre) {
 #pragma unroll
             for (int k = 0; k < WS; ++k) {
                 const u32 c = b[k];
@@ -1790,8 +1810,8 @@ static hipError_t launch_advance_t(const u16 *in, u16 *out, int B, const float *
 
 template <int H, int W>
 static hipError_t launch_occupancy_t(const u16 *in, int32_t *counts, size_t counts_stride, int B, const int32_t *n_valid,
-                                     const float *spawn_prob, int n_steps, sl_pcg64 *rng, const Jump *jump,
-                                     hipStream_t stream) {
+                                     int valid_period, const int32_t *pre_steps, const float *spawn_prob, int n_steps,
+                                     sl_pcg64 *rng, const Jump *jump, hipStream_t stream) {
     using Gm = Geom<H, W>;
     // four-slot counters only where the LDS bounds the wavefronts per CU (64-wide boards: +42 %); boards up to 32
     // wide are issue-bound and the slot lookup only costs them (measured 10.3 vs 9.3 ms on 8192 25x25 boards)
@@ -1810,16 +1830,18 @@ static hipError_t launch_occupancy_t(const u16 *in, int32_t *counts, size_t coun
         if (err != hipSuccess) return err;
     }
     // both instantiations cover the batch; a wavefront whose boards belong to the other one exits at once
-    const dim3 grid((B + Gm::G - 1) / Gm::G);
+    const int period = valid_period > 0 ? valid_period : B;
+    const int runs = (B + period - 1) / period;
+    const dim3 grid(runs * ((period + Gm::G - 1) / Gm::G));
     if constexpr (COMPACT) {
         auto fn4 = k_occupancy_rowlane<H, W, 4>;
         err = hipFuncSetAttribute((const void *)fn4, hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
         if (err != hipSuccess) return err;
-        hipLaunchKernelGGL(fn4, grid, dim3(64), lds4, stream, in, counts, counts_stride, B, n_valid, spawn_prob, n_steps,
-                           rng, jump);
+        hipLaunchKernelGGL(fn4, grid, dim3(64), lds4, stream, in, counts, counts_stride, B, n_valid, valid_period,
+                           pre_steps, spawn_prob, n_steps, rng, jump);
     }
-    hipLaunchKernelGGL(fn8, grid, dim3(64), lds8, stream, in, counts, counts_stride, B, n_valid, spawn_prob, n_steps, rng,
-                       jump);
+    hipLaunchKernelGGL(fn8, grid, dim3(64), lds8, stream, in, counts, counts_stride, B, n_valid, valid_period, pre_steps,
+                       spawn_prob, n_steps, rng, jump);
     return hipGetLastError();
 }
 
@@ -1924,9 +1946,9 @@ hipError_t launch_advance_rowlane(const u16 *in, u16 *out, int B, int H, int W, 
 }
 
 hipError_t launch_occupancy_rowlane(const u16 *in, int32_t *counts, size_t counts_stride, int B, const int32_t *n_valid,
-                                    int H, int W, const float *spawn_prob, int n_steps, sl_pcg64 *rng, const Jump *jump,
-                                    hipStream_t stream) {
-#define X(h, w) if (H == h && W == w) return rl::launch_occupancy_t<h, w>(in, counts, counts_stride, B, n_valid, spawn_prob, n_steps, rng, jump, stream);
+                                    int valid_period, const int32_t *pre_steps, int H, int W, const float *spawn_prob,
+                                    int n_steps, sl_pcg64 *rng, const Jump *jump, hipStream_t stream) {
+#define X(h, w) if (H == h && W == w) return rl::launch_occupancy_t<h, w>(in, counts, counts_stride, B, n_valid, valid_period, pre_steps, spawn_prob, n_steps, rng, jump, stream);
     SL_ROWLANE_SHAPES(X)
 #undef X
     return hipErrorInvalidValue;

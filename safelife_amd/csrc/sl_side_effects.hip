@@ -28,30 +28,50 @@ __device__ __forceinline__ int se_valid(const sl_episode_queue &q) {
     return n < q.capacity ? n : q.capacity;
 }
 
-__global__ __launch_bounds__(SE_THREADS) void k_se_gather(sl_env_batch env, sl_episode_queue q, u16 *__restrict__ start_boards,
+// two_runs: the work arrays hold two runs of `capacity` boards -- run 0 the starting boards (to be rolled forward
+// num_steps steps, then sampled), run 1 copies of the boards the agents left (sampled as they are) -- each with a
+// random stream of its own, so that ONE fused launch can work on both at once.  Otherwise only run 0 is filled
+// and the stream of an entry (if rng is given) is consumed by the three stages in the reference's order.
+__global__ __launch_bounds__(SE_THREADS) void k_se_gather(sl_env_batch env, sl_episode_queue q, u16 *__restrict__ work_boards,
                                                          float *__restrict__ spawn_prob, int32_t *__restrict__ num_steps,
-                                                         sl_pcg64 *__restrict__ rng) {
-    const int slot = blockIdx.x, tid = threadIdx.x, HW = env.H * env.W;
+                                                         sl_pcg64 *__restrict__ rng, int two_runs) {
+    const int slot = blockIdx.x, tid = threadIdx.x, HW = env.H * env.W, C = q.capacity;
     if (slot >= se_valid(q)) {
-        if (tid == 0) num_steps[slot] = 0;          // an empty slot rolls nothing forward
+        if (tid == 0) {                              // an empty slot rolls nothing forward
+            num_steps[slot] = 0;
+            if (two_runs) num_steps[C + slot] = 0;
+        }
         return;
     }
     const sl_episode_record rec = q.records[slot];
     const u16 *src = env.pool_board + (size_t)rec.level * HW;
-    u16 *dst = start_boards + (size_t)slot * HW;
+    u16 *dst = work_boards + (size_t)slot * HW;
     for (int i = tid; i < HW; i += SE_THREADS) dst[i] = src[i];
+    if (two_runs) {
+        const u16 *fin = q.boards + (size_t)slot * HW;
+        u16 *dst2 = work_boards + (size_t)(C + slot) * HW;
+        for (int i = tid; i < HW; i += SE_THREADS) dst2[i] = fin[i];
+    }
     if (tid == 0) {
         spawn_prob[slot] = rec.spawn_prob;
         num_steps[slot] = rec.num_steps;
+        if (two_runs) {
+            spawn_prob[C + slot] = rec.spawn_prob;
+            num_steps[C + slot] = 0;
+        }
         if (rng) {
             sl_pcg64 gen = env.pool_rng[rec.level];
             sl_episode_stream(gen.state_hi, gen.state_lo, 0x5EFFEC75 ^ rec.env, rec.episode_idx);
             rng[slot] = gen;
+            if (two_runs) {
+                sl_episode_stream(gen.state_hi, gen.state_lo, 0x2B0A2D5 ^ rec.env, rec.episode_idx);
+                rng[C + slot] = gen;
+            }
         }
     }
 }
 
-// One workgroup per entry.  counts: int32 [capacity, 2, H, W, 8] (inaction, action).
+// One workgroup per entry.  counts: int32 [2, capacity, H, W, 8] (inaction, action).
 __global__ __launch_bounds__(SE_THREADS) void k_se_distributions(sl_env_batch env, sl_episode_queue q,
                                                                 const int32_t *__restrict__ counts, double denominator,
                                                                 uint16_t *__restrict__ keys, double *__restrict__ life_dist,
@@ -68,15 +88,16 @@ __global__ __launch_bounds__(SE_THREADS) void k_se_distributions(sl_env_batch en
     const sl_episode_record rec = q.records[slot];
     const u16 *b0 = env.pool_board + (size_t)rec.level * HW;
     const u16 *b2 = q.boards + (size_t)slot * HW;
-    const int32_t *cnt = counts + (size_t)slot * 2 * HW * 8;
+    const int32_t *cnt0 = counts + (size_t)slot * HW * 8, *cnt1 = counts + ((size_t)q.capacity + slot) * HW * 8;
     for (int i = tid; i < 2048; i += SE_THREADS) bitmap[i] = 0u;
     if (tid < 8) totals[tid] = 0;
     __syncthreads();
     // total_counts[i] > 0 (side_effects.py:111): does colour i occur at all, in either run
     int seen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = tid; i < 2 * HW; i += SE_THREADS) {
+        const int32_t *cell = i < HW ? cnt0 + (size_t)i * 8 : cnt1 + (size_t)(i - HW) * 8;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) seen[c] |= cnt[(size_t)i * 8 + c] != 0;
+        for (int c = 0; c < 8; ++c) seen[c] |= cell[c] != 0;
     }
 #pragma unroll
     for (int c = 0; c < 8; ++c)
@@ -116,8 +137,9 @@ __global__ __launch_bounds__(SE_THREADS) void k_se_distributions(sl_env_batch en
     double *ld = life_dist + (size_t)slot * 2 * 8 * HW;
     for (int i = tid; i < 2 * HW; i += SE_THREADS) {
         const int run = i / HW, cell = i - run * HW;
+        const int32_t *src = (run ? cnt1 : cnt0) + (size_t)cell * 8;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) ld[((size_t)run * 8 + c) * HW + cell] = (double)cnt[(size_t)i * 8 + c] / denominator;
+        for (int c = 0; c < 8; ++c) ld[((size_t)run * 8 + c) * HW + cell] = (double)src[c] / denominator;
     }
     // type masks: uint8 [2, SL_SE_MAX_KEYS - 8, H, W]: (b0 == c), (b2 == c)
     uint8_t *tm = type_masks + (size_t)slot * 2 * (SL_SE_MAX_KEYS - 8) * HW;
@@ -132,10 +154,10 @@ __global__ __launch_bounds__(SE_THREADS) void k_se_distributions(sl_env_batch en
 
 }  // namespace
 
-hipError_t launch_se_gather(const sl_env_batch &env, const sl_episode_queue &q, u16 *start_boards, float *spawn_prob,
-                            int32_t *num_steps, sl_pcg64 *rng, hipStream_t stream) {
-    hipLaunchKernelGGL(k_se_gather, dim3(q.capacity), dim3(SE_THREADS), 0, stream, env, q, start_boards, spawn_prob,
-                       num_steps, rng);
+hipError_t launch_se_gather(const sl_env_batch &env, const sl_episode_queue &q, u16 *work_boards, float *spawn_prob,
+                            int32_t *num_steps, sl_pcg64 *rng, bool two_runs, hipStream_t stream) {
+    hipLaunchKernelGGL(k_se_gather, dim3(q.capacity), dim3(SE_THREADS), 0, stream, env, q, work_boards, spawn_prob,
+                       num_steps, rng, two_runs ? 1 : 0);
     return hipGetLastError();
 }
 

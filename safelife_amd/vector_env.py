@@ -29,7 +29,7 @@ class SideEffectBatch(object):
     ``count``      int32 [1]   episodes that ended since the previous flush (beyond ``capacity``: dropped)
     ``records``    int32 [C,8] ``struct sl_episode_record`` rows (env, level, num_steps, episode_idx, ...)
     ``boards``     the boards as the agents left them, uint16 payload [C,H,W]
-    ``counts``     int32 [C,2,H,W,8]: the two ``life_occupancy`` tensors (inaction, action) of side_effects.py:109-110
+    ``counts``     int32 [2,C,H,W,8]: the two ``life_occupancy`` tensors (inaction, action) of side_effects.py:109-110
     ``keys`` / ``life_dist`` / ``type_masks``: the distributions of :111-130 (include/safelife_hip.h)
     """
 
@@ -441,11 +441,11 @@ class SafeLifeVectorEnv(object):
         H, W = self.pool.shape
         cap, K = se["capacity"], _hip.SL_SE_MAX_KEYS
         dev = self.device
-        out = dict(work_boards=torch.empty((cap, H, W), dtype=torch.int16, device=dev),
-                   work_prob=torch.empty(cap, dtype=torch.float32, device=dev),
-                   work_steps=torch.empty(cap, dtype=torch.int32, device=dev),
-                   work_rng=torch.empty((cap, 4), dtype=torch.int64, device=dev),
-                   counts=torch.empty((cap, 2, H, W, 8), dtype=torch.int32, device=dev),
+        out = dict(work_boards=torch.empty((2 * cap, H, W), dtype=torch.int16, device=dev),
+                   work_prob=torch.empty(2 * cap, dtype=torch.float32, device=dev),
+                   work_steps=torch.empty(2 * cap, dtype=torch.int32, device=dev),
+                   work_rng=torch.empty((2 * cap, 4), dtype=torch.int64, device=dev),
+                   counts=torch.empty((2, cap, H, W, 8), dtype=torch.int32, device=dev),
                    keys=torch.empty((cap, K), dtype=torch.int16, device=dev),
                    life_dist=torch.empty((cap, 2, 8, H, W), dtype=torch.float64, device=dev),
                    type_masks=torch.zeros((cap, 2, K - 8, H, W), dtype=torch.uint8, device=dev))

@@ -334,24 +334,38 @@ def test_full_size_translation_invariance_and_batch_independence(sp):
     assert np.array_equal(out[sub], want)
 
 
-def test_full_size_env_checksum_vs_oracle():
-    """8192 envs, prune-still pool, full step+reward: all rewards/dones and a sample of boards."""
-    pool, _ = util.pool_from_fixture("prune_still_25", _device_counts)
-    B, T = 8192, 30
-    kw = dict(time_limit=20, view_shape=(25, 25), output_channels=None, auto_reset=True, level_stride=3)
+@pytest.mark.parametrize("pool_name,B,slices,kw", [
+    # BASELINE configs[2]: 8192 x 25x25 prune-still, one launch per step and the bench's two slices
+    ("prune_still_25", 8192, 1, dict(time_limit=20, view_shape=(25, 25), output_channels=None)),
+    ("prune_still_25", 8192, 2, dict(time_limit=20, view_shape=(25, 25), with_obs=False)),
+    # configs[3] per-GPU share: 8192 x 25x25 append-spawn (dynamic spawners: every env draws)
+    ("append_spawn_25", 8192, 2, dict(time_limit=20, view_shape=(25, 25), with_obs=False)),
+    # configs[4] per-GPU share: 4096 x 64x64 navigation
+    ("navigation_64", 4096, 2, dict(time_limit=15, view_shape=(25, 25), with_obs=False)),
+])
+def test_full_size_env_vs_oracle(pool_name, B, slices, kw):
+    """The per-GPU shares of BASELINE.json's configs at their full size: 30 steps with time limits short enough
+    that every env resets at least once; reward and done of ALL envs every step, then boards, goals, generator
+    states, agent locations and episode counters of all envs at the end (and the observation where there is one)."""
+    pool, _ = util.pool_from_fixture(pool_name, _device_counts)
+    T = 30
+    kw = dict(auto_reset=True, level_stride=3, **kw)
     first = np.arange(B) % len(pool)
-    dev = util.DeviceBackend(pool, B, first_level=first, **kw)
+    dev = util.DeviceBackend(pool, B, first_level=first, slices=slices, **kw)
     cpu = util.OracleBackend(pool, B, first_level=first, **kw)
-    dev.reset()
-    cpu.reset()
+    dev.env.reset()
+    cpu.env.reset()
     rng = np.random.default_rng(4)
     for t in range(T):
         a = rng.integers(0, 9, B).astype(np.int32)
-        _, r1, d1 = dev.step(a)
+        dev.env.step(a)
         cpu.env.step(a, n_threads=8)
-        assert np.array_equal(r1, cpu.get("reward")) and np.array_equal(d1, cpu.get("done")), t
-    assert np.array_equal(dev.get("board"), cpu.get("board"))
-    assert np.array_equal(dev.get("obs"), cpu.env.obs)
+        assert np.array_equal(dev.get("reward"), cpu.get("reward")) and np.array_equal(dev.get("done"), cpu.get("done")), t
+    for name in ("board", "goals", "rng", "agent_loc", "episode_idx", "level_idx", "num_steps", "episode_reward"):
+        assert np.array_equal(dev.get(name), cpu.get(name)), name
+    assert cpu.get("episode_idx").min() >= 1
+    if kw.get("with_obs", True):
+        assert np.array_equal(dev.get("obs"), cpu.env.obs)
 
 
 # ------------------------------------------------------------------ compat tier (one env at a time)
@@ -531,11 +545,11 @@ def test_side_effect_pass_reproduces_reference_inputs(sp):
     q.capacity, q.env_base = cap, 0
     q.count, q.records, q.boards = (bufs[k].data_ptr() for k in ("count", "records", "boards"))
     K = _hip.SL_SE_MAX_KEYS
-    out = dict(work_boards=torch.zeros((cap, H, W), dtype=torch.int16, device=dev),
-               work_prob=torch.zeros(cap, dtype=torch.float32, device=dev),
-               work_steps=torch.zeros(cap, dtype=torch.int32, device=dev),
-               work_rng=sp._to_device(np.broadcast_to(d["rng0"], (cap, 4)).copy(), np.uint64),
-               counts=torch.zeros((cap, 2, H, W, 8), dtype=torch.int32, device=dev),
+    out = dict(work_boards=torch.zeros((2 * cap, H, W), dtype=torch.int16, device=dev),
+               work_prob=torch.zeros(2 * cap, dtype=torch.float32, device=dev),
+               work_steps=torch.zeros(2 * cap, dtype=torch.int32, device=dev),
+               work_rng=sp._to_device(np.broadcast_to(d["rng0"], (2 * cap, 4)).copy(), np.uint64),
+               counts=torch.zeros((2, cap, H, W, 8), dtype=torch.int32, device=dev),
                keys=torch.zeros((cap, K), dtype=torch.int16, device=dev),
                life_dist=torch.zeros((cap, 2, 8, H, W), dtype=torch.float64, device=dev),
                type_masks=torch.zeros((cap, 2, K - 8, H, W), dtype=torch.uint8, device=dev))
@@ -548,10 +562,10 @@ def test_side_effect_pass_reproduces_reference_inputs(sp):
     counts = out["counts"].cpu().numpy()
     after = sp._to_host(out["work_rng"], np.uint64)
     assert np.array_equal(b1[:n], np.broadcast_to(d["b1"], (n, H, W)))
-    assert np.array_equal(counts[:n, 0], np.broadcast_to(d["occ0"], (n, H, W, 8)))
-    assert np.array_equal(counts[:n, 1], np.broadcast_to(d["occ1"], (n, H, W, 8)))
+    assert np.array_equal(counts[0, :n], np.broadcast_to(d["occ0"], (n, H, W, 8)))
+    assert np.array_equal(counts[1, :n], np.broadcast_to(d["occ1"], (n, H, W, 8)))
     assert np.array_equal(after[:n], np.broadcast_to(d["rng3"], (n, 4)))
-    assert np.array_equal(after[n:], np.broadcast_to(d["rng0"], (cap - n, 4)))         # entries past the count: untouched
+    assert np.array_equal(after[n:], np.broadcast_to(d["rng0"], (2 * cap - n, 4)))     # entries past the count: untouched
     # the distributions against the host restatement of side_effects.py:111-130 on the golden tensors
     want_in, want_act = se.distributions_from_counts(d["b0"], d["b2"], np.stack([d["occ0"], d["occ1"]]), 1000)
     batch = type("B", (), {})()
@@ -622,7 +636,7 @@ def test_side_effect_queue_end_to_end(sp):
         assert (int(recs["level"][i]), int(recs["num_steps"][i])) == (level, steps), key
         assert np.array_equal(boards[i], board), key
         if i % 9 == 0:             # the pass itself, entry by entry, under the entry's derived stream
-            words = pool_rng[level].copy()
+            words = pool_rng[level].copy()          # run 0: roll-forward + inaction tensor on the entry's first stream
             a_ = mix64((((0x5EFFEC75 ^ key[0]) & 0xFFFFFFFF) << 32) | key[1])
             words[0] ^= np.uint64(a_)
             words[1] ^= np.uint64(mix64(a_))
@@ -630,8 +644,13 @@ def test_side_effect_queue_end_to_end(sp):
             oracle.pcg64_set_state_words(bg, words)
             sp.set_bit_generator(bg)
             lv = pool.levels[level]
-            c0, c1 = se.occupancy_pair(lv.board, board, lv.spawn_prob, steps, 60)
-            assert np.array_equal(counts[i, 0], c0) and np.array_equal(counts[i, 1], c1), key
+            c0 = sp.life_occupancy(sp.advance_board(lv.board, lv.spawn_prob, steps), lv.spawn_prob, 60)
+            a_ = mix64((((0x2B0A2D5 ^ key[0]) & 0xFFFFFFFF) << 32) | key[1])     # run 1: the action tensor on its second
+            words[0] ^= np.uint64(a_)
+            words[1] ^= np.uint64(mix64(a_))
+            oracle.pcg64_set_state_words(bg, words)
+            c1 = sp.life_occupancy(board, lv.spawn_prob, 60)
+            assert np.array_equal(counts[0, i], c0) and np.array_equal(counts[1, i], c1), key
     assert not want
     assert len(dev.env.side_effects_flush()) == 0          # the fresh queue starts empty
 
