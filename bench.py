@@ -236,10 +236,18 @@ def main():
     # device time per step: every slice stream runs its K launches back to back, all streams concurrently
     slice_ms = [e0.elapsed_time(e1) / K for e0, e1 in evs]
     kernel_ms = max(slice_ms)
+    per_rank = None
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        # per-rank breakdown for the scaling run: wall time of the region, device time per step, host enqueue time
+        # per step, and the time the rank spent blocked in the gather (its exposed part)
+        mine = torch.tensor([elapsed, kernel_ms, (t_enqueued - t_start) / K * 1e3, gather.exposed_s], device=dev,
+                            dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": r, "elapsed_ms": float(v[0]) * 1e3, "device_ms_per_step": float(v[1]),
+                     "host_enqueue_ms_per_step": float(v[2]), "gather_exposed_ms": float(v[3]) * 1e3}
+                    for r, v in enumerate(allr)]
+        elapsed = max(float(v[0]) for v in allr)
 
     parity = None
     if args.cpu_baseline and world == 1:
@@ -452,6 +460,8 @@ def main():
                          # first launch from an idle GPU and the final synchronize)
                          "frac_wall": bytes_per_step * B / (elapsed / K) / 1e9 / HBM_PEAK_GBS},
         }
+        if per_rank:
+            out["per_rank"] = per_rank
         if extra:
             out["extra"] = extra
         if args.cpu_baseline and world == 1:

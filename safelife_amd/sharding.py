@@ -11,6 +11,7 @@ gathered with ONE RCCL ``gather`` per ``every`` steps, issued asynchronously so 
 following steps; two buffers alternate.
 """
 import os
+import time
 
 import numpy as np
 
@@ -48,13 +49,16 @@ class RewardGather(object):
                          for _ in range(2)]
         self.work = [None, None]
         self.last = None
+        self.exposed_s = 0.0          # host time spent issuing / waiting on the collective (what is not overlapped)
         self._slot_ptr = [[b.data_ptr() + self.RECORD_BYTES * slot * B for slot in range(self.every)]
                           for b in self.buf]
 
     def before_step(self, t):
         slot, which = t % self.every, (t // self.every) % 2
         if slot == 0 and self.work[which] is not None:
+            t0 = time.perf_counter()
             self.work[which].wait()          # stream-level wait: buffer is free again
+            self.exposed_s += time.perf_counter() - t0
             self.work[which] = None
             if getattr(self.env, "slices", 1) > 1:
                 self.env.fence()             # ... for the slice streams too
@@ -67,10 +71,12 @@ class RewardGather(object):
         self.last = which
         if self.world > 1 or self.force:
             import torch.distributed as dist
+            t0 = time.perf_counter()
             if getattr(self.env, "slices", 1) > 1:
                 self.env.join()              # the window was written on the slice streams
             self.work[which] = dist.gather(self.buf[which], self.recv[which] if self.rank == 0 else None,
                                            dst=0, group=self.group, async_op=True)
+            self.exposed_s += time.perf_counter() - t0
 
     def flush(self):
         """Wait (stream-level) for outstanding gathers and hand the step outputs back to the env's own

@@ -1,0 +1,48 @@
+"""Run by tests/test_hip_parity.py::test_reward_gather_through_rccl in a process of its own: the real
+SafeLifeVectorEnv (two slices) + RewardGather with the RCCL collective forced on for a single rank."""
+import os
+import sys
+
+os.environ["SAFELIFE_FORCE_GATHER"] = "1"
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29541")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import torch.distributed as dist
+from safelife_amd import _hip
+from safelife_amd.levels import _device_counts
+from safelife_amd.sharding import RewardGather
+from safelife_amd.vector_env import SafeLifeVectorEnv
+from tests import util
+
+dev = _hip.device()
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+pool, _ = util.pool_from_fixture("append_spawn_25", _device_counts, n=16)
+B, every, T = 256, 8, 40
+kw = dict(time_limit=12, view_shape=(9, 9), auto_reset=True, with_obs=False)
+env = SafeLifeVectorEnv(pool, B, slices=2, **kw)
+ref = SafeLifeVectorEnv(pool, B, **kw)          # same envs, outputs read directly every step
+env.reset(), ref.reset()
+gather = RewardGather(env, every=every, world=1, rank=0)
+rng = np.random.default_rng(3)
+want_r, want_d = [], []
+for t in range(T):
+    a = torch.from_numpy(rng.integers(0, 9, B).astype(np.int32)).to(dev)
+    torch.cuda.synchronize()
+    gather.before_step(t)
+    env.step_async(a)
+    gather.after_step(t)
+    ref.step(a)
+    want_r.append(ref.numpy("reward"))
+    want_d.append(ref.numpy("done"))
+    if t % every == every - 1:
+        rw, dn = gather.latest()                # waits for the collective that filled the window
+        assert rw.shape == (1, every, B)
+        assert np.array_equal(rw[0].cpu().numpy(), np.stack(want_r[-every:])), t
+        assert np.array_equal(dn[0].cpu().numpy(), np.stack(want_d[-every:])), t
+gather.flush()
+assert np.array_equal(env.numpy("board"), ref.numpy("board"))
+dist.destroy_process_group()
+print("rccl gather ok")

@@ -860,6 +860,16 @@ def test_manual_reset_moves_on_and_episode_streams():
     assert episodes.min() >= 2 and np.array_equal(dev.get("level_idx"), (2 * episodes) % len(pool))
 
 
+def test_reward_gather_through_rccl():
+    """The real env (two slices, outputs redirected into the gather windows) + RewardGather with the RCCL
+    collective forced on for a single rank (SAFELIFE_FORCE_GATHER=1): every window against the rewards / dones
+    of an identical env read directly.  Own process: it initialises torch.distributed with the nccl backend."""
+    import subprocess, sys
+    out = subprocess.check_output([sys.executable, os.path.join(util.REPO, "tests", "rccl_gather_check.py")],
+                                  stderr=subprocess.STDOUT, timeout=300).decode()
+    assert "rccl gather ok" in out, out
+
+
 def test_sharded_equals_unsharded():
     """env e behaves the same whichever rank owns it -- two half-size envs with
     env_offset 0 / B/2 (what ranks 0 and 1 of a 2-GPU run hold) against one env of size B."""
