@@ -295,6 +295,23 @@ def main():
             extra[tag + "_roofline_frac"] = (3 * H * Wd * 2 + obs_b) * B / (us * 1e-6) / (HBM_PEAK_GBS * 1e9)
             del env2
 
+        # f4: the observation written by the step kernel in the policy network's layout ([B,C,W,H] uint8), no (h,w,c) tensor
+        env2 = SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25), output_channels=TRAIN_CHANNELS,
+                                 auto_reset=True, level_stride=1, with_obs=False, policy_layout="uint8")
+        env2.reset()
+        for t in range(20):
+            env2.step(actions[t])
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = min(K, 200)
+        e0.record()
+        for t in range(n):
+            env2.step(actions[t])
+        e1.record()
+        torch.cuda.synchronize()
+        extra["obs_policy_layout_u8_25x25x15_us_per_step"] = e0.elapsed_time(e1) / n * 1e3
+        del env2
+
         def time_steps(env3, n_envs, n=200):
             acts = torch.randint(0, 9, (n + 20, n_envs), generator=gen, device=dev, dtype=torch.int32)
             env3.reset()

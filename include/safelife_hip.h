@@ -243,6 +243,13 @@ typedef struct sl_env_batch {
     /* per-step outputs */
     sl_step_out *out;            /* [B] */
     uint8_t *obs;                /* [B,vh,vw,C] uint8, or uint32 [B,vh,vw] if n_channels == 0; NULL = skip */
+    void *policy_obs;            /* the same observation as the policy network takes it (training/models.py:100-103
+                                    transposes (h,w,c) -> (c,w,h); training/ppo.py:64 casts to float32), written by
+                                    the step / reset kernels themselves: [B,C,vw,vh], policy_obs[b][c][x][y] = bit
+                                    channels[c] of the view word at (y,x); uint8 or float32 (policy_dtype).  Needs
+                                    n_channels >= 1.  NULL = skip */
+    int32_t policy_dtype;        /* 0 = uint8, 1 = float32 */
+    int32_t reserved1;
     /* workspace */
     int8_t *score_lut;           /* [n_tables,4096+65536] per-cell score tables derived from points_table by
                                     slhip_env_prepare(); NULL => the size-generic kernels are used */

@@ -101,6 +101,8 @@ int check_env(const sl_env_batch *env) {
                           env->pool_scalars, env->out};
     for (const void *p : need)
         if (!p) return fail(SL_E_ARG, "null pointer in sl_env_batch");
+    if (env->policy_obs && (env->n_channels < 1 || (env->policy_dtype != 0 && env->policy_dtype != 1)))
+        return fail(SL_E_ARG, "policy_obs needs n_channels >= 1 and policy_dtype 0 (uint8) or 1 (float32)");
     const sl_episode_queue &q = env->finished;
     if (q.capacity < 0 || (q.capacity > 0 && (!q.count || !q.records || !q.boards)))
         return fail(SL_E_ARG, "finished-episode queue: negative capacity or null buffers");
@@ -138,6 +140,9 @@ sl_env_batch env_slice(const sl_env_batch &env, int e0, int n) {
         const size_t cell = env.n_channels > 0 ? (size_t)env.n_channels : 4;     // uint8 channels, or the raw uint32 view
         s.obs = env.obs + (size_t)e0 * env.view_h * env.view_w * cell;
     }
+    if (env.policy_obs)
+        s.policy_obs = (char *)env.policy_obs + (size_t)e0 * env.n_channels * env.view_h * env.view_w *
+                                                    (env.policy_dtype ? sizeof(float) : 1);
     if (env.wrap.flags) {
         s.wrap.state = env.wrap.state + e0;
         s.wrap.shaped_reward = env.wrap.shaped_reward + e0;
@@ -273,6 +278,8 @@ static bool use_rowlane(const sl_env_batch *env, int e_first) {
              (slice_bytes & 15))
         why = "board / goals / rng / score_lut (or the slice start) not 16-byte aligned";
     else if (env->E > 8) why = "more than 8 exit slots";
+    else if (env->policy_obs && env->view_h * env->view_w > sl::rowlane_policy_room(env->H, env->W))
+        why = "view too large for the fused policy-layout observation";
     else if (env->wrap.flags && (((env->wrap.flags & SL_WRAP_SIDE_EFFECT) && !env->wrap.pool_baseline) ||
                                  (((uintptr_t)env->wrap.state | (uintptr_t)env->wrap.move_table) & 15)))
         why = "wrapper workspace missing or unaligned";

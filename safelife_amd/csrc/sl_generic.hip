@@ -243,7 +243,7 @@ __device__ bool recolor_exits(u16 *board, int W, int ly, int lx, const int32_t *
 // SafeLifeEnv.get_obs for env e from the board in LDS; goals through `goals` (LDS or global).
 __device__ void write_obs(const sl_env_batch &env, int e, const u16 *board, const u16 *goals,
                           int ly, int lx, const int32_t *exits) {
-    if (!env.obs) return;
+    if (!env.obs && !env.policy_obs) return;
     const int H = env.H, W = env.W, vh = env.view_h, vw = env.view_w, C = env.n_channels;
     const int y0 = ly >= 0 ? ly : 0, x0 = ly >= 0 ? lx : 0;
     const int nv = vh * vw;
@@ -266,11 +266,21 @@ __device__ void write_obs(const sl_env_batch &env, int e, const u16 *board, cons
             jx = min(max(jx, 0), vw - 1);
             if (jy == vy && jx == vx) word = obs_word(board[ex], goals[ex], env.remove_white_goals);
         }
-        if (C == 0) {
-            ((u32 *)env.obs)[(size_t)e * nv + v] = word;
-        } else {
-            uint8_t *o = env.obs + ((size_t)e * nv + v) * C;
-            for (int c = 0; c < C; ++c) o[c] = (word >> env.channels[c]) & 1u;
+        if (env.obs) {
+            if (C == 0) {
+                ((u32 *)env.obs)[(size_t)e * nv + v] = word;
+            } else {
+                uint8_t *o = env.obs + ((size_t)e * nv + v) * C;
+                for (int c = 0; c < C; ++c) o[c] = (word >> env.channels[c]) & 1u;
+            }
+        }
+        if (env.policy_obs) {        // channel-first, spatial axes swapped: [C, vw, vh] (training/models.py:100-103)
+            const size_t base = (size_t)e * C * nv + (size_t)vx * vh + vy;
+            for (int c = 0; c < C; ++c) {
+                const u32 bit = (word >> env.channels[c]) & 1u;
+                if (env.policy_dtype == 0) ((uint8_t *)env.policy_obs)[base + (size_t)c * nv] = (uint8_t)bit;
+                else ((float *)env.policy_obs)[base + (size_t)c * nv] = (float)bit;
+            }
         }
     }
 }

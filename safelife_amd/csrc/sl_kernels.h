@@ -30,6 +30,7 @@ hipError_t launch_obs_to_policy(const u32 *view, int B, int vh, int vw, const sl
 
 // sl_rowlane.hip : row-per-lane SWAR kernels for the shapes listed in SL_ROWLANE_SHAPES
 bool rowlane_supports(int H, int W);
+int rowlane_policy_room(int H, int W);
 hipError_t launch_build_score_lut(const int32_t *points_table, int n_tables, int8_t *lut, hipStream_t stream);
 hipError_t launch_build_baseline(const sl_env_batch &env, hipStream_t stream);
 // n_each (device, optional): one step count per board instead of n_steps; n_valid (device, optional): only

@@ -1294,6 +1294,62 @@ __device__ __forceinline__ void write_obs_block(const sl_env_batch &env, const u
     }
 }
 
+// The observation in the layout the policy network convolves (training/models.py:100-103, ppo.py:64): channel
+// first, spatial axes swapped, out[b][c][x][y] = bit channels[c] of the view word at (y, x); uint8 or float32.
+// The raw view words of a few boards at a time are parked in LDS (the goal-word / score-table regions are dead
+// by now), then every thread produces four consecutive output elements -- contiguous along y -- per store.
+template <int H, int W>
+__device__ __forceinline__ void write_policy_block(const sl_env_batch &env, unsigned char *smem, int e0b, int nbb, int tid) {
+    using Gm = Geom<H, W>;
+    const int vh = env.view_h, vw = env.view_w, nv = vh * vw, C = env.n_channels;
+    const float inv_nv = 1.0f / (float)nv, inv_vw = 1.0f / (float)vw, inv_vh = 1.0f / (float)vh;
+    const float inv_cnv = 1.0f / (float)(C * nv);
+    const int n_exits = min(env.E, OBS_MAX_EXITS);
+    constexpr int STAGE_OFF = (Gm::NB * OBS_PAR_INTS * 4 + 15) & ~15;       // behind the per-board view parameters
+    constexpr int ROOM = (Gm::GSH_BYTES + 4096 - STAGE_OFF) / 4;            // dwords
+    u32 *stage = (u32 *)(smem + Gm::OFF_GSH + STAGE_OFF);
+    const int per_round = ROOM / nv;            // boards per round (the launcher guarantees >= 1)
+    for (int b0 = 0; b0 < nbb; b0 += per_round) {
+        const int nb = min(per_round, nbb - b0);
+        __syncthreads();
+        ObsSource<H, W> cu;
+        for (int c = tid; c < nb * nv; c += 64 * WAVES) {
+            cu.start(smem, b0 * nv + c, nv, vw, inv_nv, inv_vw);
+            stage[c] = obs_fetch<H, W>(env, smem, cu, n_exits);
+        }
+        __syncthreads();
+        const int total = nb * C * nv;          // output elements of this round: [nb][C][vw][vh]
+        const size_t out0 = (size_t)(e0b + b0) * C * nv;
+        for (int o = 4 * tid; o < total; o += 4 * 64 * WAVES) {
+            u32 bits[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int oj = min(o + j, total - 1);
+                const int bq = div_small(oj, C * nv, inv_cnv), rem = oj - bq * C * nv;
+                const int ch = div_small(rem, nv, inv_nv), xy = rem - ch * nv;
+                const int x = div_small(xy, vh, inv_vh), y = xy - x * vh;
+                bits[j] = (stage[bq * nv + y * vw + x] >> env.channels[ch]) & 1u;
+            }
+            if (env.policy_dtype == 0) {
+                uint8_t *dst = (uint8_t *)env.policy_obs + out0 + o;
+                if (o + 4 <= total && ((out0 + o) & 3) == 0) {
+                    *(u32 *)dst = bits[0] | (bits[1] << 8) | (bits[2] << 16) | (bits[3] << 24);
+                } else {
+                    for (int j = 0; j < 4 && o + j < total; ++j) dst[j] = (uint8_t)bits[j];
+                }
+            } else {
+                float *dst = (float *)env.policy_obs + out0 + o;
+                if (o + 4 <= total && ((out0 + o) & 3) == 0) {
+                    typedef float f32x4 __attribute__((ext_vector_type(4)));
+                    *(f32x4 *)dst = f32x4{(float)bits[0], (float)bits[1], (float)bits[2], (float)bits[3]};
+                } else {
+                    for (int j = 0; j < 4 && o + j < total; ++j) dst[j] = (float)bits[j];
+                }
+            }
+        }
+    }
+}
+
 // ---- fused env step / rollout ---------------------------------------------------------------------
 
 template <int H, int W, bool LDS_LUT, bool SPAWN, bool WRAP>
@@ -1711,7 +1767,7 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
     }
 #endif
     // observation (safelife_env.py:105-146) from the LDS images of the final state
-    if (env.obs) {
+    if (env.obs || env.policy_obs) {
         // per board: view centre and, per exit slot, the view cell it is painted on + its board cell
         int *par = (int *)(smem + Gm::OFF_GSH);                 // goal words are dead by now
         if (leader) {
@@ -1736,9 +1792,12 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
             }
         }
         __syncthreads();
-        if (env.n_channels == 15) write_obs_block<H, W, 15>(env, smem, e0b, nbb, tid);
-        else if (env.n_channels == 19) write_obs_block<H, W, 19>(env, smem, e0b, nbb, tid);
-        else write_obs_block<H, W, 0>(env, smem, e0b, nbb, tid);
+        if (env.obs) {
+            if (env.n_channels == 15) write_obs_block<H, W, 15>(env, smem, e0b, nbb, tid);
+            else if (env.n_channels == 19) write_obs_block<H, W, 19>(env, smem, e0b, nbb, tid);
+            else write_obs_block<H, W, 0>(env, smem, e0b, nbb, tid);
+        }
+        if (env.policy_obs) write_policy_block<H, W>(env, smem, e0b, nbb, tid);
     }
 }
 
@@ -1916,6 +1975,16 @@ static hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_c
 }  // namespace rl
 
 #define SL_ROWLANE_SHAPES(X) X(25, 25) X(26, 26) X(15, 15) X(20, 20) X(10, 10) X(64, 64)
+
+// view cells the fused policy-layout epilogue can stage per board (its LDS room), 0 for unsupported shapes
+int rowlane_policy_room(int H, int W) {
+#define X(h, w)                                                                                              \
+    if (H == h && W == w)                                                                                    \
+        return (rl::Geom<h, w>::GSH_BYTES + 4096 - ((rl::Geom<h, w>::NB * rl::OBS_PAR_INTS * 4 + 15) & ~15)) / 4;
+    SL_ROWLANE_SHAPES(X)
+#undef X
+    return 0;
+}
 
 bool rowlane_supports(int H, int W) {
 #define X(h, w) if (H == h && W == w) return true;

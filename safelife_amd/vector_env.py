@@ -112,6 +112,12 @@ class SafeLifeVectorEnv(object):
                                    then differ the way the reference's per-game ``SeedSequence.spawn`` children
                                    do (level_iterator.py:218).  False: an episode on pool level l starts from
                                    ``pool.rng[l]`` exactly (replaying recorded traces of the reference).
+    policy_layout : None, "uint8" or "float32"
+                                   the step / reset kernels also write the observation the way the policy network
+                                   takes it -- ``env.policy_tensor`` ``[B, C, view_w, view_h]`` (channel first,
+                                   spatial axes swapped: training/models.py:100-103; float32: ppo.py:64) -- so
+                                   nothing has to be transposed or cast afterwards; combine with ``with_obs=False``
+                                   to skip the (h, w, c) tensor altogether.
     side_effects : dict or None    ``dict(capacity=N, num_samples=1000)``: the step kernels queue every episode that
                                    ends (record + the board as the agent left it, taken before an auto-reset
                                    reloads the slot) and ``side_effects_flush()`` runs the episode-end pass of the
@@ -131,7 +137,8 @@ class SafeLifeVectorEnv(object):
     def __init__(self, pool, num_envs, *, time_limit=1000, remove_white_goals=True,
                  view_shape=(15, 15), output_channels=_DEFAULT_CHANNELS, auto_reset=True,
                  first_level=None, level_stride=1, env_offset=0, with_obs=True,
-                 points_on_level_exit=1, wrappers=None, slices=1, episode_streams=True, side_effects=None):
+                 points_on_level_exit=1, wrappers=None, slices=1, episode_streams=True, side_effects=None,
+                 policy_layout=None):
         import torch
         self.torch = torch
         if not isinstance(pool, LevelPool):
@@ -179,6 +186,12 @@ class SafeLifeVectorEnv(object):
             self.obs = torch.zeros((B, vh, vw, len(chans)), dtype=torch.uint8, device=dev)
         else:
             self.obs = torch.zeros((B, vh, vw), dtype=torch.int32, device=dev)   # uint32 payload
+        self.policy_tensor = None
+        if policy_layout is not None:
+            if policy_layout not in ("uint8", "float32") or not chans:
+                raise ValueError("policy_layout must be 'uint8' or 'float32' and needs output_channels")
+            self.policy_tensor = torch.zeros((B, len(chans), vw, vh), device=dev,
+                                             dtype=torch.uint8 if policy_layout == "uint8" else torch.float32)
         if first_level is None:
             first_level = (int(env_offset) + np.arange(B)) % len(pool)
         first = np.broadcast_to(np.asarray(first_level, np.int32), (B,)).copy()
@@ -204,6 +217,8 @@ class SafeLifeVectorEnv(object):
         for name in _hip.ENV_STATE_PTRS + _hip.ENV_POOL_PTRS + _hip.ENV_OUT_PTRS:
             if name == "obs":
                 s.obs = None if self.obs is None else self.obs.data_ptr()
+                s.policy_obs = None if self.policy_tensor is None else self.policy_tensor.data_ptr()
+                s.policy_dtype = 0 if policy_layout != "float32" else 1
             else:
                 setattr(s, name, t[name].data_ptr())
         # views of the per-step output records (struct sl_step_out)

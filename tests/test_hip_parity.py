@@ -870,6 +870,117 @@ def test_reward_gather_through_rccl():
     assert "rccl gather ok" in out, out
 
 
+@pytest.mark.parametrize("pool_name,B,kw", [
+    ("prune_still_25", 200, dict(view_shape=(25, 25), time_limit=25,
+                                 output_channels=(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 25, 26, 27))),
+    ("append_spawn_25", 90, dict(view_shape=(15, 9), time_limit=20)),
+    ("navigation_64", 40, dict(view_shape=(25, 25), time_limit=20)),
+    ("append_still_26", 50, dict(view_shape=(33, 33), time_limit=20, remove_white_goals=False)),
+])
+@pytest.mark.parametrize("layout", ["uint8", "float32"])
+def test_policy_layout_from_the_step(pool_name, B, kw, layout):
+    """f4: the step / reset kernels write the observation as the policy network takes it, [B,C,view_w,view_h]
+    (training/models.py:100-103 transposes (h,w,c) -> (c,w,h); ppo.py:64 casts to float32): every step and
+    after resets against the ORACLE's (h,w,c) observation transposed on the host; with and without the (h,w,c)
+    tensor next to it."""
+    import torch
+    pool, _ = util.pool_from_fixture(pool_name, _device_counts, min_performance_fraction=0.05)
+    first = (np.arange(B) * 3) % len(pool)
+    common = dict(first_level=first, auto_reset=True, level_stride=2, **kw)
+    dev = util.DeviceBackend(pool, B, policy_layout=layout, with_obs=(layout == "uint8"), **common)
+    cpu = util.OracleBackend(pool, B, **common)
+    dev.env.reset()
+    want = cpu.reset()
+
+    def check(tag):
+        got = dev.env.policy_tensor.cpu().numpy()
+        assert got.dtype == (np.uint8 if layout == "uint8" else np.float32)
+        assert np.array_equal(got, np.transpose(want, (0, 3, 2, 1)).astype(got.dtype)), tag
+        if layout == "uint8":
+            assert np.array_equal(dev.get("obs"), want), tag
+    check("reset")
+    rng = np.random.default_rng(8)
+    for t in range(45):
+        a = rng.integers(0, 9, B).astype(np.int32)
+        dev.env.step(a)
+        want, _, _ = cpu.step(a)
+        check(t)
+
+
+def test_policy_layout_generic_kernels():
+    """... and through the size-generic kernels (a board shape without row kernels)."""
+    from safelife_amd.cell_types import CellTypes as CT
+    from safelife_amd.levels import Level, LevelPool
+    rng = np.random.default_rng(2)
+    levels = []
+    for _ in range(3):
+        b = util.random_boards(rng, 1, 9, 13, 1)[0]
+        b[4, 6] = CT.player
+        levels.append(Level(b, (rng.integers(0, 8, (9, 13)) << 9).astype(np.uint16), [[4, 6]], min_performance=-1))
+    pool = LevelPool(levels, counts_fn=_device_counts)
+    kw = dict(first_level=np.arange(7) % 3, auto_reset=True, time_limit=9, view_shape=(7, 5))
+    dev = util.DeviceBackend(pool, 7, policy_layout="float32", **kw)
+    cpu = util.OracleBackend(pool, 7, **kw)
+    dev.env.reset()
+    want = cpu.reset()
+    for t in range(25):
+        assert np.array_equal(dev.env.policy_tensor.cpu().numpy(), np.transpose(want, (0, 3, 2, 1)).astype(np.float32)), t
+        a = rng.integers(0, 9, 7).astype(np.int32)
+        dev.env.step(a)
+        want, _, _ = cpu.step(a)
+
+
+@pytest.mark.parametrize("name", ["v10_append-spawn", "v10_prune-still_open", "v10_navigation", "append_still_1_chan19"])
+def test_vector_runner_replays_reference_trace(name):
+    """VectorRunner (obs -> policy -> device-side action draw -> fused step -> reset bookkeeping, the batched
+    training/base_algo.py:152-244) driven by a scripted policy that puts all probability on the action the
+    reference's trace took: observations (policy layout), rewards, dones and agent ids step by step against
+    the recorded SafeLifeEnv run, across its resets."""
+    import torch
+    from safelife_amd.runner import VectorRunner
+    from safelife_amd.vector_env import SafeLifeVectorEnv
+    tr = util.load_trace(name)
+    pool = util.pool_from_trace(tr, _device_counts)
+    kw = util.env_kwargs_from_trace(tr)
+    chans = kw.get("output_channels") or tuple(range(16)) + (25, 26, 27)
+    raw = not kw.get("output_channels")
+    kw["output_channels"] = chans
+
+    def policy_view(obs):        # the trace's observation -> [C, W, H] float32
+        if raw:                  # recorded as the uint32 view: unpack the channels here
+            obs = np.stack([(obs >> c) & 1 for c in chans], axis=-1)
+        return np.transpose(obs, (2, 1, 0)).astype(np.float32)
+    env = SafeLifeVectorEnv(pool, 1, first_level=0, auto_reset=True, level_stride=1, episode_streams=False,
+                            policy_layout="float32", with_obs=False, **kw)
+    actions = tr["trace_actions"]
+    step_no = [0]
+
+    def scripted(obs):
+        probs = torch.zeros((obs.shape[0], 9), device=obs.device)
+        probs[:, int(actions[step_no[0]])] = 1.0
+        return torch.zeros(obs.shape[0], device=obs.device), probs
+    runner = VectorRunner(env, scripted)
+    n_levels, n_resets = len(tr["trace_reset_obs"]), 0
+    for t in range(len(tr["trace_reward"])):
+        step_no[0] = t
+        res = runner.take_one_step()
+        assert int(res.actions[0]) == int(actions[t])
+        assert float(res.rewards[0]) == float(tr["trace_reward"][t]), t
+        assert bool(res.done[0]) == bool(tr["trace_done"][t]), t
+        assert int(res.agent_ids[0][0]) == 0 and int(res.agent_ids[1][0]) == n_resets, t
+        if t == 0:
+            assert np.array_equal(res.obs[0].cpu().numpy(), policy_view(tr["trace_reset_obs"][0]))
+        nxt = res.next_obs[0].cpu().numpy()
+        if bool(res.done[0]):
+            n_resets += 1
+            if n_resets >= n_levels:
+                break                   # the reference ran out of levels here
+            assert np.array_equal(nxt, policy_view(tr["trace_reset_obs"][n_resets])), t
+        else:
+            assert np.array_equal(nxt, policy_view(tr["trace_obs"][t])), t
+    assert int(runner.num_resets[0]) == n_resets
+
+
 def test_sharded_equals_unsharded():
     """env e behaves the same whichever rank owns it -- two half-size envs with
     env_offset 0 / B/2 (what ranks 0 and 1 of a 2-GPU run hold) against one env of size B."""
