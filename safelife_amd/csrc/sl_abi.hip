@@ -390,6 +390,15 @@ int slhip_env_obs(const sl_env_batch *env, void *stream) {
     int rc = check_env(env);
     if (rc) return rc;
     if (env->B == 0) return SL_OK;
+    if (use_rowlane(env, 0)) {
+        // the fused kernel with zero steps: load, observation epilogue, store (its action argument is only read,
+        // never used, with T == 0: any B readable int32 do)
+        const sl::Jump *jump;
+        if ((rc = jump_table(&jump))) return rc;
+        hipError_t err = sl::launch_env_rollout_rowlane(*env, 0, env->B, (const int32_t *)env->scalars, 0, env->B, nullptr,
+                                                        nullptr, jump, (hipStream_t)stream);
+        return err == hipSuccess ? SL_OK : hip_fail(err, "env_obs launch");
+    }
     hipError_t err = sl::launch_env_obs_generic(*env, (hipStream_t)stream);
     return err == hipSuccess ? SL_OK : hip_fail(err, "env_obs launch");
 }

@@ -981,6 +981,35 @@ def test_vector_runner_replays_reference_trace(name):
     assert int(runner.num_resets[0]) == n_resets
 
 
+@pytest.mark.parametrize("pool_name,B,kw", [
+    ("prune_still_25", 130, dict(view_shape=(25, 25), output_channels=(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 25, 26, 27))),
+    ("navigation_64", 21, dict(view_shape=(15, 15), output_channels=None)),
+    ("append_still_26", 33, dict(view_shape=(9, 9), wrappers=TRAINING_WRAPPERS)),
+])
+def test_get_obs_leaves_state_alone(pool_name, B, kw):
+    """SafeLifeEnv.get_obs() on the batch (slhip_env_obs: the fused kernel with zero steps): the observation of
+    the current state is rebuilt, and nothing else moves."""
+    pool, _ = util.pool_from_fixture(pool_name, _device_counts, min_performance_fraction=0.05)
+    common = dict(first_level=np.arange(B) % len(pool), auto_reset=True, time_limit=14, **kw)
+    dev, cpu = util.DeviceBackend(pool, B, **common), util.OracleBackend(pool, B, **common)
+    dev.reset(), cpu.reset()
+    rng = np.random.default_rng(6)
+    for t in range(20):
+        a = rng.integers(0, 9, B).astype(np.int32)
+        dev.env.step(a)
+        want, _, _ = cpu.step(a)
+    before = {name: dev.get(name) for name in ENV_STATE}
+    dev.env.obs.zero_()
+    dev.env.get_obs()
+    assert np.array_equal(dev.get("obs"), want)
+    for name in ENV_STATE:
+        assert np.array_equal(dev.get(name), before[name]), name
+    a = rng.integers(0, 9, B).astype(np.int32)          # and the run goes on as if nothing had happened
+    dev.env.step(a)
+    want, r2, d2 = cpu.step(a)
+    assert np.array_equal(dev.get("obs"), want) and np.array_equal(dev.get("reward"), r2)
+
+
 def test_sharded_equals_unsharded():
     """env e behaves the same whichever rank owns it -- two half-size envs with
     env_offset 0 / B/2 (what ranks 0 and 1 of a 2-GPU run hold) against one env of size B."""
