@@ -1352,7 +1352,11 @@ __device__ __forceinline__ void write_policy_block(const sl_env_batch &env, unsi
 
 // ---- fused env step / rollout ---------------------------------------------------------------------
 
-template <int H, int W, bool LDS_LUT, bool SPAWN, bool WRAP>
+// LEAN: the instantiation for batches without observation, policy-layout tensor, finished-episode queue and
+// wrappers -- the plain step of the headline workload.  The kernel sits at its register limit (126 of 128
+// VGPRs at four wavefronts per SIMD): every cold feature compiled into it costs the hot path scheduling freedom
+// (the queue, the policy layout and the episode streams together: 9.1 vs 8.5 us per two-slice C3 step).
+template <int H, int W, bool LDS_LUT, bool SPAWN, bool WRAP, bool LEAN>
 __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_env_rollout_rowlane(
     // the eight arguments the prologue needs before anything else come first: with
     // -amdgpu-kernarg-preload-count=8 they arrive in SGPRs with the wave instead of behind an s_load
@@ -1470,6 +1474,17 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
             goal_bits |= b[k];
         }
     }
+    // Goals still undecided (the first step after a reset; the reference finds out by advancing them once,
+    // safelife_game.py:753-760): a goal array without a single ALIVE or SPAWNING cell cannot change and draws
+    // nothing, so it IS static and the second CA pass of that step is skipped -- the usual case for every level a
+    // reset loads.  Decided here, once per launch, for the step this launch is about to take (an env that
+    // resets in the middle of a T-step launch takes the two-pass route for one step).
+#ifndef SL_NO_SHORTCUT1
+    if (T > 0 && __ballot(rowl && gstatic == 0)) {
+        const int restless = group_total<H, W>(live && (goal_bits & 0x00810081u) ? 1 : 0, rowl ? g : 0);
+        if (rowl && gstatic == 0 && restless == 0) gstatic = 1;
+    }
+#endif
     bool goals_dirty = false;
     SL_STAMP(3);
 
@@ -1482,22 +1497,15 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
                 __builtin_amdgcn_global_load_lds((glds_src_t)(src + k), (glds_dst_t)(base_rows + k * 256), 4, 0, 0);
         }
         // safelife_env.py:151
+#ifndef SL_EXP_NOACT
         if (leader && ly >= 0) {
             if (t > 0) action = actions[(size_t)t * B + e];
             act_gather<H, W>(board16, ly, lx, action);
         }
+#endif
         wave_sync();
         SL_STAMP(4);
-        // safelife_env.py:152 : board first, then goals unless they are static (safelife_game.py:746-761).
-        // Goals still undecided (first step after a reset; the reference finds out by advancing them once,
-        // :753-760): a goal array without a single ALIVE or SPAWNING cell cannot change and draws nothing, so it
-        // IS static and the second CA pass of this step is skipped -- the usual case for every level a reset loads.
-#ifndef SL_NO_SHORTCUT1
-        if (__ballot(rowl && gstatic == 0)) {
-            const int restless = group_total<H, W>(live && (goal_bits & 0x00810081u) ? 1 : 0, rowl ? g : 0);
-            if (rowl && gstatic == 0 && restless == 0) gstatic = 1;
-        }
-#endif
+        // safelife_env.py:152 : board first, then goals unless they are static (safelife_game.py:746-761)
         const bool dyn = rowl && gstatic != 1;
         const int passes = __ballot(dyn) ? 2 : 1;
 #pragma nounroll
@@ -1614,7 +1622,7 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
         }
         // the step that ends an episode queues it for the side-effect pass (include/safelife_hip.h): a record and
         // the board as the agent left it, taken from the LDS image before any auto-reset reloads the slot
-        if (env.finished.capacity > 0 && __ballot(ended)) {
+        if (!LEAN && env.finished.capacity > 0 && __ballot(ended)) {
             int slot = -1;
             if (ended) {
                 slot = atomicAdd(env.finished.count, 1);
@@ -1675,17 +1683,14 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
                 goals_dirty = true;
             }
             wave_sync();
-            u32 new_goal_bits = 0;
             if (mine) {
                 read_row<H, W>(goals, gb, r, b);
 #pragma unroll
                 for (int k = 0; k < WS; ++k) {
                     gsh_lane[k] = goal_shift(b[k]);
-                    new_goal_bits |= b[k];
                 }
                 read_row<H, W>(board, gb, r, b);
             }
-            if (mine) goal_bits = new_goal_bits;
             const int s0 = group_total<H, W>(
                 mine ? row_score<H, W, LDS_LUT>(b, gsh_lane, lut, lut_base, lds_lut, cell_mask, c100) : 0,
                 live ? g : 0);
@@ -1767,7 +1772,7 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
     }
 #endif
     // observation (safelife_env.py:105-146) from the LDS images of the final state
-    if (env.obs || env.policy_obs) {
+    if (!LEAN && (env.obs || env.policy_obs)) {
         // per board: view centre and, per exit slot, the view cell it is painted on + its board cell
         int *par = (int *)(smem + Gm::OFF_GSH);                 // goal words are dead by now
         if (leader) {
@@ -1909,15 +1914,18 @@ static hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_c
                                    int tstride, float *reward_t, uint8_t *done_t, const Jump *jump,
                                    hipStream_t stream) {
     using Gm = Geom<H, W>;
-    const int variant = (env.n_tables == 1 ? 1 : 0) | (env.spawner_free ? 2 : 0) | (env.wrap.flags ? 4 : 0);
+    const bool lean = !env.wrap.flags && !env.obs && !env.policy_obs && env.finished.capacity == 0;
+    const int variant = (env.n_tables == 1 ? 1 : 0) | (env.spawner_free ? 2 : 0) | (env.wrap.flags ? 4 : (lean ? 8 : 0));
     typedef void (*kernel_t)(const u16 *, const u16 *, const sl_pcg64 *, sl_env_scalars *, const int8_t *,
                              const int32_t *, int, int, sl_env_batch, int, int, int, sl_step_out *, float *,
                              uint8_t *, double *, const Jump *);
-    static const kernel_t table[8] = {
-        k_env_rollout_rowlane<H, W, false, true, false>, k_env_rollout_rowlane<H, W, true, true, false>,
-        k_env_rollout_rowlane<H, W, false, false, false>, k_env_rollout_rowlane<H, W, true, false, false>,
-        k_env_rollout_rowlane<H, W, false, true, true>,  k_env_rollout_rowlane<H, W, true, true, true>,
-        k_env_rollout_rowlane<H, W, false, false, true>,  k_env_rollout_rowlane<H, W, true, false, true>};
+    static const kernel_t table[12] = {
+        k_env_rollout_rowlane<H, W, false, true, false, false>, k_env_rollout_rowlane<H, W, true, true, false, false>,
+        k_env_rollout_rowlane<H, W, false, false, false, false>, k_env_rollout_rowlane<H, W, true, false, false, false>,
+        k_env_rollout_rowlane<H, W, false, true, true, false>,  k_env_rollout_rowlane<H, W, true, true, true, false>,
+        k_env_rollout_rowlane<H, W, false, false, true, false>,  k_env_rollout_rowlane<H, W, true, false, true, false>,
+        k_env_rollout_rowlane<H, W, false, true, false, true>, k_env_rollout_rowlane<H, W, true, true, false, true>,
+        k_env_rollout_rowlane<H, W, false, false, false, true>, k_env_rollout_rowlane<H, W, true, false, false, true>};
     const kernel_t fn = table[variant];
     const bool spawn = !(variant & 2), base_in_gsh = !spawn && Gm::WAVES_PER_SIMD == 4;
     const int lds = !(variant & 4) ? Gm::LDS_BYTES : (base_in_gsh ? Gm::LDS_WRAP_GSHREG : Gm::LDS_WRAP_GSHLDS);
@@ -1926,7 +1934,7 @@ static hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_c
         std::atomic<hipFunction_t> fn{nullptr};
         std::atomic<bool> ready{false};
     };
-    static Entry cache[8][16];
+    static Entry cache[12][16];
     int dev = 0;
     hipError_t err = hipGetDevice(&dev);
     if (err != hipSuccess) return err;
