@@ -445,8 +445,8 @@ def main():
         try:    # HBM bytes per launch from the committed PMC passes (tools/pmc_run.sh), if they match this run
             with open(os.path.join(REPO, "profiles", "traffic_latest.json")) as f:
                 tj = json.load(f)
-            if tj.get("envs_per_gpu") == B and tj.get("obs") == args.obs:
-                traffic = tj["hbm_bytes_per_launch"]
+            if tj.get("envs_per_gpu") == B and tj.get("obs") == args.obs and tj.get("slices", 1) == env.slices:
+                traffic = tj.get("hbm_bytes_per_step", tj["hbm_bytes_per_launch"])      # all launches of one step
         except (OSError, ValueError, KeyError):
             pass
         out = {
