@@ -315,13 +315,16 @@ def main():
         def time_steps(env3, n_envs, n=200):
             acts = torch.randint(0, 9, (n + 20, n_envs), generator=gen, device=dev, dtype=torch.int32)
             env3.reset()
+            torch.cuda.synchronize()
             for t in range(20):
-                env3.step(acts[t])
+                env3.step_async(acts[t])
+            env3.join()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for t in range(20, 20 + n):
-                env3.step(acts[t])
+                env3.step_async(acts[t])
+            env3.join()
             e1.record()
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) / n * 1e3
@@ -369,7 +372,7 @@ def main():
 
         # the same step with the training wrappers of env_factory.py:277-283 fused in (float64 shaped reward)
         us = time_steps(SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25), output_channels=TRAIN_CHANNELS,
-                                          auto_reset=True, with_obs=False,
+                                          auto_reset=True, with_obs=False, slices=args.slices,
                                           wrappers=dict(movement_bonus=0.1, exit_bonus=0.5, penalty_coef=0.3)), B)
         extra["training_wrappers_us_per_step"] = us
         # per-GPU shares of the sharded configs of BASELINE.json (C4: append-spawn 25x25, C5: navigation 64x64)
@@ -377,7 +380,7 @@ def main():
             if not os.path.exists(os.path.join(REPO, "tests", "golden", "pool_%s.npz" % pname)):
                 continue
             p2 = load_pool(pname, _device_counts)
-            us = time_steps(SafeLifeVectorEnv(p2, n_envs, time_limit=1000, view_shape=(25, 25),
+            us = time_steps(SafeLifeVectorEnv(p2, n_envs, time_limit=1000, view_shape=(25, 25), slices=args.slices,
                                               output_channels=TRAIN_CHANNELS, auto_reset=True, with_obs=False), n_envs)
             extra[tag + "_us_per_step"] = us
             extra[tag + "_env_steps_per_s_per_gpu"] = n_envs / (us * 1e-6)
@@ -407,23 +410,25 @@ def main():
                 # (host, pyemd: parity unpinned) are not.
                 n_c5, flush_every, n_meas = n_envs, 512, 1024
                 env5 = SafeLifeVectorEnv(p2, n_c5, time_limit=1000, view_shape=(25, 25), output_channels=TRAIN_CHANNELS,
-                                         auto_reset=True, with_obs=False,
+                                         auto_reset=True, with_obs=False, slices=args.slices,
                                          side_effects=dict(capacity=2 * (n_c5 * flush_every // 1000 + 64), num_samples=1000))
                 env5.reset()
                 env5.t["scalars"][:, _hip.SCALAR_COLS["num_steps"]] = (
                     torch.arange(n_c5, device=dev, dtype=torch.int32) * 997) % 1000
                 acts5 = torch.randint(0, 9, (n_meas + 20, n_c5), generator=gen, device=dev, dtype=torch.int32)
+                torch.cuda.synchronize()
                 for t in range(20):
-                    env5.step(acts5[t])
+                    env5.step_async(acts5[t])
                 env5.side_effects_flush()
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 batches = []
                 e0.record()
                 for t in range(20, 20 + n_meas):
-                    env5.step(acts5[t])
+                    env5.step_async(acts5[t])
                     if (t - 19) % flush_every == 0:
                         batches.append(env5.side_effects_flush())
+                env5.join()
                 e1.record()
                 torch.cuda.synchronize()
                 ms = e0.elapsed_time(e1)

@@ -324,7 +324,9 @@ int slhip_env_obs(const sl_env_batch *env, void *stream);
  * convolves: channel-first with the spatial axes swapped, out[b][c][x][y] = (view[b][y][x] >> channels[c]) & 1,
  * i.e. what training/models.py:100-103 (obs.transpose(-1, -3)) and the float cast of training/ppo.py:64
  * produce from the (h, w, c) uint8 observation.  dtype: 0 = uint8, 1 = float32.  view: [B,vh,vw],
- * out: [B,C,vw,vh].  The step then only writes 4 bytes per view cell instead of C. */
+ * out: [B,C,vw,vh].  The step then only writes 4 bytes per view cell instead of C.
+ * `channels` is a HOST pointer (C int32 values, copied into the launch); view and out are device pointers.
+ * (sl_env_batch.policy_obs makes the step kernel write this layout itself.) */
 int slhip_obs_to_policy(const uint32_t *view, int B, int vh, int vw, const int32_t *channels, int C,
                         void *out, int dtype, void *stream);
 

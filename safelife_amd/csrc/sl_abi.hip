@@ -421,7 +421,8 @@ int slhip_obs_to_policy(const uint32_t *view, int B, int vh, int vw, const int32
 
 }  // extern "C"
 
-// ---- experiment (not part of the ABI yet): n slices of one batch, each on its own stream -------------
+// ---- experiment harness (tools/exp/pipe_exp.py): compiled only into the A/B libraries of tools/exp/build_variants.sh
+#ifdef SL_EXPERIMENTS
 #include <chrono>
 #include <thread>
 #include <atomic>
@@ -468,3 +469,5 @@ extern "C" int slhip_exp_pipeline(const sl_env_batch *envs, int n, const int32_t
     for (int i = 0; i < n; ++i) (void)hipStreamDestroy(streams[i]);
     return hipGetLastError() == hipSuccess ? SL_OK : fail(SL_E_HIP, "pipeline");
 }
+
+#endif  // SL_EXPERIMENTS

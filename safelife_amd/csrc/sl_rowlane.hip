@@ -1294,6 +1294,58 @@ __device__ __forceinline__ void write_obs_block(const sl_env_batch &env, const u
     }
 }
 
+// One round of write_policy_block: PER consecutive cells of a board's transposed view per work item (16 for
+// uint8, 4 for float32: 16 output bytes per channel either way, one store).
+template <int PER>
+__device__ __forceinline__ void policy_planes(const sl_env_batch &env, const u32 *stage, int pnv, int nb, int nv, int C,
+                                              size_t first_board, int tid) {
+    typedef u32 u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
+    const int cpb = (nv + PER - 1) / PER;           // chunks per board
+    const float inv_cpb = 1.0f / (float)cpb;
+    for (int it = tid; it < nb * cpb; it += 64 * WAVES) {
+        const int bq = div_small(it, cpb, inv_cpb), xy0 = (it - bq * cpb) * PER;
+        const int n_el = min(PER, nv - xy0);
+        const u32 *view = stage + bq * pnv;
+        u32 v[PER];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int i0 = min(xy0 + q, nv - 1);
+            v[q] = view[i0 + (i0 >> 4)];
+        }
+        const size_t o = (first_board + bq) * C * nv + xy0;
+        for (int c = 0; c < C; ++c) {
+            const u32 shift = (u32)env.channels[c];
+            u32 b[PER];
+#pragma unroll
+            for (int q = 0; q < PER; ++q) b[q] = (v[q] >> shift) & 1u;
+            if (PER == 16) {
+                uint8_t *dst = (uint8_t *)env.policy_obs + o + (size_t)c * nv;
+                if (n_el == PER) {
+                    u32 w[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        w[q] = b[(4 * q) % PER] | (b[(4 * q + 1) % PER] << 8) | (b[(4 * q + 2) % PER] << 16) | (b[(4 * q + 3) % PER] << 24);
+                    *(u32x4_a1 *)dst = u32x4_a1{w[0], w[1], w[2], w[3]};
+                } else {
+#pragma unroll
+                    for (int q = 0; q < PER; ++q)
+                        if (q < n_el) dst[q] = (uint8_t)b[q];
+                }
+            } else {
+                u32 *dst = (u32 *)env.policy_obs + o + (size_t)c * nv;
+                if (n_el == PER) {
+                    *(u32x4_a4 *)dst = u32x4_a4{b[0] ? 0x3F800000u : 0u, b[1 % PER] ? 0x3F800000u : 0u,
+                                                b[2 % PER] ? 0x3F800000u : 0u, b[3 % PER] ? 0x3F800000u : 0u};
+                } else {
+#pragma unroll
+                    for (int q = 0; q < PER; ++q)
+                        if (q < n_el) dst[q] = b[q] ? 0x3F800000u : 0u;
+                }
+            }
+        }
+    }
+}
+
 // The observation in the layout the policy network convolves (training/models.py:100-103, ppo.py:64): channel
 // first, spatial axes swapped, out[b][c][x][y] = bit channels[c] of the view word at (y, x); uint8 or float32.
 // The raw view words of a few boards at a time are parked in LDS (the goal-word / score-table regions are dead
@@ -1303,50 +1355,39 @@ __device__ __forceinline__ void write_policy_block(const sl_env_batch &env, unsi
     using Gm = Geom<H, W>;
     const int vh = env.view_h, vw = env.view_w, nv = vh * vw, C = env.n_channels;
     const float inv_nv = 1.0f / (float)nv, inv_vw = 1.0f / (float)vw, inv_vh = 1.0f / (float)vh;
-    const float inv_cnv = 1.0f / (float)(C * nv);
     const int n_exits = min(env.E, OBS_MAX_EXITS);
     constexpr int STAGE_OFF = (Gm::NB * OBS_PAR_INTS * 4 + 15) & ~15;       // behind the per-board view parameters
     constexpr int ROOM = (Gm::GSH_BYTES + 4096 - STAGE_OFF) / 4;            // dwords
     u32 *stage = (u32 *)(smem + Gm::OFF_GSH + STAGE_OFF);
-    const int per_round = ROOM / nv;            // boards per round (the launcher guarantees >= 1)
+    // a board's words are padded by one per sixteen: lanes read 16 apart (one 16-element chunk each), which
+    // would put a whole wave on two LDS banks
+    const int pnv = nv + (nv >> 4) + 1;
+    const int per_round = ROOM / pnv;           // boards per round (the launcher guarantees >= 1)
     for (int b0 = 0; b0 < nbb; b0 += per_round) {
         const int nb = min(per_round, nbb - b0);
         __syncthreads();
+        // the view words of the round's boards, stored TRANSPOSED (x-major): the output runs along y, so a
+        // thread's 16 output elements then come from 16 consecutive words
         ObsSource<H, W> cu;
-        for (int c = tid; c < nb * nv; c += 64 * WAVES) {
-            cu.start(smem, b0 * nv + c, nv, vw, inv_nv, inv_vw);
-            stage[c] = obs_fetch<H, W>(env, smem, cu, n_exits);
+        {
+            const int qy = (64 * WAVES) / vw, qx = (64 * WAVES) - qy * vw;
+            cu.start(smem, b0 * nv + tid, nv, vw, inv_nv, inv_vw);
+            for (int c = tid; c < nb * nv; c += 64 * WAVES, cu.jump(smem, 64 * WAVES, qy, qx, nv, vw, vh)) {
+                const int i = cu.vx * vh + cu.vy;
+                stage[(cu.bq - b0) * pnv + i + (i >> 4)] = obs_fetch<H, W>(env, smem, cu, n_exits);
+            }
         }
         __syncthreads();
-        const int total = nb * C * nv;          // output elements of this round: [nb][C][vw][vh]
-        const size_t out0 = (size_t)(e0b + b0) * C * nv;
-        for (int o = 4 * tid; o < total; o += 4 * 64 * WAVES) {
-            u32 bits[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int oj = min(o + j, total - 1);
-                const int bq = div_small(oj, C * nv, inv_cnv), rem = oj - bq * C * nv;
-                const int ch = div_small(rem, nv, inv_nv), xy = rem - ch * nv;
-                const int x = div_small(xy, vh, inv_vh), y = xy - x * vh;
-                bits[j] = (stage[bq * nv + y * vw + x] >> env.channels[ch]) & 1u;
-            }
-            if (env.policy_dtype == 0) {
-                uint8_t *dst = (uint8_t *)env.policy_obs + out0 + o;
-                if (o + 4 <= total && ((out0 + o) & 3) == 0) {
-                    *(u32 *)dst = bits[0] | (bits[1] << 8) | (bits[2] << 16) | (bits[3] << 24);
-                } else {
-                    for (int j = 0; j < 4 && o + j < total; ++j) dst[j] = (uint8_t)bits[j];
-                }
-            } else {
-                float *dst = (float *)env.policy_obs + out0 + o;
-                if (o + 4 <= total && ((out0 + o) & 3) == 0) {
-                    typedef float f32x4 __attribute__((ext_vector_type(4)));
-                    *(f32x4 *)dst = f32x4{(float)bits[0], (float)bits[1], (float)bits[2], (float)bits[3]};
-                } else {
-                    for (int j = 0; j < 4 && o + j < total; ++j) dst[j] = (float)bits[j];
-                }
-            }
-        }
+        // outputs of this round: [nb][C][vw][vh].  A work item is 16 consecutive cells of one board's transposed
+        // view: its 16 words are read once and give a 16-element chunk of EVERY channel plane (one store per
+        // channel, 16 uint8 or 4 float32 elements) -- the channel loop is wave-uniform, so the channel's bit
+        // position is a scalar.  Planes are nv elements apart, i.e. the uint8 stores are only byte-aligned; a wave
+        // still writes 1 KiB contiguously per channel.  (Chunks cut from the flat output run instead -- aligned
+        // stores, but a division per chunk and per-element plane-crossing logic -- cost 55 us per C3 step, this
+        // form 38; a divergent slow path for the one chunk in 39 that crosses a plane cost 77: some lane of
+        // nearly every wave has such a chunk.)
+        if (env.policy_dtype == 0) policy_planes<16>(env, stage, pnv, nb, nv, C, (size_t)(e0b + b0), tid);
+        else policy_planes<4>(env, stage, pnv, nb, nv, C, (size_t)(e0b + b0), tid);
     }
 }
 
@@ -1988,7 +2029,7 @@ static hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_c
 int rowlane_policy_room(int H, int W) {
 #define X(h, w)                                                                                              \
     if (H == h && W == w)                                                                                    \
-        return (rl::Geom<h, w>::GSH_BYTES + 4096 - ((rl::Geom<h, w>::NB * rl::OBS_PAR_INTS * 4 + 15) & ~15)) / 4;
+        return ((rl::Geom<h, w>::GSH_BYTES + 4096 - ((rl::Geom<h, w>::NB * rl::OBS_PAR_INTS * 4 + 15) & ~15)) / 4 - 1) * 16 / 17;
     SL_ROWLANE_SHAPES(X)
 #undef X
     return 0;
