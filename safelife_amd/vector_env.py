@@ -250,7 +250,10 @@ class SafeLifeVectorEnv(object):
         # slice 0 runs on the stream that is current now (the caller's), the others on side streams: one stream
         # fewer to fence, join and synchronize (a device-wide synchronize costs ~10 us per stream it has to visit)
         self._primary = torch.cuda.current_stream(dev)
-        self._side_streams = [torch.cuda.Stream(device=dev) for _ in range(n_sl - 1)]
+        # (high priority: HIP keeps separate hardware-queue pools per priority, so the side streams cannot end up
+        #  on the hardware queue the caller's stream or RCCL's streams use -- sharing one serialises the slices:
+        #  measured 16.5 instead of 8.8 us per step once a process group had been initialised)
+        self._side_streams = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(n_sl - 1)]
         self._slice_streams = ([self._primary] + self._side_streams) if n_sl > 1 else []
         self._stream_ptrs = (C.c_void_p * max(1, n_sl))(*[st.cuda_stream for st in self._slice_streams])
         self._primary_ptr = C.c_void_p(self._primary.cuda_stream)
