@@ -135,7 +135,9 @@ def main():
     ap.add_argument("--pool", default="prune_still_25")
     ap.add_argument("--obs", type=int, default=0,
                     help="1: also write the 25x25x15 uint8 observation; 2: the raw 25x25 uint32 view")
-    ap.add_argument("--gather-every", type=int, default=32)
+    ap.add_argument("--gather-every", type=int, default=16,
+                    help="steps per gather window (one RCCL gather of the window to rank 0 when --gpus > 1); 16 puts one "
+                         "collective inside the driver's 20-step timed region")
     ap.add_argument("--slices", type=int, default=2,
                     help="slices of the per-GPU batch, each stepped by its own launch on its own stream "
                          "(1 = one launch per step on one stream)")
