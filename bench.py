@@ -135,9 +135,10 @@ def main():
     ap.add_argument("--pool", default="prune_still_25")
     ap.add_argument("--obs", type=int, default=0,
                     help="1: also write the 25x25x15 uint8 observation; 2: the raw 25x25 uint32 view")
-    ap.add_argument("--gather-every", type=int, default=16,
-                    help="steps per gather window (one RCCL gather of the window to rank 0 when --gpus > 1); 16 puts one "
-                         "collective inside the driver's 20-step timed region")
+    ap.add_argument("--gather-every", type=int, default=32,
+                    help="steps per gather window (one RCCL gather of the window to rank 0 when --gpus > 1).  Handing "
+                         "a window to torch.distributed costs the stepping thread ~55 us; a step leaves ~2.5 us of host "
+                         "slack, so 32 steps hide it and 16 do not (DESIGN.md section 5)")
     ap.add_argument("--slices", type=int, default=2,
                     help="slices of the per-GPU batch, each stepped by its own launch on its own stream "
                          "(1 = one launch per step on one stream)")
@@ -177,13 +178,27 @@ def main():
     gen.manual_seed(7 + rank)
     actions = torch.randint(0, 9, (K + W, B), generator=gen, device=dev, dtype=torch.int32)
     gather = RewardGather(env, every=args.gather_every, world=world, rank=rank)
+    gather.prime()
 
     # one step = every env stepped once = one launch per slice, each on the slice's own stream; the action
     # tensor is complete before the loop starts, so nothing has to be fenced per step (step_async)
     act_ptr = [actions[t].data_ptr() for t in range(K + W)]
     before, after, step, every = gather.before_step, gather.after_step, env.step_async, gather.every
 
+    step_host = []
+
     def run(t0, n):
+        if os.environ.get("SL_BENCH_DEBUG") == "2":      # per-call host times (slows the loop down)
+            for t in range(t0, t0 + n):
+                a = time.perf_counter()
+                before(t)
+                b = time.perf_counter()
+                step(act_ptr[t])
+                c = time.perf_counter()
+                if t % every == every - 1:
+                    after(t)
+                step_host.append((t, (b - a) * 1e6, (c - b) * 1e6, (time.perf_counter() - c) * 1e6))
+            return
         for t in range(t0, t0 + n):
             before(t)
             step(act_ptr[t])
@@ -231,6 +246,9 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
+    if step_host:
+        print("per-step host us (t, before, step, after):", " ".join("%d:%.0f/%.0f/%.0f" % x for x in step_host[-K:]),
+              file=sys.stderr)
     if dbg:
         print("timeline us: enqueue loop %.1f | e1 record %.1f | flush %.1f | synchronize %.1f | total %.1f"
               % ((t_enqueued - t_start) * 1e6, (t_b - t_enqueued) * 1e6, (t_c - t_b) * 1e6,

@@ -53,6 +53,18 @@ class RewardGather(object):
         self._slot_ptr = [[b.data_ptr() + self.RECORD_BYTES * slot * B for slot in range(self.every)]
                           for b in self.buf]
 
+    def prime(self):
+        """One throw-away gather of each (empty) window buffer, issued the way ``after_step`` issues it: the
+        first asynchronous exchange of a process group sets up its channels and work objects and costs
+        300-500 us on the host -- keep that out of the stepping loop."""
+        if self.world > 1 or self.force:
+            import torch.distributed as dist
+            for which in (0, 1):
+                work = dist.gather(self.buf[which], self.recv[which] if self.rank == 0 else None, dst=0,
+                                   group=self.group, async_op=True)
+                work.wait()
+            self.torch.cuda.synchronize()
+
     def before_step(self, t):
         slot, which = t % self.every, (t // self.every) % 2
         if slot == 0 and self.work[which] is not None:

@@ -255,6 +255,7 @@ class SafeLifeVectorEnv(object):
         #  measured 16.5 instead of 8.8 us per step once a process group had been initialised)
         self._side_streams = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(n_sl - 1)]
         self._slice_streams = ([self._primary] + self._side_streams) if n_sl > 1 else []
+        self._ev_ring, self._ev_next = [], -1
         self._stream_ptrs = (C.c_void_p * max(1, n_sl))(*[st.cuda_stream for st in self._slice_streams])
         self._primary_ptr = C.c_void_p(self._primary.cuda_stream)
         rc = self._lib.slhip_env_prepare(self._sref, _hip.current_stream_ptr())
@@ -349,9 +350,12 @@ class SafeLifeVectorEnv(object):
         """Slice streams wait for everything enqueued so far on the caller's current stream (call after
         producing actions, resetting, or touching env state there)."""
         cur = self.torch.cuda.current_stream()
-        for st in self._slice_streams:
-            if st != cur:
-                st.wait_stream(cur)
+        side = [st for st in self._slice_streams if st != cur]
+        if side:
+            ev = self._sync_event()
+            ev.record(cur)
+            for st in side:
+                st.wait_event(ev)
 
     def join(self):
         """The caller's current stream waits for every slice's enqueued steps (call before consuming
@@ -359,7 +363,19 @@ class SafeLifeVectorEnv(object):
         cur = self.torch.cuda.current_stream()
         for st in self._slice_streams:
             if st != cur:
-                cur.wait_stream(st)
+                ev = self._sync_event()
+                ev.record(st)
+                cur.wait_event(ev)
+
+    def _sync_event(self):
+        """Ordering events come from a small ring (creating one per call is most of what torch's wait_stream
+        costs); an event is only reused long after the wait that named it was enqueued."""
+        ring = self._ev_ring
+        if len(ring) < 16:
+            ring.append(self.torch.cuda.Event())
+            return ring[-1]
+        self._ev_next = (self._ev_next + 1) % 16
+        return ring[self._ev_next]
 
     def step_async(self, actions):
         """One step per env, one launch per slice on the slice's own stream; nothing is fenced.  `actions`:
