@@ -78,7 +78,8 @@ def parity_replay(pool, actions, n_envs, device_env, checkpoints, threads):
         env.step(np.ascontiguousarray(a[:n_envs]), n_threads=threads)
         snap = checkpoints.get(t + 1)
         if snap is not None:
-            ok = ok and all(bool(np.array_equal(snap[name][:n_envs], arrays[name])) for name in snap)
+            ok = ok and all(bool(np.array_equal(device_env.numpy(name, snapshot=snap)[:n_envs], arrays[name]))
+                            for name in ("board", "rng", "agent_loc", "num_steps", "episode_idx"))
             checked.append(t + 1)
     for name in names:
         ok = ok and bool(np.array_equal(device_env.numpy(name)[:n_envs], arrays[name]))
@@ -176,13 +177,15 @@ def main():
     env.reset()
     gen = torch.Generator(device=dev)
     gen.manual_seed(7 + rank)
-    actions = torch.randint(0, 9, (K + W, B), generator=gen, device=dev, dtype=torch.int32)
+    # P checkpointed steps for the parity replay, then W warm-up steps, then the K timed ones
+    P = 8 if (args.cpu_baseline and world == 1) else 0
+    actions = torch.randint(0, 9, (P + W + K, B), generator=gen, device=dev, dtype=torch.int32)
     gather = RewardGather(env, every=args.gather_every, world=world, rank=rank)
     gather.prime()
 
     # one step = every env stepped once = one launch per slice, each on the slice's own stream; the action
     # tensor is complete before the loop starts, so nothing has to be fenced per step (step_async)
-    act_ptr = [actions[t].data_ptr() for t in range(K + W)]
+    act_ptr = [actions[t].data_ptr() for t in range(P + W + K)]
     before, after, step, every = gather.before_step, gather.after_step, env.step_async, gather.every
 
     step_host = []
@@ -208,15 +211,14 @@ def main():
     # the first steps since the reset run one at a time, with a snapshot of the device state after each
     # (untimed; the CPU replay of the cpu_baseline leg compares every one of them)
     checkpoints = {}
-    n_check = min(W, 8) if (args.cpu_baseline and world == 1) else 0
+    n_check = P
     for t in range(n_check):
         before(t)
         step(act_ptr[t])
         if t % every == every - 1:
             after(t)
-        env.join()
-        checkpoints[t + 1] = {name: env.numpy(name) for name in ("board", "rng", "agent_loc", "num_steps", "episode_idx")}
-    run(n_check, W - n_check)
+        checkpoints[t + 1] = env.snapshot()     # device-side copies: nothing crosses to the host before the timed region
+    run(P, W)              # the W untimed warm-up steps, issued exactly like the timed ones
     gather.flush()
     torch.cuda.synchronize()
     if world > 1:
@@ -233,7 +235,7 @@ def main():
     #  covers the whole timed region, and its ~3 us of host time stays out of it)
     evs[0][0].record(streams[0])
     t_start = time.perf_counter()
-    run(W, K)
+    run(P + W, K)
     t_enqueued = time.perf_counter()
     evs[0][1].record(streams[0])
     # (completion is left to the synchronize below: polling hipStreamQuery / hipEventQuery first was measured
@@ -273,7 +275,7 @@ def main():
     if args.cpu_baseline and world == 1:
         # the state the timed launches left behind against a CPU replay of the same envs and actions
         threads = max(1, min(16, len(os.sched_getaffinity(0))))
-        parity = parity_replay(pool, actions[:W + K].cpu().numpy(), B, env, checkpoints, threads)
+        parity = parity_replay(pool, actions[:P + W + K].cpu().numpy(), B, env, checkpoints, threads)
 
     extra = {}
     if args.rollout > 0:

@@ -98,8 +98,8 @@ class SafeLifeVectorEnv(object):
     env_offset : int               global index of this process's env 0 (multi-GPU sharding)
     with_obs : bool                False skips observation writes entirely
     slices : int                   >1: the batch is cut into this many contiguous slices, each stepped by its
-                                   own launch on its own HIP stream (``slhip_env_step_slices``; slice 0 on the
-                                   stream that is current at construction, the others on side streams).  Envs are
+                                   own launch on its own HIP stream (``slhip_env_step_slices``; the streams are
+                                   the env's own, none of them the caller's).  Envs are
                                    independent, so consecutive steps of different slices overlap on the chip
                                    (the load / store phases and the launch boundary of one slice hide under
                                    the compute phase of the other).  ``step()`` keeps the one-stream
@@ -247,14 +247,13 @@ class SafeLifeVectorEnv(object):
         self.slices = n_sl
         self.slice_bounds = tuple(bounds)
         self._bounds = (C.c_int32 * (n_sl + 1))(*bounds)
-        # slice 0 runs on the stream that is current now (the caller's), the others on side streams: one stream
-        # fewer to fence, join and synchronize (a device-wide synchronize costs ~10 us per stream it has to visit)
+        # Every slice gets a stream of its own from torch's pool, at normal priority.  Measured alternatives:
+        # slice 0 on the caller's stream (one stream fewer to fence and join) is as fast until a process group has
+        # been initialised -- then the caller's (null) stream and the side stream serialise, 16.5 instead of 8.9 us
+        # per C3 step; a high-priority side stream cures that but starves the other slice of 64x64 boards (67-84
+        # instead of 36 us per navigation step).
         self._primary = torch.cuda.current_stream(dev)
-        # (high priority: HIP keeps separate hardware-queue pools per priority, so the side streams cannot end up
-        #  on the hardware queue the caller's stream or RCCL's streams use -- sharing one serialises the slices:
-        #  measured 16.5 instead of 8.8 us per step once a process group had been initialised)
-        self._side_streams = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(n_sl - 1)]
-        self._slice_streams = ([self._primary] + self._side_streams) if n_sl > 1 else []
+        self._slice_streams = [torch.cuda.Stream(device=dev) for _ in range(n_sl)] if n_sl > 1 else []
         self._ev_ring, self._ev_next = [], -1
         self._stream_ptrs = (C.c_void_p * max(1, n_sl))(*[st.cuda_stream for st in self._slice_streams])
         self._primary_ptr = C.c_void_p(self._primary.cuda_stream)
@@ -519,8 +518,21 @@ class SafeLifeVectorEnv(object):
 
     # ------------------------------------------------------------------ host views
 
-    def numpy(self, name):
+    def snapshot(self):
+        """Device-side copy of the per-env state (board, goals, generator, per-env record), ordered after the steps
+        enqueued so far; read it later with ``numpy(name, snapshot=...)`` -- nothing crosses to the host now."""
+        if self.slices > 1:
+            self.join()
+        return {name: self.t[name].clone() for name in ("board", "goals", "rng", "scalars")}
+
+    def numpy(self, name, snapshot=None):
         """Host copy of a state array under the reference's / oracle's name and dtype."""
+        if snapshot is not None:
+            live, self.t = self.t, dict(self.t, **snapshot)
+            try:
+                return self.numpy(name)
+            finally:
+                self.t = live
         if self.slices > 1:
             self.join()
         if name == "obs":
