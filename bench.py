@@ -218,6 +218,12 @@ def main():
         if t % every == every - 1:
             after(t)
         checkpoints[t + 1] = env.snapshot()     # device-side copies: nothing crosses to the host before the timed region
+    # (no garbage-collector pass inside the timed region: with ~20 steps in it, one young-generation pass of the
+    #  interpreter -- whose position depends on how many objects the set-up happened to allocate -- shows up as
+    #  +1 us per step; timeit does the same)
+    import gc
+    gc.collect()
+    gc.disable()
     run(P, W)              # the W untimed warm-up steps, issued exactly like the timed ones
     gather.flush()
     torch.cuda.synchronize()
@@ -248,6 +254,7 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
+    gc.enable()
     if step_host:
         print("per-step host us (t, before, step, after):", " ".join("%d:%.0f/%.0f/%.0f" % x for x in step_host[-K:]),
               file=sys.stderr)
