@@ -2,6 +2,7 @@
 // the per-device PCG64 jump table, and dispatch to the gfx950 kernels.
 #include <cstdint>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
@@ -322,6 +323,27 @@ int slhip_env_rollout(const sl_env_batch *env, const int32_t *actions, int T, fl
 
 int slhip_env_step(const sl_env_batch *env, const int32_t *actions, void *stream) {
     return slhip_env_rollout(env, actions, 1, nullptr, nullptr, stream);
+}
+
+int slhip_streams_concurrent(void *stream_a, void *stream_b, int *concurrent) {
+    if (!concurrent) return fail(SL_E_ARG, "null pointer");
+    hipStream_t a = (hipStream_t)stream_a, b = (hipStream_t)stream_b;
+    const long long ticks = 10000;                 // 100 us of the 100 MHz counter
+    hipError_t err = hipStreamSynchronize(a);
+    if (err == hipSuccess) err = hipStreamSynchronize(b);
+    double best = 1e30;
+    for (int rep = 0; rep < 2 && err == hipSuccess; ++rep) {        // (first pass also warms the kernel up)
+        const auto t0 = std::chrono::steady_clock::now();
+        err = sl::launch_idle(ticks, a);
+        if (err == hipSuccess) err = sl::launch_idle(ticks, b);
+        if (err == hipSuccess) err = hipStreamSynchronize(a);
+        if (err == hipSuccess) err = hipStreamSynchronize(b);
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (us < best) best = us;
+    }
+    if (err != hipSuccess) return hip_fail(err, "streams_concurrent");
+    *concurrent = best < 160.0 ? 1 : 0;            // one after the other: >= 200 us
+    return SL_OK;
 }
 
 int slhip_env_step_slices(const sl_env_batch *env, int n_slices, const int32_t *bounds, const int32_t *actions,

@@ -625,4 +625,16 @@ hipError_t launch_env_obs_generic(const sl_env_batch &env, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// ---- do two streams run concurrently? -----------------------------------------------------------------
+// One wavefront that does nothing for `ticks` of the 100 MHz s_memrealtime counter.
+__global__ void k_idle(long long ticks) {
+    const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+    while ((long long)__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+hipError_t launch_idle(long long ticks, hipStream_t stream) {
+    hipLaunchKernelGGL(k_idle, dim3(1), dim3(64), 0, stream, ticks);
+    return hipGetLastError();
+}
+
 }  // namespace sl

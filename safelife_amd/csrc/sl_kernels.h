@@ -33,6 +33,7 @@ bool rowlane_supports(int H, int W);
 int rowlane_policy_room(int H, int W);
 hipError_t launch_build_score_lut(const int32_t *points_table, int n_tables, int8_t *lut, hipStream_t stream);
 hipError_t launch_build_baseline(const sl_env_batch &env, hipStream_t stream);
+hipError_t launch_idle(long long ticks, hipStream_t stream);
 // n_each (device, optional): one step count per board instead of n_steps; n_valid (device, optional): only
 // the first *n_valid boards exist
 hipError_t launch_advance_rowlane(const u16 *in, u16 *out, int B, int H, int W, const float *spawn_prob,

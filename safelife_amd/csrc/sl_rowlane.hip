@@ -1692,6 +1692,10 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
             const bool mine = live && flag != 0;
             if (rowl && flag != 0) gstatic = 0;
             if (mine) {
+                // (opaque copy of the row index: addresses of this rare block are formed here, not hoisted above the
+                //  step loop as loop invariants and spilled)
+                int r2 = r;
+                asm volatile("" : "+v"(r2));
                 level = (level + env.level_stride) % env.L;
                 const u16 *pb = env.pool_board + (size_t)level * HW, *pg = env.pool_goals + (size_t)level * HW;
                 u16 *gdst = (u16 *)(goals + Gm::PAD) + gb * HW;
@@ -1700,7 +1704,7 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
                 // one memory round trip for the board and one for the goals, not one per cell (a wave that resets
                 // holds up its whole workgroup at the end barrier, and the launch behind it)
                 typedef u32 u32_a2 __attribute__((aligned(2)));
-                const u16 *rows[2] = {pb + r * W, pg + r * W};
+                const u16 *rows[2] = {pb + r2 * W, pg + r2 * W};
                 u16 *imgs[2] = {board16, gdst};
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
@@ -1718,8 +1722,8 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
                 lut_base = (u32)env.pool_scalars[level].table_idx * (u32)SCORE_LUT_BYTES;
                 p = (double)env.pool_scalars[level].spawn_prob;
                 gstatic = 0;
-                if (r < 4) rng_lds[4 * g + r] = ((const u64 *)(env.pool_rng + level))[r];
-                for (int k = r; k < E; k += H)
+                if (r2 < 4) rng_lds[4 * g + r2] = ((const u64 *)(env.pool_rng + level))[r2];
+                for (int k = r2; k < E; k += H)
                     env.exit_locs[(size_t)e * E + k] = env.pool_exit_locs[(size_t)level * E + k];
                 goals_dirty = true;
             }
@@ -1794,12 +1798,18 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
     __syncthreads();
     const int dirty = *dirty_flag;
     SL_STAMP(8);
-    store_span<H, W>(env.board + (size_t)e0b * HW, board, nbb, tid);
-    if (dirty) store_span<H, W>(env.goals + (size_t)e0b * HW, goals, nbb, tid);
-    if (lane < 4 * Gm::G && wave * Gm::G + (lane >> 2) < nbb)
-        ((u64 *)(env.rng + e0b + wave * Gm::G))[lane] = rng_lds[lane];
+    // (an opaque copy of the thread index: the stores' per-lane addresses are formed HERE -- left alone the compiler
+    //  hoists them above the step loop, where a handful of live 64-bit pointers tips the variants that sit at the
+    //  register limit into scratch; a kernel that uses scratch at all costs ~3 us more per launch)
+    int tid2 = tid;
+    asm volatile("" : "+v"(tid2));
+    const int lane2 = tid2 & 63, wave2 = tid2 >> 6;
+    store_span<H, W>(env.board + (size_t)e0b * HW, board, nbb, tid2);
+    if (dirty) store_span<H, W>(env.goals + (size_t)e0b * HW, goals, nbb, tid2);
+    if (lane2 < 4 * Gm::G && wave2 * Gm::G + (lane2 >> 2) < nbb)
+        ((u64 *)(env.rng + e0b + wave2 * Gm::G))[lane2] = ((const u64 *)(smem + Gm::OFF_RNG) + 4 * Gm::G * wave2)[lane2];
     if (WRAP)       // (10-row boards: 24 per workgroup, more state words than threads)
-        for (int i = tid; i < nbb * (int)(sizeof(sl_wrap_state) / 4); i += 64 * WAVES)
+        for (int i = tid2; i < nbb * (int)(sizeof(sl_wrap_state) / 4); i += 64 * WAVES)
             ((u32 *)(env.wrap.state + e0b))[i] = ((const u32 *)wst)[i];
 
     SL_STAMP(9);

@@ -253,7 +253,7 @@ class SafeLifeVectorEnv(object):
         # per C3 step; a high-priority side stream cures that but starves the other slice of 64x64 boards (67-84
         # instead of 36 us per navigation step).
         self._primary = torch.cuda.current_stream(dev)
-        self._slice_streams = [torch.cuda.Stream(device=dev) for _ in range(n_sl)] if n_sl > 1 else []
+        self._slice_streams = self._pick_streams(n_sl) if n_sl > 1 else []
         self._ev_ring, self._ev_next = [], -1
         self._stream_ptrs = (C.c_void_p * max(1, n_sl))(*[st.cuda_stream for st in self._slice_streams])
         self._primary_ptr = C.c_void_p(self._primary.cuda_stream)
@@ -344,6 +344,29 @@ class SafeLifeVectorEnv(object):
         return self.obs, self.reward, self.done, self.info
 
     # ---- sliced stepping (slices > 1): no implicit ordering against the caller's stream
+
+    def _pick_streams(self, n):
+        """n streams whose kernels overlap on the device.  HIP multiplexes streams onto a few hardware queues and
+        two streams of torch's pool may share one -- which streams collide depends on what else the process has
+        created (RCCL's streams, other envs), and a collision silently serialises the slices (measured: 24 instead
+        of 13.5 us per step).  So every candidate is probed against the streams already chosen
+        (``slhip_streams_concurrent``: two idle 100 us kernels); a few hundred microseconds per probe, once."""
+        torch, dev = self.torch, self.device
+        chosen, spare = [], []
+        for _ in range(4 * n + 4):
+            cand = torch.cuda.Stream(device=dev)
+            ok = C.c_int(1)
+            for st in chosen:
+                _hip.check(self._lib.slhip_streams_concurrent(st.cuda_stream, cand.cuda_stream, C.byref(ok)))
+                if not ok.value:
+                    break
+            if ok.value:
+                chosen.append(cand)
+                if len(chosen) == n:
+                    return chosen
+            else:
+                spare.append(cand)
+        return chosen + spare[:n - len(chosen)]      # (no concurrent set found: correct, just not overlapped)
 
     def fence(self):
         """Slice streams wait for everything enqueued so far on the caller's current stream (call after
