@@ -47,6 +47,7 @@ class RewardGather(object):
         if (self.world > 1 or self.force) and self.rank == 0:
             self.recv = [[torch.zeros(shape, dtype=torch.int32, device=env.device) for _ in range(self.world)]
                          for _ in range(2)]
+        self.collective = self.world > 1 or self.force     # False: one rank, nothing to gather
         self.work = [None, None]
         self.last = None
         self.exposed_s = 0.0          # host time spent issuing / waiting on the collective (what is not overlapped)

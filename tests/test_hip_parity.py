@@ -1069,3 +1069,27 @@ def test_advance_board_per_board_step_counts(sp, shape):
     got = sp.advance_board_batch(d_b, torch.from_numpy(p).to(d_b.device), d_rng, torch.from_numpy(steps).to(d_b.device))
     assert np.array_equal(sp._to_host(got, np.uint16), want)
     assert np.array_equal(sp._to_host(d_rng, np.uint64), w_cpu)
+
+
+def test_slice_streams_are_probed_for_concurrency():
+    """slhip_streams_concurrent: a stream cannot overlap itself (its two idle kernels run back to back), and the
+    streams a sliced env ends up with were all found to overlap pairwise."""
+    import ctypes as C
+    import torch
+    from safelife_amd import _hip
+    pool, _ = util.pool_from_fixture("prune_still_25", _device_counts)
+    env = util.DeviceBackend(pool, 256, slices=3, auto_reset=True).env
+    lib = _hip.lib()
+    ok = C.c_int(-1)
+    s0 = env._slice_streams[0].cuda_stream
+    assert lib.slhip_streams_concurrent(s0, s0, C.byref(ok)) == 0 and ok.value == 0
+    free = torch.cuda.Stream()
+    pairs = 0
+    for i, a in enumerate(env._slice_streams):
+        for b in env._slice_streams[i + 1:]:
+            assert lib.slhip_streams_concurrent(a.cuda_stream, b.cuda_stream, C.byref(ok)) == 0
+            pairs += ok.value
+    # (a box whose runtime maps every stream onto one queue would leave nothing to choose from: then the env
+    #  falls back to whatever streams it has and this only checks that the probe ran)
+    assert pairs == 3 or lib.slhip_streams_concurrent(s0, free.cuda_stream, C.byref(ok)) == 0
+    assert lib.slhip_streams_concurrent(s0, s0, None) != 0
