@@ -2033,7 +2033,7 @@ static hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_c
 
 }  // namespace rl
 
-#define SL_ROWLANE_SHAPES(X) X(25, 25) X(26, 26) X(15, 15) X(20, 20) X(10, 10) X(64, 64)
+#define SL_ROWLANE_SHAPES(X) X(25, 25) X(26, 26) X(15, 15) X(20, 20) X(10, 10) X(64, 64) X(8, 8) X(12, 12) X(16, 16) X(24, 24) X(30, 30) X(32, 32) X(40, 40) X(48, 48)
 
 // view cells the fused policy-layout epilogue can stage per board (its LDS room), 0 for unsupported shapes
 int rowlane_policy_room(int H, int W) {

@@ -115,7 +115,9 @@ def test_side_effect_occupancy_tensors(sp):
 @pytest.mark.parametrize("shape,B", [((25, 25), 1024), ((26, 26), 300), ((64, 64), 64), ((3, 3), 50),
                                      ((15, 15), 130), ((20, 20), 77), ((10, 10), 100), ((25, 25), 5),
                                      ((5, 64), 33), ((64, 5), 33), ((10, 33), 40), ((31, 17), 40),
-                                     ((100, 100), 6), ((128, 128), 2)])
+                                     ((100, 100), 6), ((128, 128), 2),
+                                     ((8, 8), 70), ((12, 12), 45), ((16, 16), 37), ((24, 24), 19), ((30, 30), 21),
+                                     ((32, 32), 18), ((40, 40), 9), ((48, 48), 7)])
 @pytest.mark.parametrize("kind", [0, 1, 2])
 def test_advance_board_vs_oracle(sp, shape, B, kind):
     rng = np.random.default_rng(hash((shape, kind)) % 2**31)
@@ -132,7 +134,9 @@ def test_advance_board_vs_oracle(sp, shape, B, kind):
 
 @pytest.mark.parametrize("shape,B,n_step", [((25, 25), 70, 1000), ((26, 26), 33, 300), ((64, 64), 9, 400),
                                             ((20, 20), 10, 100), ((15, 15), 13, 100), ((10, 10), 25, 100),
-                                            ((9, 31), 6, 60), ((25, 25), 3, 0)])
+                                            ((9, 31), 6, 60), ((25, 25), 3, 0), ((8, 8), 40, 50), ((12, 12), 11, 50),
+                                            ((16, 16), 9, 50), ((24, 24), 5, 50), ((30, 30), 5, 50), ((32, 32), 6, 50),
+                                            ((40, 40), 5, 50), ((48, 48), 3, 50)])
 @pytest.mark.parametrize("kind", [0, 1])
 def test_life_occupancy_vs_oracle(sp, shape, B, n_step, kind):
     import torch

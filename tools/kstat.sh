@@ -10,7 +10,7 @@ import re, sys
 txt = open(sys.argv[1]).read()
 for m in re.finditer(r"^(_ZN2sl2rl\w+):.*?; codeLenInByte = (\d+).*?; NumVgprs: (\d+).*?; ScratchSize: (\d+).*?; Occupancy: (\d+)", txt, re.S | re.M):
     name = m.group(1)
-    if "rollout_rowlaneILi25ELi25" in name or "rollout_rowlaneILi64" in name or "advance" in name or "occupancy" in name:
+    if "rollout_rowlane" in name or "advance" in name or "occupancy" in name:
         short = re.sub(r"EEv.*", "", name.replace("_ZN2sl2rl", ""))
         print("%-60s code %6s B  vgpr %3s  scratch %4s  occupancy %s" % (short, m.group(2), m.group(3), m.group(4), m.group(5)))
 PY

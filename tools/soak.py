@@ -46,7 +46,8 @@ def random_level(H, W, spawners, n_exits, dynamic_goals, agent):
 
 t_end, n_cfg, n_steps = time.time() + budget, 0, 0
 while time.time() < t_end:
-    H, W = [(25, 25), (26, 26), (64, 64), (15, 15), (20, 20), (10, 10), (9, 13), (12, 12)][rng.integers(0, 8)]
+    H, W = [(25, 25), (26, 26), (64, 64), (15, 15), (20, 20), (10, 10), (9, 13), (12, 12), (8, 8), (16, 16), (24, 24),
+            (30, 30), (32, 32), (40, 40), (48, 48)][rng.integers(0, 15)]
     spawners = int(rng.choice([0, 0, 3, 12]))
     L = int(rng.integers(1, 7))
     levels = [random_level(H, W, spawners, int(rng.integers(0, 9)), rng.random() < 0.3, rng.random() < 0.9)
