@@ -1857,6 +1857,7 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
     }
 }
 
+#ifndef SL_ROWLANE_PART
 // ---- score table ------------------------------------------------------------------------------------
 
 __global__ void k_build_score_lut(const int32_t *__restrict__ points_table, int n_tables, int8_t *__restrict__ lut) {
@@ -1910,8 +1911,10 @@ __global__ void k_build_baseline(sl_env_batch env) {
     }
 }
 
+#endif  // !SL_ROWLANE_PART
+
 template <int H, int W>
-static hipError_t launch_advance_t(const u16 *in, u16 *out, int B, const float *spawn_prob, int n_steps,
+hipError_t launch_advance_t(const u16 *in, u16 *out, int B, const float *spawn_prob, int n_steps,
                                    const int32_t *n_each, const int32_t *n_valid, sl_pcg64 *rng, const Jump *jump,
                                    hipStream_t stream) {
     using Gm = Geom<H, W>;
@@ -1924,7 +1927,7 @@ static hipError_t launch_advance_t(const u16 *in, u16 *out, int B, const float *
 }
 
 template <int H, int W>
-static hipError_t launch_occupancy_t(const u16 *in, int32_t *counts, size_t counts_stride, int B, const int32_t *n_valid,
+hipError_t launch_occupancy_t(const u16 *in, int32_t *counts, size_t counts_stride, int B, const int32_t *n_valid,
                                      int valid_period, const int32_t *pre_steps, const float *spawn_prob, int n_steps,
                                      sl_pcg64 *rng, const Jump *jump, hipStream_t stream) {
     using Gm = Geom<H, W>;
@@ -1961,7 +1964,7 @@ static hipError_t launch_occupancy_t(const u16 *in, int32_t *counts, size_t coun
 }
 
 template <int H, int W>
-static hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, const int32_t *actions, int T,
+hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, const int32_t *actions, int T,
                                    int tstride, float *reward_t, uint8_t *done_t, const Jump *jump,
                                    hipStream_t stream) {
     using Gm = Geom<H, W>;
@@ -2033,7 +2036,35 @@ static hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_c
 
 }  // namespace rl
 
-#define SL_ROWLANE_SHAPES(X) X(25, 25) X(26, 26) X(15, 15) X(20, 20) X(10, 10) X(64, 64) X(8, 8) X(12, 12) X(16, 16) X(24, 24) X(30, 30) X(32, 32) X(40, 40) X(48, 48)
+// The shapes are compiled in three translation units (this file, and sl_rowlane_b.hip / sl_rowlane_c.hip, which
+// include it with SL_ROWLANE_PART defined): the launcher templates of a part's shapes are explicitly instantiated
+// there -- their kernels with them -- and only declared here.
+#define SL_ROWLANE_SHAPES_A(X) X(25, 25) X(26, 26) X(64, 64) X(24, 24)
+#define SL_ROWLANE_SHAPES_B(X) X(15, 15) X(20, 20) X(10, 10) X(8, 8) X(12, 12) X(16, 16)
+#define SL_ROWLANE_SHAPES_C(X) X(30, 30) X(32, 32) X(40, 40) X(48, 48)
+#define SL_ROWLANE_SHAPES(X) SL_ROWLANE_SHAPES_A(X) SL_ROWLANE_SHAPES_B(X) SL_ROWLANE_SHAPES_C(X)
+
+#define SL_ROWLANE_LAUNCHERS(PREFIX, h, w)                                                                                 \
+    PREFIX template hipError_t rl::launch_advance_t<h, w>(const u16 *, u16 *, int, const float *, int, const int32_t *,   \
+                                                          const int32_t *, sl_pcg64 *, const Jump *, hipStream_t);         \
+    PREFIX template hipError_t rl::launch_occupancy_t<h, w>(const u16 *, int32_t *, size_t, int, const int32_t *, int,    \
+                                                            const int32_t *, const float *, int, sl_pcg64 *, const Jump *, \
+                                                            hipStream_t);                                                  \
+    PREFIX template hipError_t rl::launch_rollout_t<h, w>(const sl_env_batch &, int, int, const int32_t *, int, int,      \
+                                                          float *, uint8_t *, const Jump *, hipStream_t);
+#ifdef SL_ROWLANE_PART
+#define X(h, w) SL_ROWLANE_LAUNCHERS(, h, w)
+#if SL_ROWLANE_PART == 1
+SL_ROWLANE_SHAPES_B(X)
+#else
+SL_ROWLANE_SHAPES_C(X)
+#endif
+#undef X
+#else
+#define X(h, w) SL_ROWLANE_LAUNCHERS(extern, h, w)
+SL_ROWLANE_SHAPES_B(X)
+SL_ROWLANE_SHAPES_C(X)
+#undef X
 
 // view cells the fused policy-layout epilogue can stage per board (its LDS room), 0 for unsupported shapes
 int rowlane_policy_room(int H, int W) {
@@ -2090,5 +2121,7 @@ hipError_t launch_env_rollout_rowlane(const sl_env_batch &env, int e_first, int 
 #undef X
     return hipErrorInvalidValue;
 }
+
+#endif  // !SL_ROWLANE_PART
 
 }  // namespace sl
