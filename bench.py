@@ -136,10 +136,10 @@ def main():
     ap.add_argument("--pool", default="prune_still_25")
     ap.add_argument("--obs", type=int, default=0,
                     help="1: also write the 25x25x15 uint8 observation; 2: the raw 25x25 uint32 view")
-    ap.add_argument("--gather-every", type=int, default=32,
-                    help="steps per gather window (one RCCL gather of the window to rank 0 when --gpus > 1).  Handing "
-                         "a window to torch.distributed costs the stepping thread ~55 us; a step leaves ~2.5 us of host "
-                         "slack, so 32 steps hide it and 16 do not (DESIGN.md section 5)")
+    ap.add_argument("--gather-every", type=int, default=64,
+                    help="steps per gather window (one RCCL gather of the window to rank 0 when --gpus > 1).  Handing a "
+                         "window to torch.distributed costs the stepping thread ~100 us all told; a step leaves ~2.5 us of "
+                         "host slack, so 64 steps hide it and 32 do not (DESIGN.md section 5)")
     ap.add_argument("--slices", type=int, default=2,
                     help="slices of the per-GPU batch, each stepped by its own launch on its own stream "
                          "(1 = one launch per step on one stream)")
