@@ -284,6 +284,12 @@ int slhip_env_rollout(const sl_env_batch *env, const int32_t *actions, int T,
  * stream, and compares the wall time with one; *concurrent = 1 if they overlapped.  Synchronises both streams. */
 int slhip_streams_concurrent(void *stream_a, void *stream_b, int *concurrent);
 
+/* Stream ordering without a host wait: every stream of `after` waits for what has been enqueued so far on every
+ * stream of `before` (HOST arrays of hipStream_t; a stream that appears on both sides is skipped).  The fence and join
+ * of sliced stepping: order({caller}, slices) before a step whose actions the caller's stream produced, and
+ * order(slices, {caller}) before the caller's stream reads the outputs.  Events come from a ring inside the library. */
+int slhip_streams_order(void *const *before, int n_before, void *const *after, int n_after);
+
 /* One step for every env, issued as n_slices launches: slice i = envs [bounds[i], bounds[i+1]) on
  * streams[i] (bounds: HOST int32 [n_slices+1], bounds[0] = 0, bounds[n_slices] = B; streams: HOST array of
  * hipStream_t).  Envs are independent, so the slices need no ordering among themselves: on distinct

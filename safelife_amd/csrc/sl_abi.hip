@@ -325,6 +325,32 @@ int slhip_env_step(const sl_env_batch *env, const int32_t *actions, void *stream
     return slhip_env_rollout(env, actions, 1, nullptr, nullptr, stream);
 }
 
+int slhip_streams_order(void *const *before, int n_before, void *const *after, int n_after) {
+    if (n_before < 0 || n_after < 0 || (n_before && !before) || (n_after && !after)) return fail(SL_E_ARG, "bad stream lists");
+    // ordering events: a ring of timing-less events, created on first use (an event may be re-recorded once the
+    // waits that named it have been enqueued, which they have by the time the ring comes round)
+    constexpr int RING = 64;
+    static hipEvent_t ring[RING];
+    static std::atomic<unsigned> next{0};
+    static std::once_flag once;
+    static hipError_t made = hipSuccess;
+    std::call_once(once, [] {
+        for (int i = 0; i < RING && made == hipSuccess; ++i) made = hipEventCreateWithFlags(&ring[i], hipEventDisableTiming);
+    });
+    if (made != hipSuccess) return hip_fail(made, "streams_order events");
+    for (int i = 0; i < n_before; ++i) {
+        bool needed = false;
+        for (int j = 0; j < n_after; ++j) needed |= after[j] != before[i];
+        if (!needed) continue;
+        hipEvent_t ev = ring[next.fetch_add(1, std::memory_order_relaxed) % RING];
+        hipError_t err = hipEventRecord(ev, (hipStream_t)before[i]);
+        for (int j = 0; j < n_after && err == hipSuccess; ++j)
+            if (after[j] != before[i]) err = hipStreamWaitEvent((hipStream_t)after[j], ev, 0);
+        if (err != hipSuccess) return hip_fail(err, "streams_order");
+    }
+    return SL_OK;
+}
+
 int slhip_streams_concurrent(void *stream_a, void *stream_b, int *concurrent) {
     if (!concurrent) return fail(SL_E_ARG, "null pointer");
     hipStream_t a = (hipStream_t)stream_a, b = (hipStream_t)stream_b;

@@ -102,10 +102,11 @@ class SafeLifeVectorEnv(object):
                                    the env's own, none of them the caller's).  Envs are
                                    independent, so consecutive steps of different slices overlap on the chip
                                    (the load / store phases and the launch boundary of one slice hide under
-                                   the compute phase of the other).  ``step()`` keeps the one-stream
-                                   semantics (it fences the slice streams against the caller's stream on
-                                   both sides); ``step_async()`` + ``join()`` leave the fences to the caller
-                                   and are what a pipelined driver uses.
+                                   the compute phase of the other).  That is ``step_async()`` + ``join()``,
+                                   what a pipelined driver uses.  ``step()`` keeps the one-stream semantics and
+                                   is ONE launch on the caller's stream whatever ``slices`` says (fencing every
+                                   step in and out of the slice streams costs four times the step); the env
+                                   joins / fences by itself when a caller switches between the two.
     episode_streams : bool         True: every episode gets its own random stream, derived from the level's
                                    generator, the env's global index (``env_offset`` + e) and the env's episode
                                    count -- envs that replay one pool level, and successive replays by one env,
@@ -254,7 +255,8 @@ class SafeLifeVectorEnv(object):
         # instead of 36 us per navigation step).
         self._primary = torch.cuda.current_stream(dev)
         self._slice_streams = self._pick_streams(n_sl) if n_sl > 1 else []
-        self._ev_ring, self._ev_next = [], -1
+        self._async_pending = False      # step_async() left work on the slice streams that the caller has not joined
+        self._caller_ahead = True        # the caller's stream holds work the slice streams have not been fenced against
         self._stream_ptrs = (C.c_void_p * max(1, n_sl))(*[st.cuda_stream for st in self._slice_streams])
         self._primary_ptr = C.c_void_p(self._primary.cuda_stream)
         rc = self._lib.slhip_env_prepare(self._sref, _hip.current_stream_ptr())
@@ -313,12 +315,10 @@ class SafeLifeVectorEnv(object):
         m = None
         if mask is not None:
             m = self.torch.as_tensor(mask, device=self.device).to(self.torch.uint8).contiguous()
-        if self.slices > 1:
-            self.join()
+        self._settle()
         rc = self._lib.slhip_env_reset(self._sref, _hip.ptr(m), _hip.current_stream_ptr())
         _hip.check(rc)
-        if self.slices > 1:
-            self.fence()
+        self._caller_ahead = True
         return self.obs
 
     def _actions(self, actions, shape):
@@ -334,13 +334,13 @@ class SafeLifeVectorEnv(object):
         """actions: int [B] in 0..8.  Returns (obs, reward, done, info) as device tensors that are
         overwritten by the next call.  Ordered on the caller's current stream, sliced or not."""
         a = self._actions(actions, (self.num_envs,))
-        if self.slices > 1:
-            self.fence()
-            self.step_async(a)
-            self.join()
-        else:
-            rc = self._lib.slhip_env_step(self._sref, _hip.ptr(a), _hip.current_stream_ptr())
-            _hip.check(rc)
+        # one-stream semantics leave nothing to overlap (every step would be fenced in and joined out: measured 51 us
+        # per step with two slices against 12 with one launch), so this is ONE launch on the caller's stream whatever
+        # `slices` says; the slices are for step_async()
+        self._settle()
+        rc = self._lib.slhip_env_step(self._sref, _hip.ptr(a), _hip.current_stream_ptr())
+        _hip.check(rc)
+        self._caller_ahead = True
         return self.obs, self.reward, self.done, self.info
 
     # ---- sliced stepping (slices > 1): no implicit ordering against the caller's stream
@@ -371,33 +371,23 @@ class SafeLifeVectorEnv(object):
     def fence(self):
         """Slice streams wait for everything enqueued so far on the caller's current stream (call after
         producing actions, resetting, or touching env state there)."""
-        cur = self.torch.cuda.current_stream()
-        side = [st for st in self._slice_streams if st != cur]
-        if side:
-            ev = self._sync_event()
-            ev.record(cur)
-            for st in side:
-                st.wait_event(ev)
+        if self._slice_streams:
+            cur = (C.c_void_p * 1)(self.torch.cuda.current_stream().cuda_stream)
+            _hip.check(self._lib.slhip_streams_order(cur, 1, self._stream_ptrs, len(self._slice_streams)))
+        self._caller_ahead = False
 
     def join(self):
         """The caller's current stream waits for every slice's enqueued steps (call before consuming
         reward / done / obs / state there)."""
-        cur = self.torch.cuda.current_stream()
-        for st in self._slice_streams:
-            if st != cur:
-                ev = self._sync_event()
-                ev.record(st)
-                cur.wait_event(ev)
+        if self._slice_streams:
+            cur = (C.c_void_p * 1)(self.torch.cuda.current_stream().cuda_stream)
+            _hip.check(self._lib.slhip_streams_order(self._stream_ptrs, len(self._slice_streams), cur, 1))
+        self._async_pending = False
 
-    def _sync_event(self):
-        """Ordering events come from a small ring (creating one per call is most of what torch's wait_stream
-        costs); an event is only reused long after the wait that named it was enqueued."""
-        ring = self._ev_ring
-        if len(ring) < 16:
-            ring.append(self.torch.cuda.Event())
-            return ring[-1]
-        self._ev_next = (self._ev_next + 1) % 16
-        return ring[self._ev_next]
+    def _settle(self):
+        """Before the env is touched on the caller's stream: join the slices if step_async() left work on them."""
+        if self._async_pending:
+            self.join()
 
     def step_async(self, actions):
         """One step per env, one launch per slice on the slice's own stream; nothing is fenced.  `actions`:
@@ -405,7 +395,10 @@ class SafeLifeVectorEnv(object):
         device address as an int.  Outputs are valid on the caller's stream after ``join()``."""
         ptr = actions if isinstance(actions, int) else actions.data_ptr()
         if self.slices > 1:
+            if self._caller_ahead:      # a reset / step() / rollout() on the caller's stream since the last fence
+                self.fence()
             rc = self._lib.slhip_env_step_slices(self._sref, self.slices, self._bounds, ptr, self._stream_ptrs)
+            self._async_pending = True
         else:
             rc = self._lib.slhip_env_step(self._sref, ptr, _hip.current_stream_ptr())
         if rc:
@@ -423,14 +416,12 @@ class SafeLifeVectorEnv(object):
         if self.shaped_reward is not None:      # wrapped reward of every step: env.shaped_reward_t [T,B]
             self.shaped_reward_t = torch.empty((T, self.num_envs), dtype=torch.float64, device=self.device)
             self.struct.wrap.shaped_reward_t = self.shaped_reward_t.data_ptr()
-        if self.slices > 1:
-            self.join()
+        self._settle()
         rc = self._lib.slhip_env_rollout(self._sref, _hip.ptr(a), T, _hip.ptr(reward_out),
                                          _hip.ptr(done_out), _hip.current_stream_ptr())
         self.struct.wrap.shaped_reward_t = None
         _hip.check(rc)
-        if self.slices > 1:
-            self.fence()
+        self._caller_ahead = True
         return reward_out, done_out
 
     def set_step_outputs(self, out_ptr):
@@ -441,10 +432,10 @@ class SafeLifeVectorEnv(object):
 
 
     def get_obs(self):
-        if self.slices > 1:
-            self.join()
+        self._settle()
         rc = self._lib.slhip_env_obs(self._sref, _hip.current_stream_ptr())
         _hip.check(rc)
+        self._caller_ahead = True
         return self.obs
 
     def policy_obs(self, channels=_DEFAULT_CHANNELS, dtype=None, out=None):
@@ -487,13 +478,11 @@ class SafeLifeVectorEnv(object):
         if self._se is None:
             raise ValueError("construct the env with side_effects=dict(capacity=...) first")
         torch, se = self.torch, self._se
-        if self.slices > 1:
-            self.join()                               # the queue was filled on the slice streams
+        self._settle()                                # the queue was filled on the slice streams
         q, bufs = se["queue"]
         se["queue"] = self._new_queue()               # the step kernels fill a fresh queue from here on
         self.struct.finished = se["queue"][0]
-        if self.slices > 1:
-            self.fence()
+        self._caller_ahead = True                     # (the fresh queue's counter is zeroed on the caller's stream)
         H, W = self.pool.shape
         cap, K = se["capacity"], _hip.SL_SE_MAX_KEYS
         dev = self.device
@@ -544,8 +533,7 @@ class SafeLifeVectorEnv(object):
     def snapshot(self):
         """Device-side copy of the per-env state (board, goals, generator, per-env record), ordered after the steps
         enqueued so far; read it later with ``numpy(name, snapshot=...)`` -- nothing crosses to the host now."""
-        if self.slices > 1:
-            self.join()
+        self._settle()
         return {name: self.t[name].clone() for name in ("board", "goals", "rng", "scalars")}
 
     def numpy(self, name, snapshot=None):
@@ -556,8 +544,7 @@ class SafeLifeVectorEnv(object):
                 return self.numpy(name)
             finally:
                 self.t = live
-        if self.slices > 1:
-            self.join()
+        self._settle()
         if name == "obs":
             a = self.obs.cpu().numpy()
             return a.view(np.uint32) if self.output_channels is None else a
