@@ -1504,16 +1504,14 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
 
     RowWords<H, W> b;
     Elig elig;
+    // (lanes without a row compute on whatever their registers hold -- nothing of theirs is ever stored or summed;
+    //  "defined, value irrelevant" costs no instruction, thirteen zeroing moves would)
 #pragma unroll
-    for (int k = 0; k < WS; ++k) b[k] = 0;
-    u32 goal_bits = 0;
+    for (int k = 0; k < WS; ++k) asm volatile("" : "=v"(b[k]));
     if (live) {
         read_row<H, W>(goals, gb, r, b);
 #pragma unroll
-        for (int k = 0; k < WS; ++k) {
-            gsh_lane[k] = goal_shift(b[k]);
-            goal_bits |= b[k];
-        }
+        for (int k = 0; k < WS; ++k) gsh_lane[k] = goal_shift(b[k]);
     }
     // Goals still undecided (the first step after a reset; the reference finds out by advancing them once,
     // safelife_game.py:753-760): a goal array without a single ALIVE or SPAWNING cell cannot change and draws
@@ -1522,6 +1520,11 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
     // resets in the middle of a T-step launch takes the two-pass route for one step).
 #ifndef SL_NO_SHORTCUT1
     if (T > 0 && __ballot(rowl && gstatic == 0)) {
+        u32 goal_bits = 0;              // (b still holds the goal row; halves beyond an odd width are zero)
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < WS; ++k) goal_bits |= b[k];
+        }
         const int restless = group_total<H, W>(live && (goal_bits & 0x00810081u) ? 1 : 0, rowl ? g : 0);
         if (rowl && gstatic == 0 && restless == 0) gstatic = 1;
     }
