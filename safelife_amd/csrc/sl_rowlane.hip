@@ -567,11 +567,32 @@ template <int H, int W>
 __device__ __forceinline__ void act_gather(u16 *board, int &ly, int &lx, int action) {
     using Gm = Geom<H, W>;
     const int dir = (action - 1) & 3;
-    const int dy = (dir & 1) ? 0 : dir - 1, dx = (dir & 1) ? 2 - dir : 0;
-    const int y1 = wrap1(ly + dy, H), x1 = wrap1(lx + dx, W);
-    const int i0 = Gm::cell(ly, lx), i1 = Gm::cell(y1, x1);
-    const int i2 = Gm::cell(wrap1(ly + 2 * dy, H), wrap1(lx + 2 * dx, W));
-    const int i3 = Gm::cell(wrap1(ly - dy, H), wrap1(lx - dx, W));
+    int y1, x1, i0, i1, i2, i3;
+    if (Gm::SWZ) {
+        const int dy = (dir & 1) ? 0 : dir - 1, dx = (dir & 1) ? 2 - dir : 0;
+        y1 = wrap1(ly + dy, H);
+        x1 = wrap1(lx + dx, W);
+        i0 = Gm::cell(ly, lx);
+        i1 = Gm::cell(y1, x1);
+        i2 = Gm::cell(wrap1(ly + 2 * dy, H), wrap1(lx + 2 * dx, W));
+        i3 = Gm::cell(wrap1(ly - dy, H), wrap1(lx - dx, W));
+    } else {
+        // the move runs along ONE axis: wrap three positions on that axis and scale them by the axis' pitch in the
+        // row-major image, instead of wrapping three (row, column) pairs (a third of the instructions; every wave
+        // executes this block for the sake of its leader lanes, and the kernel is bound by vector-ALU issue)
+        const bool horiz = (dir & 1) != 0;
+        const int pos = horiz ? lx : ly, n = horiz ? W : H;
+        const int s = horiz ? 2 - dir : dir - 1;                     // +1 / -1
+        const int p1 = wrap1(pos + s, n), p2 = wrap1(p1 + s, n), p3 = wrap1(pos - s, n);
+        const int pitch = horiz ? 1 : W;
+        const int base = horiz ? __mul24(ly, W) : lx;                // the cell index minus the moving coordinate's share
+        i0 = __mul24(ly, W) + lx;
+        i1 = base + __mul24(p1, pitch);
+        i2 = base + __mul24(p2, pitch);
+        i3 = base + __mul24(p3, pitch);
+        y1 = horiz ? ly : p1;
+        x1 = horiz ? p1 : lx;
+    }
     u32 c0 = board[i0], c1 = board[i1], c2 = board[i2], c3 = board[i3];
     if (action == 0 || !(c0 & AGENT)) return;
     c0 = (c0 & ~ORIENT_MASK) | ((u32)dir << ORIENT_SHIFT);
