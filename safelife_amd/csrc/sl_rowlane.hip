@@ -354,11 +354,12 @@ __device__ __forceinline__ Consts make_consts() {
 //      can carry across a 16-bit half: every half stays below 0x3000)
 //   w: colour bits of spawner cells, plus, after each pass, the "seen twice" bits -- all at the
 //      cells' native bit positions, so the new cell is assembled without shifts.
-template <int H, int W, bool SPAWN>
+template <int H, int W, bool SPAWN, bool COLFIRST = false>
 __device__ __forceinline__ void ca_rows(const RowWords<H, W> &b, RowWords<H, W> &n, Elig &elig, int up, int dn,
                                         const Consts &c) {
     using Gm = Geom<H, W>;
     constexpr int WS = Gm::WS;
+    static_assert(!(SPAWN && COLFIRST), "column-first reduction: spawner-free variants only");
     RowWords<H, W> o, w;
 #pragma unroll
     for (int k = 0; k < WS; ++k) {
@@ -367,28 +368,61 @@ __device__ __forceinline__ void ca_rows(const RowWords<H, W> &b, RowWords<H, W> 
         o[k] = BO3_ORAND(bb, (bb >> 5) & c.eight, m);               // exit (bit 8) joins destructible on bit 3
         w[k] = SPAWN ? (bb & __umul24(bb & c.spawn, 0x1Cu)) : 0u;   // colours of spawners
     }
-    const Seams<H, W> so = make_seams<H, W>(o);
-    Seams<H, W> sw = {0u, 0u, 0u};
-    if (SPAWN) sw = make_seams<H, W>(w);
+    // Spawner-free boards reduce the COLUMN first: the lanes above and below hand over the raw summary words
+    // (two DPP moves per word instead of four: with the row pass first, its OR and its "twice" word both have to
+    // travel), the per-column OR / majority / count stay in the lane, and the row pass runs on neighbouring
+    // registers.  14 -> 10 vector instructions per word for the 3x3 reduction.  (Three arrays stay live between the
+    // passes -- four with spawners: only the plain step's variant has the registers for it, COLFIRST.)
+    RowWords<H, W> xc, mc, sc;
+    Seams<H, W> sx = {0u, 0u, 0u}, sm = {0u, 0u, 0u}, ss = {0u, 0u, 0u};
+    if (COLFIRST) {
+#pragma unroll
+        for (int k = 0; k < WS; ++k) {
+            const u32 U = from_above<Gm::VERT>(up, o[k]), D = from_below<Gm::VERT>(dn, o[k]);
+            xc[k] = BO3_OR3(U, o[k], D);
+            mc[k] = BO3_MAJ(U, o[k], D);
+            sc[k] = U + o[k] + D;                                    // bits 0-1: alive cells in the column triple
+        }
+        sx = make_seams<H, W>(xc);
+        sm = make_seams<H, W>(mc);
+        ss = make_seams<H, W>(sc);
+    }
+    Seams<H, W> so = {0u, 0u, 0u}, sw = {0u, 0u, 0u};
+    if (!COLFIRST) {
+        so = make_seams<H, W>(o);
+        if (SPAWN) sw = make_seams<H, W>(w);
+    }
     elig.clear();
 #pragma unroll
     for (int k = 0; k < WS; ++k) {
-        const u32 oL = left_of<H, W>(o, so, k), oR = right_of<H, W>(o, so, k);
-        const u32 wL = left_of<H, W>(w, sw, k), wR = right_of<H, W>(w, sw, k);
-        // row pass
-        const u32 xo = BO3_OR3(oL, o[k], oR);
-        const u32 mj = BO3_MAJ(oL, o[k], oR);
-        const u32 wr = SPAWN ? BO3_OR_AND(BO3_OR3(wL, w[k], wR), mj, c.once) : (mj & c.once);
-        const u32 cs = oL + o[k] + oR;                               // bits 0-1: alive cells in the row triple
-        const u32 ro = BO3_INSERT(xo, cs, c.three);
-        // column pass
-        const u32 Uo = from_above<Gm::VERT>(up, ro), Do = from_below<Gm::VERT>(dn, ro);
-        const u32 Uw = from_above<Gm::VERT>(up, wr), Dw = from_below<Gm::VERT>(dn, wr);
-        const u32 X = BO3_OR3(Uo, ro, Do);
-        const u32 m2 = BO3_MAJ(Uo, ro, Do);
-        const u32 xw2 = BO3_OR3(Uw, wr, Dw);
-        const u32 tw = BO3_OR_AND(xw2, m2, c.once);                  // seen twice: bit 3 + colours
-        const u32 sum = Uo + ro + Do;                                // bits 0-2: alive count mod 8
+        u32 X, tw, sum;
+        if (COLFIRST) {
+            const u32 xL = left_of<H, W>(xc, sx, k), xR = right_of<H, W>(xc, sx, k);
+            X = BO3_OR3(xL, xc[k], xR);
+            const u32 m2 = BO3_MAJ(xL, xc[k], xR);                   // at least two columns saw it
+            const u32 mL = left_of<H, W>(mc, sm, k), mR = right_of<H, W>(mc, sm, k);
+            const u32 t1 = BO3_OR3(mL, mc[k], mR);                   // a column saw it twice
+            tw = BO3_OR_AND(t1, m2, c.once);                         // seen twice: bit 3 + colours
+            const u32 sL = left_of<H, W>(sc, ss, k), sR = right_of<H, W>(sc, ss, k);
+            sum = sL + sc[k] + sR;                                   // bits 0-2: alive count mod 8
+        } else {
+            const u32 oL = left_of<H, W>(o, so, k), oR = right_of<H, W>(o, so, k);
+            const u32 wL = left_of<H, W>(w, sw, k), wR = right_of<H, W>(w, sw, k);
+            // row pass
+            const u32 xo = BO3_OR3(oL, o[k], oR);
+            const u32 mj = BO3_MAJ(oL, o[k], oR);
+            const u32 wr = SPAWN ? BO3_OR_AND(BO3_OR3(wL, w[k], wR), mj, c.once) : (mj & c.once);
+            const u32 cs = oL + o[k] + oR;                           // bits 0-1: alive cells in the row triple
+            const u32 ro = BO3_INSERT(xo, cs, c.three);
+            // column pass
+            const u32 Uo = from_above<Gm::VERT>(up, ro), Do = from_below<Gm::VERT>(dn, ro);
+            const u32 Uw = from_above<Gm::VERT>(up, wr), Dw = from_below<Gm::VERT>(dn, wr);
+            X = BO3_OR3(Uo, ro, Do);
+            const u32 m2 = BO3_MAJ(Uo, ro, Do);
+            const u32 xw2 = BO3_OR3(Uw, wr, Dw);
+            tw = BO3_OR_AND(xw2, m2, c.once);                        // seen twice: bit 3 + colours
+            sum = Uo + ro + Do;                                      // bits 0-2: alive count mod 8
+        }
         const u32 c1 = sum >> 1, c2 = sum >> 2;
         const u32 s34 = SL_BO3((TA & TB & ~TC) | (~TA & ~TB & TC), sum, c1, c2);   // count in {3,4}
         const u32 is3 = SL_BO3(TA & TB & ~TC, sum, c1, c2);
@@ -1579,7 +1613,9 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
             const bool mine = has && lm.real;
             unsigned char *img = pass == 0 ? board : goals;
             if (has) read_row<H, W>(img, gb, r, b);
-            ca_rows<H, W, SPAWN>(b, b, elig, up, dn, cst);   // in place: b now holds the new cells
+            // (column-first reduction where its three arrays fit beside the row: not at 15-16 words with 128 registers)
+            constexpr bool COLFIRST = LEAN && !SPAWN && (WS <= 13 || Gm::WAVES_PER_SIMD < 4);
+            ca_rows<H, W, SPAWN, COLFIRST>(b, b, elig, up, dn, cst);   // in place: b now holds the new cells
             if (!mine) elig.clear();
             if (SPAWN && __ballot(elig.any())) {
                 RowWords<H, W> old;                          // failed draws keep the old cell: re-read it
