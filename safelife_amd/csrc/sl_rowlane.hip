@@ -548,7 +548,7 @@ __device__ __forceinline__ int row_score(const RowWords<H, W> &n, const u32 *gsh
     for (int k = 0; k < Gm::WS; ++k) {
         u32 idx = BO3_AND_OR(n[k], cell_mask, gsh_lane[k]);
         if (LDS_LUT) {
-            idx = BO3_AND_OR(n[k] >> 7, c100, idx) & 0x0FFF0FFFu;       // pullable -> bit 8, drop bit 15
+            idx = BO3_AND_OR(n[k] >> 7, c100, idx);       // pullable -> bit 8 (cell_mask leaves bit 15 out in this form)
             s += lds_lut[idx & 0xFFFFu];
             if (!(Gm::ODD && k == Gm::WS - 1)) s += lds_lut[idx >> 16];
         } else {
@@ -1499,7 +1499,7 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
     const double *mvt = (const double *)(smem + Gm::OFF_MVT);
     const int8_t *__restrict__ lut = env.score_lut + 4096;        // wide form of table t at + t * SCORE_LUT_BYTES
     const Consts cst = make_consts();
-    const u32 cell_mask = vreg(SCORE_CELL_MASK), c100 = vreg(0x01000100u);
+    const u32 cell_mask = vreg(LDS_LUT ? (SCORE_CELL_MASK & 0x7FFF7FFFu) : SCORE_CELL_MASK), c100 = vreg(0x01000100u);
 
     SL_STAMP(0);
     // Prologue, written so that nothing waits before the bulk loads are in flight:
