@@ -512,8 +512,8 @@ def main():
                          # first launch from an idle GPU and the final synchronize)
                          "frac_wall": bytes_per_step * B / (elapsed / K) / 1e9 / HBM_PEAK_GBS,
                          "note": "launch_ms = device time of ONE step (HIP events), i.e. of launches_per_step concurrent "
-                                 "launches; rocprofv3 serialises them (7.9 us per 4096-env launch in "
-                                 "profiles/round2_c_slices2_kernel_trace.txt; --slices 1: 11.3 us per launch by events "
+                                 "launches; rocprofv3 serialises them (7.9-8.5 us per 4096-env launch in "
+                                 "profiles/round2_c_slices2_kernel_trace.txt; --slices 1: 11.3-11.6 us per launch by events "
                                  "and by the trace alike).  The kernel is not byte-bound at this size: its vector ALUs "
                                  "are ~75 % busy (SQ_ACTIVE_INST_VALU in profiles/round2_c_slices2_pmc.txt, DESIGN 6.0)"},
         }
