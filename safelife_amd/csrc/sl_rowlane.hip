@@ -30,6 +30,7 @@
 #include <atomic>
 
 #include "sl_kernels.h"
+#include "sl_planes.h"
 
 // A/B knobs of the span moves (cache policy of the LDS DMA loads, flavour of the span stores)
 #ifndef SL_LOAD_AUX
@@ -511,6 +512,84 @@ __device__ void resolve_draws(const RowWords<H, W> &b, RowWords<H, W> &n, const 
     wave_sync();
 }
 
+// The same for the bit-plane step (sl_planes.h): `elig` is a plane -- bit 1+k = cell k, bit 17+k = cell WS+k --
+// and so is the result, the cells whose draw succeeded.  Row-major order = ascending bits of the low half, then
+// of the high half.
+template <int H, int W>
+__device__ u32 resolve_draws_planes(u32 elig, u64 *rng_lds, int g, double p, const Jump *__restrict__ jump) {
+    using Gm = Geom<H, W>;
+    const int mine = __popc(elig);
+    const int incl = wave_scan(mine);
+    int before = 0, total = 0;
+#pragma unroll
+    for (int q = 0; q < Gm::G; ++q) {
+        const int lo = q ? __builtin_amdgcn_readlane(incl, LaneMap<H, W>::first_lane(q) - 1) : 0;
+        const int hi = __builtin_amdgcn_readlane(incl, LaneMap<H, W>::last_lane(q));
+        if (g == q) {
+            before = lo;
+            total = hi - lo;
+        }
+    }
+    const int excl = incl - mine - before;
+    const U128 st = {rng_lds[4 * g + 0], rng_lds[4 * g + 1]}, inc = {rng_lds[4 * g + 2], rng_lds[4 * g + 3]};
+    wave_sync();     // every lane has read the old state before a leader replaces it
+    u32 ok = 0;
+    if (mine > 0) {
+        U128 cur = pcg_jump(jump, excl, st, inc);
+        u32 part = elig & 0xFFFFu, base = 0;
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            while (part) {
+                const u32 bit = part & (0u - part);
+                cur = pcg_step(cur, inc);
+                if (pcg_output_double(cur) < p) ok |= bit << base;              // advance_board.c:115
+                part ^= bit;
+            }
+            part = elig >> 16;
+            base = 16;
+        }
+        if (excl + mine == total) {     // the lane that made the board's last draw holds its new state
+            rng_lds[4 * g + 0] = cur.hi;
+            rng_lds[4 * g + 1] = cur.lo;
+        }
+    }
+    wave_sync();
+    return ok;
+}
+
+// One CA step on a lane's row, in place.  Rows of up to 28 cells take the bit-plane form (sl_planes.h), wider
+// ones the word form above.  `mine`: the lane owns a row of a board that is advancing.  Returns (wave-uniform)
+// whether any cell of the wave changed -- the word form does not know and says yes.  `take`: the lane takes the
+// new row even if it is not `mine` (the halo copies of the word form compute their own rows).
+template <int H, int W>
+constexpr bool use_planes() { return (W + 1) / 2 + 2 <= 16; }
+
+template <int H, int W, bool SPAWN, bool COLFIRST>
+__device__ __forceinline__ bool ca_step(RowWords<H, W> &b, bool mine, bool take, int up, int dn, const Consts &c,
+                                        const pl::PConsts &pc, u64 *rng_lds, int g, double p,
+                                        const Jump *__restrict__ jump) {
+    using Gm = Geom<H, W>;
+    if constexpr (use_planes<H, W>()) {
+        static_assert((int)pl::PV_BPERM == (int)V_BPERM && (int)pl::PV_SHIFT == (int)V_SHIFT && (int)pl::PV_ROTATE == (int)V_ROTATE, "");
+        const pl::VCtx<Gm::VERT> vc = {up, dn};
+        const u32 realm = mine ? vreg(pl::PG<W>::REAL) : 0u;
+        return pl::ca_planes<W, Gm::VERT, SPAWN>(b, vc, realm, pc, [&](u32 elig) {
+            return resolve_draws_planes<H, W>(elig, rng_lds, g, p, jump);
+        });
+    } else {
+        Elig elig;
+        RowWords<H, W> n;
+        ca_rows<H, W, SPAWN, COLFIRST>(b, n, elig, up, dn, c);
+        if (!mine) elig.clear();
+        if (SPAWN && __ballot(elig.any())) resolve_draws<H, W>(b, n, elig, rng_lds, g, p, jump);
+        if (take) {
+#pragma unroll
+            for (int k = 0; k < Gm::WS; ++k) b[k] = n[k];
+        }
+        return true;
+    }
+}
+
 // Sum of a per-lane value over the lanes of the caller's board (every lane gets its board's total).
 template <int H, int W>
 __device__ __forceinline__ int group_total(int v, int g) {
@@ -813,21 +892,15 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_ad
     }
     __syncthreads();
     const Consts cst = make_consts();
-    RowWords<H, W> b, n;
-    Elig elig;
+    const pl::PConsts pcst = pl::make_pconsts();
+    RowWords<H, W> b;
 #pragma unroll
     for (int k = 0; k < Gm::WS; ++k) b[k] = 0;
     if (rowl) read_row<H, W>(board, gb, r, b);
     for (int s = 0; s < wave_n; ++s) {
         const bool going = s < my_n;
-        ca_rows<H, W, true>(b, n, elig, up, dn, cst);
-        if (!live || !going) elig.clear();
-        if (__ballot(elig.any())) resolve_draws<H, W>(b, n, elig, rng_lds, live ? g : 0, p, jump);
-        if (going) {
-#pragma unroll
-            for (int k = 0; k < Gm::WS; ++k) b[k] = n[k];
-        }
-        if (Gm::VERT == V_SHIFT && s + 1 < wave_n) {      // refresh the halo copies through LDS
+        const bool changed = ca_step<H, W, true, false>(b, live && going, going, up, dn, cst, pcst, rng_lds, live ? g : 0, p, jump);
+        if (Gm::VERT == V_SHIFT && s + 1 < wave_n && changed) {      // refresh the halo copies through LDS
             if (live) write_row<H, W>(board, gb, r, b);
             wave_sync();
             if (rowl && !lm.real) read_row<H, W>(board, gb, r, b);
@@ -920,8 +993,7 @@ __global__ __launch_bounds__(64) void k_occupancy_rowlane(const u16 *__restrict_
     const bool rowl = lane < Gm::NL && g < nbb;
     const bool live = rowl && lm.real;
     const unsigned e = e0b + (rowl ? g : 0);
-    RowWords<H, W> b, n;
-    Elig elig;
+    RowWords<H, W> b;
     {   // the row straight from HBM (once per launch)
         const u16 *row = in + ((size_t)e * H + r) * W;
 #pragma unroll
@@ -979,6 +1051,7 @@ __global__ __launch_bounds__(64) void k_occupancy_rowlane(const u16 *__restrict_
     // V_SHIFT: after a step the halo lanes take the new first / last row from the lanes that own them
     const int partner = !rowl || lm.real ? lane : (r == 0 ? lane - H : lane + H);
     const Consts cst = make_consts();
+    const pl::PConsts pcst = pl::make_pconsts();
     // pre_steps (optional): the board is first rolled forward that many steps without counting -- the side-effect
     // pass's advance_board(b0, p, num_steps) (side_effects.py:108) fused in front of its life_occupancy
     const int my_pre = pre_steps ? (rowl ? max(0, pre_steps[e]) : 0) : 0;
@@ -990,13 +1063,10 @@ __global__ __launch_bounds__(64) void k_occupancy_rowlane(const u16 *__restrict_
     int since_drain = 0;
     for (int s = 0; s < wave_end; ++s) {
         const bool going = s < my_end;
-        ca_rows<H, W, true>(b, n, elig, lm.up, lm.dn, cst);
-        if (!live || !going) elig.clear();
-        if (__ballot(elig.any())) resolve_draws<H, W>(b, n, elig, rng_lds, rowl ? g : 0, p, jump);
+        const bool changed = ca_step<H, W, true, false>(b, live && going, going, lm.up, lm.dn, cst, pcst, rng_lds, rowl ? g : 0, p, jump);
+        if (Gm::VERT == V_SHIFT && changed) {
 #pragma unroll
-        for (int k = 0; k < WS; ++k) {
-            const u32 nk = going ? n[k] : b[k];
-            b[k] = Gm::VERT == V_SHIFT ? bperm(4 * partner, nk) : nk;
+            for (int k = 0; k < WS; ++k) b[k] = bperm(4 * partner, b[k]);
         }
         if (!__ballot(going && s >= my_pre)) continue;          // nobody counts yet
 #ifndef SL_OCC_NOCOUNT
@@ -1499,6 +1569,7 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
     const double *mvt = (const double *)(smem + Gm::OFF_MVT);
     const int8_t *__restrict__ lut = env.score_lut + 4096;        // wide form of table t at + t * SCORE_LUT_BYTES
     const Consts cst = make_consts();
+    const pl::PConsts pcst = pl::make_pconsts();
     const u32 cell_mask = vreg(LDS_LUT ? (SCORE_CELL_MASK & 0x7FFF7FFFu) : SCORE_CELL_MASK), c100 = vreg(0x01000100u);
 
     SL_STAMP(0);
@@ -1613,22 +1684,32 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
             const bool mine = has && lm.real;
             unsigned char *img = pass == 0 ? board : goals;
             if (has) read_row<H, W>(img, gb, r, b);
-            // (column-first reduction where its three arrays fit beside the row: not at 15-16 words with 128 registers)
-            constexpr bool COLFIRST = LEAN && !SPAWN && (WS <= 13 || Gm::WAVES_PER_SIMD < 4);
-            ca_rows<H, W, SPAWN, COLFIRST>(b, b, elig, up, dn, cst);   // in place: b now holds the new cells
-            if (!mine) elig.clear();
-            if (SPAWN && __ballot(elig.any())) {
-                RowWords<H, W> old;                          // failed draws keep the old cell: re-read it
+            bool changed = true;                             // (wave-uniform) some cell of the wave's rows changed
+            if constexpr (use_planes<H, W>()) {
+                changed = ca_step<H, W, SPAWN, false>(b, mine, mine, up, dn, cst, pcst, rng_lds, live ? g : 0, p, jump);
+            } else {
+                // (column-first reduction where its three arrays fit beside the row: not at 15-16 words with 128 registers)
+                constexpr bool COLFIRST = LEAN && !SPAWN && (WS <= 13 || Gm::WAVES_PER_SIMD < 4);
+                ca_rows<H, W, SPAWN, COLFIRST>(b, b, elig, up, dn, cst);   // in place: b now holds the new cells
+                if (!mine) elig.clear();
+                if (SPAWN && __ballot(elig.any())) {
+                    RowWords<H, W> old;                          // failed draws keep the old cell: re-read it
 #pragma unroll
-                for (int k = 0; k < WS; ++k) old[k] = 0;
-                if (mine) read_row<H, W>(img, gb, r, old);
-                resolve_draws<H, W>(old, b, elig, rng_lds, live ? g : 0, p, jump);
+                    for (int k = 0; k < WS; ++k) old[k] = 0;
+                    if (mine) read_row<H, W>(img, gb, r, old);
+                    resolve_draws<H, W>(old, b, elig, rng_lds, live ? g : 0, p, jump);
+                }
             }
             if (pass == 1) {
                 u32 diff = 0;
                 if (mine) {
                     RowWords<H, W> old;
-                    read_row<H, W>(img, gb, r, old);
+                    if (changed) {
+                        read_row<H, W>(img, gb, r, old);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < WS; ++k) old[k] = b[k];
+                    }
 #pragma unroll
                     for (int k = 0; k < WS; ++k)
                         diff |= ((b[k] ^ old[k]) | (b[k] & 0x00800080u)) & (Gm::vm1(k) * 0xFFFFu);
@@ -1641,7 +1722,7 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
                     goals_dirty = true;
                 }
             }
-            if (mine) write_row<H, W>(img, gb, r, b);
+            if (mine && changed) write_row<H, W>(img, gb, r, b);
         }
         if (passes == 2) {               // board rows back into registers for scoring
             wave_sync();

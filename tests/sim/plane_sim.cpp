@@ -1,0 +1,158 @@
+// plane_sim.cpp -- CPU model of one wavefront running the bit-plane CA step of safelife_amd/csrc/sl_planes.h.
+//
+// TEST INFRASTRUCTURE: compiled by tests/test_plane_sim.py with g++ (-DSL_PLANES_HOST_SIM: every value of the
+// kernel text becomes the 64 lanes of a wave, the vertical lane moves become index tables that follow the DPP
+// wave shift / wave rotate / ds_bpermute of the three lane layouts of sl_rowlane.hip).  The test feeds random
+// boards through `steps` CA steps here and through the CPU oracle and compares boards and generator states.
+//
+//   plane_sim <in.bin> <out.bin>
+//   in : int32 {H, W, B, steps, spawn}, u16 boards[B*H*W], f32 spawn_prob[B], u64 rng[B*4]
+//   out: u16 boards[B*H*W], u64 rng[B*4]
+#define SL_PLANES_HOST_SIM 1
+#include "../../safelife_amd/csrc/sl_planes.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+using namespace sl::pl;
+typedef unsigned __int128 u128;
+
+enum { V_BPERM = 0, V_SHIFT = 1, V_ROTATE = 2 };
+
+struct Pcg {
+    u128 state, inc;
+    double next() {
+        const u128 mult = ((u128)0x2360ED051FC65DA4ull << 64) | 0x4385DF649FCCF645ull;
+        state = state * mult + inc;
+        const uint64_t hi = (uint64_t)(state >> 64), lo = (uint64_t)state;
+        const uint64_t x = hi ^ lo;
+        const unsigned rot = (unsigned)(hi >> 58);
+        const uint64_t o = (x >> rot) | (x << ((64u - rot) & 63u));
+        return (double)(o >> 11) * (1.0 / 9007199254740992.0);
+    }
+};
+
+template <int W, int VERT, bool SPAWN>
+static void run(int H, int B, int steps, std::vector<uint16_t> &boards, const std::vector<float> &prob,
+                std::vector<uint64_t> &rng) {
+    constexpr int WS = (W + 1) / 2;
+    const int GL = H + (VERT == V_SHIFT ? 2 : 0), G = 64 / GL;
+    VCtx<VERT> vc;
+    int lane_g[64], lane_r[64];
+    bool lane_real[64], lane_in[64];
+    for (int l = 0; l < 64; ++l) {
+        const int g = l / GL < G ? l / GL : G - 1, j = l - g * GL;
+        const bool in = l < G * GL;
+        lane_in[l] = in;
+        lane_g[l] = g;
+        if (VERT == V_SHIFT) {
+            lane_real[l] = in && j >= 1 && j <= H;
+            lane_r[l] = j == 0 ? H - 1 : (j == H + 1 ? 0 : j - 1);
+            vc.up_src[l] = l - 1;                       // wave_shr:1 (lane 0 reads zero)
+            vc.dn_src[l] = l + 1 < 64 ? l + 1 : -1;     // wave_shl:1
+        } else if (VERT == V_ROTATE) {
+            lane_real[l] = in;
+            lane_r[l] = j;
+            vc.up_src[l] = (l + 63) % 64;
+            vc.dn_src[l] = (l + 1) % 64;
+        } else {
+            lane_real[l] = in;
+            lane_r[l] = in ? j : 0;
+            vc.up_src[l] = in ? (lane_r[l] == 0 ? l + H - 1 : l - 1) : l;
+            vc.dn_src[l] = in ? (lane_r[l] == H - 1 ? l - (H - 1) : l + 1) : l;
+        }
+        if (!in) lane_r[l] = 0;
+    }
+    const PConsts cst = make_pconsts();
+    for (int e0 = 0; e0 < B; e0 += G) {
+        const int nbb = B - e0 < G ? B - e0 : G;
+        for (int s = 0; s < steps; ++s) {
+            V b[WS], realm;
+            for (int l = 0; l < 64; ++l) {
+                const bool rowl = lane_in[l] && lane_g[l] < nbb;
+                realm.l[l] = rowl && lane_real[l] ? PG<W>::REAL : 0u;
+                const uint16_t *row = rowl ? &boards[((size_t)(e0 + lane_g[l]) * H + lane_r[l]) * W] : nullptr;
+                for (int k = 0; k < WS; ++k) {
+                    const uint32_t lo = row ? row[k] : 0xBEEFu, hi = row && k + WS < W ? row[k + WS] : (row ? 0u : 0xDEADu);
+                    b[k].l[l] = lo | (hi << 16);
+                }
+            }
+            auto draw = [&](const V &elig) {
+                V ok = pconst(0);
+                for (int g = 0; g < nbb; ++g) {
+                    Pcg gen;
+                    uint64_t *st = &rng[(size_t)(e0 + g) * 4];
+                    gen.state = ((u128)st[0] << 64) | st[1];
+                    gen.inc = ((u128)st[2] << 64) | st[3];
+                    const double p = (double)prob[e0 + g];
+                    for (int l = 0; l < 64; ++l) {
+                        if (!lane_in[l] || lane_g[l] != g || !lane_real[l]) continue;
+                        // rows are in lane order; within a row: low half (cells 0..WS-1), then high half
+                        for (int part = 0; part < 2; ++part)
+                            for (int i = 1; i <= WS; ++i) {
+                                const uint32_t bit = 1u << (16 * part + i);
+                                if (elig.l[l] & bit)
+                                    if (gen.next() < p) ok.l[l] |= bit;
+                            }
+                    }
+                    st[0] = (uint64_t)(gen.state >> 64);
+                    st[1] = (uint64_t)gen.state;
+                }
+                return ok;
+            };
+            ca_planes<W, VERT, SPAWN>(b, vc, realm, cst, draw);
+            for (int l = 0; l < 64; ++l) {
+                if (!(lane_in[l] && lane_g[l] < nbb && lane_real[l])) continue;
+                uint16_t *row = &boards[((size_t)(e0 + lane_g[l]) * H + lane_r[l]) * W];
+                for (int k = 0; k < WS; ++k) {
+                    row[k] = (uint16_t)b[k].l[l];
+                    if (k + WS < W) row[k + WS] = (uint16_t)(b[k].l[l] >> 16);
+                }
+            }
+        }
+    }
+}
+
+template <int W>
+static bool run_w(int H, int B, int steps, bool spawn, std::vector<uint16_t> &boards, const std::vector<float> &prob,
+                  std::vector<uint64_t> &rng) {
+    const int vert = H == 64 ? V_ROTATE : (64 / (H + 2) == 64 / H ? V_SHIFT : V_BPERM);
+#define SL_CASE(v)                                                                      \
+    if (vert == v) {                                                                    \
+        if (spawn) run<W, v, true>(H, B, steps, boards, prob, rng);                     \
+        else run<W, v, false>(H, B, steps, boards, prob, rng);                          \
+        return true;                                                                    \
+    }
+    SL_CASE(V_SHIFT) SL_CASE(V_ROTATE) SL_CASE(V_BPERM)
+#undef SL_CASE
+    return false;
+}
+
+int main(int argc, char **argv) {
+    if (argc != 3) return 2;
+    FILE *f = fopen(argv[1], "rb");
+    if (!f) return 2;
+    int32_t hdr[5];
+    if (fread(hdr, 4, 5, f) != 5) return 2;
+    const int H = hdr[0], W = hdr[1], B = hdr[2], steps = hdr[3];
+    const bool spawn = hdr[4] != 0;
+    std::vector<uint16_t> boards((size_t)B * H * W);
+    std::vector<float> prob(B);
+    std::vector<uint64_t> rng((size_t)B * 4);
+    if (fread(boards.data(), 2, boards.size(), f) != boards.size()) return 2;
+    if (fread(prob.data(), 4, prob.size(), f) != prob.size()) return 2;
+    if (fread(rng.data(), 8, rng.size(), f) != rng.size()) return 2;
+    fclose(f);
+    bool ok = false;
+#define SL_W(w) if (W == w) ok = run_w<w>(H, B, steps, spawn, boards, prob, rng);
+    SL_W(4) SL_W(5) SL_W(8) SL_W(10) SL_W(12) SL_W(15) SL_W(16) SL_W(20) SL_W(24) SL_W(25) SL_W(26) SL_W(27) SL_W(28)
+#undef SL_W
+    if (!ok) return 3;
+    f = fopen(argv[2], "wb");
+    if (!f) return 2;
+    fwrite(boards.data(), 2, boards.size(), f);
+    fwrite(rng.data(), 8, rng.size(), f);
+    fclose(f);
+    return 0;
+}
