@@ -33,12 +33,13 @@ struct Pcg {
     }
 };
 
-template <int W, int VERT, bool SPAWN>
-static void run(int H, int B, int steps, std::vector<uint16_t> &boards, const std::vector<float> &prob,
+// (the lane tables carry the layout here, so one instantiation of the kernel text serves all three)
+template <int W, bool SPAWN>
+static void run(int VERT, int H, int B, int steps, std::vector<uint16_t> &boards, const std::vector<float> &prob,
                 std::vector<uint64_t> &rng) {
     constexpr int WS = (W + 1) / 2;
     const int GL = H + (VERT == V_SHIFT ? 2 : 0), G = 64 / GL;
-    VCtx<VERT> vc;
+    VCtx<0> vc;
     int lane_g[64], lane_r[64];
     bool lane_real[64], lane_in[64];
     for (int l = 0; l < 64; ++l) {
@@ -101,7 +102,7 @@ static void run(int H, int B, int steps, std::vector<uint16_t> &boards, const st
                 }
                 return ok;
             };
-            ca_planes<W, VERT, SPAWN>(b, vc, realm, cst, draw);
+            ca_planes<W, 0, SPAWN>(b, vc, realm, cst, draw);
             for (int l = 0; l < 64; ++l) {
                 if (!(lane_in[l] && lane_g[l] < nbb && lane_real[l])) continue;
                 uint16_t *row = &boards[((size_t)(e0 + lane_g[l]) * H + lane_r[l]) * W];
@@ -118,15 +119,9 @@ template <int W>
 static bool run_w(int H, int B, int steps, bool spawn, std::vector<uint16_t> &boards, const std::vector<float> &prob,
                   std::vector<uint64_t> &rng) {
     const int vert = H == 64 ? V_ROTATE : (64 / (H + 2) == 64 / H ? V_SHIFT : V_BPERM);
-#define SL_CASE(v)                                                                      \
-    if (vert == v) {                                                                    \
-        if (spawn) run<W, v, true>(H, B, steps, boards, prob, rng);                     \
-        else run<W, v, false>(H, B, steps, boards, prob, rng);                          \
-        return true;                                                                    \
-    }
-    SL_CASE(V_SHIFT) SL_CASE(V_ROTATE) SL_CASE(V_BPERM)
-#undef SL_CASE
-    return false;
+    if (spawn) run<W, true>(vert, H, B, steps, boards, prob, rng);
+    else run<W, false>(vert, H, B, steps, boards, prob, rng);
+    return true;
 }
 
 int main(int argc, char **argv) {
