@@ -94,6 +94,14 @@ __device__ __forceinline__ u32 pack_lo_lo(u32 lo_src, u32 hi_src) {        // (l
 __device__ __forceinline__ u32 pack_hi_lo(u32 lo_src, u32 hi_src) {        // (hi(lo_src), lo(hi_src))
     return __builtin_amdgcn_perm(hi_src, lo_src, 0x05040302u);
 }
+// Workgroup barrier that orders LDS traffic.  The explicit wait is not redundant: on the back edge of the step loop
+// hipcc (ROCm 7.2) emitted the barrier of a plain __syncthreads() WITHOUT a preceding s_waitcnt lgkmcnt(0) although
+// LDS stores and an LDS atomic were outstanding on that path -- a wave could read the mailbox before the leader's
+// writes had landed and take a different number of barriers than the rest of its workgroup.
+__device__ __forceinline__ void wg_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+}
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -142,7 +150,9 @@ struct Geom {
     static constexpr int OFF_BOARD = 0;
     static constexpr int OFF_GOALS = REGION;
     static constexpr int OFF_RNG = 2 * REGION;             // NB x 4 u64
-    static constexpr int OFF_GSH = OFF_RNG + NB * 32;      // per lane WS words: goal colours, pre-shifted
+    static constexpr int OFF_BOX = OFF_RNG + NB * 32;      // NB x BoardBox: rows <-> leader lanes (fused step)
+    static constexpr int OFF_REC = OFF_BOX + NB * 32;      // NB x sl_env_scalars: the leaders' working copies
+    static constexpr int OFF_GSH = OFF_REC + NB * 64;      // per lane WS words: goal colours, pre-shifted
     // (boards wider than 32 cells keep the goal words in registers in every variant: the region shrinks
     //  to the few hundred bytes the observation epilogue parks its per-board parameters in)
     static constexpr int GSH_BYTES = WAVES_PER_SIMD < 4 ? 512 : WAVES * 64 * WS * 4;
@@ -234,7 +244,11 @@ __device__ __forceinline__ void write_row(unsigned char *region, int gb, int r, 
         }
         return;
     }
+#ifdef SL_EXP_WROW16
+    volatile u16 *c = (volatile u16 *)(region + Gm::PAD) + gb * Gm::HW + r * W;
+#else
     u16 *c = (u16 *)(region + Gm::PAD) + gb * Gm::HW + r * W;
+#endif
 #pragma unroll
     for (int k = 0; k < Gm::WS; ++k) {
         c[k] = (u16)n[k];
@@ -672,42 +686,54 @@ __device__ __forceinline__ int row_side_effect(const RowWords<H, W> &b, const u3
     return (int)((acc & 0xFFFFu) + (acc >> 16));
 }
 
-// ---- execute_actions for one agent with the four touched cells gathered up front ----------------
-// (advance_board.c:217-300; valid for H, W >= 4 where the four cells are distinct)
+// ---- execute_actions for one agent ------------------------------------------------------------------
 __device__ __forceinline__ int wrap1(int v, int n) { return v < 0 ? v + n : (v >= n ? v - n : v); }
 
+// The four cells an action can touch: the agent's (0), one ahead (1), two ahead (2), one behind (3).
+// img: indices into the LDS image (Geom::cell), gix: row-major indices (global memory); (y1, x1): the cell ahead.
 template <int H, int W>
-__device__ __forceinline__ void act_gather(u16 *board, int &ly, int &lx, int action) {
+__device__ __forceinline__ void act_cells(int ly, int lx, int action, int (&img)[4], int (&gix)[4], int &y1, int &x1) {
     using Gm = Geom<H, W>;
     const int dir = (action - 1) & 3;
-    int y1, x1, i0, i1, i2, i3;
     if (Gm::SWZ) {
         const int dy = (dir & 1) ? 0 : dir - 1, dx = (dir & 1) ? 2 - dir : 0;
         y1 = wrap1(ly + dy, H);
         x1 = wrap1(lx + dx, W);
-        i0 = Gm::cell(ly, lx);
-        i1 = Gm::cell(y1, x1);
-        i2 = Gm::cell(wrap1(ly + 2 * dy, H), wrap1(lx + 2 * dx, W));
-        i3 = Gm::cell(wrap1(ly - dy, H), wrap1(lx - dx, W));
+        const int y2 = wrap1(ly + 2 * dy, H), x2 = wrap1(lx + 2 * dx, W), y3 = wrap1(ly - dy, H), x3 = wrap1(lx - dx, W);
+        img[0] = Gm::cell(ly, lx);
+        img[1] = Gm::cell(y1, x1);
+        img[2] = Gm::cell(y2, x2);
+        img[3] = Gm::cell(y3, x3);
+        gix[0] = __mul24(ly, W) + lx;
+        gix[1] = __mul24(y1, W) + x1;
+        gix[2] = __mul24(y2, W) + x2;
+        gix[3] = __mul24(y3, W) + x3;
     } else {
         // the move runs along ONE axis: wrap three positions on that axis and scale them by the axis' pitch in the
-        // row-major image, instead of wrapping three (row, column) pairs (a third of the instructions; every wave
-        // executes this block for the sake of its leader lanes, and the kernel is bound by vector-ALU issue)
+        // row-major image, instead of wrapping three (row, column) pairs
         const bool horiz = (dir & 1) != 0;
         const int pos = horiz ? lx : ly, n = horiz ? W : H;
         const int s = horiz ? 2 - dir : dir - 1;                     // +1 / -1
         const int p1 = wrap1(pos + s, n), p2 = wrap1(p1 + s, n), p3 = wrap1(pos - s, n);
         const int pitch = horiz ? 1 : W;
         const int base = horiz ? __mul24(ly, W) : lx;                // the cell index minus the moving coordinate's share
-        i0 = __mul24(ly, W) + lx;
-        i1 = base + __mul24(p1, pitch);
-        i2 = base + __mul24(p2, pitch);
-        i3 = base + __mul24(p3, pitch);
+        img[0] = __mul24(ly, W) + lx;
+        img[1] = base + __mul24(p1, pitch);
+        img[2] = base + __mul24(p2, pitch);
+        img[3] = base + __mul24(p3, pitch);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gix[k] = img[k];
         y1 = horiz ? ly : p1;
         x1 = horiz ? p1 : lx;
     }
-    u32 c0 = board[i0], c1 = board[i1], c2 = board[i2], c3 = board[i3];
-    if (action == 0 || !(c0 & AGENT)) return;
+}
+
+// execute_actions for one agent on the four cells gathered up front (advance_board.c:217-300; valid for
+// H, W >= 4 where the four cells are distinct).  Returns whether the cells are to be written back.
+__device__ __forceinline__ bool act_rule(u32 (&c)[4], int action, int &ly, int &lx, int y1, int x1) {
+    u32 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+    if (action == 0 || !(c0 & AGENT)) return false;
+    const int dir = (action - 1) & 3;
     c0 = (c0 & ~ORIENT_MASK) | ((u32)dir << ORIENT_SHIFT);
     const bool can_push = (~c0 & c1 & PUSHABLE) != 0;
     if (action >= 5) {
@@ -749,10 +775,23 @@ __device__ __forceinline__ void act_gather(u16 *board, int &ly, int &lx, int act
             }
         }
     }
-    board[i0] = (u16)c0;
-    board[i1] = (u16)c1;
-    board[i2] = (u16)c2;
-    board[i3] = (u16)c3;
+    c[0] = c0;
+    c[1] = c1;
+    c[2] = c2;
+    c[3] = c3;
+    return true;
+}
+
+template <int H, int W>
+__device__ __forceinline__ void act_gather(u16 *board, int &ly, int &lx, int action) {
+    int img[4], gix[4], y1, x1;
+    act_cells<H, W>(ly, lx, action, img, gix, y1, x1);
+    u32 c[4] = {board[img[0]], board[img[1]], board[img[2]], board[img[3]]};
+    if (!act_rule(c, action, ly, lx, y1, x1)) return;
+    board[img[0]] = (u16)c[0];
+    board[img[1]] = (u16)c[1];
+    board[img[2]] = (u16)c[2];
+    board[img[3]] = (u16)c[3];
 }
 
 // update_exit_colors for the board of a leader lane, on the flat LDS image.
@@ -799,14 +838,15 @@ typedef __attribute__((address_space(3))) void *glds_dst_t;
 // SWZ: LDS slot s (16-byte chunk) receives global chunk swz_chunk(s) -- the board-image swizzle of Geom.
 __device__ __forceinline__ int swz_chunk(int s) { return s ^ ((s >> 4) & 7); }     // 8 chunks per row; key (row>>1)&7
 
-template <int MAX_BYTES, bool SWZ = false>
+// NW: number of waves that share the move (wave = 0..NW-1 among them).
+template <int MAX_BYTES, bool SWZ = false, int NW = WAVES>
 __device__ __forceinline__ void dma_to_lds(const unsigned char *__restrict__ src, unsigned char *dst, int bytes,
                                            int lane, int wave) {
     const int nv = bytes >> 4;
     constexpr int NCH = (MAX_BYTES + 1023) / 1024;
 #pragma unroll
-    for (int j = 0; j < (NCH + WAVES - 1) / WAVES; ++j) {
-        const int c = wave + WAVES * j;
+    for (int j = 0; j < (NCH + NW - 1) / NW; ++j) {
+        const int c = wave + NW * j;
         const int s = c * 64 + lane;
         if (s < nv)
             __builtin_amdgcn_global_load_lds((glds_src_t)(src + (SWZ ? swz_chunk(s) : s) * 16),
@@ -814,13 +854,13 @@ __device__ __forceinline__ void dma_to_lds(const unsigned char *__restrict__ src
     }
 }
 
-template <int H, int W>
-__device__ __forceinline__ void load_span(const u16 *__restrict__ src, unsigned char *region, int nbb, int tid) {
+template <int H, int W, int NW = WAVES>
+__device__ __forceinline__ void load_span(const u16 *__restrict__ src, unsigned char *region, int nbb, int lane, int wave) {
     using Gm = Geom<H, W>;
     const int bytes = nbb * Gm::HW * 2;
-    dma_to_lds<Gm::SPAN, Gm::SWZ>((const unsigned char *)src, region + Gm::PAD, bytes, tid & 63, tid >> 6);
+    dma_to_lds<Gm::SPAN, Gm::SWZ, NW>((const unsigned char *)src, region + Gm::PAD, bytes, lane, wave);
     const int nv = bytes >> 4, rem = (bytes & 15) >> 1;          // leftover cells: tail workgroup only
-    if (tid < rem) ((u16 *)(region + Gm::PAD))[nv * 8 + tid] = src[nv * 8 + tid];
+    if (wave == 0 && lane < rem) ((u16 *)(region + Gm::PAD))[nv * 8 + lane] = src[nv * 8 + lane];
 }
 
 __device__ __forceinline__ void store16(u32x4 *p, u32x4 v) {
@@ -878,7 +918,7 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_ad
     unsigned char *board = smem + Gm::OFF_BOARD;
     u64 *rng_lds = (u64 *)(smem + Gm::OFF_RNG) + 4 * Gm::G * wave;
 
-    load_span<H, W>(in + (size_t)e0b * Gm::HW, board, nbb, tid);
+    load_span<H, W>(in + (size_t)e0b * Gm::HW, board, nbb, lane, wave);
     if (lane < 4 * Gm::G && wave * Gm::G + (lane >> 2) < nbb)
         rng_lds[lane] = ((const u64 *)(rng + e0b + wave * Gm::G))[lane];
     const double p = live ? (double)spawn_prob[e] : 0.0;
@@ -1518,11 +1558,39 @@ __device__ __forceinline__ void write_policy_block(const sl_env_batch &env, unsi
 
 // ---- fused env step / rollout ---------------------------------------------------------------------
 
+// Per-board mailbox between a board's row lanes and its leader lane (LDS).
+struct BoardBox {
+    int score;          // rows -> leader: sum(points_table * alive_counts) of the board after the CA step
+    int side;           // rows -> leader (WRAP): cells that differ from the side-effect baseline
+    int gstat;          // rows -> leader: goals_static as the rows see it
+    int reset_level;    // leader -> rows: pool level to load now, or -1
+    int qslot;          // leader -> rows: slot of the finished-episode queue that takes the board, or -1
+    int score0;         // rows -> leader: score of the freshly loaded level
+    int any;            // (box 0 only) bit 0: some board of the workgroup resets, bit 1: some board is queued
+    int pad;
+};
+static_assert(sizeof(BoardBox) == 32, "mailbox stride");
+
 // LEAN: the instantiation for batches without observation, policy-layout tensor, finished-episode queue and
-// wrappers -- the plain step of the headline workload.  The kernel sits at its register limit (126 of 128
-// VGPRs at four wavefronts per SIMD): every cold feature compiled into it costs the hot path scheduling freedom
-// (the queue, the policy layout and the episode streams together: 9.1 vs 8.5 us per two-slice C3 step).
-template <int H, int W, bool LDS_LUT, bool SPAWN, bool WRAP, bool LEAN>
+// wrappers -- the plain step of the headline workload; every cold feature compiled into it costs the hot path
+// scheduling freedom.
+//
+// Division of labour (round 3).  Everything that concerns a board as a whole -- the agent's move, the exit repaint,
+// reward / done / episode accounting, the wrappers' arithmetic, the decision to reset -- is serial, branchy code
+// for ONE lane per board.  Run by the board's first row lane (as rounds 1-2 did), every wavefront executes it for the
+// sake of two lanes, and its latency chain (dependent LDS and global accesses) sits between the loads and the CA.
+// Now wavefront 0 is the workgroup's LEADER wave: its lane q speaks for board q of the workgroup, and
+//   * it issues none of the bulk DMA (the other three waves move the spans), so its memory counters are free for the
+//     dependent loads of the agent's move: record + action, then the four cells the move can touch, straight from
+//     global memory (the previous launch's board) -- the move is DECIDED while the spans are in flight and costs
+//     four LDS stores once they have landed;
+//   * row lanes and leader lanes talk through a mailbox in LDS and workgroup barriers (four per single step).
+//
+// ONE: the instantiation for single-step launches (T == 1, what step() issues).  Without a step loop there is nothing
+// for the compiler to hoist: left as a loop, every loop-invariant address and constant of the RARE blocks (reset, exit
+// tables, queue, the division by the pool size) is computed ahead of the loop by every wave of every launch --
+// some 150 instructions between the load barrier and the first CA pass.
+template <int H, int W, bool LDS_LUT, bool SPAWN, bool WRAP, bool LEAN, bool ONE>
 __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_env_rollout_rowlane(
     // the eight arguments the prologue needs before anything else come first: with
     // -amdgpu-kernarg-preload-count=8 they arrive in SGPRs with the wave instead of behind an s_load
@@ -1534,11 +1602,12 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
     // 13.8 in the first steps after a reset: loads through a global pointer are not invariant for the compiler,
     // which re-fetches fields after every store with a scalar-cache round trip each time, on the leader's
     // critical path; kernel-argument loads are.)
-    sl_env_batch env, int hot_E, int tstride, int T, sl_step_out *__restrict__ out_rec,
+    sl_env_batch env, int hot_E, int tstride, int T_arg, sl_step_out *__restrict__ out_rec,
     float *__restrict__ reward_t, uint8_t *__restrict__ done_t, double *__restrict__ shaped_t,
     const Jump *__restrict__ jump) {
     using Gm = Geom<H, W>;
     constexpr int WS = Gm::WS, HW = Gm::HW;
+    const int T = ONE ? 1 : T_arg;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // envs [hot_first, hot_end) of the batch: one slice (slhip_env_step_slices) or all of it
@@ -1551,13 +1620,20 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
     const int gb = wave * Gm::G + g;
     const bool rowl = lane < Gm::NL && gb < nbb;       // holds a row: its own, or a halo copy (V_SHIFT)
     const bool live = rowl && lm.real;                 // owns row r of board gb
-    const bool leader = live && r == 0;
-    const unsigned e = e0b + (rowl ? gb : 0);
+    const bool rlead = live && r == 0;                 // the row lane that writes the board's mailbox
+    const bool lwave = wave == 0;                      // the leader wave ...
+    const bool lead = lwave && lane < nbb;             // ... whose lane q is the leader of board q
+    const int lq = lead ? lane : 0;
+    const unsigned e = e0b + (rowl ? gb : 0);          // the row lane's env
+    const unsigned el = e0b + lq;                      // the leader lane's env
     unsigned char *board = smem + Gm::OFF_BOARD, *goals = smem + Gm::OFF_GOALS;
     u16 *board16 = (u16 *)(board + Gm::PAD) + (live ? gb : 0) * HW;
+    u16 *lboard16 = (u16 *)(board + Gm::PAD) + lq * HW;
     u64 *rng_lds = (u64 *)(smem + Gm::OFF_RNG) + 4 * Gm::G * wave;
+    u64 *lrng = (u64 *)(smem + Gm::OFF_RNG) + 4 * lq;
+    BoardBox *box = (BoardBox *)(smem + Gm::OFF_BOX);
     // goal colours of the lane's row, pre-shifted for the score index: in registers where the
-    // budget allows (spawner-free variants: 119 VGPRs; 64-wide boards run 2 waves/SIMD), else in LDS
+    // budget allows (spawner-free variants; 64-wide boards run 2 waves/SIMD), else in LDS
     constexpr bool GSH_REG = !SPAWN || Gm::WAVES_PER_SIMD < 4;
     u32 gsh_reg[GSH_REG ? WS : 1];
     u32 *gsh_lane = GSH_REG ? gsh_reg : (u32 *)(smem + Gm::OFF_GSH) + (wave * 64 + lane) * WS;
@@ -1573,37 +1649,66 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
     const u32 cell_mask = vreg(LDS_LUT ? (SCORE_CELL_MASK & 0x7FFF7FFFu) : SCORE_CELL_MASK), c100 = vreg(0x01000100u);
 
     SL_STAMP(0);
-    // Prologue, written so that nothing waits before the bulk loads are in flight:
-    //  * the kernel arguments the loads need are fetched in one batch (the compiler otherwise sinks
-    //    each s_load next to its first use: six dependent scalar-cache round trips in a row);
-    //  * the per-board record is loaded by EVERY lane, unconditionally (a load inside `if (leader)`
-    //    is waited for at the end of that block, in front of the DMA issue).  Only the leader lane's
-    //    copy of the per-episode fields is ever used or updated.
+    // Prologue.  The kernel arguments the loads need are fetched in one batch (the compiler otherwise sinks each
+    // s_load next to its first use: dependent scalar-cache round trips in a row).
     const u16 *k_board = hot_board, *k_goals = hot_goals;
     const sl_pcg64 *k_rng = hot_rng;
     const int8_t *k_lut = hot_lut;
-    sl_env_scalars *const sc = hot_scalars + e;
-    const int32_t *k_act = actions + e;
     asm volatile("" ::"s"(k_board), "s"(k_goals), "s"(k_rng), "s"(k_lut));
-    const sl_env_scalars rec = *sc;     // one 64-byte record (same address within a board: broadcast)
-    int action = *k_act;
-    // everything bulky goes through the LDS DMA
-    dma_to_lds<Gm::NB * 32>((const unsigned char *)(k_rng + e0b), smem + Gm::OFF_RNG, nbb * 32, lane, wave);
-    if (LDS_LUT) dma_to_lds<4096>((const unsigned char *)k_lut, smem + Gm::OFF_LUT, 4096, lane, wave);
-    load_span<H, W>(k_board + (size_t)e0b * HW, board, nbb, tid);
-    load_span<H, W>(k_goals + (size_t)e0b * HW, goals, nbb, tid);
-    if (WRAP) {
-        dma_to_lds<Gm::NB * (int)sizeof(sl_wrap_state)>((const unsigned char *)(env.wrap.state + e0b),
-                                                        smem + Gm::OFF_WST, nbb * (int)sizeof(sl_wrap_state),
-                                                        lane, wave);
-        if (env.wrap.flags & SL_WRAP_MOVEMENT)
-            dma_to_lds<Gm::MVT_N * 8>((const unsigned char *)env.wrap.move_table, smem + Gm::OFF_MVT,
-                                      min(env.wrap.move_table_len & ~1, Gm::MVT_N) * 8, lane, wave);
+    // what the rows need of their board's record (every lane loads, unconditionally: a load inside a branch is
+    // waited for at the end of that branch, in front of the DMA issue)
+    const sl_env_scalars *const sc = hot_scalars + e;
+    int gstatic = sc->goals_static, level = sc->level_idx;
+    double p = (double)sc->spawn_prob;
+    u32 lut_base = (u32)sc->table_idx * (u32)SCORE_LUT_BYTES;
+    // The leader lanes' view of their boards: the env records are copied to LDS by the DMA and worked on there (a
+    // dozen per-board values held in registers for the whole launch cost every wave of the kernel those registers);
+    // only the agent's location, which the move of step 0 needs before the copies have landed, is loaded directly.
+    static_assert(sizeof(sl_env_scalars) == 64, "record stride");
+    sl_env_scalars *const lrec = (sl_env_scalars *)(smem + Gm::OFF_REC) + lq;
+    int ly = -1, lx = 0, exit0 = -1, action = 0;
+    bool pool_exits = false;                            // the board's exit table: its own row of env.exit_locs, or
+                                                        // (after a reset in this launch) the pool level's
+    int pre_i[4] = {0, 0, 0, 0}, pre_y1 = 0, pre_x1 = 0;   // the move of step 0, on cells taken from global memory
+    u32 pre_c[4] = {0u, 0u, 0u, 0u};
+    bool pre_write = false;
+    if (lwave) {
+        ly = hot_scalars[el].agent_row;
+        lx = hot_scalars[el].agent_col;
+        action = actions[el];
+        exit0 = env.exit_locs[(size_t)el * E];
+        if (T > 0 && lead && ly >= 0) {
+            // safelife_env.py:151 for the first step of the launch: the four cells the move can touch are
+            // fetched from global memory now (the previous launch's board); they are not waited for here --
+            // the leader wave goes through the load barrier and its own goal rows first
+            int gi[4];
+            act_cells<H, W>(ly, lx, action, pre_i, gi, pre_y1, pre_x1);
+            const u16 *src = k_board + (size_t)el * HW;
+            pre_c[0] = src[gi[0]];
+            pre_c[1] = src[gi[1]];
+            pre_c[2] = src[gi[2]];
+            pre_c[3] = src[gi[3]];
+        }
+    } else {
+        // everything bulky goes through the LDS DMA, issued by the three row-only waves
+        constexpr int DW = WAVES - 1;
+        const int dw = wave - 1;
+        dma_to_lds<Gm::NB * 32, false, DW>((const unsigned char *)(k_rng + e0b), smem + Gm::OFF_RNG, nbb * 32, lane, dw);
+        dma_to_lds<Gm::NB * 64, false, DW>((const unsigned char *)(hot_scalars + e0b), smem + Gm::OFF_REC, nbb * 64, lane, dw);
+        if (LDS_LUT) dma_to_lds<4096, false, DW>((const unsigned char *)k_lut, smem + Gm::OFF_LUT, 4096, lane, dw);
+        load_span<H, W, DW>(k_board + (size_t)e0b * HW, board, nbb, lane, dw);
+        load_span<H, W, DW>(k_goals + (size_t)e0b * HW, goals, nbb, lane, dw);
+        if (WRAP) {
+            dma_to_lds<Gm::NB * (int)sizeof(sl_wrap_state), false, DW>((const unsigned char *)(env.wrap.state + e0b),
+                                                                       smem + Gm::OFF_WST,
+                                                                       nbb * (int)sizeof(sl_wrap_state), lane, dw);
+            if (env.wrap.flags & SL_WRAP_MOVEMENT)
+                dma_to_lds<Gm::MVT_N * 8, false, DW>((const unsigned char *)env.wrap.move_table, smem + Gm::OFF_MVT,
+                                                     min(env.wrap.move_table_len & ~1, Gm::MVT_N) * 8, lane, dw);
+        }
     }
     // Every kernel argument the rest of the kernel needs that did not arrive preloaded: fetched in ONE batch
-    // here, in the shadow of the bulk loads.  (Left alone the compiler fetches them in dependent groups: each
-    // is a scalar-cache miss on a kernel-argument segment the host has just rewritten, ~0.35 us apiece --
-    // the exit table's pointer used to be waited for on its own ahead of this batch.)
+    // here, in the shadow of the bulk loads.
     {
         const int a0 = env.time_limit, a1 = env.exit_points, a2 = env.auto_reset, a3 = env.L, a4 = env.level_stride;
         const void *p0 = out_rec, *p1 = env.pool_board, *p2 = env.pool_goals, *p3 = env.pool_exit_locs;
@@ -1611,21 +1716,16 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
         asm volatile("" ::"s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(T), "s"(p0), "s"(p1), "s"(p2), "s"(p3),
                      "s"(p4), "s"(p5), "s"(p6), "s"(reward_t), "s"(done_t));
     }
-    const int32_t *exits = env.exit_locs + (size_t)e * E;
-    int exit0 = exits[0];
-    int ly = rec.agent_row, lx = rec.agent_col, steps = rec.num_steps, old_value = rec.old_value;
-    int required = rec.required_points, initial = rec.initial_points, ep_len = rec.episode_length;
-    int gstatic = rec.goals_static, level = rec.level_idx, episodes = rec.episode_idx;
-    float ep_rew = rec.episode_reward;
-    bool active = rec.is_active != 0;
-    double p = (double)rec.spawn_prob;
-    u32 lut_base = (u32)rec.table_idx * (u32)SCORE_LUT_BYTES;
-    int open0 = rec.exit_open_at_reset;                 // exit paint of the side-effect baseline
     typedef __attribute__((address_space(3))) int *lds_int;       // (a generic volatile pointer would go through FLAT)
     lds_int dirty_flag = (lds_int)(smem + Gm::OFF_GOALS);              // in the region's leading pad
     if (tid == 0) *dirty_flag = 0;
+    const bool has_queue = !LEAN && env.finished.capacity > 0;
+    const bool hand_over = env.auto_reset || has_queue;           // (uniform) leaders may ask the rows for something
     SL_STAMP(1);
-    __syncthreads();
+    // the load barrier: the DMA waves wait for their loads, the leader wave only for its LDS stores (it moved none
+    // of the spans, and what it has in flight is its own business)
+    if (lwave) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else __syncthreads();
     SL_STAMP(2);
 
     RowWords<H, W> b;
@@ -1634,17 +1734,18 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
     //  "defined, value irrelevant" costs no instruction, thirteen zeroing moves would)
 #pragma unroll
     for (int k = 0; k < WS; ++k) asm volatile("" : "=v"(b[k]));
+#ifndef SL_EXP_NOSCORE
     if (live) {
         read_row<H, W>(goals, gb, r, b);
 #pragma unroll
         for (int k = 0; k < WS; ++k) gsh_lane[k] = goal_shift(b[k]);
     }
+#endif
     // Goals still undecided (the first step after a reset; the reference finds out by advancing them once,
     // safelife_game.py:753-760): a goal array without a single ALIVE or SPAWNING cell cannot change and draws
     // nothing, so it IS static and the second CA pass of that step is skipped -- the usual case for every level a
     // reset loads.  Decided here, once per launch, for the step this launch is about to take (an env that
     // resets in the middle of a T-step launch takes the two-pass route for one step).
-#ifndef SL_NO_SHORTCUT1
     if (T > 0 && __ballot(rowl && gstatic == 0)) {
         u32 goal_bits = 0;              // (b still holds the goal row; halves beyond an odd width are zero)
         if (live) {
@@ -1654,11 +1755,125 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
         const int restless = group_total<H, W>(live && (goal_bits & 0x00810081u) ? 1 : 0, rowl ? g : 0);
         if (rowl && gstatic == 0 && restless == 0) gstatic = 1;
     }
-#endif
-    bool goals_dirty = false;
+    if (rlead) box[gb].gstat = gstatic;
     SL_STAMP(3);
 
-    for (int t = 0; t < T; ++t) {
+    // What the leaders ask of the rows at the end of a step -- queue the finished episode's board, load the next
+    // level -- is carried out behind the NEXT workgroup barrier: the one at the top of the following step, or the
+    // one in front of the final stores.
+    auto hand_over_block = [&]() {
+        const int any = box[0].any;
+        if (!LEAN && (any & 2)) {
+            // the step that ended an episode queued it for the side-effect pass (include/safelife_hip.h): the board
+            // as the agent left it, from the LDS image, before any reset reloads the slot
+            const int slot = rowl ? box[gb].qslot : -1;
+            if (live && slot >= 0) {
+                u16 *dst = env.finished.boards + (size_t)slot * HW + r * W;
+#pragma unroll 1
+                for (int x = 0; x < W; ++x) dst[x] = board16[Gm::cell(r, x)];      // (rare: kept out of the register budget)
+            }
+        }
+        if (!(any & 1)) return;
+        // on-device auto-reset (training/base_algo.py:231-236 calls env.reset() after a done step)
+        const int new_level = rowl ? box[gb].reset_level : -1;
+        const bool mine = live && new_level >= 0;
+        if (rowl && new_level >= 0) gstatic = 0;
+        if (mine) {
+            // (opaque copy of the row index: addresses of this rare block are formed here, not hoisted above the
+            //  step loop as loop invariants and spilled)
+            int r2 = r;
+            asm volatile("" : "+v"(r2));
+            level = new_level;
+            const u16 *pb = env.pool_board + (size_t)level * HW, *pg = env.pool_goals + (size_t)level * HW;
+            u16 *gdst = (u16 *)(goals + Gm::PAD) + gb * HW;
+            // each lane copies its OWN row of the new level: W cells = one contiguous run, fetched as 4-byte
+            // pairs (2-byte aligned: the hardware splits what it must) all issued before the first is used --
+            // one memory round trip for the board and one for the goals, not one per cell
+            typedef u32 u32_a2 __attribute__((aligned(2)));
+            const u16 *rows[2] = {pb + r2 * W, pg + r2 * W};
+            u16 *imgs[2] = {board16, gdst};
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                u32 tw[WS];
+#pragma unroll
+                for (int j = 0; j < W / 2; ++j) tw[j] = *(const u32_a2 *)(rows[a] + 2 * j);
+                if (Gm::ODD) tw[WS - 1] = rows[a][W - 1];
+#pragma unroll
+                for (int j = 0; j < W / 2; ++j) {
+                    imgs[a][Gm::cell(r, 2 * j)] = (u16)tw[j];
+                    imgs[a][Gm::cell(r, 2 * j + 1)] = (u16)(tw[j] >> 16);
+                }
+                if (Gm::ODD) imgs[a][Gm::cell(r, W - 1)] = (u16)tw[WS - 1];
+            }
+            lut_base = (u32)env.pool_scalars[level].table_idx * (u32)SCORE_LUT_BYTES;
+            p = (double)env.pool_scalars[level].spawn_prob;
+            if (r2 < 4) rng_lds[4 * g + r2] = ((const u64 *)(env.pool_rng + level))[r2];
+            for (int k = r2; k < E; k += H)
+                env.exit_locs[(size_t)e * E + k] = env.pool_exit_locs[(size_t)level * E + k];
+            *dirty_flag = 1;                             // (any wave that changes its goals raises the flag)
+        }
+        wave_sync();
+        if (mine) {
+            read_row<H, W>(goals, gb, r, b);
+#pragma unroll
+            for (int k = 0; k < WS; ++k) gsh_lane[k] = goal_shift(b[k]);
+            read_row<H, W>(board, gb, r, b);
+        }
+        const int s0 = group_total<H, W>(
+            mine ? row_score<H, W, LDS_LUT>(b, gsh_lane, lut, lut_base, lds_lut, cell_mask, c100) : 0, live ? g : 0);
+        if (rlead) {
+            box[gb].score0 = s0;
+            box[gb].gstat = gstatic;
+        }
+        wg_sync();
+        if (lead && box[lq].reset_level >= 0) {
+            const int l_level = box[lq].reset_level;
+            const int episodes = lrec->episode_idx + 1;
+            if (env.stream_salt) {          // the new episode's own stream (the rows wrote the level's state above)
+                u64 hi = lrng[0], lo = lrng[1];
+                sl_episode_stream(hi, lo, env.stream_salt + (int)el, episodes);
+                lrng[0] = hi;
+                lrng[1] = lo;
+            }
+            pool_exits = true;                                  // (the pool's table: never written by this launch)
+            const int32_t *exits = env.pool_exit_locs + (size_t)l_level * E;
+            exit0 = exits[0];
+            const sl_level_scalars lv = env.pool_scalars[l_level];
+            ly = lv.agent_row;
+            lx = lv.agent_col;
+            const int fresh = box[lq].score0;
+            const int open0 = recolor_exits_lds<H, W>(lboard16, ly, lx, exits, exit0, E, fresh, lv.initial_points,
+                                                      lv.required_reset, env.exit_points) ? 1 : 0;
+            if (WRAP) wrap_reset(wst[lq], ly, lx);
+            const int exited = ly >= 0 ? (has_exited(lboard16[Gm::cell(ly, lx)]) ? 1 : 0) : 0;
+            sl_env_scalars rec;
+            rec.agent_row = ly;
+            rec.agent_col = lx;
+            rec.num_steps = 0;
+            rec.old_value = fresh + env.exit_points * exited;
+            rec.required_points = lv.required_step;
+            rec.initial_points = lv.initial_points;
+            rec.table_idx = lv.table_idx;
+            rec.level_idx = l_level;
+            rec.episode_idx = episodes;
+            rec.episode_length = 0;
+            rec.episode_reward = 0.0f;
+            rec.spawn_prob = lv.spawn_prob;
+            rec.goals_static = 0;
+            rec.is_active = 1;
+            rec.exit_open_at_reset = open0;
+            rec.loaded = 1;
+            *lrec = rec;
+        }
+        wg_sync();
+    };
+
+    for (int t = 0;; ++t) {
+        if (t > 0) {
+            wg_sync();                             // the leaders' requests of the step before; after the last
+            if (hand_over) hand_over_block();            // step also the barrier in front of the stores
+        }
+        if (t >= T) break;
         if (WRAP && (env.wrap.flags & SL_WRAP_SIDE_EFFECT)) {
             // baseline row (level, r) of every lane -> LDS, asynchronously; read after the CA pass
             const u32 *src = env.wrap.pool_baseline + ((size_t)level * H + r) * WS;
@@ -1667,13 +1882,21 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
                 __builtin_amdgcn_global_load_lds((glds_src_t)(src + k), (glds_dst_t)(base_rows + k * 256), 4, 0, 0);
         }
         // safelife_env.py:151
-#ifndef SL_EXP_NOACT
-        if (leader && ly >= 0) {
-            if (t > 0) action = actions[(size_t)t * B + e];
-            act_gather<H, W>(board16, ly, lx, action);
+        if (lwave) {
+            if (t == 0) {
+                if (lead && ly >= 0) pre_write = act_rule(pre_c, action, ly, lx, pre_y1, pre_x1);
+                if (pre_write) {
+                    lboard16[pre_i[0]] = (u16)pre_c[0];
+                    lboard16[pre_i[1]] = (u16)pre_c[1];
+                    lboard16[pre_i[2]] = (u16)pre_c[2];
+                    lboard16[pre_i[3]] = (u16)pre_c[3];
+                }
+            } else if (lead && ly >= 0) {
+                action = actions[(size_t)t * B + el];
+                act_gather<H, W>(lboard16, ly, lx, action);
+            }
         }
-#endif
-        wave_sync();
+        wg_sync();                                 // the move is in the image
         SL_STAMP(4);
         // safelife_env.py:152 : board first, then goals unless they are static (safelife_game.py:746-761)
         const bool dyn = rowl && gstatic != 1;
@@ -1714,12 +1937,12 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
                     for (int k = 0; k < WS; ++k)
                         diff |= ((b[k] ^ old[k]) | (b[k] & 0x00800080u)) & (Gm::vm1(k) * 0xFFFFu);
                 }
-                const int changed = group_total<H, W>(mine && diff ? 1 : 0, rowl ? g : 0);
-                if (has && gstatic == 0) gstatic = changed ? 2 : 1;
+                const int moved = group_total<H, W>(mine && diff ? 1 : 0, rowl ? g : 0);
+                if (has && gstatic == 0) gstatic = moved ? 2 : 1;
                 if (mine) {
 #pragma unroll
                     for (int k = 0; k < WS; ++k) gsh_lane[k] = goal_shift(b[k]);
-                    goals_dirty = true;
+                    *dirty_flag = 1;
                 }
             }
             if (mine && changed) write_row<H, W>(img, gb, r, b);
@@ -1730,57 +1953,101 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
         }
         SL_STAMP(5);
         // safelife_env.py:153-160
-        const int score = group_total<H, W>(
+#ifdef SL_EXP_NOSCORE
+        const int score_rows = 0;
+#else
+        const int score_rows = group_total<H, W>(
             live ? row_score<H, W, LDS_LUT>(b, gsh_lane, lut, lut_base, lds_lut, cell_mask, c100) : 0, live ? g : 0);
-        wave_sync();
+#endif
+        if (rlead) {
+            box[gb].score = score_rows;
+            box[gb].gstat = gstatic;
+        }
+        wg_sync();                                 // scores in the mailbox, new boards in the images
         SL_STAMP(6);
-        bool done = false, ended = false, q_success = false;
-        float w_reward = 0.0f;          // WRAP: this step's outputs, kept for the wrapper stage below
+        bool done = false;
+        float w_reward = 0.0f, w_ep_rew = 0.0f;     // WRAP: this step's outputs, kept for the wrapper stage below
         bool w_times_up = false, w_open = false;
         int w_exits = 0;
-        if (leader) {
-            w_open = recolor_exits_lds<H, W>(board16, ly, lx, exits, exit0, E, score, initial, required,
-                                       env.exit_points, WRAP ? &w_exits : nullptr);
-            steps += 1;
-            const bool times_up = steps >= env.time_limit;
-            float reward = 0.0f;
-            bool success = false;
-            done = true;
-            if (ly >= 0) {
-                const u32 cell = board16[Gm::cell(ly, lx)];
-                success = has_exited(cell);
-                const int value = score + (success ? env.exit_points : 0);
-                reward = (float)((value - old_value) * (active ? 1 : 0));
-                old_value = value;
-                done = !(cell & AGENT) || times_up;
-            }
-            ep_rew += reward;
-            ep_len += active ? 1 : 0;
-            ended = done && active;             // this step ends the episode
-            q_success = success;
-            active = active && !done;
-            w_reward = reward;
-            w_times_up = times_up;
-            sl_step_out o;
-            o.reward = reward;
-            o.done = done;
-            o.success = success;
-            o.times_up = times_up;
-            o.reserved = 0;
-            o.episode_reward = ep_rew;
-            o.episode_length = ep_len;
-            unsigned e3 = e;
-            asm volatile("" : "+v"(e3));
-            out_rec[e3] = o;
+        if (lwave) {
+            if (lane == 0) box[0].any = 0;
+            if (lead) {
+                const int score = box[lq].score;
+                const int32_t *exits = pool_exits ? env.pool_exit_locs + (size_t)lrec->level_idx * E
+                                                  : env.exit_locs + (size_t)el * E;
+                const bool active = lrec->is_active != 0;
+                w_open = recolor_exits_lds<H, W>(lboard16, ly, lx, exits, exit0, E, score, lrec->initial_points,
+                                                 lrec->required_points, env.exit_points, WRAP ? &w_exits : nullptr);
+                const int steps = lrec->num_steps + 1;
+                const bool times_up = steps >= env.time_limit;
+                float reward = 0.0f;
+                bool success = false;
+                done = true;
+                if (ly >= 0) {
+                    const u32 cell = lboard16[Gm::cell(ly, lx)];
+                    success = has_exited(cell);
+                    const int value = score + (success ? env.exit_points : 0);
+                    reward = (float)((value - lrec->old_value) * (active ? 1 : 0));
+                    lrec->old_value = value;
+                    done = !(cell & AGENT) || times_up;
+                }
+                const float ep_rew = lrec->episode_reward + reward;
+                const int ep_len = lrec->episode_length + (active ? 1 : 0);
+                const bool ended = done && active;      // this step ends the episode
+                lrec->agent_row = ly;
+                lrec->agent_col = lx;
+                lrec->num_steps = steps;
+                lrec->episode_reward = ep_rew;
+                lrec->episode_length = ep_len;
+                lrec->is_active = active && !done ? 1 : 0;
+                w_reward = reward;
+                w_times_up = times_up;
+                w_ep_rew = ep_rew;
+                sl_step_out o;
+                o.reward = reward;
+                o.done = done;
+                o.success = success;
+                o.times_up = times_up;
+                o.reserved = 0;
+                o.episode_reward = ep_rew;
+                o.episode_length = ep_len;
+                unsigned e3 = el;
+                asm volatile("" : "+v"(e3));
+                out_rec[e3] = o;
 #ifndef SL_TRACE
-            if (reward_t) reward_t[(size_t)t * B + e] = reward;
-            if (done_t) done_t[(size_t)t * B + e] = done;
+                if (reward_t) reward_t[(size_t)t * B + el] = reward;
+                if (done_t) done_t[(size_t)t * B + el] = done;
 #endif
+                if (hand_over) {
+                    int slot = -1, next_level = -1, any = 0;
+                    if (has_queue && ended) {
+                        slot = atomicAdd(env.finished.count, 1);
+                        if (slot < env.finished.capacity) {
+                            // (the 32-byte record as two vector stores assembled in registers: a struct temporary
+                            //  ends up in scratch memory here)
+                            const u32 flags = (success ? 1u : 0u) | ((times_up ? 1u : 0u) << 8);
+                            u32x4 *qdst = (u32x4 *)(env.finished.records + slot);
+                            qdst[0] = u32x4{(u32)((int)el + env.finished.env_base), (u32)lrec->level_idx, (u32)steps,
+                                            (u32)lrec->episode_idx};
+                            qdst[1] = u32x4{__float_as_uint(lrec->spawn_prob), __float_as_uint(ep_rew), (u32)ep_len, flags};
+                            any |= 2;
+                        } else {
+                            slot = -1;
+                        }
+                    }
+                    if (env.auto_reset && done) {
+                        next_level = (lrec->level_idx + env.level_stride) % env.L;
+                        any |= 1;
+                    }
+                    box[lq].qslot = slot;
+                    box[lq].reset_level = next_level;
+                    if (any) atomicOr(&box[0].any, any);
+                }
+            }
         }
         if (WRAP) {     // env_wrappers.py: movement bonus, exit bonus, side-effect penalty (float64)
-            int side = 0;
             if (env.wrap.flags & SL_WRAP_SIDE_EFFECT) {
-                wave_sync();                                     // the leader's exit repaint is in LDS
+                wg_sync();                                 // the leaders' exit repaint is in the images
                 int mine = 0;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // baseline rows have landed
                 if (live) {
@@ -1789,154 +2056,40 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
                                                  (env.wrap.flags & SL_WRAP_IGNORE_REWARD_CELLS) != 0,
                                                  vreg(~(PLAYER | (PLAYER << 16))), cst.m1);
                 }
-                side = group_total<H, W>(mine, rowl ? g : 0);
+                const int side_rows = group_total<H, W>(mine, rowl ? g : 0);
+                if (rlead) box[gb].side = side_rows;
+                wg_sync();
             }
-            if (leader) {
+            if (lead) {
+                int side = (env.wrap.flags & SL_WRAP_SIDE_EFFECT) ? box[lq].side : 0;
                 // exit cells are ignored by the reference; here they all differ from the baseline (its
                 // exits carry the reset's paint) or none does
-                if (w_open != (open0 != 0)) side -= w_exits;
-                const double shaped = wrap_step(env.wrap, wst[gb], mvt, w_reward, done, w_times_up, ep_rew, ly, lx, side);
-                unsigned e4 = e;
+                if (w_open != (lrec->exit_open_at_reset != 0)) side -= w_exits;
+                const double shaped = wrap_step(env.wrap, wst[lq], mvt, w_reward, done, w_times_up, w_ep_rew, ly, lx, side);
+                unsigned e4 = el;
                 asm volatile("" : "+v"(e4));
                 env.wrap.shaped_reward[e4] = shaped;
                 if (shaped_t) shaped_t[(size_t)t * B + e4] = shaped;
             }
         }
-        // the step that ends an episode queues it for the side-effect pass (include/safelife_hip.h): a record and
-        // the board as the agent left it, taken from the LDS image before any auto-reset reloads the slot
-        if (!LEAN && env.finished.capacity > 0 && __ballot(ended)) {
-            int slot = -1;
-            if (ended) {
-                slot = atomicAdd(env.finished.count, 1);
-                if (slot < env.finished.capacity) {
-                    // (the 32-byte record as two vector stores assembled in registers: a struct temporary ends
-                    //  up in scratch memory here)
-                    const u32 flags = (q_success ? 1u : 0u) | ((steps >= env.time_limit ? 1u : 0u) << 8);
-                    u32x4 *qdst = (u32x4 *)(env.finished.records + slot);
-                    qdst[0] = u32x4{(u32)((int)e + env.finished.env_base), (u32)level, (u32)steps, (u32)episodes};
-                    qdst[1] = u32x4{__float_as_uint((float)p), __float_as_uint(ep_rew), (u32)ep_len, flags};
-                } else {
-                    slot = -1;
-                }
-            }
-            wave_sync();                         // the leader's exit repaint is in the LDS image
-            const int mine_slot = group_total<H, W>(slot + 1, rowl ? g : 0) - 1;     // only leaders contribute
-            if (live && mine_slot >= 0) {
-                u16 *dst = env.finished.boards + (size_t)mine_slot * HW + r * W;
-#pragma unroll 1
-                for (int x = 0; x < W; ++x) dst[x] = board16[Gm::cell(r, x)];      // (rare: kept out of the register budget)
-            }
-        }
-        // on-device auto-reset (training/base_algo.py:231-236 calls env.reset() after a done step)
-        if (env.auto_reset && __ballot(leader && done)) {
-            const int flag = group_total<H, W>(leader && done ? 1 : 0, rowl ? g : 0);
-            const bool mine = live && flag != 0;
-            if (rowl && flag != 0) gstatic = 0;
-            if (mine) {
-                // (opaque copy of the row index: addresses of this rare block are formed here, not hoisted above the
-                //  step loop as loop invariants and spilled)
-                int r2 = r;
-                asm volatile("" : "+v"(r2));
-                level = (level + env.level_stride) % env.L;
-                const u16 *pb = env.pool_board + (size_t)level * HW, *pg = env.pool_goals + (size_t)level * HW;
-                u16 *gdst = (u16 *)(goals + Gm::PAD) + gb * HW;
-                // each lane copies its OWN row of the new level: W cells = one contiguous run, fetched as 4-byte
-                // pairs (2-byte aligned: the hardware splits what it must) all issued before the first is used --
-                // one memory round trip for the board and one for the goals, not one per cell (a wave that resets
-                // holds up its whole workgroup at the end barrier, and the launch behind it)
-                typedef u32 u32_a2 __attribute__((aligned(2)));
-                const u16 *rows[2] = {pb + r2 * W, pg + r2 * W};
-                u16 *imgs[2] = {board16, gdst};
-#pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    u32 tw[WS];
-#pragma unroll
-                    for (int j = 0; j < W / 2; ++j) tw[j] = *(const u32_a2 *)(rows[a] + 2 * j);
-                    if (Gm::ODD) tw[WS - 1] = rows[a][W - 1];
-#pragma unroll
-                    for (int j = 0; j < W / 2; ++j) {
-                        imgs[a][Gm::cell(r, 2 * j)] = (u16)tw[j];
-                        imgs[a][Gm::cell(r, 2 * j + 1)] = (u16)(tw[j] >> 16);
-                    }
-                    if (Gm::ODD) imgs[a][Gm::cell(r, W - 1)] = (u16)tw[WS - 1];
-                }
-                lut_base = (u32)env.pool_scalars[level].table_idx * (u32)SCORE_LUT_BYTES;
-                p = (double)env.pool_scalars[level].spawn_prob;
-                gstatic = 0;
-                if (r2 < 4) rng_lds[4 * g + r2] = ((const u64 *)(env.pool_rng + level))[r2];
-                for (int k = r2; k < E; k += H)
-                    env.exit_locs[(size_t)e * E + k] = env.pool_exit_locs[(size_t)level * E + k];
-                goals_dirty = true;
-            }
-            wave_sync();
-            if (mine) {
-                read_row<H, W>(goals, gb, r, b);
-#pragma unroll
-                for (int k = 0; k < WS; ++k) {
-                    gsh_lane[k] = goal_shift(b[k]);
-                }
-                read_row<H, W>(board, gb, r, b);
-            }
-            const int s0 = group_total<H, W>(
-                mine ? row_score<H, W, LDS_LUT>(b, gsh_lane, lut, lut_base, lds_lut, cell_mask, c100) : 0,
-                live ? g : 0);
-            if (mine && r == 0) {
-                episodes += 1;
-                if (env.stream_salt) {      // the new episode's own stream (lanes r < 4 wrote the level's state above)
-                    u64 hi = rng_lds[4 * g + 0], lo = rng_lds[4 * g + 1];
-                    sl_episode_stream(hi, lo, env.stream_salt + (int)e, episodes);
-                    rng_lds[4 * g + 0] = hi;
-                    rng_lds[4 * g + 1] = lo;
-                }
-                exits = env.pool_exit_locs + (size_t)level * E;   // never written by this launch
-                exit0 = exits[0];
-                const sl_level_scalars lv = env.pool_scalars[level];
-                ly = lv.agent_row;
-                lx = lv.agent_col;
-                initial = lv.initial_points;
-                open0 = recolor_exits_lds<H, W>(board16, ly, lx, exits, exit0, E, s0, initial, lv.required_reset,
-                                          env.exit_points) ? 1 : 0;
-                if (WRAP) wrap_reset(wst[gb], ly, lx);
-                const int exited = ly >= 0 ? (has_exited(board16[Gm::cell(ly, lx)]) ? 1 : 0) : 0;
-                old_value = s0 + env.exit_points * exited;
-                required = lv.required_step;
-                steps = 0;
-                active = true;
-                ep_rew = 0.0f;
-                ep_len = 0;
-            }
-            wave_sync();
-        }
     }
 
+    if (T <= 0) wg_sync();
     SL_STAMP(7);
-    // write-back
-    if (leader) {
-        sl_env_scalars rec;
-        rec.agent_row = ly;
-        rec.agent_col = lx;
-        rec.num_steps = steps;
-        rec.old_value = old_value;
-        rec.required_points = required;
-        rec.initial_points = initial;
-        rec.table_idx = (int)(lut_base / (u32)SCORE_LUT_BYTES);
-        rec.level_idx = level;
-        rec.episode_idx = episodes;
-        rec.episode_length = ep_len;
-        rec.episode_reward = ep_rew;
-        rec.spawn_prob = (float)p;
-        rec.goals_static = gstatic;
-        rec.is_active = active ? 1 : 0;
-        rec.exit_open_at_reset = open0;
-        rec.loaded = 1;
-        unsigned e2 = e;                      // recompute the record address here instead of keeping
-        asm volatile("" : "+v"(e2));          // a 64-bit pointer alive (and spilled) across the kernel
-        env.scalars[e2] = rec;
+    // write-back of the records: the leaders complete their LDS copies, the leader wave stores them
+    if (lwave) {
+        if (lead) {
+            lrec->agent_row = ly;
+            lrec->agent_col = lx;
+            lrec->goals_static = box[lq].gstat;
+            lrec->loaded = 1;
+        }
+        wave_sync();
+        int lane3 = lane;
+        asm volatile("" : "+v"(lane3));
+        for (int i = lane3; i < nbb * 4; i += 64)
+            ((u32x4 *)(env.scalars + e0b))[i] = ((const u32x4 *)(smem + Gm::OFF_REC))[i];
     }
-    // one barrier (the library's __syncthreads_or costs three): any wave that changed its goals raises the
-    // flag, which was cleared before the load barrier
-    if (goals_dirty) *dirty_flag = 1;
-    __syncthreads();
     const int dirty = *dirty_flag;
     SL_STAMP(8);
     // (an opaque copy of the thread index: the stores' per-lane addresses are formed HERE -- left alone the compiler
@@ -1967,15 +2120,17 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
     if (!LEAN && (env.obs || env.policy_obs)) {
         // per board: view centre and, per exit slot, the view cell it is painted on + its board cell
         int *par = (int *)(smem + Gm::OFF_GSH);                 // goal words are dead by now
-        if (leader) {
-            int *pp = par + gb * OBS_PAR_INTS;
+        if (lead) {
+            int *pp = par + lq * OBS_PAR_INTS;
+            const int32_t *obs_exits = pool_exits ? env.pool_exit_locs + (size_t)lrec->level_idx * E
+                                                  : env.exit_locs + (size_t)el * E;
             const int y0 = ly >= 0 ? ly : 0, x0 = ly >= 0 ? lx : 0;
             const int vh = env.view_h, vw = env.view_w;
             pp[0] = pos_mod(y0 - vh / 2, H);
             pp[1] = pos_mod(x0 - vw / 2, W);
             for (int k = 0; k < OBS_MAX_EXITS; ++k) {
                 int tv = -1, xk = -1;
-                if (k < E) xk = k == 0 ? exit0 : exits[k];
+                if (k < E) xk = k == 0 ? exit0 : obs_exits[k];
                 if (xk >= 0) {      // helper_utils.py:64-74: offset wrapped into [-H/2, H/2), clipped to the view
                     const int iy = xk / W, ix = xk - iy * W;
                     int jy = pos_mod(iy - y0 + H / 2, H) - H / 2 + vh / 2;
@@ -1988,7 +2143,7 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
                 pp[2 + OBS_MAX_EXITS + k] = xk;
             }
         }
-        __syncthreads();
+        wg_sync();
         if (env.obs) {
             if (env.n_channels == 15) write_obs_block<H, W, 15>(env, smem, e0b, nbb, tid);
             else if (env.n_channels == 19) write_obs_block<H, W, 19>(env, smem, e0b, nbb, tid);
@@ -2114,14 +2269,17 @@ hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, c
     typedef void (*kernel_t)(const u16 *, const u16 *, const sl_pcg64 *, sl_env_scalars *, const int8_t *,
                              const int32_t *, int, int, sl_env_batch, int, int, int, sl_step_out *, float *,
                              uint8_t *, double *, const Jump *);
-    static const kernel_t table[12] = {
-        k_env_rollout_rowlane<H, W, false, true, false, false>, k_env_rollout_rowlane<H, W, true, true, false, false>,
-        k_env_rollout_rowlane<H, W, false, false, false, false>, k_env_rollout_rowlane<H, W, true, false, false, false>,
-        k_env_rollout_rowlane<H, W, false, true, true, false>,  k_env_rollout_rowlane<H, W, true, true, true, false>,
-        k_env_rollout_rowlane<H, W, false, false, true, false>,  k_env_rollout_rowlane<H, W, true, false, true, false>,
-        k_env_rollout_rowlane<H, W, false, true, false, true>, k_env_rollout_rowlane<H, W, true, true, false, true>,
-        k_env_rollout_rowlane<H, W, false, false, false, true>, k_env_rollout_rowlane<H, W, true, false, false, true>};
-    const kernel_t fn = table[variant];
+#define SL_VARIANTS(ONE)                                                                                               \
+    k_env_rollout_rowlane<H, W, false, true, false, false, ONE>, k_env_rollout_rowlane<H, W, true, true, false, false, ONE>,   \
+    k_env_rollout_rowlane<H, W, false, false, false, false, ONE>, k_env_rollout_rowlane<H, W, true, false, false, false, ONE>, \
+    k_env_rollout_rowlane<H, W, false, true, true, false, ONE>, k_env_rollout_rowlane<H, W, true, true, true, false, ONE>,     \
+    k_env_rollout_rowlane<H, W, false, false, true, false, ONE>, k_env_rollout_rowlane<H, W, true, false, true, false, ONE>,   \
+    k_env_rollout_rowlane<H, W, false, true, false, true, ONE>, k_env_rollout_rowlane<H, W, true, true, false, true, ONE>,     \
+    k_env_rollout_rowlane<H, W, false, false, false, true, ONE>, k_env_rollout_rowlane<H, W, true, false, false, true, ONE>
+    static const kernel_t table[24] = {SL_VARIANTS(false), SL_VARIANTS(true)};
+#undef SL_VARIANTS
+    const int slot = variant + (T == 1 ? 12 : 0);
+    const kernel_t fn = table[slot];
     const bool spawn = !(variant & 2), base_in_gsh = !spawn && Gm::WAVES_PER_SIMD == 4;
     const int lds = !(variant & 4) ? Gm::LDS_BYTES : (base_in_gsh ? Gm::LDS_WRAP_GSHREG : Gm::LDS_WRAP_GSHLDS);
     // per (device, variant), once: raise the dynamic LDS limit and look up the module-level handle of the kernel
@@ -2129,11 +2287,11 @@ hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, c
         std::atomic<hipFunction_t> fn{nullptr};
         std::atomic<bool> ready{false};
     };
-    static Entry cache[12][16];
+    static Entry cache[24][16];
     int dev = 0;
     hipError_t err = hipGetDevice(&dev);
     if (err != hipSuccess) return err;
-    Entry &ce = cache[variant][dev & 15];
+    Entry &ce = cache[slot][dev & 15];
     if (!ce.ready.load(std::memory_order_acquire)) {
         err = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (err != hipSuccess) return err;
