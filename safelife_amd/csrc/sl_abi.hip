@@ -372,6 +372,20 @@ int slhip_streams_concurrent(void *stream_a, void *stream_b, int *concurrent) {
     return SL_OK;
 }
 
+#ifdef SL_TRACE
+// profiling builds: every launch of slhip_env_step_slices writes its waves' phase stamps to the next slot of this buffer
+static char *g_trace_base = nullptr;
+static long long g_trace_bytes = 0;
+static int g_trace_slots = 0, g_trace_next = 0;
+extern "C" int slhip_trace_set(void *base, long long bytes_per_launch, int slots) {
+    g_trace_base = (char *)base;
+    g_trace_bytes = bytes_per_launch;
+    g_trace_slots = slots;
+    g_trace_next = 0;
+    return SL_OK;
+}
+#endif
+
 int slhip_env_step_slices(const sl_env_batch *env, int n_slices, const int32_t *bounds, const int32_t *actions,
                           void *const *streams) {
     int rc = check_env(env);
@@ -382,7 +396,11 @@ int slhip_env_step_slices(const sl_env_batch *env, int n_slices, const int32_t *
         if (bounds[i + 1] < bounds[i]) return fail(SL_E_ARG, "slice bounds must not decrease");
         const int n = bounds[i + 1] - bounds[i];
         if (n == 0) continue;
-        rc = rollout_range(env, bounds[i], n, actions, 1, env->B, nullptr, nullptr, streams[i]);
+        float *trace = nullptr;
+#ifdef SL_TRACE
+        if (g_trace_base && g_trace_next < g_trace_slots) trace = (float *)(g_trace_base + g_trace_bytes * g_trace_next++);
+#endif
+        rc = rollout_range(env, bounds[i], n, actions, 1, env->B, trace, nullptr, streams[i]);
         if (rc) return rc;
     }
     return SL_OK;

@@ -37,12 +37,13 @@
 #define SL_LOAD_AUX 0
 #endif
 #ifndef SL_STORE
-#define SL_STORE 0   /* plain stores.  Write-through (sc1) stores are 0.8 us per step faster with ONE launch per step
-                        (10.7 vs 11.5 us: the board bytes leave L2 while other workgroups still compute instead of
-                        in the end-of-kernel write-back) and make no difference with two overlapping launches -- but
-                        with concurrent launches they produced WRONG boards now and then (an env whose workgroup
-                        lands on another XCD than last step reads a stale line; 64x64 spawner levels, ~1 run in 3),
-                        so they stay an experiment knob */
+#define SL_STORE 1   /* 0 plain, 1 non-temporal, 2 sc1 (write-through), 3 sc0 sc1.  Round 3, two-slice C3 step: 8.2-8.3 us
+                        plain, 7.9 non-temporal, 7.95-8.0 either write-through form.  What the flavours change is the
+                        kernel BOUNDARY: in-kernel clocks (tools/trace_overlap.py) put 2.0-2.5 us between a slice's last
+                        acknowledged store and the first wave of its next launch, of which ~0.9 us are the write-back
+                        of the 5.6 MB the launch left dirty in L2; streaming lines leave earlier.  Non-temporal stores
+                        keep the ordinary coherence rules.  The write-through forms produced WRONG boards now and then
+                        under concurrent launches in round 2 (64x64 spawner levels, ~1 run in 3) and stay a knob. */
 #endif
 
 namespace sl {
@@ -141,6 +142,12 @@ struct Geom {
     static_assert(G >= 1, "H must be <= 64");
     static_assert(WS <= 32 && W >= 4 && H >= 4, "row-per-lane path: 4 <= W <= 64, H >= 4");
     static constexpr int WAVES_PER_SIMD = WS <= 16 ? 4 : 2;   // VGPR budget: 128 / 256 registers
+    // fused step, LEAN variants of the narrow shapes: a fifth wavefront that holds no rows leads the workgroup
+    // (four workgroups per CU -> five waves per SIMD -> 96 registers)
+    // -- measured and switched off: the wave's lifetime drops (4.7 -> 4.57 us at 4096 envs) but the two-slice step does
+    //    not move (8.26 us) and the one-launch step loses (9.6 -> 10.9 us: twenty waves per CU spread unevenly over
+    //    the SIMDs)
+    static constexpr bool LEADX_OK = false;
     static constexpr int NL = G * GL;                      // lanes in use
     static constexpr int NB = WAVES * G;                   // boards per workgroup
     static_assert((NB * HW) % 8 == 0, "workgroup span must be a multiple of 16 bytes");
@@ -794,36 +801,46 @@ __device__ __forceinline__ void act_gather(u16 *board, int &ly, int &lx, int act
     board[img[3]] = (u16)c[3];
 }
 
-// update_exit_colors for the board of a leader lane, on the flat LDS image.
+// update_exit_colors for the board of a leader lane, on the flat LDS image.  agent_cell (optional): receives the
+// cell at the agent's location as it stands afterwards (an agent that has left through an exit stands ON an exit
+// cell, which the paint then covers), so that the caller need not read it back.
 template <int H, int W>
 __device__ __forceinline__ bool recolor_exits_lds(u16 *board, int ly, int lx, const int32_t *exits,
                                                   int exit0, int E, int score, int initial, int required,
-                                                  int exit_points, int *n_exits = nullptr) {
+                                                  int exit_points, int *n_exits = nullptr, u32 *agent_cell = nullptr) {
     using Gm = Geom<H, W>;
     bool any_can = false;
+    int at = -1;
+    u32 mine = 0;
     if (ly >= 0) {
-        u16 *cell = board + Gm::cell(ly, lx);
-        const u32 c = *cell;
+        at = Gm::cell(ly, lx);
+        const u32 c = board[at];
         int earned = score - initial + (has_exited(c) ? exit_points : 0);
         if (earned < 0) earned = 0;
         const bool can = (c & AGENT) && earned >= required;
-        *cell = (u16)((c & ~EXIT) | (can ? EXIT : 0u));
+        mine = (c & ~EXIT) | (can ? EXIT : 0u);
+        board[at] = (u16)mine;
         any_can = can;
     }
     const u16 paint = (u16)(FROZEN | EXIT | (any_can ? COLOR_R : 0u));
     int nx = 0;
     if (exit0 >= 0) {                             // slot 0 was prefetched; the usual level has one exit
-        board[Gm::flat(exit0)] = paint;
+        const int i = Gm::flat(exit0);
+        board[i] = paint;
+        if (i == at) mine = paint;
         nx = 1;
     }
     for (int k = 1; k < E; ++k) {
         const int ex = exits[k];
         if (ex >= 0) {
-            board[Gm::flat(ex)] = paint;
+            const int i = Gm::flat(ex);
+            board[i] = paint;
+            if (i == at) mine = paint;
             ++nx;
         }
     }
     if (n_exits) *n_exits = nx;
+    if (agent_cell) *agent_cell = mine;
     return any_can;
 }
 
@@ -1590,8 +1607,16 @@ static_assert(sizeof(BoardBox) == 32, "mailbox stride");
 // for the compiler to hoist: left as a loop, every loop-invariant address and constant of the RARE blocks (reset, exit
 // tables, queue, the division by the pool size) is computed ahead of the loop by every wave of every launch --
 // some 150 instructions between the load barrier and the first CA pass.
+//
+// LEADX (the LEAN variants of the narrow shapes): the leader wave is a FIFTH wavefront that holds no rows, so the
+// move is in the image as soon as the spans have landed, and what the leaders do around the scores overlaps the rows'
+// CA instead of following it.
+template <int H, int W, bool LEAN>
+constexpr bool leadx() { return LEAN && Geom<H, W>::LEADX_OK; }
+
 template <int H, int W, bool LDS_LUT, bool SPAWN, bool WRAP, bool LEAN, bool ONE>
-__global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_env_rollout_rowlane(
+__global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
+                             (leadx<H, W, LEAN>() ? 5 : Geom<H, W>::WAVES_PER_SIMD)) void k_env_rollout_rowlane(
     // the eight arguments the prologue needs before anything else come first: with
     // -amdgpu-kernarg-preload-count=8 they arrive in SGPRs with the wave instead of behind an s_load
     const u16 *__restrict__ hot_board, const u16 *__restrict__ hot_goals, const sl_pcg64 *__restrict__ hot_rng,
@@ -1621,7 +1646,9 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
     const bool rowl = lane < Gm::NL && gb < nbb;       // holds a row: its own, or a halo copy (V_SHIFT)
     const bool live = rowl && lm.real;                 // owns row r of board gb
     const bool rlead = live && r == 0;                 // the row lane that writes the board's mailbox
-    const bool lwave = wave == 0;                      // the leader wave ...
+    constexpr bool LEADX = leadx<H, W, LEAN>();
+    const bool lwave = wave == (LEADX ? WAVES : 0);    // the leader wave ...
+    const bool rwave = !(LEADX && lwave);              // waves that hold rows
     const bool lead = lwave && lane < nbb;             // ... whose lane q is the leader of board q
     const int lq = lead ? lane : 0;
     const unsigned e = e0b + (rowl ? gb : 0);          // the row lane's env
@@ -1690,9 +1717,9 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
             pre_c[3] = src[gi[3]];
         }
     } else {
-        // everything bulky goes through the LDS DMA, issued by the three row-only waves
-        constexpr int DW = WAVES - 1;
-        const int dw = wave - 1;
+        // everything bulky goes through the LDS DMA, issued by the waves that are not the leader
+        constexpr int DW = LEADX ? WAVES : WAVES - 1;
+        const int dw = LEADX ? wave : wave - 1;
         dma_to_lds<Gm::NB * 32, false, DW>((const unsigned char *)(k_rng + e0b), smem + Gm::OFF_RNG, nbb * 32, lane, dw);
         dma_to_lds<Gm::NB * 64, false, DW>((const unsigned char *)(hot_scalars + e0b), smem + Gm::OFF_REC, nbb * 64, lane, dw);
         if (LDS_LUT) dma_to_lds<4096, false, DW>((const unsigned char *)k_lut, smem + Gm::OFF_LUT, 4096, lane, dw);
@@ -1734,13 +1761,12 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
     //  "defined, value irrelevant" costs no instruction, thirteen zeroing moves would)
 #pragma unroll
     for (int k = 0; k < WS; ++k) asm volatile("" : "=v"(b[k]));
-#ifndef SL_EXP_NOSCORE
+    if (rwave) {
     if (live) {
         read_row<H, W>(goals, gb, r, b);
 #pragma unroll
         for (int k = 0; k < WS; ++k) gsh_lane[k] = goal_shift(b[k]);
     }
-#endif
     // Goals still undecided (the first step after a reset; the reference finds out by advancing them once,
     // safelife_game.py:753-760): a goal array without a single ALIVE or SPAWNING cell cannot change and draws
     // nothing, so it IS static and the second CA pass of that step is skipped -- the usual case for every level a
@@ -1756,6 +1782,7 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
         if (rowl && gstatic == 0 && restless == 0) gstatic = 1;
     }
     if (rlead) box[gb].gstat = gstatic;
+    }
     SL_STAMP(3);
 
     // What the leaders ask of the rows at the end of a step -- queue the finished episode's board, load the next
@@ -1899,6 +1926,7 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
         wg_sync();                                 // the move is in the image
         SL_STAMP(4);
         // safelife_env.py:152 : board first, then goals unless they are static (safelife_game.py:746-761)
+        if (rwave) {
         const bool dyn = rowl && gstatic != 1;
         const int passes = __ballot(dyn) ? 2 : 1;
 #pragma nounroll
@@ -1953,15 +1981,26 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
         }
         SL_STAMP(5);
         // safelife_env.py:153-160
-#ifdef SL_EXP_NOSCORE
-        const int score_rows = 0;
-#else
         const int score_rows = group_total<H, W>(
             live ? row_score<H, W, LDS_LUT>(b, gsh_lane, lut, lut_base, lds_lut, cell_mask, c100) : 0, live ? g : 0);
-#endif
         if (rlead) {
             box[gb].score = score_rows;
             box[gb].gstat = gstatic;
+        }
+        }
+        // the leaders: what does not depend on the scores is read before the barrier (in the LEADX kernels, under
+        // the rows' CA pass)
+        int b_initial = 0, b_required = 0, b_old_value = 0, b_steps = 0, b_ep_len = 0;
+        float b_ep_rew = 0.0f;
+        bool b_active = false;
+        if (lead) {
+            b_initial = lrec->initial_points;
+            b_required = lrec->required_points;
+            b_old_value = lrec->old_value;
+            b_steps = lrec->num_steps + 1;
+            b_ep_len = lrec->episode_length;
+            b_ep_rew = lrec->episode_reward;
+            b_active = lrec->is_active != 0;
         }
         wg_sync();                                 // scores in the mailbox, new boards in the images
         SL_STAMP(6);
@@ -1975,24 +2014,24 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
                 const int score = box[lq].score;
                 const int32_t *exits = pool_exits ? env.pool_exit_locs + (size_t)lrec->level_idx * E
                                                   : env.exit_locs + (size_t)el * E;
-                const bool active = lrec->is_active != 0;
-                w_open = recolor_exits_lds<H, W>(lboard16, ly, lx, exits, exit0, E, score, lrec->initial_points,
-                                                 lrec->required_points, env.exit_points, WRAP ? &w_exits : nullptr);
-                const int steps = lrec->num_steps + 1;
+                const bool active = b_active;
+                u32 cell = 0;
+                w_open = recolor_exits_lds<H, W>(lboard16, ly, lx, exits, exit0, E, score, b_initial, b_required,
+                                                 env.exit_points, WRAP ? &w_exits : nullptr, &cell);
+                const int steps = b_steps;
                 const bool times_up = steps >= env.time_limit;
                 float reward = 0.0f;
                 bool success = false;
                 done = true;
                 if (ly >= 0) {
-                    const u32 cell = lboard16[Gm::cell(ly, lx)];
                     success = has_exited(cell);
                     const int value = score + (success ? env.exit_points : 0);
-                    reward = (float)((value - lrec->old_value) * (active ? 1 : 0));
+                    reward = (float)((value - b_old_value) * (active ? 1 : 0));
                     lrec->old_value = value;
                     done = !(cell & AGENT) || times_up;
                 }
-                const float ep_rew = lrec->episode_reward + reward;
-                const int ep_len = lrec->episode_length + (active ? 1 : 0);
+                const float ep_rew = b_ep_rew + reward;
+                const int ep_len = b_ep_len + (active ? 1 : 0);
                 const bool ended = done && active;      // this step ends the episode
                 lrec->agent_row = ly;
                 lrec->agent_col = lx;
@@ -2098,8 +2137,10 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_en
     int tid2 = tid;
     asm volatile("" : "+v"(tid2));
     const int lane2 = tid2 & 63, wave2 = tid2 >> 6;
-    store_span<H, W>(env.board + (size_t)e0b * HW, board, nbb, tid2);
-    if (dirty) store_span<H, W>(env.goals + (size_t)e0b * HW, goals, nbb, tid2);
+    if (rwave) {
+        store_span<H, W>(env.board + (size_t)e0b * HW, board, nbb, tid2);
+        if (dirty) store_span<H, W>(env.goals + (size_t)e0b * HW, goals, nbb, tid2);
+    }
     if (lane2 < 4 * Gm::G && wave2 * Gm::G + (lane2 >> 2) < nbb)
         ((u64 *)(env.rng + e0b + wave2 * Gm::G))[lane2] = ((const u64 *)(smem + Gm::OFF_RNG) + 4 * Gm::G * wave2)[lane2];
     if (WRAP)       // (10-row boards: 24 per workgroup, more state words than threads)
@@ -2279,6 +2320,7 @@ hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, c
     static const kernel_t table[24] = {SL_VARIANTS(false), SL_VARIANTS(true)};
 #undef SL_VARIANTS
     const int slot = variant + (T == 1 ? 12 : 0);
+    const unsigned threads = 64 * (WAVES + ((variant & 8) && Gm::LEADX_OK ? 1 : 0));     // LEAN: a fifth, leader wave
     const kernel_t fn = table[slot];
     const bool spawn = !(variant & 2), base_in_gsh = !spawn && Gm::WAVES_PER_SIMD == 4;
     const int lds = !(variant & 4) ? Gm::LDS_BYTES : (base_in_gsh ? Gm::LDS_WRAP_GSHREG : Gm::LDS_WRAP_GSHLDS);
@@ -2325,9 +2367,9 @@ hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, c
                   env.E, tstride, T, env.out, reward_t, done_t, env.wrap.shaped_reward_t, jump};
         size_t size = sizeof(args);
         void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-        return hipModuleLaunchKernel(f, grid, 1, 1, 64 * WAVES, 1, 1, (unsigned)lds, stream, nullptr, extra);
+        return hipModuleLaunchKernel(f, grid, 1, 1, threads, 1, 1, (unsigned)lds, stream, nullptr, extra);
     }
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * WAVES), lds, stream, env.board, env.goals, env.rng, env.scalars,
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(threads), lds, stream, env.board, env.goals, env.rng, env.scalars,
                        env.score_lut, actions, e_first, e_first + e_count, env, env.E, tstride, T, env.out, reward_t,
                        done_t, env.wrap.shaped_reward_t, jump);
     return hipGetLastError();
