@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SL_ABI_VERSION 4
+#define SL_ABI_VERSION 5
 #define SL_MAX_CELLS 16384        /* H*W limit of one board */
 #define SL_MAX_CHANNELS 32
 
@@ -329,6 +329,29 @@ int slhip_env_step_slices(const sl_env_batch *env, int n_slices, const int32_t *
 int slhip_side_effects(const sl_env_batch *env, const sl_episode_queue *queue, int num_samples, int derive_streams,
                        uint16_t *work_boards, float *work_prob, int32_t *work_steps, sl_pcg64 *work_rng,
                        int32_t *counts, uint16_t *keys, double *life_dist, uint8_t *type_masks, void *stream);
+
+/* ---- multi-GPU: the per-step records of every rank's envs -> rank 0 ----------------------------
+ * Boards never cross GPUs; the only exchange of the path is what a learner on rank 0 needs from the other ranks:
+ * their sl_step_out records.  A rank's step kernels write the records of a WINDOW of consecutive steps straight
+ * into one device buffer; these entry points move a window to rank 0 with RCCL point-to-point calls
+ * (ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd: xGMI is point-to-point, the seven peers' windows arrive over
+ * seven links at once) on a stream of the caller's choosing, so the exchange overlaps the following steps.  RCCL is
+ * loaded on first use (dlopen of librccl.so.1 -- the copy the process already has, if any); a process that never
+ * gathers never touches it.  Replaces, for this path, what training/base_algo.py does with Python lists of
+ * per-env results (there is one process and no exchange in the reference).
+ *
+ *   slhip_gather_unique_id   rank 0: a fresh ncclUniqueId (SL_GATHER_ID_BYTES bytes, host memory) for the caller to
+ *                            broadcast over whatever it has (the existing torch.distributed process group)
+ *   slhip_gather_init        every rank, same id: ncclCommInitRank on the current device; *comm is an opaque handle
+ *   slhip_gather_window      one window: rank r sends `bytes` from `send` to rank 0; rank 0 receives rank r's window
+ *                            at recv + r * bytes (its own included), all inside one RCCL group, enqueued on `stream`.
+ *                            recv is ignored on the other ranks.  Returns once the calls are enqueued.
+ *   slhip_gather_destroy     releases the communicator */
+#define SL_GATHER_ID_BYTES 128
+int slhip_gather_unique_id(void *id_out);
+int slhip_gather_init(const void *id, int world, int rank, void **comm);
+int slhip_gather_window(void *comm, const void *send, void *recv, size_t bytes, void *stream);
+int slhip_gather_destroy(void *comm);
 
 /* SafeLifeEnv.get_obs() for the current state. */
 int slhip_env_obs(const sl_env_batch *env, void *stream);

@@ -8,6 +8,8 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include <dlfcn.h>
+#include <string.h>
 
 #include "sl_kernels.h"
 
@@ -152,6 +154,66 @@ sl_env_batch env_slice(const sl_env_batch &env, int e0, int n) {
 }
 
 }  // namespace
+
+// ---- the records of every rank's envs -> rank 0, through RCCL point-to-point calls ----------------------------------
+// RCCL's C API, resolved at first use (librccl.so.1: the copy already in the process -- torch's -- if there is one).
+namespace {
+struct Rccl {
+    typedef struct { char internal[SL_GATHER_ID_BYTES]; } unique_id;      // ncclUniqueId
+    int (*GetUniqueId)(unique_id *) = nullptr;
+    int (*CommInitRank)(void **, int, unique_id, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok = false;
+    std::string why;
+};
+const Rccl &rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void *h = nullptr;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
+        if (!h) {
+            r.why = std::string("dlopen(librccl): ") + dlerror();
+            return;
+        }
+        bool all = true;
+        auto sym = [&](const char *n) {
+            void *p = dlsym(h, n);
+            if (!p) {
+                all = false;
+                r.why = std::string("librccl lacks ") + n;
+            }
+            return p;
+        };
+        r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+        r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+        r.Send = (decltype(r.Send))sym("ncclSend");
+        r.Recv = (decltype(r.Recv))sym("ncclRecv");
+        r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+        r.ok = all;
+    });
+    return r;
+}
+int rccl_fail(const Rccl &r, int code, const char *what) {
+    return fail(SL_E_HIP, std::string(what) + ": " + (r.GetErrorString ? r.GetErrorString(code) : "RCCL error"));
+}
+struct GatherComm {
+    void *comm;
+    int world, rank;
+};
+}  // namespace
+
 
 extern "C" {
 
@@ -330,19 +392,27 @@ int slhip_streams_order(void *const *before, int n_before, void *const *after, i
     // ordering events: a ring of timing-less events, created on first use (an event may be re-recorded once the
     // waits that named it have been enqueued, which they have by the time the ring comes round)
     constexpr int RING = 64;
-    static hipEvent_t ring[RING];
-    static std::atomic<unsigned> next{0};
-    static std::once_flag once;
-    static hipError_t made = hipSuccess;
-    std::call_once(once, [] {
-        for (int i = 0; i < RING && made == hipSuccess; ++i) made = hipEventCreateWithFlags(&ring[i], hipEventDisableTiming);
+    struct Ring {
+        hipEvent_t ev[RING];
+        std::atomic<unsigned> next{0};
+        std::once_flag once;
+        hipError_t made = hipSuccess;
+    };
+    static Ring rings[kMaxDevices];                 // one per device: an event belongs to the device it was made on
+    int dev = 0;
+    hipError_t derr = hipGetDevice(&dev);
+    if (derr != hipSuccess) return hip_fail(derr, "hipGetDevice");
+    if (dev < 0 || dev >= kMaxDevices) return fail(SL_E_UNSUPPORTED, "device index out of range");
+    Ring &rg = rings[dev];
+    std::call_once(rg.once, [&rg] {
+        for (int i = 0; i < RING && rg.made == hipSuccess; ++i) rg.made = hipEventCreateWithFlags(&rg.ev[i], hipEventDisableTiming);
     });
-    if (made != hipSuccess) return hip_fail(made, "streams_order events");
+    if (rg.made != hipSuccess) return hip_fail(rg.made, "streams_order events");
     for (int i = 0; i < n_before; ++i) {
         bool needed = false;
         for (int j = 0; j < n_after; ++j) needed |= after[j] != before[i];
         if (!needed) continue;
-        hipEvent_t ev = ring[next.fetch_add(1, std::memory_order_relaxed) % RING];
+        hipEvent_t ev = rg.ev[rg.next.fetch_add(1, std::memory_order_relaxed) % RING];
         hipError_t err = hipEventRecord(ev, (hipStream_t)before[i]);
         for (int j = 0; j < n_after && err == hipSuccess; ++j)
             if (after[j] != before[i]) err = hipStreamWaitEvent((hipStream_t)after[j], ev, 0);
@@ -404,6 +474,58 @@ int slhip_env_step_slices(const sl_env_batch *env, int n_slices, const int32_t *
         if (rc) return rc;
     }
     return SL_OK;
+}
+
+// ---- the records of every rank's envs -> rank 0 (RCCL point-to-point calls; helpers above) ----------------------
+int slhip_gather_unique_id(void *id_out) {
+    if (!id_out) return fail(SL_E_ARG, "null pointer");
+    const Rccl &r = rccl();
+    if (!r.ok) return fail(SL_E_UNSUPPORTED, r.why);
+    Rccl::unique_id id;
+    const int rc = r.GetUniqueId(&id);
+    if (rc) return rccl_fail(r, rc, "ncclGetUniqueId");
+    memcpy(id_out, &id, sizeof(id));
+    return SL_OK;
+}
+
+int slhip_gather_init(const void *id, int world, int rank, void **comm) {
+    if (!id || !comm || world < 1 || rank < 0 || rank >= world) return fail(SL_E_ARG, "bad gather arguments");
+    const Rccl &r = rccl();
+    if (!r.ok) return fail(SL_E_UNSUPPORTED, r.why);
+    Rccl::unique_id uid;
+    memcpy(&uid, id, sizeof(uid));
+    void *c = nullptr;
+    const int rc = r.CommInitRank(&c, world, uid, rank);
+    if (rc) return rccl_fail(r, rc, "ncclCommInitRank");
+    *comm = new GatherComm{c, world, rank};
+    return SL_OK;
+}
+
+int slhip_gather_window(void *comm, const void *send, void *recv, size_t bytes, void *stream) {
+    GatherComm *g = (GatherComm *)comm;
+    if (!g || !send || (g->rank == 0 && !recv)) return fail(SL_E_ARG, "bad gather arguments");
+    if (bytes == 0) return SL_OK;
+    const Rccl &r = rccl();
+    hipStream_t st = (hipStream_t)stream;
+    int rc = r.GroupStart();
+    if (rc) return rccl_fail(r, rc, "ncclGroupStart");
+    const int kChar = 0;                                            // ncclInt8
+    rc = r.Send(send, bytes, kChar, 0, g->comm, st);
+    if (g->rank == 0)
+        for (int peer = 0; peer < g->world && !rc; ++peer) rc = r.Recv((char *)recv + (size_t)peer * bytes, bytes, kChar, peer, g->comm, st);
+    const int rc_end = r.GroupEnd();
+    if (rc) return rccl_fail(r, rc, "ncclSend / ncclRecv");
+    if (rc_end) return rccl_fail(r, rc_end, "ncclGroupEnd");
+    return SL_OK;
+}
+
+int slhip_gather_destroy(void *comm) {
+    GatherComm *g = (GatherComm *)comm;
+    if (!g) return SL_OK;
+    const Rccl &r = rccl();
+    const int rc = r.ok ? r.CommDestroy(g->comm) : 0;
+    delete g;
+    return rc ? rccl_fail(r, rc, "ncclCommDestroy") : SL_OK;
 }
 
 int slhip_side_effects(const sl_env_batch *env, const sl_episode_queue *queue, int num_samples, int derive_streams,
@@ -486,54 +608,3 @@ int slhip_obs_to_policy(const uint32_t *view, int B, int vh, int vw, const int32
 }
 
 }  // extern "C"
-
-// ---- experiment harness (tools/exp/pipe_exp.py): compiled only into the A/B libraries of tools/exp/build_variants.sh
-#ifdef SL_EXPERIMENTS
-#include <chrono>
-#include <thread>
-#include <atomic>
-extern "C" int slhip_exp_pipeline(const sl_env_batch *envs, int n, const int32_t *const *actions, int K, int stride,
-                                  int threaded, double *us_out) {
-    const sl::Jump *jump;
-    int rc;
-    if ((rc = jump_table(&jump))) return rc;
-    std::vector<hipStream_t> streams(n);
-    for (int i = 0; i < n; ++i)
-        if (hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking) != hipSuccess) return fail(SL_E_HIP, "stream");
-    auto run_slice = [&](int i, int k0, int k1) {
-        for (int t = k0; t < k1; ++t)
-            (void)sl::launch_env_rollout_rowlane(envs[i], 0, envs[i].B, actions[i] + (size_t)t * stride, 1, envs[i].B, nullptr, nullptr, jump, streams[i]);
-    };
-    // warm-up
-    for (int i = 0; i < n; ++i) run_slice(i, 0, 5);
-    (void)hipDeviceSynchronize();
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const auto t0 = std::chrono::steady_clock::now();
-    if (threaded & 1) {
-        std::vector<std::thread> th;
-        for (int i = 0; i < n; ++i)
-            th.emplace_back([&, i] {
-                (void)hipSetDevice(dev);
-                run_slice(i, 5, 5 + K);
-            });
-        for (auto &t : th) t.join();
-    } else {
-        for (int t = 5; t < 5 + K; ++t)
-            for (int i = 0; i < n; ++i)
-                (void)sl::launch_env_rollout_rowlane(envs[i], 0, envs[i].B, actions[i] + (size_t)t * stride, 1, envs[i].B, nullptr, nullptr, jump, streams[i]);
-    }
-    const auto t1 = std::chrono::steady_clock::now();
-    if (threaded & 2) {                       // spin on hipStreamQuery instead of a blocking wait
-        for (int i = 0; i < n; ++i)
-            while (hipStreamQuery(streams[i]) == hipErrorNotReady) {}
-    }
-    for (int i = 0; i < n; ++i) (void)hipStreamSynchronize(streams[i]);
-    const auto t2 = std::chrono::steady_clock::now();
-    us_out[0] = std::chrono::duration<double, std::micro>(t1 - t0).count();     // host enqueue time
-    us_out[1] = std::chrono::duration<double, std::micro>(t2 - t0).count();     // until everything finished
-    for (int i = 0; i < n; ++i) (void)hipStreamDestroy(streams[i]);
-    return hipGetLastError() == hipSuccess ? SL_OK : fail(SL_E_HIP, "pipeline");
-}
-
-#endif  // SL_EXPERIMENTS

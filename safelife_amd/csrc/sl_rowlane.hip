@@ -2329,11 +2329,12 @@ hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, c
         std::atomic<hipFunction_t> fn{nullptr};
         std::atomic<bool> ready{false};
     };
-    static Entry cache[24][16];
+    static Entry cache[24][64];                     // (64 = the device limit of sl_abi.hip)
     int dev = 0;
     hipError_t err = hipGetDevice(&dev);
     if (err != hipSuccess) return err;
-    Entry &ce = cache[slot][dev & 15];
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    Entry &ce = cache[slot][dev];
     if (!ce.ready.load(std::memory_order_acquire)) {
         err = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (err != hipSuccess) return err;

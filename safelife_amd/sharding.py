@@ -6,10 +6,22 @@ The only cross-GPU traffic of the path is what a centralised learner on rank 0 n
 other ranks each step: the per-step output record of every env (``struct sl_step_out``: float32 reward, done / success /
 times_up flags, episode reward and length -- 16 bytes).  xGMI is point-to-point, and a message of a
 few bytes per env per step is purely latency bound, so the records of ``every`` consecutive steps
-are written by the step kernel straight into one device buffer (``sl_step_out[every, B]``) and
-gathered with ONE RCCL ``gather`` per ``every`` steps, issued asynchronously so it overlaps the
-following steps; two buffers alternate.
+are written by the step kernel straight into one device buffer (``sl_step_out[every, B]``, a WINDOW) and
+moved to rank 0 once per window, asynchronously, so that the exchange overlaps the following steps; two
+buffers alternate.
+
+Two transports:
+
+* ``"rccl"`` (device tensors): the library's own ``slhip_gather_*`` entry points -- one RCCL group of
+  ``ncclSend`` / ``ncclRecv`` per window on a side stream of this class, ordered against the streams that
+  wrote the window by events only; the communicator is bootstrapped from a unique id that rank 0 broadcasts
+  over the existing ``torch.distributed`` process group.  The stepping thread never waits on the host.  (Round 2
+  handed every window to ``torch.distributed.gather``: ~100 us of host time per window, 200-350 us for the
+  first, against ~2.4 us of host slack per step.)
+* ``"torch"``: ``torch.distributed.gather`` -- CPU tensors over gloo (the CPU test-suite, ``bench.py
+  --dry-run``), or any backend when ``SAFELIFE_GATHER_BACKEND=torch``.
 """
+import ctypes as C
 import os
 import time
 
@@ -26,54 +38,120 @@ def shard_bounds(total_envs, world, rank):
 class RewardGather(object):
     """Per-step output records of a SafeLifeVectorEnv -> rank 0, batched.
 
-    Usage per step t:  ``before_step(t); env.step(a); after_step(t)``; ``flush()`` at the end.
+    Usage per step t:  ``before_step(t); env.step(a) or env.step_async(a); after_step(t)``; ``flush()`` at the end.
     On rank 0, ``latest()`` returns (reward[world, every, B] float32, done[world, every, B] uint8) of
     the last completed window (views into the receive buffers); ``latest_records()`` the raw records.
+
+    Which streams wrote a window is read off the env when the window closes: its slice streams after
+    ``step_async()``, the caller's current stream after ``step()`` (the env orders the two against each other when a
+    caller switches, so the last writer is ordered behind every earlier one).
     """
 
     RECORD_BYTES = 16
 
-    def __init__(self, env, every=32, world=1, rank=0, group=None):
+    def __init__(self, env, every=32, world=1, rank=0, group=None, backend=None):
         import torch
         self.torch = torch
         self.env, self.every, self.world, self.rank, self.group = env, int(every), int(world), int(rank), group
         self.B = B = env.num_envs
         shape = (self.every, B, 4)
+        self.cuda = torch.device(env.device).type == "cuda"
+        # SAFELIFE_FORCE_GATHER=1 runs the exchange even with one rank (exercises the RCCL path on a one-GPU box)
+        self.force = os.environ.get("SAFELIFE_FORCE_GATHER", "0") == "1"
+        self.collective = self.world > 1 or self.force     # False: one rank, nothing to gather
+        if backend is None:
+            backend = os.environ.get("SAFELIFE_GATHER_BACKEND") or ("rccl" if self.cuda else "torch")
+        if backend not in ("rccl", "torch"):
+            raise ValueError("backend must be 'rccl' or 'torch'")
+        if backend == "rccl" and not self.cuda:
+            raise ValueError("the rccl transport needs device tensors")
+        self.backend = backend
         self.buf = [torch.zeros(shape, dtype=torch.int32, device=env.device) for _ in range(2)]
         self.recv = None
-        # SAFELIFE_FORCE_GATHER=1 issues the collective even with one rank (exercises the RCCL path
-        # on a single-GPU box)
-        self.force = os.environ.get("SAFELIFE_FORCE_GATHER", "0") == "1"
-        if (self.world > 1 or self.force) and self.rank == 0:
-            self.recv = [[torch.zeros(shape, dtype=torch.int32, device=env.device) for _ in range(self.world)]
-                         for _ in range(2)]
-        self.collective = self.world > 1 or self.force     # False: one rank, nothing to gather
-        self.cuda = torch.device(env.device).type == "cuda"
-        self._join_ev = ([torch.cuda.Event() for _ in (getattr(env, "_slice_streams", None) or [None])[1:]]
-                         if self.cuda else [])
-        self.work = [None, None]
+        if self.collective and self.rank == 0:
+            self.recv = [torch.zeros((self.world,) + shape, dtype=torch.int32, device=env.device) for _ in range(2)]
+        self.work = [None, None]      # torch transport: the outstanding collective of each buffer
+        self.busy = [False, False]    # rccl transport: a gather of this buffer has been enqueued and not fenced yet
         self.last = None
-        self.exposed_s = 0.0          # host time spent issuing / waiting on the collective (what is not overlapped)
+        self.windows = 0              # windows handed to the transport so far
+        self.exposed_s = 0.0          # host time spent issuing / waiting on the exchange (what is not overlapped)
         self._slot_ptr = [[b.data_ptr() + self.RECORD_BYTES * slot * B for slot in range(self.every)]
                           for b in self.buf]
+        self._comm = None
+        self._join_ev = []
+        if self.collective and self.backend == "rccl":
+            self._init_rccl()
+        elif self.cuda:
+            self._join_ev = [torch.cuda.Event() for _ in (getattr(env, "_slice_streams", None) or [None])[1:]]
+
+    # ------------------------------------------------------------------ rccl transport
+    def _init_rccl(self):
+        from . import _hip
+        torch = self.torch
+        self._lib = lib = _hip.lib()
+        ident = torch.zeros(_hip.SL_GATHER_ID_BYTES, dtype=torch.uint8)
+        if self.rank == 0:
+            raw = (C.c_ubyte * _hip.SL_GATHER_ID_BYTES)()
+            _hip.check(lib.slhip_gather_unique_id(raw))
+            ident = torch.tensor(list(raw), dtype=torch.uint8)
+        if self.world > 1:
+            import torch.distributed as dist
+            if dist.get_backend(self.group) == "gloo":
+                dist.broadcast(ident, 0, group=self.group)
+            else:
+                dev_ident = ident.to(self.env.device)
+                dist.broadcast(dev_ident, 0, group=self.group)
+                ident = dev_ident.cpu()
+        raw = (C.c_ubyte * _hip.SL_GATHER_ID_BYTES)(*ident.tolist())
+        comm = C.c_void_p()
+        _hip.check(lib.slhip_gather_init(raw, self.world, self.rank, C.byref(comm)))
+        self._comm = comm
+        self._stream = torch.cuda.Stream(device=self.env.device)       # the exchange's own stream
+        self._gptr = (C.c_void_p * 1)(self._stream.cuda_stream)
+        self._done_ev = [torch.cuda.Event(), torch.cuda.Event()]        # recorded behind each buffer's exchange
+
+    def _order(self, before, after):
+        """Streams of `after` wait for what is enqueued on the streams of `before` (events, no host wait)."""
+        from . import _hip
+        b = (C.c_void_p * len(before))(*[s.cuda_stream for s in before])
+        a = (C.c_void_p * len(after))(*[s.cuda_stream for s in after])
+        _hip.check(self._lib.slhip_streams_order(b, len(before), a, len(after)))
+
+    def close(self):
+        if self._comm is not None:
+            self.torch.cuda.synchronize()
+            self._lib.slhip_gather_destroy(self._comm)
+            self._comm = None
 
     # ------------------------------------------------------------------ stream plumbing
-    # The window is written on the env's slice streams.  The collective is issued ON slice 0's stream (made to wait
-    # for the other slices first), and when a buffer comes round again every slice stream waits for the collective's
-    # own completion directly.  What this avoids -- measured, one rank through RCCL: making the slice streams wait
-    # on an event freshly recorded on the caller's stream behind the collective's wait (work.wait() + env.fence())
-    # left hipModuleLaunchKernel at 10-45 us instead of 3 for the next dozen steps, ~3 us per step on average.
     def _writer_streams(self):
+        """The streams the env's step kernels are currently enqueued on."""
         if not self.cuda:
             return []
-        return getattr(self.env, "_slice_streams", None) or [self.torch.cuda.current_stream()]
+        slices = getattr(self.env, "_slice_streams", None)
+        if slices and getattr(self.env, "_async_pending", True):
+            return list(slices)
+        return [self.torch.cuda.current_stream()]
 
     def _issue(self, which):
-        import torch.distributed as dist
-        torch, dst = self.torch, (self.recv[which] if self.rank == 0 else None)
+        from . import _hip
+        torch = self.torch
         streams = self._writer_streams()
+        self.windows += 1
+        if self.backend == "rccl":
+            self._order(streams, [self._stream])
+            recv = self.recv[which].data_ptr() if self.rank == 0 else None
+            _hip.check(self._lib.slhip_gather_window(self._comm, self.buf[which].data_ptr(), recv,
+                                                     self.buf[which].numel() * 4, self._gptr[0]))
+            self._done_ev[which].record(self._stream)
+            self.busy[which] = True
+            return None
+        import torch.distributed as dist
+        dst = list(self.recv[which].unbind(0)) if self.rank == 0 else None
         if not streams:                                    # CPU tensors (gloo): nothing to order
             return dist.gather(self.buf[which], dst, dst=0, group=self.group, async_op=True)
+        # torch transport on device tensors: issued ON the first writer stream, made to wait for the others; when the
+        # buffer comes round again every writer waits for the collective's own completion
         lead = streams[0]
         for st, ev in zip(streams[1:], self._join_ev):
             ev.record(st)
@@ -81,8 +159,17 @@ class RewardGather(object):
         with torch.cuda.stream(lead):
             return dist.gather(self.buf[which], dst, dst=0, group=self.group, async_op=True)
 
-    def _wait(self, work, streams):
-        """`streams` wait (stream-level) for the collective."""
+    def _wait(self, which, streams):
+        """`streams` wait (stream-level) for the exchange of buffer `which`."""
+        if self.backend == "rccl":
+            # (a window later the exchange has long finished: one event query instead of an event record and a
+            #  stream wait per writer -- 1 us instead of ~13)
+            if self.busy[which] and streams and not self._done_ev[which].query():
+                self._order([self._stream], streams)
+            return
+        work = self.work[which]
+        if work is None:
+            return
         if not self.cuda:
             work.wait()
             return
@@ -92,21 +179,23 @@ class RewardGather(object):
                 work.wait()
 
     def prime(self):
-        """One throw-away gather of each (empty) window buffer, issued the way ``after_step`` issues it: the
-        first asynchronous exchange of a process group sets up its channels and work objects and costs
-        300-500 us on the host -- keep that out of the stepping loop."""
+        """One throw-away exchange of each (empty) window buffer: the first one of a communicator sets up its
+        channels (hundreds of microseconds on the host) -- keep that out of the stepping loop."""
         if self.collective:
             for which in (0, 1):
-                self._wait(self._issue(which), self._writer_streams())
+                self.work[which] = self._issue(which)
+                self._wait(which, self._writer_streams())
+                self.work[which], self.busy[which] = None, False
+            self.windows = 0
             if self.cuda:
                 self.torch.cuda.synchronize()
 
     def before_step(self, t):
         slot, which = t % self.every, (t // self.every) % 2
-        if slot == 0 and self.work[which] is not None:
+        if slot == 0 and (self.work[which] is not None or self.busy[which]):
             t0 = time.perf_counter()
-            self._wait(self.work[which], self._writer_streams())      # the buffer is free again
-            self.work[which] = None
+            self._wait(which, self._writer_streams())      # the buffer is free again
+            self.work[which], self.busy[which] = None, False
             self.exposed_s += time.perf_counter() - t0
         self.env.set_step_outputs(self._slot_ptr[which][slot])
 
@@ -121,29 +210,30 @@ class RewardGather(object):
             self.exposed_s += time.perf_counter() - t0
 
     def flush(self):
-        """Wait (stream-level, on the caller's current stream and the writers') for outstanding gathers and hand the step outputs
-        back to the env's own tensor.  While a gather is active, ``env.reward`` / ``env.done`` / ``env.info`` are
-        NOT written -- the records go to the window buffers; read them through ``latest()``."""
+        """Wait (stream-level, on the caller's current stream and the writers') for outstanding exchanges and hand
+        the step outputs back to the env's own tensor.  While a gather is active, ``env.reward`` / ``env.done`` /
+        ``env.info`` are NOT written -- the records go to the window buffers; read them through ``latest()``."""
         for k in (0, 1):
-            if self.work[k] is not None:        # (the writers too: their next window may reuse the buffer)
+            if self.work[k] is not None or self.busy[k]:        # (the writers too: their next window may reuse the buffer)
                 streams = self._writer_streams()
                 if self.cuda and self.torch.cuda.current_stream() not in streams:
                     streams = streams + [self.torch.cuda.current_stream()]
-                self._wait(self.work[k], streams)
-                self.work[k] = None
+                self._wait(k, streams)
+                self.work[k], self.busy[k] = None, False
         self.env.set_step_outputs(None)
 
     def latest_records(self):
-        """Records of the last COMPLETED window, int32 [world, every, B, 4] (the gather that filled it is
+        """Records of the last COMPLETED window, int32 [world, every, B, 4] (the exchange that filled it is
         waited for on the current stream first)."""
         if self.last is None:
             return None
-        if self.work[self.last] is not None:
-            self._wait(self.work[self.last], [self.torch.cuda.current_stream()] if self.cuda else [])
+        if self.work[self.last] is not None or self.busy[self.last]:
+            self._wait(self.last, [self.torch.cuda.current_stream()] if self.cuda else [])
         elif self.cuda and getattr(self.env, "slices", 1) > 1:
-            self.env.join()                                 # no collective in flight: the window sits on the slice streams
-        bufs = self.recv[self.last] if self.recv is not None else [self.buf[self.last]]
-        return self.torch.stack(bufs)
+            self.env.join()                                 # no exchange in flight: the window sits on the slice streams
+        if self.recv is not None:
+            return self.recv[self.last]
+        return self.buf[self.last][None]
 
     def latest(self):
         rec = self.latest_records()

@@ -572,6 +572,65 @@ def gen_side_effect_inputs(R, out):
                         rng0=w0, rng1=w1, rng2=w2, rng3=w3)
 
 
+def gen_nav64(R, out, n):
+    """64x64 navigation (BASELINE.json configs[4]): the level pool, one SafeLifeEnv trace on two of its levels, and the
+    internals of side_effect_score (side_effects.py:103-113) on an episode played on a third -- the sizes the
+    C5 numbers are quoted on.  ~33 s of procgen per level."""
+    Game = R.game.SafeLifeGame
+    sp = R.speedups
+    it = R.levels.SafeLifeLevelIterator("random/navigation", seed=2027, num_workers=0)
+    for fd in it.file_data:
+        fd[2]["board_shape"] = [64, 64]
+    games, recs = [], []
+    for i in range(n):
+        game = next(it)
+        games.append(game)
+        rec = level_record(game)
+        rec["rng"] = words(game._rng.bit_generator)
+        rec["required_points"] = np.int64(game.required_points()[0])
+        rec["initial_available_points"] = np.int64(game.initial_available_points()[0])
+        recs.append(rec)
+        print("  level %d / %d" % (i + 1, n), flush=True)
+    blob = {"n_levels": np.array(n), "spec": np.array("navigation"), "seed": np.array(2027)}
+    for k in recs[0]:
+        blob[k] = np.stack([np.asarray(r[k]) for r in recs])
+    np.savez_compressed(os.path.join(out, "pool_navigation_64.npz"), **blob)
+    print("pool navigation_64: %d levels" % n)
+
+    # a SafeLifeEnv trace on two of the levels: heads for the exit, so the first episode ends by success
+    rng = np.random.default_rng(64)
+    datas = [normalize_level(games[k]._init_data) for k in (0, 1)]
+    acts = []
+    for d in datas:
+        acts += greedy_actions(R, Game.loaddata(d), rng, 110, p_random=0.3)
+    acts += list(rng.integers(0, 9, 40))
+    tr = trace_blob(R, "nav64", datas, [21, 22], np.array(acts), dict(view_shape=(25, 25), output_channels=None,
+                                                                     time_limit=150, should_calculate_side_effects=False))
+    np.savez_compressed(os.path.join(out, "trace_nav64.npz"), **tr)
+
+    # side_effect_score internals at 64x64 (spawners all over the board: the draws dominate)
+    game = seeded(Game.loaddata(normalize_level(games[2]._init_data)), 9)
+    for a in rng.integers(0, 9, 60):
+        game.execute_actions(int(a))
+        game.advance_board()
+        game.update_exit_colors()
+    glob = np.random.PCG64(6464)
+    w0 = words(glob)
+    sp.set_bit_generator(glob)
+    b0 = game._init_data["board"]
+    b1 = sp.advance_board(b0, game.spawn_prob, game.num_steps)
+    w1 = words(glob)
+    occ0 = sp.life_occupancy(b1, game.spawn_prob, 1000)
+    w2 = words(glob)
+    occ1 = sp.life_occupancy(game.board, game.spawn_prob, 1000)
+    w3 = words(glob)
+    np.savez_compressed(os.path.join(out, "side_effect_inputs_64.npz"),
+                        b0=b0, b2=game.board, num_steps=np.array(game.num_steps),
+                        spawn_prob=np.array(game.spawn_prob), b1=b1, occ0=occ0, occ1=occ1,
+                        rng0=w0, rng1=w1, rng2=w2, rng3=w3)
+    print("side_effect_inputs_64: %d steps, %d cells ever alive" % (game.num_steps, int((occ1.sum(-1) > 0).sum())))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--nav64", type=int, default=0, help="number of 64x64 navigation levels (slow)")
@@ -595,7 +654,7 @@ def main():
         gen_pool(R, out, "append-spawn", (25, 25), 64, 2025, "append_spawn_25")
         gen_pool(R, out, "append-still", (26, 26), 32, 2026, "append_still_26")
     if args.nav64:
-        gen_pool(R, out, "navigation", (64, 64), args.nav64, 2027, "navigation_64")
+        gen_nav64(R, out, args.nav64)
 
 
 if __name__ == "__main__":

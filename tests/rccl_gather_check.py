@@ -1,5 +1,8 @@
 """Run by tests/test_hip_parity.py::test_reward_gather_through_rccl in a process of its own: the real
-SafeLifeVectorEnv (two slices) + RewardGather with the RCCL collective forced on for a single rank."""
+SafeLifeVectorEnv (two slices) + RewardGather with the exchange forced on for a single rank -- the library's own
+RCCL entry points (slhip_gather_*: rank 0 sends to and receives from itself inside one RCCL group, on the gather's
+side stream).  Two phases: step_async() (the windows are written on the slice streams) and step() on the SAME
+sliced env (one launch on the caller's stream: the gather has to follow the writer)."""
 import os
 import sys
 
@@ -26,6 +29,8 @@ env = SafeLifeVectorEnv(pool, B, slices=2, **kw)
 ref = SafeLifeVectorEnv(pool, B, **kw)          # same envs, outputs read directly every step
 env.reset(), ref.reset()
 gather = RewardGather(env, every=every, world=1, rank=0)
+assert gather.backend == "rccl" and gather.collective
+gather.prime()
 rng = np.random.default_rng(3)
 want_r, want_d = [], []
 for t in range(T):
@@ -42,7 +47,26 @@ for t in range(T):
         assert rw.shape == (1, every, B)
         assert np.array_equal(rw[0].cpu().numpy(), np.stack(want_r[-every:])), t
         assert np.array_equal(dn[0].cpu().numpy(), np.stack(want_d[-every:])), t
+# phase 2: step() on the sliced env -- ONE launch on the caller's stream; a gather that still followed the slice
+# streams would ship half-written windows
+side = torch.cuda.Stream()
+for t in range(T, 2 * T):
+    a = torch.from_numpy(rng.integers(0, 9, B).astype(np.int32)).to(dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        gather.before_step(t)
+        env.step(a)
+        gather.after_step(t)
+    ref.step(a)
+    want_r.append(ref.numpy("reward"))
+    want_d.append(ref.numpy("done"))
+    if t % every == every - 1:
+        rw, dn = gather.latest()
+        assert np.array_equal(rw[0].cpu().numpy(), np.stack(want_r[-every:])), t
+        assert np.array_equal(dn[0].cpu().numpy(), np.stack(want_d[-every:])), t
 gather.flush()
+torch.cuda.synchronize()
 assert np.array_equal(env.numpy("board"), ref.numpy("board"))
+gather.close()
 dist.destroy_process_group()
 print("rccl gather ok")

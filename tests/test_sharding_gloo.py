@@ -103,3 +103,34 @@ def test_reward_gather_single_process():
     assert np.array_equal(rw[0, 1].numpy(), (3 + np.arange(16) / 64.0).astype(np.float32))
     gather.flush()
     assert env.out_ptr == env.own.ctypes.data
+
+
+def test_bench_launches_itself_and_gathers_inside_the_region():
+    """`python bench.py --gpus 2` without a launcher (how the driver starts the N = 1 line, and what it would
+    type for N > 1) re-executes under torch.distributed.run; --dry-run swaps the GPU step for a stand-in, so the
+    launcher, the env partition, the gather windows (at least one must close inside the 20 timed steps) and the
+    one-line JSON contract are checked on the CPU."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.check_output([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--dry-run",
+                                   "--steps", "20", "--warmup", "5"], stderr=subprocess.DEVNULL, timeout=300).decode()
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5
+    assert d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["gather_windows_in_region"] >= 1 and d["gather_ok"] is True
+    assert [r["rank"] for r in d["per_rank"]] == [0, 1]
+    assert d["config"]["last_rank_envs"] == [256, 512]
+
+
+def test_gather_window_always_closes_inside_the_region():
+    import bench
+    for requested, steps in ((64, 20), (64, 400), (8, 20), (64, 1), (64, 2), (1, 20)):
+        every = bench.gather_window(requested, steps)
+        assert 1 <= every <= max(1, requested)
+        for first in range(0, 70):                     # wherever the timed region starts
+            assert any(t % every == every - 1 for t in range(first, first + steps)) or steps < every
+        assert steps >= every

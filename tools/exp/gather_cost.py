@@ -1,26 +1,44 @@
-"""Host cost of handing one window to RCCL (1 rank): gather(list) vs all_gather_into_tensor vs a copy."""
-import os, time, torch, torch.distributed as dist
-os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29611")
-dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
-dev = torch.device("cuda:0")
-buf = torch.zeros((16, 8192, 4), dtype=torch.int32, device=dev)
-recv = [torch.zeros_like(buf)]
-out = torch.zeros((1,) + tuple(buf.shape), dtype=torch.int32, device=dev)
-def t(fn, n=20):
-    fn(); torch.cuda.synchronize()
-    xs = []
-    for _ in range(n):
-        t0 = time.perf_counter(); w = fn(); xs.append(time.perf_counter() - t0)
-        torch.cuda.synchronize()
-    xs.sort(); return xs[len(xs) // 2] * 1e6, xs[-1] * 1e6
-print("gather(list) async", t(lambda: dist.gather(buf, recv, dst=0, async_op=True)))
-print("all_gather_into_tensor async", t(lambda: dist.all_gather_into_tensor(out, buf, async_op=True)))
-print("all_gather(list) async", t(lambda: dist.all_gather(recv, buf, async_op=True)))
-print("reduce async", t(lambda: dist.reduce(buf, dst=0, async_op=True)))
-print("copy_", t(lambda: out[0].copy_(buf, non_blocking=True)))
-s = torch.cuda.Stream(priority=-1)
-e = torch.cuda.Event()
-def ev():
-    e.record(); s.wait_event(e)
-print("event record+wait", t(ev))
-dist.destroy_process_group()
+"""Host cost of one gather window through slhip_gather_* (one rank: self send/recv), next to a stepping loop."""
+import os, sys, time
+os.environ["SAFELIFE_FORCE_GATHER"] = "1"
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+import bench
+from safelife_amd.levels import _device_counts
+from safelife_amd.vector_env import SafeLifeVectorEnv
+from safelife_amd.sharding import RewardGather
+pool = bench.load_pool("prune_still_25", _device_counts)
+env = SafeLifeVectorEnv(pool, 8192, time_limit=1000, view_shape=(25, 25), output_channels=bench.TRAIN_CHANNELS,
+                        auto_reset=True, with_obs=False, slices=2)
+env.reset()
+every = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+g = RewardGather(env, every=every, world=1, rank=0)
+g.prime()
+acts = torch.randint(0, 9, (400, 8192), device="cuda", dtype=torch.int32)
+ptrs = [acts[t].data_ptr() for t in range(400)]
+tb, ts, ta = [], [], []
+for t in range(400):
+    a = time.perf_counter(); g.before_step(t); b = time.perf_counter(); env.step_async(ptrs[t]); c = time.perf_counter(); g.after_step(t); d = time.perf_counter()
+    tb.append(b - a); ts.append(c - b); ta.append(d - c)
+torch.cuda.synchronize()
+tb, ts, ta = (np.array(x) * 1e6 for x in (tb, ts, ta))
+close = np.arange(400) % every == every - 1
+first = np.arange(400) % every == 0
+print("every", every, "| step %.1f us (median) %.1f (mean)" % (np.median(ts), ts.mean()),
+      "| after_step at window close: median %.1f mean %.1f" % (np.median(ta[close]), ta[close].mean()),
+      "| before_step at window start: median %.1f mean %.1f, else %.2f" % (np.median(tb[first]), tb[first].mean(), np.median(tb[~first])),
+      "| steps right after a close: %.1f" % np.median(ts[np.roll(close, 1)]))
+# pieces
+import ctypes as C
+lib = g._lib
+ws = g._writer_streams()
+t0 = time.perf_counter()
+for _ in range(50): g._order(ws, [g._stream])
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+for _ in range(50): lib.slhip_gather_window(g._comm, g.buf[0].data_ptr(), g.recv[0].data_ptr(), g.buf[0].numel() * 4, g._gptr[0])
+t3 = time.perf_counter()
+torch.cuda.synchronize()
+print("streams_order %.1f us, gather_window %.1f us per call (idle GPU)" % ((t1 - t0) / 50 * 1e6, (t3 - t2) / 50 * 1e6))

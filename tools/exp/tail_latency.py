@@ -36,11 +36,23 @@ def region(mode):
             assert rc == 0, rc
         while not (fl[0] and fl[1]):
             pass
+    if mode in (2, 3):
+        for ev, st in zip(evs, env._slice_streams):
+            ev.record(st)
+        if mode == 2:
+            for i, s_ in enumerate(streams):
+                hip.hipStreamWriteValue32(C.c_void_p(s_), C.c_void_p(fptr + 4 * i), 1, 0)
+            while not (fl[0] and fl[1]):
+                pass
+    if mode == 4:
+        for st in env._slice_streams:
+            st.synchronize()
     t2 = time.perf_counter()
     torch.cuda.synchronize()
     t3 = time.perf_counter()
     return (t3 - t0) * 1e6, (t1 - t0) * 1e6, (t2 - t1) * 1e6, (t3 - t2) * 1e6
-for mode in (0, 1, 0, 1):
+evs = [torch.cuda.Event() for _ in streams]
+for mode in (0, 2, 3, 4, 0, 2, 3, 4):
     r = np.array([region(mode) for _ in range(25)])
     print("mode", mode, "K", K, "median total %.1f (min %.1f) | enqueue %.1f | spin %.1f | sync %.1f  -> %.2f us/step" % (
         np.median(r[:, 0]), r[:, 0].min(), np.median(r[:, 1]), np.median(r[:, 2]), np.median(r[:, 3]), np.median(r[:, 0]) / K))
