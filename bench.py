@@ -297,14 +297,27 @@ def main():
     P = 8 if (args.cpu_baseline and world == 1) else 0
     actions = torch.randint(0, 9, (P + W + K, B), generator=gen, device=dev, dtype=torch.int32)
     # N > 1: the window is cut so that at least one closes -- one RCCL exchange is issued -- inside the timed steps
-    every_used = gather_window(args.gather_every, K) if world > 1 else args.gather_every
+    forced = os.environ.get("SAFELIFE_FORCE_GATHER", "0") == "1"         # one rank, exchange on (RCCL to itself)
+    every_used = gather_window(args.gather_every, K) if (world > 1 or forced) else args.gather_every
     gather = RewardGather(env, every=every_used, world=world, rank=rank)
     gather.prime()
 
     # one step = every env stepped once = one launch per slice, each on the slice's own stream; the action
     # tensor is complete before the loop starts, so nothing has to be fenced per step (step_async)
     act_ptr = [actions[t].data_ptr() for t in range(P + W + K)]
-    before, after, step, every = gather.before_step, gather.after_step, env.step_async, gather.every
+    step, every = env.step_async, gather.every
+    # windows are counted from the END of the timed block: its last step closes one (a learner that consumes K-step
+    # rollouts exchanges once per rollout), so the hand-off -- ~30-70 us of host time -- falls where the host is
+    # ahead of the device instead of in the middle of the launches
+    shift = (every - (P + W + K) % every) % every
+    # (measured with the exchange forced on for one rank, K = 20: window closing at the last step 12.3 us per step,
+    #  five steps earlier 13.4 -- with busy queues the hand-off costs the stepping thread 35-80 us -- none 9.1)
+
+    def before(t):
+        gather.before_step(t + shift)
+
+    def after(t):
+        gather.after_step(t + shift)
 
     step_host = []
 
@@ -316,7 +329,7 @@ def main():
                 b = time.perf_counter()
                 step(act_ptr[t])
                 c = time.perf_counter()
-                if t % every == every - 1:
+                if (t + shift) % every == every - 1:
                     after(t)
                 step_host.append((t, (b - a) * 1e6, (c - b) * 1e6, (time.perf_counter() - c) * 1e6))
             return
@@ -327,7 +340,7 @@ def main():
         for t in range(t0, t0 + n):
             before(t)
             step(act_ptr[t])
-            if t % every == every - 1:
+            if (t + shift) % every == every - 1:
                 after(t)
 
     # the first steps since the reset run one at a time, with a snapshot of the device state after each

@@ -194,7 +194,11 @@ typedef struct sl_episode_record {    /* 32 bytes */
     float spawn_prob;
     float episode_reward;
     int32_t episode_length;
-    uint8_t success, times_up, reserved[2];
+    uint8_t success, times_up;
+    uint8_t n_cell_types;         /* written by slhip_side_effects: frozen movable / destructible cell types on the
+                                     starting board (saturating); more than SL_SE_MAX_KEYS - 8 means keys and
+                                     type_masks of this entry are cut short (rebuild them from `counts` on the host) */
+    uint8_t reserved;
 } sl_episode_record;
 
 typedef struct sl_episode_queue {

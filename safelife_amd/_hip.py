@@ -83,7 +83,7 @@ class EpisodeRecord(C.Structure):
     """`struct sl_episode_record` (32 bytes)."""
     _fields_ = [("env", C.c_int32), ("level", C.c_int32), ("num_steps", C.c_int32), ("episode_idx", C.c_int32),
                 ("spawn_prob", C.c_float), ("episode_reward", C.c_float), ("episode_length", C.c_int32),
-                ("success", C.c_uint8), ("times_up", C.c_uint8), ("reserved", C.c_uint8 * 2)]
+                ("success", C.c_uint8), ("times_up", C.c_uint8), ("n_cell_types", C.c_uint8), ("reserved", C.c_uint8)]
 
 
 class EpisodeQueue(C.Structure):

@@ -442,7 +442,7 @@ __global__ __launch_bounds__(GB) void k_env_rollout_generic(sl_env_batch env,
                     rec.episode_length = ep_l;
                     rec.success = success;
                     rec.times_up = times_up;
-                    rec.reserved[0] = rec.reserved[1] = 0;
+                    rec.n_cell_types = rec.reserved = 0;
                     env.finished.records[slot] = rec;
                 } else {
                     slot = -1;

@@ -132,6 +132,9 @@ __global__ __launch_bounds__(SE_THREADS) void k_se_distributions(sl_env_batch en
         }
     }
     if (tid < SL_SE_MAX_KEYS - 8 && tid >= n_types) my_keys[8 + tid] = 0xFFFFu;
+    // how many such cell types the board really has (saturating): more than the key slots hold means the
+    // device-side distributions of this entry are incomplete, and the host says so (SideEffectBatch)
+    if (tid == 0) q.records[slot].n_cell_types = (uint8_t)min(scan[SE_THREADS - 1], 255);
     __syncthreads();
     // life distributions: float64 counts / denominator, laid out [2, 8, H, W]
     double *ld = life_dist + (size_t)slot * 2 * 8 * HW;

@@ -57,13 +57,19 @@ class VectorRunner(object):
         return self.env.policy_tensor, (self.env_ids, self.num_resets.clone())
 
     def act_on_envs(self, actions):
-        """Step every env with its action; returns ``(next_obs, rewards, done)``.  An env whose episode ended has
+        """Step every env with its action; returns ``(next_obs, rewards, done)`` -- ``rewards`` is the wrapped
+        (float64) reward when the env was built with ``wrappers=``, the game's float32 reward otherwise; the raw one
+        stays available as ``env.reward``.  An env whose episode ended has
         already been reset: its ``next_obs`` row is the new episode's first observation and its reset counter is
         bumped (training/base_algo.py:231-238)."""
         torch = self.torch
         a = actions.to(device=self.env.device, dtype=torch.int32).contiguous()
         self.env.step(a)
-        rewards, done = self.env.reward.clone(), self.env.done.to(torch.bool)
+        # what the reference's trainers see is the reward as the wrapper stack hands it on (movement bonus, exit
+        # bonus, side-effect penalty: env_factory.py:277-283 wraps the env before base_algo steps it)
+        shaped = getattr(self.env, "shaped_reward", None)
+        rewards = shaped.clone() if shaped is not None else self.env.reward.clone()
+        done = self.env.done.to(torch.bool)
         self.num_resets += done.to(torch.int64)
         self.num_steps += 1
         return self.env.policy_tensor, rewards, done

@@ -52,10 +52,24 @@ class SideEffectBatch(object):
         flags = raw[:, 7:8].copy().view(np.uint8)
         return dict(env=raw[:, 0], level=raw[:, 1], num_steps=raw[:, 2], episode_idx=raw[:, 3],
                     spawn_prob=raw[:, 4].copy().view(np.float32), episode_reward=raw[:, 5].copy().view(np.float32),
-                    episode_length=raw[:, 6], success=flags[:, 0], times_up=flags[:, 1])
+                    episode_length=raw[:, 6], success=flags[:, 0], times_up=flags[:, 1], n_cell_types=flags[:, 2])
+
+    def dropped(self):
+        """Episodes that ended while the queue was full (they were not recorded)."""
+        return max(0, int(self.count.item()) - self.rec_tensor.shape[0])
 
     def distributions(self, i):
         """(inaction, action): ``{cell type: float64 [H,W]}`` of entry i, as side_effects.py:113-130 builds them."""
+        rec = self.rec_tensor[i].cpu().numpy()
+        n_types = int(rec[7:8].copy().view(np.uint8)[2])
+        if n_types > _hip.SL_SE_MAX_KEYS - 8:
+            # more frozen movable / destructible cell types on the starting board than the device-side key slots
+            # hold: this entry's distributions are rebuilt on the host from the occupancy tensors (which are complete)
+            from . import side_effects as se
+            b0 = np.asarray(self.env.pool.arrays()["pool_board"][int(rec[1])], np.uint16)
+            b2 = self.boards[i].cpu().numpy().view(np.uint16)
+            found_in, found_act = se.distributions_from_counts(b0, b2, self.counts[:, i].cpu().numpy(), self.num_samples)
+            return ({int(k): v for k, v in found_in.items()}, {int(k): v for k, v in found_act.items()})
         keys = self.keys[i].cpu().numpy().view(np.uint16)
         life = self.life_dist[i].cpu().numpy()
         masks = self.type_masks[i].cpu().numpy()
@@ -393,7 +407,14 @@ class SafeLifeVectorEnv(object):
         """One step per env, one launch per slice on the slice's own stream; nothing is fenced.  `actions`:
         a contiguous int32 device tensor [B] that is already complete (or ordered by ``fence()``), or its
         device address as an int.  Outputs are valid on the caller's stream after ``join()``."""
-        ptr = actions if isinstance(actions, int) else actions.data_ptr()
+        if isinstance(actions, int):
+            ptr = actions
+        else:           # (a tensor: the checks step() makes through _actions(), without its conversions)
+            if (actions.dtype != self.torch.int32 or not actions.is_contiguous() or actions.numel() != self.num_envs
+                    or actions.device != self.device):
+                raise ValueError("step_async() takes a contiguous int32 tensor [num_envs] on the env's device "
+                                 "(or its address); got %s %s on %s" % (actions.dtype, tuple(actions.shape), actions.device))
+            ptr = actions.data_ptr()
         if self.slices > 1:
             if self._caller_ahead:      # a reset / step() / rollout() on the caller's stream since the last fence
                 self.fence()

@@ -94,10 +94,11 @@ def test_patterns_known_answers(sp):
                 assert np.array_equal(sp.advance_board(d[name + "_in"], 0.3, n), d["%s_n%d" % (name, n)])
 
 
-def test_side_effect_occupancy_tensors(sp):
+@pytest.mark.parametrize("fixture", ["side_effect_inputs.npz", "side_effect_inputs_64.npz"])
+def test_side_effect_occupancy_tensors(sp, fixture):
     """Config C5's pinned part: advance(n) + both life_occupancy tensors of side_effect_score
-    (side_effects.py:103-113), all on one generator, in the reference's order."""
-    with np.load(os.path.join(util.GOLDEN, "side_effect_inputs.npz")) as d:
+    (side_effects.py:103-113), all on one generator, in the reference's order (25x25 and 64x64)."""
+    with np.load(os.path.join(util.GOLDEN, fixture)) as d:
         bg = np.random.PCG64(0)
         oracle.pcg64_set_state_words(bg, d["rng0"])
         sp.set_bit_generator(bg)
@@ -519,11 +520,14 @@ def test_side_effect_score_pipeline(sp):
             assert dist >= 0 and mass >= 0
 
 
-def test_side_effect_pass_reproduces_reference_inputs(sp):
-    """slhip_side_effects (the batched episode-end pass) on a queue of 80 entries that all replay the pinned case
-    of the reference's side_effect_score (tests/golden/side_effect_inputs.npz: starting board, final board,
-    episode length, generator state): roll-forward, both occupancy tensors and the distributions of
-    side_effects.py:111-130, every entry -- with a device-side entry count below the capacity."""
+@pytest.mark.parametrize("fixture", ["side_effect_inputs.npz", "side_effect_inputs_64.npz"])
+def test_side_effect_pass_reproduces_reference_inputs(sp, fixture):
+    """slhip_side_effects (the batched episode-end pass) on a queue of 80 entries that all replay a pinned case
+    of the reference's side_effect_score (tests/golden/side_effect_inputs*.npz: starting board, final board,
+    episode length, generator state -- a 25x25 benchmark level, and a 64x64 navigation level, the size C5's
+    number is quoted on: compact counters, pre-roll and the two-run launch at W = 64): roll-forward, both
+    occupancy tensors and the distributions of side_effects.py:111-130, every entry -- with a device-side entry
+    count below the capacity."""
     import ctypes as C
     import torch
     from safelife_amd import _hip, side_effects as se
@@ -585,17 +589,21 @@ def test_side_effect_pass_reproduces_reference_inputs(sp):
     assert isinstance(batch.scores(0), dict)
 
 
-def test_side_effect_queue_end_to_end(sp):
-    """auto_reset=True, 128 envs, short episodes: the step kernels queue every finished episode (record + the
+@pytest.mark.parametrize("pool_name,n_levels,B,time_limit,capacity,n_samples", [
+    ("append_spawn_25", 12, 128, 11, 600, 60),
+    ("navigation_64", 32, 64, 9, 300, 40),         # C5's shape: 64-wide rows, ~70 spawners per level
+])
+def test_side_effect_queue_end_to_end(sp, pool_name, n_levels, B, time_limit, capacity, n_samples):
+    """auto_reset=True, short episodes: the step kernels queue every finished episode (record + the
     board as the agent left it, before the reset reloads the slot); side_effects_flush() runs the pass without
     any host read.  Checked: the queue against a replay on the oracle (which episode ended when, with which
     board), and every entry's occupancy tensors against the one-board primitives under the entry's own stream."""
     from safelife_amd import side_effects as se
-    pool, _ = util.pool_from_fixture("append_spawn_25", _device_counts, n=12, min_performance_fraction=0.05)
-    B, T = 128, 34
+    pool, _ = util.pool_from_fixture(pool_name, _device_counts, n=n_levels, min_performance_fraction=0.05)
+    T = 34
     first = np.arange(B) % len(pool)
-    kw = dict(first_level=first, auto_reset=True, level_stride=1, time_limit=11, view_shape=(9, 9))
-    dev = util.DeviceBackend(pool, B, slices=2, side_effects=dict(capacity=600, num_samples=60), **kw)
+    kw = dict(first_level=first, auto_reset=True, level_stride=1, time_limit=time_limit, view_shape=(9, 9))
+    dev = util.DeviceBackend(pool, B, slices=2, side_effects=dict(capacity=capacity, num_samples=n_samples), **kw)
     cpu = util.OracleBackend(pool, B, **kw)
     dev.reset(), cpu.reset()
     rng = np.random.default_rng(31)
@@ -648,12 +656,12 @@ def test_side_effect_queue_end_to_end(sp):
             oracle.pcg64_set_state_words(bg, words)
             sp.set_bit_generator(bg)
             lv = pool.levels[level]
-            c0 = sp.life_occupancy(sp.advance_board(lv.board, lv.spawn_prob, steps), lv.spawn_prob, 60)
+            c0 = sp.life_occupancy(sp.advance_board(lv.board, lv.spawn_prob, steps), lv.spawn_prob, n_samples)
             a_ = mix64((((0x2B0A2D5 ^ key[0]) & 0xFFFFFFFF) << 32) | key[1])     # run 1: the action tensor on its second
             words[0] ^= np.uint64(a_)
             words[1] ^= np.uint64(mix64(a_))
             oracle.pcg64_set_state_words(bg, words)
-            c1 = sp.life_occupancy(board, lv.spawn_prob, 60)
+            c1 = sp.life_occupancy(board, lv.spawn_prob, n_samples)
             assert np.array_equal(counts[0, i], c0) and np.array_equal(counts[1, i], c1), key
     assert not want
     assert len(dev.env.side_effects_flush()) == 0          # the fresh queue starts empty
@@ -932,6 +940,94 @@ def test_policy_layout_generic_kernels():
         a = rng.integers(0, 9, 7).astype(np.int32)
         dev.env.step(a)
         want, _, _ = cpu.step(a)
+
+
+@pytest.mark.parametrize("name", ["wrap_train_append-still", "wrap_train_navigation"])
+def test_vector_runner_hands_on_the_wrapped_reward(name):
+    """A learner driven by VectorRunner must see what the reference's trainers see: the reward AFTER the wrapper
+    stack (movement bonus, exit bonus, side-effect penalty), float64 -- against traces recorded through the
+    reference's own wrappers."""
+    import torch
+    from safelife_amd.runner import VectorRunner
+    from safelife_amd.vector_env import SafeLifeVectorEnv
+    tr = util.load_trace(name)
+    pool = util.pool_from_trace(tr, _device_counts)
+    kw = util.env_kwargs_from_trace(tr)
+    kw["output_channels"] = kw.get("output_channels") or tuple(range(16)) + (25, 26, 27)
+    env = SafeLifeVectorEnv(pool, 1, first_level=0, auto_reset=True, level_stride=1, episode_streams=False,
+                            policy_layout="uint8", with_obs=False, wrappers=util.wrappers_from_trace(tr), **kw)
+    actions = tr["trace_actions"]
+    step_no = [0]
+
+    def scripted(obs):
+        probs = torch.zeros((obs.shape[0], 9), device=obs.device)
+        probs[:, int(actions[step_no[0]])] = 1.0
+        return torch.zeros(obs.shape[0], device=obs.device), probs
+    runner = VectorRunner(env, scripted)
+    n_levels, n_resets = len(tr["trace_reset_obs"]), 0
+    for t in range(len(tr["trace_reward"])):
+        step_no[0] = t
+        res = runner.take_one_step()
+        assert res.rewards.dtype == torch.float64
+        assert float(res.rewards[0]) == float(tr["trace_shaped_reward"][t]), t
+        assert float(env.reward[0]) == float(tr["trace_reward"][t]), t
+        if bool(res.done[0]):
+            n_resets += 1
+            if n_resets >= n_levels:
+                break
+
+
+def test_step_async_rejects_what_it_would_misread():
+    """step_async() takes the tensor's address: an int64 tensor (torch's default for randint / argmax / multinomial)
+    or a strided view would be read as something else -- it has to say so, like step() does."""
+    import torch
+    from safelife_amd.vector_env import SafeLifeVectorEnv
+    pool, _ = util.pool_from_fixture("prune_still_25", _device_counts, n=4)
+    env = SafeLifeVectorEnv(pool, 128, with_obs=False, slices=2)
+    env.reset()
+    good = torch.zeros(128, dtype=torch.int32, device=env.device)
+    env.step_async(good)
+    env.step_async(good.data_ptr())
+    for bad in (torch.zeros(128, dtype=torch.int64, device=env.device),
+                torch.zeros((128, 2), dtype=torch.int32, device=env.device)[:, 0],
+                torch.zeros(64, dtype=torch.int32, device=env.device),
+                torch.zeros(128, dtype=torch.int32)):
+        with pytest.raises(ValueError):
+            env.step_async(bad)
+    env.join()
+
+
+def test_side_effect_keys_overflow_is_reported_and_survived():
+    """A starting board with more frozen movable / destructible cell types than the device-side key slots hold
+    (SL_SE_MAX_KEYS - 8 = 16): the record says how many there are, and the batch rebuilds that entry's
+    distributions on the host instead of silently dropping types."""
+    from safelife_amd import _hip, side_effects as se
+    from safelife_amd.cell_types import CellTypes as CT
+    from safelife_amd.levels import Level, LevelPool
+    H = W = 25
+    b = np.zeros((H, W), np.uint16)
+    kinds = [int(CT.frozen) | int(CT.destructible) | (c << 9) | extra for c in range(8) for extra in (0, int(CT.pushable), int(CT.pullable))]
+    for i, v in enumerate(kinds):                         # 24 distinct frozen cell types
+        b[2 + i // 8 * 3, 2 + (i % 8) * 2] = v
+    b[20, 20] = CT.player
+    b[10, 10:13] = CT.life | CT.color_g                  # a blinker for the occupancy tensors
+    lv = Level(b, np.zeros_like(b), [[20, 20]], min_performance=-1)
+    pool = LevelPool([lv], counts_fn=_device_counts)
+    dev = util.DeviceBackend(pool, 4, auto_reset=True, time_limit=3, view_shape=(9, 9), with_obs=False,
+                             side_effects=dict(capacity=16, num_samples=20))
+    dev.env.reset()
+    for t in range(3):
+        dev.env.step(np.zeros(4, np.int32))
+    batch = dev.env.side_effects_flush()
+    assert len(batch) == 4 and batch.dropped() == 0
+    recs = batch.records()
+    assert (recs["n_cell_types"] == len(kinds)).all() and len(kinds) > _hip.SL_SE_MAX_KEYS - 8
+    got_in, got_act = batch.distributions(1)
+    want_in, want_act = se.distributions_from_counts(b, batch.boards[1].cpu().numpy().view(np.uint16),
+                                                     batch.counts[:, 1].cpu().numpy(), 20)
+    assert set(got_in) == set(int(k) for k in want_in) and len([k for k in got_in if k & CT.frozen]) == len(kinds)
+    for k in want_in:
+        assert np.array_equal(got_in[int(k)], want_in[k]) and np.array_equal(got_act[int(k)], want_act[k])
 
 
 @pytest.mark.parametrize("name", ["v10_append-spawn", "v10_prune-still_open", "v10_navigation", "append_still_1_chan19"])

@@ -127,3 +127,21 @@ def test_env_trace(name):
 def test_env_trace_terminal_states(name):
     tr = util.load_trace(name)
     assert util.replay_trace_terminal(tr, util.OracleBackend, util.oracle_counts) >= 1
+
+
+@pytest.mark.parametrize("fixture", ["side_effect_inputs.npz", "side_effect_inputs_64.npz"])
+def test_side_effect_score_internals(fixture):
+    """The inputs of the reference's side_effect_score (side_effects.py:103-113) -- roll the starting board forward by
+    the episode's length, then 1000 steps of life_occupancy from there and from the board the agent left -- as the
+    reference computed them under one generator (25x25 benchmark level and 64x64 navigation level): the oracle
+    reproduces boards, both occupancy tensors and the generator state after each stage."""
+    with np.load(os.path.join(util.GOLDEN, fixture)) as d:
+        d = {k: d[k] for k in d.files}
+    p, n = float(d["spawn_prob"]), int(d["num_steps"])
+    words = d["rng0"].copy()[None]                      # [1, 4] uint64, advanced in place by the batch primitives
+    b1 = oracle.advance_board_batch(d["b0"][None], p, n, words)
+    assert np.array_equal(b1[0], d["b1"]) and np.array_equal(words[0], d["rng1"])
+    occ0 = oracle.life_occupancy_batch(b1, p, 1000, words)
+    assert np.array_equal(occ0[0], d["occ0"]) and np.array_equal(words[0], d["rng2"])
+    occ1 = oracle.life_occupancy_batch(d["b2"][None], p, 1000, words)
+    assert np.array_equal(occ1[0], d["occ1"]) and np.array_equal(words[0], d["rng3"])
