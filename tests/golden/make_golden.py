@@ -631,6 +631,64 @@ def gen_nav64(R, out, n):
     print("side_effect_inputs_64: %d steps, %d cells ever alive" % (game.num_steps, int((occ1.sum(-1) > 0).sum())))
 
 
+BULK_STEPS = 100
+
+
+def bulk_hash(board, goals, rewards, dones, rng_words, agent_loc):
+    """64-bit digest of what an env looks like after its action stream (tests/util.py restates it)."""
+    import hashlib
+    h = hashlib.blake2b(digest_size=8)
+    for a, dt in ((board, np.uint16), (goals, np.uint16), (rewards, np.float32), (dones, np.uint8),
+                  (rng_words, np.uint64), (agent_loc, np.int32)):
+        h.update(np.ascontiguousarray(a, dtype=dt).tobytes())
+    return np.frombuffer(h.digest(), np.uint64)[0]
+
+
+def gen_bulk(R, out):
+    """Every shipped benchmark level (8 x 100 levels of benchmarks/v1.0, the 31 single-level files of v0.1) under the
+    reference's SafeLifeEnv: 100 seeded random actions each, no reset -- an env that finishes keeps stepping, as
+    SafeLifeEnv does -- and one 64-bit digest per level of (board, goals, reward stream, done stream, generator
+    state, agent location).  The archives themselves (level DATA) are copied next to the digests so that the tests can
+    load them through safelife_amd.levels.load_levels, legacy keys and all."""
+    import glob
+    import shutil
+    Game = R.game.SafeLifeGame
+    dst_root = os.path.join(out, "levels")
+    files, digests, counts = [], [], []
+    idx = 0
+    for ver in ("v1.0", "v0.1"):
+        os.makedirs(os.path.join(dst_root, ver), exist_ok=True)
+        for path in sorted(glob.glob(os.path.join(REFERENCE, "safelife/levels/benchmarks", ver, "*.npz"))):
+            rel = os.path.join(ver, os.path.basename(path))
+            shutil.copyfile(path, os.path.join(dst_root, rel))
+            os.chmod(os.path.join(dst_root, rel), 0o644)
+            with np.load(path) as d:
+                recs = list(d["levels"]) if "levels" in d.files else [{k: d[k] for k in d.files}]
+            n = 0
+            for rec in recs:
+                game = seeded(Game.loaddata(normalize_level(rec)), 5000 + idx)
+                env = R.env.SafeLifeEnv(iter([game]), time_limit=1000, view_shape=(15, 15), output_channels=None,
+                                        should_calculate_side_effects=False)
+                env.reset()
+                acts = np.random.default_rng(idx).integers(0, 9, BULK_STEPS)
+                rewards, dones = [], []
+                for a in acts:
+                    _, r, dn, info = env.step(int(a))
+                    rewards.append(np.float32(r))
+                    dones.append(bool(dn))
+                loc = env.game.agent_locs
+                digests.append(bulk_hash(env.game.board, env.game.goals, rewards, dones,
+                                         words(env.game._rng.bit_generator), loc[0] if len(loc) else [-1, -1]))
+                idx += 1
+                n += 1
+            files.append(rel)
+            counts.append(n)
+            print("  %-32s %3d levels" % (rel, n), flush=True)
+    np.savez_compressed(os.path.join(out, "bulk_levels.npz"), files=np.array(files), counts=np.array(counts),
+                        digests=np.array(digests, np.uint64), steps=np.array(BULK_STEPS))
+    print("bulk: %d levels in %d files" % (idx, len(files)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--nav64", type=int, default=0, help="number of 64x64 navigation levels (slow)")
@@ -653,6 +711,8 @@ def main():
         gen_pool(R, out, "prune-still", (25, 25), 96, 2024, "prune_still_25")
         gen_pool(R, out, "append-spawn", (25, 25), 64, 2025, "append_spawn_25")
         gen_pool(R, out, "append-still", (26, 26), 32, 2026, "append_still_26")
+    if "bulk" in todo:
+        gen_bulk(R, out)
     if args.nav64:
         gen_nav64(R, out, args.nav64)
 

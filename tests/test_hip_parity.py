@@ -942,6 +942,15 @@ def test_policy_layout_generic_kernels():
         want, _, _ = cpu.step(a)
 
 
+def test_every_shipped_benchmark_level():
+    """All 830 shipped benchmark levels loaded through levels.load_levels and stepped in ONE batch per board shape
+    (800 x 26x26, 30 x 25x25), 100 seeded random actions each: every level's digest of (board, goals, reward stream,
+    done stream, generator state, agent location) as the reference's SafeLifeEnv left it."""
+    got, want = util.bulk_levels_digests(util.DeviceBackend, _device_counts)
+    assert len(want) == 830
+    assert np.array_equal(got, want), np.flatnonzero(got != want)[:10]
+
+
 @pytest.mark.parametrize("name", ["wrap_train_append-still", "wrap_train_navigation"])
 def test_vector_runner_hands_on_the_wrapped_reward(name):
     """A learner driven by VectorRunner must see what the reference's trainers see: the reward AFTER the wrapper

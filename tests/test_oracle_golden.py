@@ -145,3 +145,12 @@ def test_side_effect_score_internals(fixture):
     assert np.array_equal(occ0[0], d["occ0"]) and np.array_equal(words[0], d["rng2"])
     occ1 = oracle.life_occupancy_batch(d["b2"][None], p, 1000, words)
     assert np.array_equal(occ1[0], d["occ1"]) and np.array_equal(words[0], d["rng3"])
+
+
+def test_every_shipped_benchmark_level():
+    """All 830 shipped benchmark levels (8 x 100 of v1.0 -- legacy `agent_loc` (x, y) key, 26x26 -- and the 30
+    single-level files of v0.1, 25x25), 100 seeded random actions each: the oracle reproduces the reference's
+    digest of (board, goals, reward stream, done stream, generator state, agent location) for every one."""
+    got, want = util.bulk_levels_digests(util.OracleBackend, util.oracle_counts)
+    assert len(want) == 830
+    assert np.array_equal(got, want), np.flatnonzero(got != want)[:10]

@@ -257,3 +257,45 @@ def smoke_check():
         assert np.array_equal(r1, r2) and np.array_equal(d1, d2) and np.array_equal(o1, o2), t
         for name in ("board", "goals", "agent_loc", "rng", "num_steps", "level_idx"):
             assert np.array_equal(dev.get(name), cpu.get(name)), (t, name)
+
+
+# ---- the shipped benchmark levels in bulk (tests/golden/levels + bulk_levels.npz, make_golden.py gen_bulk) ----------
+
+def bulk_hash(board, goals, rewards, dones, rng_words, agent_loc):
+    import hashlib
+    h = hashlib.blake2b(digest_size=8)
+    for a, dt in ((board, np.uint16), (goals, np.uint16), (rewards, np.float32), (dones, np.uint8),
+                  (rng_words, np.uint64), (agent_loc, np.int32)):
+        h.update(np.ascontiguousarray(a, dtype=dt).tobytes())
+    return np.frombuffer(h.digest(), np.uint64)[0]
+
+
+def bulk_levels_digests(backend_cls, counts_fn):
+    """Every level of the shipped archives, loaded through safelife_amd.levels.load_levels, stepped in one batch per
+    board shape with the fixture's action streams -> (digests, expected digests), in file order."""
+    from safelife_amd.levels import LevelPool, load_levels
+    with np.load(os.path.join(GOLDEN, "bulk_levels.npz")) as d:
+        files, counts, want, T = [str(f) for f in d["files"]], d["counts"], d["digests"], int(d["steps"])
+    levels = []
+    for rel, n in zip(files, counts):
+        got = load_levels(os.path.join(GOLDEN, "levels", rel))
+        assert len(got) == n, rel
+        levels += got
+    for idx, lv in enumerate(levels):
+        lv.seed = 5000 + idx                         # SafeLifeGame.seed of the generator
+    out = np.zeros(len(levels), np.uint64)
+    for shape in sorted(set(lv.shape for lv in levels)):
+        ids = [i for i, lv in enumerate(levels) if lv.shape == shape]
+        pool = LevelPool([levels[i] for i in ids], counts_fn=counts_fn)
+        B = len(ids)
+        be = backend_cls(pool, B, first_level=np.arange(B), auto_reset=False, episode_streams=False,
+                         time_limit=1000, view_shape=(15, 15), output_channels=None)
+        be.reset()
+        acts = np.stack([np.random.default_rng(i).integers(0, 9, T) for i in ids], axis=1).astype(np.int32)
+        rewards, dones = np.zeros((T, B), np.float32), np.zeros((T, B), np.uint8)
+        for t in range(T):
+            _, rewards[t], dones[t] = be.step(np.ascontiguousarray(acts[t]))
+        board, goals, rng, loc = (be.get(k) for k in ("board", "goals", "rng", "agent_loc"))
+        for k, i in enumerate(ids):
+            out[i] = bulk_hash(board[k], goals[k], rewards[:, k], dones[:, k], rng[k], loc[k])
+    return out, want
