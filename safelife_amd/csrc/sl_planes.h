@@ -106,6 +106,11 @@ inline V pperm(const V &s0, const V &s1, uint32_t sel) {   // v_perm_b32: select
     }
     return r;
 }
+inline V palign(const V &hi, const V &lo, int sh) {        // v_alignbit_b32: ({hi, lo} >> sh)[31:0]
+    V r;
+    for (int i = 0; i < 64; ++i) r.l[i] = (uint32_t)((((uint64_t)hi.l[i] << 32) | lo.l[i]) >> sh);
+    return r;
+}
 inline bool pany(const V &a) {
     for (int i = 0; i < 64; ++i)
         if (a.l[i]) return true;
@@ -146,6 +151,7 @@ SL_PL_DEV V pb3(V a, V b, V c) {
     return __builtin_amdgcn_bitop3_b32(a, b, c, TT & 0xFFu);
 }
 SL_PL_DEV V pperm(V s0, V s1, uint32_t sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
+SL_PL_DEV V palign(V hi, V lo, int sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 SL_PL_DEV bool pany(V a) { return __ballot(a != 0) != 0; }
 enum { PV_BPERM = 0, PV_SHIFT = 1, PV_ROTATE = 2 };      // = the V_* modes of sl_rowlane.hip
 template <int VERT>
@@ -168,18 +174,22 @@ SL_PL_DEV V pdn(const VCtx<VERT> &vc, V v) {
 
 // three-input functions used below
 #define SL_PB3(expr, a, b, c) pb3<(unsigned)((expr)&0xFF)>((a), (b), (c))
-#define PB_OR3(a, b, c) SL_PB3(TA | TB | TC, a, b, c)
-#define PB_XOR3(a, b, c) SL_PB3(TA ^ TB ^ TC, a, b, c)
-#define PB_MAJ(a, b, c) SL_PB3((TA & TB) | (TA & TC) | (TB & TC), a, b, c)
 #define PB_SEL(a, b, m) SL_PB3((TA & TC) | (TB & ~TC), a, b, m)        /* (a & m) | (b & ~m) */
 
+// Geometry.  Rows of up to 28 cells: ONE word per plane -- the two halves of the split layout side by side, each
+// with the cells beyond its ends as seam bits (see the file header).  Rows of exactly 64 cells: TWO words per plane,
+// cells 0-31 and 32-63 in order, the torus' wrap a 64-bit rotate (v_alignbit), no seam bits; the row's words go
+// through two 16 x 16 transpositions (words 0-15 and 16-31) whose halves are re-paired by one byte permute each.
 template <int W>
 struct PG {
-    static constexpr int WS = (W + 1) / 2, WH = W - WS, NE = WS + 2;
+    static constexpr int WS = (W + 1) / 2, WH = W - WS;
+    static constexpr int NW = W == 64 ? 2 : 1;                      // words per plane
+    static constexpr int NG = NW;                                   // 16-entry transposition groups
+    static constexpr int NE = NW == 1 ? WS + 2 : 16;                // entries per group
     static constexpr bool ODD = (W & 1) != 0;
-    static_assert(NE <= 16 && W >= 4, "bit-plane step: rows of 4 to 28 cells");
+    static_assert((NW == 1 && WS + 2 <= 16 && W >= 4) || W == 64, "bit-plane step: rows of 4 to 28 cells, or 64");
     // the planes' bits that are cells of the row (the rest: seam copies and padding)
-    static constexpr uint32_t REAL = (((1u << WS) - 1u) << 1) | (((1u << WH) - 1u) << 17);
+    static constexpr uint32_t REAL = NW == 2 ? 0xFFFFFFFFu : (((1u << WS) - 1u) << 1) | (((1u << WH) - 1u) << 17);
 };
 
 struct PConsts {        // masks kept in VGPRs for the whole kernel
@@ -206,170 +216,321 @@ SL_PL_DEV V bf_hi_a(const V &a, int s, const V &m) { return pshr(a, s) & m; }
 SL_PL_DEV V bf_lo_b(const V &b, int s, const V &m) { return SL_PB3(TA & ~TB, pshl(b, s), m, m); }
 SL_PL_DEV V bf_hi_b(const V &b, const V &m) { return SL_PB3(TA & ~TB, b, m, m); }
 
-// Column triple of a plane: values from the rows above (u) and below (d).
-template <int VERT>
-struct Col {
-    V u, d;
-    SL_PL_DEV Col(const VCtx<VERT> &vc, const V &x) : u(pup<VERT>(vc, x)), d(pdn<VERT>(vc, x)) {}
+// ---- a plane: NW words, and the operations the rule needs on it ----------------------------------------------
+template <int NW>
+struct Pl {
+    V w[NW];
 };
+template <unsigned TT, int NW>
+SL_PL_DEV Pl<NW> qb3(const Pl<NW> &a, const Pl<NW> &b, const Pl<NW> &c) {
+    Pl<NW> r;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) r.w[i] = pb3<TT>(a.w[i], b.w[i], c.w[i]);
+    return r;
+}
+#define SL_QB3(expr, a, b, c) qb3<(unsigned)((expr)&0xFF)>((a), (b), (c))
+#define QB_OR3(a, b, c) SL_QB3(TA | TB | TC, a, b, c)
+#define QB_XOR3(a, b, c) SL_QB3(TA ^ TB ^ TC, a, b, c)
+#define QB_MAJ(a, b, c) SL_QB3((TA & TB) | (TA & TC) | (TB & TC), a, b, c)
+template <int NW>
+SL_PL_DEV Pl<NW> operator&(const Pl<NW> &a, const Pl<NW> &b) {
+    Pl<NW> r;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) r.w[i] = a.w[i] & b.w[i];
+    return r;
+}
+template <int NW>
+SL_PL_DEV Pl<NW> operator|(const Pl<NW> &a, const Pl<NW> &b) {
+    Pl<NW> r;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) r.w[i] = a.w[i] | b.w[i];
+    return r;
+}
+template <int NW>
+SL_PL_DEV Pl<NW> operator^(const Pl<NW> &a, const Pl<NW> &b) {
+    Pl<NW> r;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) r.w[i] = a.w[i] ^ b.w[i];
+    return r;
+}
+template <int NW>
+SL_PL_DEV bool qany(const Pl<NW> &a) {
+    V o = a.w[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) o = o | a.w[i];
+    return pany(o);
+}
+template <int NW>
+SL_PL_DEV Pl<NW> qzero() {
+    Pl<NW> r;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) r.w[i] = pconst(0);
+    return r;
+}
+// the left / right neighbour of every cell: one word -- the seam bits are the halo, a plain shift; two words -- the
+// row is a 64-bit ring
+SL_PL_DEV Pl<1> qleft(const Pl<1> &a) { return Pl<1>{{padd(a.w[0], a.w[0])}}; }
+SL_PL_DEV Pl<1> qright(const Pl<1> &a) { return Pl<1>{{pshr(a.w[0], 1)}}; }
+SL_PL_DEV Pl<2> qleft(const Pl<2> &a) { return Pl<2>{{palign(a.w[0], a.w[1], 31), palign(a.w[1], a.w[0], 31)}}; }
+SL_PL_DEV Pl<2> qright(const Pl<2> &a) { return Pl<2>{{palign(a.w[1], a.w[0], 1), palign(a.w[0], a.w[1], 1)}}; }
+// OR / majority / parity of a plane with its two horizontal neighbours
+template <int NW>
+SL_PL_DEV Pl<NW> row_or(const Pl<NW> &a) { return QB_OR3(qleft(a), a, qright(a)); }
+
+// Column triple of a plane: values from the rows above (u) and below (d).
+template <int VERT, int NW>
+struct Col {
+    Pl<NW> u, d;
+    SL_PL_DEV Col(const VCtx<VERT> &vc, const Pl<NW> &x) {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            u.w[i] = pup<VERT>(vc, x.w[i]);
+            d.w[i] = pdn<VERT>(vc, x.w[i]);
+        }
+    }
+};
+template <int VERT, int NW>
+SL_PL_DEV Pl<NW> box_or(const VCtx<VERT> &vc, const Pl<NW> &x) {        // OR over the 3 x 3 block
+    const Col<VERT, NW> c(vc, x);
+    return row_or(QB_OR3(c.u, x, c.d));
+}
+
+// ---- words <-> planes ------------------------------------------------------------------------------------------------
+// A transposition group: sixteen entries (split-halves words) -> the planes' 16 + 16 bits.  What the first pass leaves
+// behind for the second (destructible comes out of the low bytes' 4-stage words).
+struct Grp {
+    V x[4];
+};
+// planes 0 (alive), 4 (frozen), 5 (preserving), 6 (inhibiting), 7 (spawning) of one group; ent(i) = entry i
+template <int NE, bool SPAWN, class Ent>
+SL_PL_DEV void group_fast(Ent &&ent, const PConsts &c, Grp &g, V &A, V &Z, V &P, V &I, V &S) {
+    V w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {       // 8-stage, low bytes: word i = bits 0-7 of entries i (columns 0-7) and i + 8
+        if (i >= NE) w[i] = pconst(0);
+        else if (i + 8 >= NE) w[i] = ent(i) & c.lo8;
+        else w[i] = pperm(ent(i + 8), ent(i), 0x06020400u);
+    }
+    V x[8];                             // 4-stage: x[0..3] = bits 0-3, x[4..7] = bits 4-7
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        x[i] = bf_lo(w[i], w[i + 4], 4, c.m4);
+        x[i + 4] = bf_hi(w[i], w[i + 4], 4, c.m4);
+        g.x[i] = x[i];
+    }
+    const V y0 = bf_lo(x[0], x[2], 2, c.m2), y1 = bf_lo(x[1], x[3], 2, c.m2);              // bits 0-1
+    const V y4 = bf_lo(x[4], x[6], 2, c.m2), y5 = bf_lo(x[5], x[7], 2, c.m2);              // bits 4-5
+    const V y6 = bf_hi(x[4], x[6], 2, c.m2), y7 = bf_hi(x[5], x[7], 2, c.m2);              // bits 6-7
+    A = bf_lo(y0, y1, 1, c.m1);
+    Z = bf_lo(y4, y5, 1, c.m1);
+    P = bf_hi(y4, y5, 1, c.m1);
+    I = bf_lo(y6, y7, 1, c.m1);
+    S = SPAWN ? bf_hi(y6, y7, 1, c.m1) : A;
+}
+// planes 3 (destructible), 8 (exit), 9-11 (colours)
+template <int NE, class Ent>
+SL_PL_DEV void group_slow(Ent &&ent, const PConsts &c, const Grp &g, V &D, V &X, V &C0, V &C1, V &C2) {
+    D = bf_hi(bf_hi(g.x[0], g.x[2], 2, c.m2), bf_hi(g.x[1], g.x[3], 2, c.m2), 1, c.m1);
+    V h[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (i >= NE) h[i] = pconst(0);
+        else if (i + 8 >= NE) h[i] = pshr(ent(i), 8) & c.lo8;
+        else h[i] = pperm(ent(i + 8), ent(i), 0x07030501u);
+    }
+    V q[4];                                                              // bits 8-11
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = bf_lo(h[i], h[i + 4], 4, c.m4);
+    const V z0 = bf_lo(q[0], q[2], 2, c.m2), z1 = bf_lo(q[1], q[3], 2, c.m2);              // bits 8-9
+    const V z2 = bf_hi(q[0], q[2], 2, c.m2), z3 = bf_hi(q[1], q[3], 2, c.m2);              // bits 10-11
+    X = bf_lo(z0, z1, 1, c.m1);
+    C0 = bf_hi(z0, z1, 1, c.m1);
+    C1 = bf_lo(z2, z3, 1, c.m1);
+    C2 = bf_hi(z2, z3, 1, c.m1);
+}
+// planes 0 (fresh), 3, 9-11 of one group -> the entries' words (the same transposition, 1-stage first): lo[i] / hi[i]
+// hold the low / high bytes of entries i and i + 8
+SL_PL_DEV void group_back(const V &fresh, const V &nvD, const V (&nvC)[3], const PConsts &c, V (&lo)[8], V (&hi)[8]) {
+    const V a0 = bf_lo_a(fresh, c.m1), a1 = bf_hi_a(fresh, 1, c.m1);              // pair (0, 1): plane 1 empty
+    const V a2 = bf_lo_b(nvD, 1, c.m1), a3 = bf_hi_b(nvD, c.m1);                  // pair (2, 3): plane 2 empty
+    const V a8 = bf_lo_b(nvC[0], 1, c.m1), a9 = bf_hi_b(nvC[0], c.m1);            // pair (8, 9): plane 8 empty
+    const V a10 = bf_lo(nvC[1], nvC[2], 1, c.m1), a11 = bf_hi(nvC[1], nvC[2], 1, c.m1);
+    const V lo4[4] = {bf_lo(a0, a2, 2, c.m2), bf_lo(a1, a3, 2, c.m2), bf_hi(a0, a2, 2, c.m2), bf_hi(a1, a3, 2, c.m2)};
+    const V hi4[4] = {bf_lo(a8, a10, 2, c.m2), bf_lo(a9, a11, 2, c.m2), bf_hi(a8, a10, 2, c.m2), bf_hi(a9, a11, 2, c.m2)};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        lo[i] = bf_lo_a(lo4[i], c.m4);
+        lo[i + 4] = bf_hi_a(lo4[i], 4, c.m4);
+        hi[i] = bf_lo_a(hi4[i], c.m4);
+        hi[i + 4] = bf_hi_a(hi4[i], 4, c.m4);
+    }
+}
+SL_PL_DEV V group_entry(const V (&lo)[8], const V (&hi)[8], int i) {      // entry i of the group
+    return i < 8 ? pperm(hi[i], lo[i], 0x06020400u) : pperm(hi[i - 8], lo[i - 8], 0x07030501u);
+}
+
+// The decision of advance_board.c:94-124 on whole rows.
+template <int NW>
+struct Verdict {
+    Pl<NW> dies, born, dead_free, is3, fS;
+};
+template <int VERT, int NW, bool SPAWN>
+SL_PL_DEV Verdict<NW> decide(const VCtx<VERT> &vc, const Pl<NW> &A, const Pl<NW> &Z, const Pl<NW> &P, const Pl<NW> &I,
+                             const Pl<NW> &S, const Pl<NW> &realm) {
+    const Col<VERT, NW> cA(vc, A);
+    const Pl<NW> s0 = QB_XOR3(cA.u, A, cA.d), s1 = QB_MAJ(cA.u, A, cA.d);         // alive cells in the column: s0 + 2 s1
+    const Pl<NW> s0l = qleft(s0), s0r = qright(s0), s1l = qleft(s1), s1r = qright(s1);
+    const Pl<NW> ones = QB_XOR3(s0l, s0, s0r), c1 = QB_MAJ(s0l, s0, s0r);         // count = ones + 2 (c1 + t) + 4 c2
+    const Pl<NW> t = QB_XOR3(s1l, s1, s1r), c2 = QB_MAJ(s1l, s1, s1r);
+    const Pl<NW> u = c1 ^ t;                                                      // bit 1 of the count
+    const Pl<NW> hi3 = SL_QB3(TA | (TB & TC), c2, c1, t);                         // bits 2-3 both clear <=> !(c2 | c1 & t)
+    const Pl<NW> b2x = SL_QB3(TA ^ (TB & TC), c2, c1, t);                         // count in 4..7 with bit 3 clear
+    Verdict<NW> v;
+    v.is3 = SL_QB3(TA & TB & ~TC, ones, u, hi3);
+    const Pl<NW> is4 = SL_QB3(~TA & ~TB & TC, ones, u, b2x);
+    const Pl<NW> fP = box_or<VERT, NW>(vc, P), fI = box_or<VERT, NW>(vc, I);
+    const Pl<NW> keep_a = SL_QB3(TA | TB | TC, Z, fP, v.is3) | is4;               // an alive cell stays
+    v.dead_free = SL_QB3(TA & ~TB & ~TC, realm, A, Z | fI);                       // dead, neither frozen nor inhibited
+    v.dies = SL_QB3(TA & TB & ~TC, realm, A, keep_a);
+    v.born = v.dead_free & v.is3;
+    v.fS = SPAWN ? box_or<VERT, NW>(vc, S) : A;
+    return v;
+}
+
+// What a new cell inherits (advance_board.c:16-21,28-29): a flag an ALIVE neighbour carries, seen in at least two of
+// the nine cells.
+template <int VERT, int NW>
+SL_PL_DEV Pl<NW> seen_twice(const VCtx<VERT> &vc, const Pl<NW> &q) {
+    const Col<VERT, NW> cq(vc, q);
+    const Pl<NW> once = QB_OR3(cq.u, q, cq.d), twice = QB_MAJ(cq.u, q, cq.d);
+    return row_or(twice) | QB_MAJ(qleft(once), once, qright(once));              // a column has two | two columns have one
+}
 
 // ---- the step ---------------------------------------------------------------------------------------
 // b:      the row (split halves); replaced by the new row if anything in the wave changes
 // realm:  PG<W>::REAL on lanes that own a row of a board that is being advanced, 0 elsewhere (halo copies,
 //         idle lanes, boards that are through): only those lanes' cells die, are born or draw
-// draw:   SPAWN only; V ok = draw(V elig) makes the random draws of the flagged cells (a plane, bits as above)
-//         in row-major order and returns the cells whose draw succeeded
+// draw:   SPAWN only; ok = draw(elig) makes the random draws of the flagged cells -- planes as NW words each; one
+//         word: bit 1+k = cell k, bit 17+k = cell WS+k; two words: cell 32 i + k at bit k of word i -- in row-major
+//         order and returns the cells whose draw succeeded
 // returns whether any cell of the wave changed (wave-uniform); if not, b is untouched
 template <int W, int VERT, bool SPAWN, class Draw>
-SL_PL_DEV bool ca_planes(V (&b)[(W + 1) / 2], const VCtx<VERT> &vc, const V &realm, const PConsts &c, Draw &&draw) {
+SL_PL_DEV bool ca_planes(V (&b)[(W + 1) / 2], const VCtx<VERT> &vc, const V &realm_word, const PConsts &c, Draw &&draw) {
     using G = PG<W>;
-    constexpr int WS = G::WS, NE = G::NE;
-    // -- entries: seam words around the row's words
-    const V e_first = G::ODD ? pperm(b[WS - 1], b[WS - 2], 0x05040302u)      // (cell W-1, cell WS-1)
-                             : pperm(b[WS - 1], b[WS - 1], 0x01000302u);
-    const V e_wrap = G::ODD ? pperm(b[0], b[WS - 1], 0x05040100u) : b[WS - 1];   // odd: (cell WS-1, cell 0)
-    const V e_last = pperm(b[0], b[0], 0x01000302u);                          // (cell WS, cell 0)
-#define SL_ENT(i) ((i) == 0 ? e_first : (i) < WS ? b[(i) - 1 < 0 ? 0 : (i) - 1] : (i) == WS ? e_wrap : e_last)
-    // -- 8-stage, low bytes: word i = bits 0-7 of entries i (columns 0-7) and i + 8 (columns 8-15)
-    V w[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        if (i >= NE) w[i] = pconst(0);
-        else if (i + 8 >= NE) w[i] = SL_ENT(i) & c.lo8;
-        else w[i] = pperm(SL_ENT(i + 8), SL_ENT(i), 0x06020400u);
+    constexpr int WS = G::WS, NE = G::NE, NW = G::NW;
+    // -- entries of the transposition groups
+    V e_first = b[0], e_wrap = b[0], e_last = b[0];
+    if (NW == 1) {          // seam words around the row's words
+        e_first = G::ODD ? pperm(b[WS - 1], b[WS - 2], 0x05040302u)              // (cell W-1, cell WS-1)
+                         : pperm(b[WS - 1], b[WS - 1], 0x01000302u);
+        e_wrap = G::ODD ? pperm(b[0], b[WS - 1], 0x05040100u) : b[WS - 1];       // odd: (cell WS-1, cell 0)
+        e_last = pperm(b[0], b[0], 0x01000302u);                                 // (cell WS, cell 0)
     }
-    // -- 4-stage: x[0..3] = bits 0-3, x[4..7] = bits 4-7 (entry index mod 4 = word index mod 4)
-    V x[8];
+    auto ent0 = [&](int i) -> V {
+        if (NW == 2) return b[i];
+        return i == 0 ? e_first : i < WS ? b[i - 1 < 0 ? 0 : i - 1] : i == WS ? e_wrap : e_last;
+    };
+    auto ent1 = [&](int i) -> V { return b[NW == 2 ? 16 + i : 0]; };
+    // the planes of a group's two halves -> the row's plane words: one word as it is; two words: (cells 0-15 |
+    // 32-47) and (16-31 | 48-63) re-paired into cells 0-31 and 32-63
+    auto pair_up = [&](const V &t0, const V &t1) {
+        Pl<NW> r;
+        if (NW == 1) {
+            r.w[0] = t0;
+        } else {
+            r.w[0] = pperm(t1, t0, 0x05040100u);
+            r.w[NW - 1] = pperm(t1, t0, 0x07060302u);
+        }
+        return r;
+    };
+    Pl<NW> realm;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        x[i] = bf_lo(w[i], w[i + 4], 4, c.m4);
-        x[i + 4] = bf_hi(w[i], w[i + 4], 4, c.m4);
-    }
-    // -- 2-stage and 1-stage for the decision's planes: alive 0, frozen 4, preserving 5, inhibiting 6, spawning 7
-    const V y0 = bf_lo(x[0], x[2], 2, c.m2), y1 = bf_lo(x[1], x[3], 2, c.m2);              // bits 0-1
-    const V y4 = bf_lo(x[4], x[6], 2, c.m2), y5 = bf_lo(x[5], x[7], 2, c.m2);              // bits 4-5
-    const V y6 = bf_hi(x[4], x[6], 2, c.m2), y7 = bf_hi(x[5], x[7], 2, c.m2);              // bits 6-7
-    const V A = bf_lo(y0, y1, 1, c.m1);
-    const V Z = bf_lo(y4, y5, 1, c.m1), P = bf_hi(y4, y5, 1, c.m1);
-    const V I = bf_lo(y6, y7, 1, c.m1);
-    V S = A;
-    if (SPAWN) S = bf_hi(y6, y7, 1, c.m1);
-
-    // -- neighbourhood of the decision planes: column triple, then row triple
-    const Col<VERT> cA(vc, A), cP(vc, P), cI(vc, I);
-    const V s0 = PB_XOR3(cA.u, A, cA.d), s1 = PB_MAJ(cA.u, A, cA.d);         // alive cells in the column: s0 + 2 s1
-    const V kP = PB_OR3(cP.u, P, cP.d), kI = PB_OR3(cI.u, I, cI.d);
-    const V s0l = padd(s0, s0), s0r = pshr(s0, 1), s1l = padd(s1, s1), s1r = pshr(s1, 1);
-    const V ones = PB_XOR3(s0l, s0, s0r), c1 = PB_MAJ(s0l, s0, s0r);         // count = ones + 2 (c1 + t) + 4 c2
-    const V t = PB_XOR3(s1l, s1, s1r), c2 = PB_MAJ(s1l, s1, s1r);
-    const V u = c1 ^ t;                                                      // bit 1 of the count
-    const V hi3 = SL_PB3(TA | (TB & TC), c2, c1, t);                         // bits 2-3 both clear <=> !(c2 | c1 & t)
-    const V b2x = SL_PB3(TA ^ (TB & TC), c2, c1, t);                         // count in 4..7 with bit 3 clear
-    const V is3 = SL_PB3(TA & TB & ~TC, ones, u, hi3);
-    const V is4 = SL_PB3(~TA & ~TB & TC, ones, u, b2x);
-    const V fP = PB_OR3(padd(kP, kP), kP, pshr(kP, 1));
-    const V fI = PB_OR3(padd(kI, kI), kI, pshr(kI, 1));
-    // rule (advance_board.c:94-124)
-    const V keep_a = SL_PB3(TA | TB | TC, Z, fP, is3) | is4;                 // an alive cell stays
-    const V dead_free = SL_PB3(TA & ~TB & ~TC, realm, A, Z | fI);            // dead, neither frozen nor inhibited
-    const V dies = SL_PB3(TA & TB & ~TC, realm, A, keep_a);
-    V born = dead_free & is3;
-    V spawned = pconst(0);
+    for (int i = 0; i < NW; ++i) realm.w[i] = realm_word;
+    // -- the decision's planes: alive 0, frozen 4, preserving 5, inhibiting 6, spawning 7
+    Grp g0, g1;
+    V a0, z0, p0, i0, s0, a1, z1, p1, i1, s1;
+    group_fast<NE, SPAWN>(ent0, c, g0, a0, z0, p0, i0, s0);
+    if (NW == 2) group_fast<NE, SPAWN>(ent1, c, g1, a1, z1, p1, i1, s1);
+    else a1 = a0, z1 = z0, p1 = p0, i1 = i0, s1 = s0;
+    const Pl<NW> A = pair_up(a0, a1), Z = pair_up(z0, z1), P = pair_up(p0, p1), I = pair_up(i0, i1);
+    const Pl<NW> S = SPAWN ? pair_up(s0, s1) : A;
+    const Verdict<NW> v = decide<VERT, NW, SPAWN>(vc, A, Z, P, I, S, realm);
+    Pl<NW> spawned = qzero<NW>();
     if (SPAWN) {
-        const Col<VERT> cS(vc, S);
-        const V kS = PB_OR3(cS.u, S, cS.d);
-        const V fS = PB_OR3(padd(kS, kS), kS, pshr(kS, 1));
-        const V elig = SL_PB3(TA & ~TB & TC, dead_free, is3, fS);
-        if (pany(elig)) spawned = draw(elig);
+        const Pl<NW> elig = SL_QB3(TA & ~TB & TC, v.dead_free, v.is3, v.fS);
+        if (qany(elig)) spawned = draw(elig);
     }
-    const V fresh = SPAWN ? (born | spawned) : born;
-    const V gone = dies | fresh;                                             // cells whose old content goes
-    if (!pany(gone)) return false;
+    const Pl<NW> fresh = SPAWN ? (v.born | spawned) : v.born;
+    const Pl<NW> gone = v.dies | fresh;                                      // cells whose old content goes
+    if (!qany(gone)) return false;
 
     // -- new cells: ALIVE + what they inherit (only if the wave has any)
     V nm[WS];
 #pragma unroll
     for (int k = 0; k < WS; ++k) nm[k] = pconst(0);
-    if (pany(fresh)) {
+    if (qany(fresh)) {
         // destructible 3 from the low bytes; exit 8 and the colours 9-11 from the high bytes
-        const V D = bf_hi(bf_hi(x[0], x[2], 2, c.m2), bf_hi(x[1], x[3], 2, c.m2), 1, c.m1);
-        V h[8];
+        V d0, x0, c00, c10, c20, d1, x1, c01, c11, c21;
+        group_slow<NE>(ent0, c, g0, d0, x0, c00, c10, c20);
+        if (NW == 2) group_slow<NE>(ent1, c, g1, d1, x1, c01, c11, c21);
+        else d1 = d0, x1 = x0, c01 = c00, c11 = c10, c21 = c20;
+        const Pl<NW> D = pair_up(d0, d1), X = pair_up(x0, x1);
+        const Pl<NW> C[3] = {pair_up(c00, c01), pair_up(c10, c11), pair_up(c20, c21)};
+        // flags an ALIVE cell hands on: exit|destructible, colours
+        const Pl<NW> twD = seen_twice<VERT, NW>(vc, SL_QB3((TA | TB) & TC, X, D, A));
+        Pl<NW> nvD = v.born & twD;
+        Pl<NW> nvC[3];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (i >= NE) h[i] = pconst(0);
-            else if (i + 8 >= NE) h[i] = pshr(SL_ENT(i), 8) & c.lo8;
-            else h[i] = pperm(SL_ENT(i + 8), SL_ENT(i), 0x07030501u);
-        }
-        V g[4];                                                              // bits 8-11
-#pragma unroll
-        for (int i = 0; i < 4; ++i) g[i] = bf_lo(h[i], h[i + 4], 4, c.m4);
-        const V z0 = bf_lo(g[0], g[2], 2, c.m2), z1 = bf_lo(g[1], g[3], 2, c.m2);          // bits 8-9
-        const V z2 = bf_hi(g[0], g[2], 2, c.m2), z3 = bf_hi(g[1], g[3], 2, c.m2);          // bits 10-11
-        const V X = bf_lo(z0, z1, 1, c.m1), C0 = bf_hi(z0, z1, 1, c.m1);
-        const V C1 = bf_lo(z2, z3, 1, c.m1), C2 = bf_hi(z2, z3, 1, c.m1);
-        // flags an ALIVE cell hands on (advance_board.c:16-18,21,28-29): exit|destructible, colours
-        V q[4];
-        q[0] = SL_PB3((TA | TB) & TC, X, D, A);
-        q[1] = C0 & A;
-        q[2] = C1 & A;
-        q[3] = C2 & A;
-        V tw[4];                                                             // seen in at least two of the nine cells
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const Col<VERT> cq(vc, q[j]);
-            const V once = PB_OR3(cq.u, q[j], cq.d), twice = PB_MAJ(cq.u, q[j], cq.d);
-            const V any2 = PB_OR3(padd(twice, twice), twice, pshr(twice, 1));              // some column has two
-            const V col2 = PB_MAJ(padd(once, once), once, pshr(once, 1));                  // two columns have one
-            tw[j] = any2 | col2;
-        }
-        V nvD = born & tw[0];
-        V nvC[3];
-        if (SPAWN) {
-            // colours of SPAWNING cells go straight in (advance_board.c:19); a spawned cell is destructible (:117)
-            const V sc[3] = {S & C0, S & C1, S & C2};
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const Col<VERT> cs(vc, sc[j]);
-                const V k = PB_OR3(cs.u, sc[j], cs.d);
-                const V f = PB_OR3(padd(k, k), k, pshr(k, 1));
-                nvC[j] = SL_PB3(TA & (TB | TC), fresh, tw[j + 1], f);
+        for (int j = 0; j < 3; ++j) {
+            const Pl<NW> tw = seen_twice<VERT, NW>(vc, C[j] & A);
+            if (SPAWN) {
+                // colours of SPAWNING cells go straight in (advance_board.c:19)
+                const Pl<NW> f = box_or<VERT, NW>(vc, S & C[j]);
+                nvC[j] = SL_QB3(TA & (TB | TC), fresh, tw, f);
+            } else {
+                nvC[j] = fresh & tw;
             }
-            nvD = nvD | spawned;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) nvC[j] = fresh & tw[j + 1];
         }
-        // planes 0 (fresh), 3 (nvD), 9-11 (nvC) -> words, by the same transposition, 1-stage first
-        const V a0 = bf_lo_a(fresh, c.m1), a1 = bf_hi_a(fresh, 1, c.m1);              // pair (0, 1): plane 1 empty
-        const V a2 = bf_lo_b(nvD, 1, c.m1), a3 = bf_hi_b(nvD, c.m1);                  // pair (2, 3): plane 2 empty
-        const V a8 = bf_lo_b(nvC[0], 1, c.m1), a9 = bf_hi_b(nvC[0], c.m1);            // pair (8, 9): plane 8 empty
-        const V a10 = bf_lo(nvC[1], nvC[2], 1, c.m1), a11 = bf_hi(nvC[1], nvC[2], 1, c.m1);
-        const V b0 = bf_lo(a0, a2, 2, c.m2), b2 = bf_hi(a0, a2, 2, c.m2);
-        const V b1 = bf_lo(a1, a3, 2, c.m2), b3 = bf_hi(a1, a3, 2, c.m2);
-        const V b8 = bf_lo(a8, a10, 2, c.m2), b10 = bf_hi(a8, a10, 2, c.m2);
-        const V b9 = bf_lo(a9, a11, 2, c.m2), b11 = bf_hi(a9, a11, 2, c.m2);
-        const V lo4[4] = {b0, b1, b2, b3}, hi4[4] = {b8, b9, b10, b11};
-        V lo[8], hi[8];                                                      // low / high bytes of entries i and i + 8
+        if (SPAWN) nvD = nvD | spawned;                                      // a spawned cell is destructible (:117)
+        // planes 0 (fresh), 3 (nvD), 9-11 (nvC) -> words
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            lo[i] = bf_lo_a(lo4[i], c.m4);
-            lo[i + 4] = bf_hi_a(lo4[i], 4, c.m4);
-            hi[i] = bf_lo_a(hi4[i], c.m4);
-            hi[i + 4] = bf_hi_a(hi4[i], 4, c.m4);
-        }
+        for (int grp = 0; grp < G::NG; ++grp) {
+            V f, d, cc[3];
+            if (NW == 1) {
+                f = fresh.w[0], d = nvD.w[0];
 #pragma unroll
-        for (int k = 0; k < WS; ++k) {
-            const int i = k + 1;                                             // entry of word k
-            nm[k] = i < 8 ? pperm(hi[i], lo[i], 0x06020400u) : pperm(hi[i - 8], lo[i - 8], 0x07030501u);
+                for (int j = 0; j < 3; ++j) cc[j] = nvC[j].w[0];
+            } else {            // the group's halves back out of the plane words
+                const uint32_t sel = grp == 0 ? 0x05040100u : 0x07060302u;
+                f = pperm(fresh.w[NW - 1], fresh.w[0], sel);
+                d = pperm(nvD.w[NW - 1], nvD.w[0], sel);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) cc[j] = pperm(nvC[j].w[NW - 1], nvC[j].w[0], sel);
+            }
+            V lo[8], hi[8];
+            group_back(f, d, cc, c, lo, hi);
+            if (NW == 1) {
+#pragma unroll
+                for (int k = 0; k < WS; ++k) nm[k] = group_entry(lo, hi, k + 1);       // word k = entry k + 1
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) nm[(16 * grp + k) % WS] = group_entry(lo, hi, k);
+            }
         }
     }
     // -- merge: a cell that dies or is born loses its old content
+    V gsrc[2] = {gone.w[0], gone.w[0]};
+    if (NW == 2) {
+        gsrc[0] = pperm(gone.w[NW - 1], gone.w[0], 0x05040100u);
+        gsrc[1] = pperm(gone.w[NW - 1], gone.w[0], 0x07060302u);
+    }
 #pragma unroll
     for (int k = 0; k < WS; ++k) {
-        const V m = pmul24(pshr(gone, k + 1) & c.one2, 0xFFFFu);
+        const V src = NW == 1 ? gsrc[0] : gsrc[k / 16];
+        const int sh = NW == 1 ? k + 1 : k % 16;
+        const V m = pmul24(pshr(src, sh) & c.one2, 0xFFFFu);
         b[k] = SL_PB3((TA & ~TB) | TC, b[k], m, nm[k]);
     }
-#undef SL_ENT
     return true;
 }
 

@@ -533,13 +533,16 @@ __device__ void resolve_draws(const RowWords<H, W> &b, RowWords<H, W> &n, const 
     wave_sync();
 }
 
-// The same for the bit-plane step (sl_planes.h): `elig` is a plane -- bit 1+k = cell k, bit 17+k = cell WS+k --
-// and so is the result, the cells whose draw succeeded.  Row-major order = ascending bits of the low half, then
-// of the high half.
-template <int H, int W>
-__device__ u32 resolve_draws_planes(u32 elig, u64 *rng_lds, int g, double p, const Jump *__restrict__ jump) {
+// The same for the bit-plane step (sl_planes.h): `elig` is a plane and so is the result, the cells whose draw
+// succeeded.  One word per plane: bit 1+k = cell k, bit 17+k = cell WS+k -- row-major order = ascending bits of the
+// low half, then of the high half.  Two words (64-cell rows): cell 32 i + k = bit k of word i.
+template <int H, int W, int NW>
+__device__ pl::Pl<NW> resolve_draws_planes(const pl::Pl<NW> &elig, u64 *rng_lds, int g, double p,
+                                           const Jump *__restrict__ jump) {
     using Gm = Geom<H, W>;
-    const int mine = __popc(elig);
+    int mine = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) mine += __popc(elig.w[i]);
     const int incl = wave_scan(mine);
     int before = 0, total = 0;
 #pragma unroll
@@ -554,20 +557,30 @@ __device__ u32 resolve_draws_planes(u32 elig, u64 *rng_lds, int g, double p, con
     const int excl = incl - mine - before;
     const U128 st = {rng_lds[4 * g + 0], rng_lds[4 * g + 1]}, inc = {rng_lds[4 * g + 2], rng_lds[4 * g + 3]};
     wave_sync();     // every lane has read the old state before a leader replaces it
-    u32 ok = 0;
+    pl::Pl<NW> ok;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) ok.w[i] = 0;
     if (mine > 0) {
         U128 cur = pcg_jump(jump, excl, st, inc);
-        u32 part = elig & 0xFFFFu, base = 0;
+        // the parts of the row in row-major order: (low half, high half) of the one word, or the two words
+        u32 part[2] = {NW == 1 ? (elig.w[0] & 0xFFFFu) : elig.w[0], NW == 1 ? (elig.w[0] >> 16) : elig.w[NW - 1]};
+        u32 okp[2] = {0u, 0u};
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
-            while (part) {
-                const u32 bit = part & (0u - part);
+            u32 todo = part[half], got = 0;
+            while (todo) {
+                const u32 bit = todo & (0u - todo);
                 cur = pcg_step(cur, inc);
-                if (pcg_output_double(cur) < p) ok |= bit << base;              // advance_board.c:115
-                part ^= bit;
+                if (pcg_output_double(cur) < p) got |= bit;                     // advance_board.c:115
+                todo ^= bit;
             }
-            part = elig >> 16;
-            base = 16;
+            okp[half] = got;
+        }
+        if (NW == 1) {
+            ok.w[0] = okp[0] | (okp[1] << 16);
+        } else {
+            ok.w[0] = okp[0];
+            ok.w[NW - 1] = okp[1];
         }
         if (excl + mine == total) {     // the lane that made the board's last draw holds its new state
             rng_lds[4 * g + 0] = cur.hi;
@@ -583,7 +596,7 @@ __device__ u32 resolve_draws_planes(u32 elig, u64 *rng_lds, int g, double p, con
 // whether any cell of the wave changed -- the word form does not know and says yes.  `take`: the lane takes the
 // new row even if it is not `mine` (the halo copies of the word form compute their own rows).
 template <int H, int W>
-constexpr bool use_planes() { return (W + 1) / 2 + 2 <= 16; }
+constexpr bool use_planes() { return (W + 1) / 2 + 2 <= 16 || W == 64; }
 
 template <int H, int W, bool SPAWN, bool COLFIRST>
 __device__ __forceinline__ bool ca_step(RowWords<H, W> &b, bool mine, bool take, int up, int dn, const Consts &c,
@@ -594,8 +607,9 @@ __device__ __forceinline__ bool ca_step(RowWords<H, W> &b, bool mine, bool take,
         static_assert((int)pl::PV_BPERM == (int)V_BPERM && (int)pl::PV_SHIFT == (int)V_SHIFT && (int)pl::PV_ROTATE == (int)V_ROTATE, "");
         const pl::VCtx<Gm::VERT> vc = {up, dn};
         const u32 realm = mine ? vreg(pl::PG<W>::REAL) : 0u;
-        return pl::ca_planes<W, Gm::VERT, SPAWN>(b, vc, realm, pc, [&](u32 elig) {
-            return resolve_draws_planes<H, W>(elig, rng_lds, g, p, jump);
+        constexpr int NW = pl::PG<W>::NW;
+        return pl::ca_planes<W, Gm::VERT, SPAWN>(b, vc, realm, pc, [&](const pl::Pl<NW> &elig) {
+            return resolve_draws_planes<H, W, NW>(elig, rng_lds, g, p, jump);
         });
     } else {
         Elig elig;

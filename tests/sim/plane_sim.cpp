@@ -79,8 +79,9 @@ static void run(int VERT, int H, int B, int steps, std::vector<uint16_t> &boards
                     b[k].l[l] = lo | (hi << 16);
                 }
             }
-            auto draw = [&](const V &elig) {
-                V ok = pconst(0);
+            constexpr int NW = PG<W>::NW;
+            auto draw = [&](const Pl<NW> &elig) {
+                Pl<NW> ok = qzero<NW>();
                 for (int g = 0; g < nbb; ++g) {
                     Pcg gen;
                     uint64_t *st = &rng[(size_t)(e0 + g) * 4];
@@ -89,13 +90,23 @@ static void run(int VERT, int H, int B, int steps, std::vector<uint16_t> &boards
                     const double p = (double)prob[e0 + g];
                     for (int l = 0; l < 64; ++l) {
                         if (!lane_in[l] || lane_g[l] != g || !lane_real[l]) continue;
-                        // rows are in lane order; within a row: low half (cells 0..WS-1), then high half
-                        for (int part = 0; part < 2; ++part)
-                            for (int i = 1; i <= WS; ++i) {
-                                const uint32_t bit = 1u << (16 * part + i);
-                                if (elig.l[l] & bit)
-                                    if (gen.next() < p) ok.l[l] |= bit;
-                            }
+                        // rows are in lane order; within a row cells in order: one word = low half (bits 1..),
+                        // then high half (bits 17..); two words = word 0, then word 1, bits ascending
+                        if (NW == 1) {
+                            for (int part = 0; part < 2; ++part)
+                                for (int i = 1; i <= WS; ++i) {
+                                    const uint32_t bit = 1u << (16 * part + i);
+                                    if (elig.w[0].l[l] & bit)
+                                        if (gen.next() < p) ok.w[0].l[l] |= bit;
+                                }
+                        } else {
+                            for (int wi = 0; wi < NW; ++wi)
+                                for (int i = 0; i < 32; ++i) {
+                                    const uint32_t bit = 1u << i;
+                                    if (elig.w[wi].l[l] & bit)
+                                        if (gen.next() < p) ok.w[wi].l[l] |= bit;
+                                }
+                        }
                     }
                     st[0] = (uint64_t)(gen.state >> 64);
                     st[1] = (uint64_t)gen.state;
@@ -141,7 +152,7 @@ int main(int argc, char **argv) {
     fclose(f);
     bool ok = false;
 #define SL_W(w) if (W == w) ok = run_w<w>(H, B, steps, spawn, boards, prob, rng);
-    SL_W(4) SL_W(5) SL_W(8) SL_W(10) SL_W(12) SL_W(15) SL_W(16) SL_W(20) SL_W(24) SL_W(25) SL_W(26) SL_W(27) SL_W(28)
+    SL_W(4) SL_W(5) SL_W(8) SL_W(10) SL_W(12) SL_W(15) SL_W(16) SL_W(20) SL_W(24) SL_W(25) SL_W(26) SL_W(27) SL_W(28) SL_W(64)
 #undef SL_W
     if (!ok) return 3;
     f = fopen(argv[2], "wb");
