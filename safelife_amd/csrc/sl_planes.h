@@ -120,7 +120,14 @@ inline bool pany(const V &a) {
 template <int VERT>
 struct VCtx {
     int up_src[64], dn_src[64];
+    int partner_src[64];        // halo lanes: the lane that owns the row they copy; every other lane: itself
 };
+template <int VERT>
+inline V ppartner(const VCtx<VERT> &vc, const V &a) {
+    V r;
+    for (int i = 0; i < 64; ++i) r.l[i] = a.l[vc.partner_src[i]];
+    return r;
+}
 template <int VERT>
 inline V pup(const VCtx<VERT> &vc, const V &a) {
     V r;
@@ -157,7 +164,13 @@ enum { PV_BPERM = 0, PV_SHIFT = 1, PV_ROTATE = 2 };      // = the V_* modes of s
 template <int VERT>
 struct VCtx {
     int up, dn;       // PV_BPERM: ds_bpermute byte addresses of the lanes holding rows r-1 / r+1
+    int partner;      // PV_SHIFT, multi-step kernels: byte address of the lane that owns the row a halo lane copies
+                      // (every other lane: its own)
 };
+template <int VERT>
+SL_PL_DEV V ppartner(const VCtx<VERT> &vc, V v) {
+    return VERT == PV_SHIFT ? (V)__builtin_amdgcn_ds_bpermute(vc.partner, (int)v) : v;
+}
 template <int VERT>
 SL_PL_DEV V pup(const VCtx<VERT> &vc, V v) {
     if (VERT == PV_SHIFT) return (V)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, true);     // wave_shr:1
@@ -532,6 +545,173 @@ SL_PL_DEV bool ca_planes(V (&b)[(W + 1) / 2], const VCtx<VERT> &vc, const V &rea
         b[k] = SL_PB3((TA & ~TB) | TC, b[k], m, nm[k]);
     }
     return true;
+}
+
+// ---- many steps on chip: the row stays in plane form ---------------------------------------------------------
+// (life_occupancy's thousand steps, advance_board n: the transposition is paid once at either end.)  Between steps
+// the planes' seam bits (one-word planes) have to follow the cells they copy: instead of re-deriving them for every
+// plane, the masks a step APPLIES -- the cells that go, the new cells' bits -- are completed at the seams, and
+// planes with valid seams stay valid under them.  Halo LANES (the V_SHIFT layouts keep copies of a board's last and
+// first row in the lanes around it) take the same masks from the lanes that own those rows.
+template <int NW>
+struct PState {
+    Pl<NW> A, G, D, Z, P, I, S, X, C[3];       // alive 0, agent 1, destructible 3, frozen 4, preserving 5, inhibiting 6,
+    Pl<NW> ever;                               // spawning 7, exit 8, colours 9-11; cells that changed at least once
+};
+
+template <int W>
+SL_PL_DEV void planes_load(const V (&b)[(W + 1) / 2], const PConsts &c, PState<PG<W>::NW> &st) {
+    using G = PG<W>;
+    constexpr int WS = G::WS, NE = G::NE, NW = G::NW;
+    V e_first = b[0], e_wrap = b[0], e_last = b[0];
+    if (NW == 1) {
+        e_first = G::ODD ? pperm(b[WS - 1], b[WS - 2], 0x05040302u) : pperm(b[WS - 1], b[WS - 1], 0x01000302u);
+        e_wrap = G::ODD ? pperm(b[0], b[WS - 1], 0x05040100u) : b[WS - 1];
+        e_last = pperm(b[0], b[0], 0x01000302u);
+    }
+    auto ent0 = [&](int i) -> V {
+        if (NW == 2) return b[i];
+        return i == 0 ? e_first : i < WS ? b[i - 1 < 0 ? 0 : i - 1] : i == WS ? e_wrap : e_last;
+    };
+    auto ent1 = [&](int i) -> V { return b[NW == 2 ? 16 + i : 0]; };
+    V t[2][11];
+#pragma unroll
+    for (int g = 0; g < G::NG; ++g) {
+        Grp gr;
+        if (g == 0) {
+            group_fast<NE, true>(ent0, c, gr, t[g][0], t[g][3], t[g][4], t[g][5], t[g][6]);
+            group_slow<NE>(ent0, c, gr, t[g][2], t[g][7], t[g][8], t[g][9], t[g][10]);
+        } else {
+            group_fast<NE, true>(ent1, c, gr, t[g][0], t[g][3], t[g][4], t[g][5], t[g][6]);
+            group_slow<NE>(ent1, c, gr, t[g][2], t[g][7], t[g][8], t[g][9], t[g][10]);
+        }
+        t[g][1] = bf_hi(bf_lo(gr.x[0], gr.x[2], 2, c.m2), bf_lo(gr.x[1], gr.x[3], 2, c.m2), 1, c.m1);     // agent: bit 1
+    }
+    auto put = [&](Pl<NW> &d, int j) {
+        if (NW == 1) {
+            d.w[0] = t[0][j];
+        } else {            // (cells 0-15 | 32-47) and (16-31 | 48-63) -> cells 0-31 and 32-63
+            d.w[0] = pperm(t[NW - 1][j], t[0][j], 0x05040100u);
+            d.w[NW - 1] = pperm(t[NW - 1][j], t[0][j], 0x07060302u);
+        }
+    };
+    put(st.A, 0), put(st.G, 1), put(st.D, 2), put(st.Z, 3), put(st.P, 4), put(st.I, 5), put(st.S, 6), put(st.X, 7);
+    put(st.C[0], 8), put(st.C[1], 9), put(st.C[2], 10);
+    st.ever = qzero<NW>();
+}
+
+// a mask over the row's cells -> the same with its seam bits filled in (one-word planes; two-word planes have none)
+template <int W>
+SL_PL_DEV Pl<PG<W>::NW> with_seams(const Pl<PG<W>::NW> &m) {
+    using G = PG<W>;
+    if constexpr (G::NW == 2) {
+        return m;
+    } else {
+        constexpr int WS = G::WS, WH = G::WH;
+        const V x = m.w[0];
+        V r = x & pconst(G::REAL);
+        r = SL_PB3((TA & TB) | TC, pshr(x, 16 + WH), pconst(1u), r);                       // bit 0        <- cell W-1
+        r = SL_PB3((TA & TB) | TC, pshr(x, 16 - WS), pconst(1u << (WS + 1)), r);           // bit WS+1     <- cell WS
+        r = SL_PB3((TA & TB) | TC, pshl(x, 16 - WS), pconst(1u << 16), r);                 // bit 16       <- cell WS-1
+        r = SL_PB3((TA & TB) | TC, pshl(x, 16 + WH), pconst(1u << (17 + WH)), r);          // bit 17+WH    <- cell 0
+        Pl<G::NW> out = m;
+        out.w[0] = r;
+        return out;
+    }
+}
+
+// One step on the planes.  Returns (wave-uniform) whether any cell of the wave changed.
+template <int W, int VERT, bool SPAWN, class Draw>
+SL_PL_DEV bool planes_step(PState<PG<W>::NW> &st, const VCtx<VERT> &vc, const V &realm_word, Draw &&draw) {
+    constexpr int NW = PG<W>::NW;
+    Pl<NW> realm;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) realm.w[i] = realm_word;
+    const Verdict<NW> v = decide<VERT, NW, SPAWN>(vc, st.A, st.Z, st.P, st.I, st.S, realm);
+    Pl<NW> spawned = qzero<NW>();
+    if (SPAWN) {
+        const Pl<NW> elig = SL_QB3(TA & ~TB & TC, v.dead_free, v.is3, v.fS);
+        if (qany(elig)) spawned = draw(elig);
+    }
+    Pl<NW> fresh = SPAWN ? (v.born | spawned) : v.born;
+    Pl<NW> gone = v.dies | fresh;
+    if (!qany(gone)) return false;
+    const bool births = qany(fresh);
+    Pl<NW> nvD = qzero<NW>(), nvC[3] = {qzero<NW>(), qzero<NW>(), qzero<NW>()};
+    if (births) {
+        nvD = v.born & seen_twice<VERT, NW>(vc, SL_QB3((TA | TB) & TC, st.X, st.D, st.A));
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const Pl<NW> tw = seen_twice<VERT, NW>(vc, st.C[j] & st.A);
+            if (SPAWN) nvC[j] = SL_QB3(TA & (TB | TC), fresh, tw, (box_or<VERT, NW>(vc, st.S & st.C[j])));
+            else nvC[j] = fresh & tw;
+        }
+        if (SPAWN) nvD = nvD | spawned;
+    }
+    // the masks: seams completed, and handed to the halo lanes that copy these rows
+    auto spread = [&](Pl<NW> &m) {
+        m = with_seams<W>(m);
+#pragma unroll
+        for (int i = 0; i < NW; ++i) m.w[i] = ppartner<VERT>(vc, m.w[i]);      // (a lane's own value outside the V_SHIFT halos)
+    };
+    spread(gone);
+    if (births) {
+        spread(fresh);
+        spread(nvD);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) spread(nvC[j]);
+    }
+    st.A = SL_QB3((TA & ~TB) | TC, st.A, gone, fresh);
+    st.D = SL_QB3((TA & ~TB) | TC, st.D, gone, nvD);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) st.C[j] = SL_QB3((TA & ~TB) | TC, st.C[j], gone, nvC[j]);
+    st.G = SL_QB3(TA & ~TB, st.G, gone, gone);
+    st.Z = SL_QB3(TA & ~TB, st.Z, gone, gone);
+    st.P = SL_QB3(TA & ~TB, st.P, gone, gone);
+    st.I = SL_QB3(TA & ~TB, st.I, gone, gone);
+    st.S = SL_QB3(TA & ~TB, st.S, gone, gone);
+    st.X = SL_QB3(TA & ~TB, st.X, gone, gone);
+    st.ever = st.ever | gone;
+    return true;
+}
+
+// The row's words after the steps: a cell that never changed keeps its word, one that did holds exactly what its
+// planes say (a cell that dies is cleared, a new cell has alive / destructible / colour bits only).
+template <int W>
+SL_PL_DEV void planes_store(V (&b)[(W + 1) / 2], const PConsts &c, const PState<PG<W>::NW> &st) {
+    using G = PG<W>;
+    constexpr int WS = G::WS, NW = G::NW;
+    const Pl<NW> fa = st.A & st.ever, fd = st.D & st.ever;
+    const Pl<NW> fc[3] = {st.C[0] & st.ever, st.C[1] & st.ever, st.C[2] & st.ever};
+    V gsrc[2] = {st.ever.w[0], st.ever.w[0]};
+    if (NW == 2) {
+        gsrc[0] = pperm(st.ever.w[NW - 1], st.ever.w[0], 0x05040100u);
+        gsrc[1] = pperm(st.ever.w[NW - 1], st.ever.w[0], 0x07060302u);
+    }
+#pragma unroll
+    for (int grp = 0; grp < G::NG; ++grp) {
+        V f, d, cc[3];
+        if (NW == 1) {
+            f = fa.w[0], d = fd.w[0];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) cc[j] = fc[j].w[0];
+        } else {
+            const uint32_t sel = grp == 0 ? 0x05040100u : 0x07060302u;
+            f = pperm(fa.w[NW - 1], fa.w[0], sel);
+            d = pperm(fd.w[NW - 1], fd.w[0], sel);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) cc[j] = pperm(fc[j].w[NW - 1], fc[j].w[0], sel);
+        }
+        V lo[8], hi[8];
+        group_back(f, d, cc, c, lo, hi);
+#pragma unroll
+        for (int k = 0; k < (NW == 1 ? WS : 16); ++k) {
+            const int word = NW == 1 ? k : 16 * grp + k;
+            const V nmw = group_entry(lo, hi, NW == 1 ? k + 1 : k);
+            const V m = pmul24(pshr(gsrc[grp], NW == 1 ? k + 1 : k) & c.one2, 0xFFFFu);
+            b[word % WS] = SL_PB3((TA & ~TB) | TC, b[word % WS], m, nmw);
+        }
+    }
 }
 
 }  // namespace pl

@@ -1132,16 +1132,52 @@ __global__ __launch_bounds__(64) void k_occupancy_rowlane(const u16 *__restrict_
     for (int off = 32; off >= 1; off >>= 1) wave_end = max(wave_end, __shfl_xor(wave_end, off));
     wave_sync();
     int since_drain = 0;
+    // rows of up to 28 cells, or 64: the row stays in bit-plane form for all the steps (sl_planes.h) -- one
+    // transposition at the start, the CA on whole rows, and the counting visits only the cells that ARE alive
+    // (a handful per row) instead of every cell position
+    constexpr bool PLANES = use_planes<H, W>();
+    constexpr int NW = pl::PG<PLANES ? W : 8>::NW;
+    pl::PState<NW> st;
+    const pl::VCtx<Gm::VERT> vctx = {lm.up, lm.dn, 4 * partner};
+    if constexpr (PLANES) pl::planes_load<W>(b, pcst, st);
     for (int s = 0; s < wave_end; ++s) {
         const bool going = s < my_end;
-        const bool changed = ca_step<H, W, true, false>(b, live && going, going, lm.up, lm.dn, cst, pcst, rng_lds, rowl ? g : 0, p, jump);
-        if (Gm::VERT == V_SHIFT && changed) {
+        if constexpr (PLANES) {
+            const u32 realm = live && going ? vreg(pl::PG<W>::REAL) : 0u;
+            pl::planes_step<W, Gm::VERT, true>(st, vctx, realm, [&](const pl::Pl<NW> &elig) {
+#ifdef SL_OCC_NODRAW
+                return elig;
+#else
+                return resolve_draws_planes<H, W, NW>(elig, rng_lds, rowl ? g : 0, p, jump);
+#endif
+            });
+        } else {
+            const bool changed = ca_step<H, W, true, false>(b, live && going, going, lm.up, lm.dn, cst, pcst, rng_lds, rowl ? g : 0, p, jump);
+            if (Gm::VERT == V_SHIFT && changed) {
 #pragma unroll
-            for (int k = 0; k < WS; ++k) b[k] = bperm(4 * partner, b[k]);
+                for (int k = 0; k < WS; ++k) b[k] = bperm(4 * partner, b[k]);
+            }
         }
         if (!__ballot(going && s >= my_pre)) continue;          // nobody counts yet
 #ifndef SL_OCC_NOCOUNT
-        if (live && going && s >= my_pre) {
+        if constexpr (PLANES) {
+            const bool counting = live && going && s >= my_pre;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                // alive, not agent / frozen / exit (advance_board.c:176-181)
+                u32 tick = counting ? (st.A.w[i] & ~st.G.w[i] & ~st.Z.w[i] & ~st.X.w[i] & pl::PG<W>::REAL) : 0u;
+                while (tick) {
+                    const int pos = __ffs((int)tick) - 1;
+                    tick &= tick - 1;
+                    u32 slot = ((st.C[0].w[i] >> pos) & 1u) | (((st.C[1].w[i] >> pos) & 1u) << 1) | (((st.C[2].w[i] >> pos) & 1u) << 2);
+                    if (SLOTS == 4) slot = (lut >> (2 * slot)) & 3u;
+                    const int x = NW == 2 ? 32 * i + pos : (pos < 16 ? pos - 1 : pos - 17 + WS);     // the cell's column
+                    __hip_atomic_fetch_add(cnt + x * Oc::CELL_DWORDS + slot / Oc::PER_DWORD,
+                                           1u << (Oc::CB * (slot % Oc::PER_DWORD)), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
+            }
+        } else if (live && going && s >= my_pre) {
 #pragma unroll
             for (int k = 0; k < WS; ++k) {
                 const u32 c = b[k];

@@ -24,11 +24,11 @@ def sim(tmp_path_factory):
     return exe
 
 
-def _run(sim, tmp_path, boards, prob, words, steps, spawn):
+def _run(sim, tmp_path, boards, prob, words, steps, spawn, keep_planes=False):
     B, H, W = boards.shape
     fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
     with open(fin, "wb") as f:
-        f.write(struct.pack("5i", H, W, B, steps, int(spawn)))
+        f.write(struct.pack("5i", H, W, B, steps, int(spawn) | (2 if keep_planes else 0)))
         f.write(boards.tobytes())
         f.write(prob.tobytes())
         f.write(words.tobytes())
@@ -78,3 +78,21 @@ def test_plane_step_known_patterns(sim, tmp_path):
     got, _ = _run(sim, tmp_path, boards, prob, words, 30, False)
     exp = oracle.advance_board_batch(boards, prob, 30, words.copy())
     assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("H,W", [(25, 25), (26, 26), (10, 10), (25, 10), (9, 27), (40, 5), (64, 64), (20, 64)])
+def test_planes_kept_across_steps_match_oracle(sim, tmp_path, H, W):
+    """The multi-step form (life_occupancy's thousand steps): one transposition in, the row stays in plane form --
+    seam bits and the V_SHIFT halo lanes follow through the masks each step applies -- and one merge out."""
+    rng = np.random.default_rng(77 * H + W)
+    for spawn, kind in ((False, 0), (True, 1), (True, 2)):
+        boards = util.random_boards(rng, 5, H, W, kind)
+        if not spawn:
+            boards = boards & ~np.uint16(128)
+        words = util.random_rng_words(rng, 5)
+        prob = np.full(5, 0.25, np.float32)
+        got, got_rng = _run(sim, tmp_path, boards, prob, words, 12, spawn, keep_planes=True)
+        exp_rng = words.copy()
+        exp = oracle.advance_board_batch(boards, prob, 12, exp_rng)
+        assert np.array_equal(got, exp), (H, W, kind, spawn)
+        assert np.array_equal(got_rng, exp_rng), (H, W, kind, spawn)
