@@ -153,6 +153,20 @@ __device__ __forceinline__ double pcg_output_double(U128 s) {
     return (double)(o >> 11) * (1.0 / 9007199254740992.0);
 }
 
+// The same draw as an integer: next_double() = k * 2^-53 with k = the top 53 bits, so "next_double() < p" is
+// "k < ceil(p * 2^53)" exactly (p * 2^53 is exact in double) -- no conversion, multiply and compare in float64.
+__device__ __forceinline__ u64 pcg_output_u53(U128 s) {
+    u64 x = s.hi ^ s.lo;
+    unsigned rot = (unsigned)(s.hi >> 58);
+    u64 o = (x >> rot) | (x << ((64u - rot) & 63u));
+    return o >> 11;
+}
+__device__ __forceinline__ u64 draw_threshold(double p) {
+    if (!(p > 0.0)) return 0;
+    if (p >= 1.0) return 1ull << 53;
+    return (u64)ceil(p * 9007199254740992.0);
+}
+
 __device__ __forceinline__ int pos_mod(int a, int n) {
     int r = a % n;
     return r < 0 ? r + n : r;

@@ -560,6 +560,61 @@ __device__ pl::Pl<NW> resolve_draws_planes(const pl::Pl<NW> &elig, u64 *rng_lds,
     pl::Pl<NW> ok;
 #pragma unroll
     for (int i = 0; i < NW; ++i) ok.w[i] = 0;
+    const u64 thr = draw_threshold(p);
+    if constexpr (Gm::G == 1) {
+        // One board per wave: the board's draws are dealt out EVENLY over the 64 lanes instead of row by row (the
+        // cells around a cluster of spawners all sit in a few rows: on the 64x64 navigation levels the busiest row
+        // has ~15 of a board's ~250 draws, an even share is 4).  Lane j makes draws [j c, (j + 1) c), c a power
+        // of two; 32 / c neighbouring lanes' outcome bits make one dword (xor swizzles); a row's lane then pulls
+        // the dwords that hold ITS draws' outcomes -- consecutive bits from its prefix offset on -- across the
+        // wave and deals them to its flagged cells in order.
+        if (total <= 32 * 64) {
+            const int lane = (int)__lane_id();
+            const int need = (total + 63) >> 6;
+            const int log2c = need <= 1 ? 0 : 32 - __clz(need - 1);            // c = 2^log2c >= total / 64
+            const int first = lane << log2c;
+            const int n_here = min(max(total - first, 0), 1 << log2c);
+            u32 bits = 0;
+            if (n_here > 0) {
+                U128 cur = pcg_jump(jump, first, st, inc);
+                for (int i = 0; i < n_here; ++i) {
+                    cur = pcg_step(cur, inc);
+                    bits |= (pcg_output_u53(cur) < thr ? 1u : 0u) << i;         // advance_board.c:115
+                }
+                if (first + n_here == total) {      // the lane that made the board's last draw holds its new state
+                    rng_lds[4 * g + 0] = cur.hi;
+                    rng_lds[4 * g + 1] = cur.lo;
+                }
+            }
+            const int per = 32 >> log2c;                                        // lanes per dword of outcomes
+            u32 v = bits << ((lane & (per - 1)) << log2c);
+            if (per > 1) v |= (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x041F);      // xor 1
+            if (per > 2) v |= (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x081F);      // xor 2
+            if (per > 4) v |= (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x101F);      // xor 4
+            if (per > 8) v |= (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x201F);      // xor 8
+            if (per > 16) v |= (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);     // xor 16
+            // dword d of the outcome string sits in lanes [d per, (d + 1) per); mine start at bit `excl`
+            const int w0 = excl >> 5, sh = excl & 31;
+            const int log2per = 5 - log2c;
+            const u32 d0 = bperm(4 * min(63, w0 << log2per), v), d1 = bperm(4 * min(63, (w0 + 1) << log2per), v);
+            const u32 d2 = bperm(4 * min(63, (w0 + 2) << log2per), v);
+            u64 R = (((u64)d1 << 32) | d0) >> sh;
+            if (sh) R |= (u64)d2 << (64 - sh);
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                u32 todo = elig.w[i], got = 0;
+                while (todo) {
+                    const u32 bit = todo & (0u - todo);
+                    got |= (R & 1ull) ? bit : 0u;
+                    R >>= 1;
+                    todo ^= bit;
+                }
+                ok.w[i] = got;
+            }
+            wave_sync();
+            return ok;
+        }
+    }
     if (mine > 0) {
         U128 cur = pcg_jump(jump, excl, st, inc);
         // the parts of the row in row-major order: (low half, high half) of the one word, or the two words
@@ -571,7 +626,7 @@ __device__ pl::Pl<NW> resolve_draws_planes(const pl::Pl<NW> &elig, u64 *rng_lds,
             while (todo) {
                 const u32 bit = todo & (0u - todo);
                 cur = pcg_step(cur, inc);
-                if (pcg_output_double(cur) < p) got |= bit;                     // advance_board.c:115
+                if (pcg_output_u53(cur) < thr) got |= bit;                      // advance_board.c:115
                 todo ^= bit;
             }
             okp[half] = got;
@@ -1140,6 +1195,41 @@ __global__ __launch_bounds__(64) void k_occupancy_rowlane(const u16 *__restrict_
     pl::PState<NW> st;
     const pl::VCtx<Gm::VERT> vctx = {lm.up, lm.dn, 4 * partner};
     if constexpr (PLANES) pl::planes_load<W>(b, pcst, st);
+    constexpr int MINI_BITS = 4;
+    u32 mini[PLANES ? SLOTS : 1][MINI_BITS][NW];
+#pragma unroll
+    for (int a = 0; a < (PLANES ? SLOTS : 1); ++a)
+#pragma unroll
+        for (int k = 0; k < MINI_BITS; ++k)
+#pragma unroll
+            for (int i = 0; i < NW; ++i) mini[a][k][i] = 0;
+    int mini_steps = 0;
+    // SLOTS == 4: which colour planes are the board's two colour bits (lowest first; 3 = none)
+    const int sel_lo = (bits & 1u) ? 0 : ((bits & 2u) ? 1 : ((bits & 4u) ? 2 : 3));
+    const int sel_hi = (bits & 1u) ? ((bits & 2u) ? 1 : ((bits & 4u) ? 2 : 3)) : (((bits & 2u) && (bits & 4u)) ? 2 : 3);
+    auto flush_mini = [&]() {           // small counters -> LDS counters, visiting non-zero cells only
+#pragma unroll
+        for (int sl = 0; sl < (PLANES ? SLOTS : 1); ++sl)
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                u32 nz = 0;
+#pragma unroll
+                for (int k = 0; k < MINI_BITS; ++k) nz |= mini[sl][k][i];
+                while (nz) {
+                    const int pos = __ffs((int)nz) - 1;
+                    nz &= nz - 1;
+                    u32 val = 0;
+#pragma unroll
+                    for (int k = 0; k < MINI_BITS; ++k) val |= ((mini[sl][k][i] >> pos) & 1u) << k;
+                    const int x = NW == 2 ? 32 * i + pos : (pos < 16 ? pos - 1 : pos - 17 + WS);     // the cell's column
+                    __hip_atomic_fetch_add(cnt + x * Oc::CELL_DWORDS + sl / Oc::PER_DWORD,
+                                           val << (Oc::CB * (sl % Oc::PER_DWORD)), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
+#pragma unroll
+                for (int k = 0; k < MINI_BITS; ++k) mini[sl][k][i] = 0;
+            }
+    };
     for (int s = 0; s < wave_end; ++s) {
         const bool going = s < my_end;
         if constexpr (PLANES) {
@@ -1161,21 +1251,37 @@ __global__ __launch_bounds__(64) void k_occupancy_rowlane(const u16 *__restrict_
         if (!__ballot(going && s >= my_pre)) continue;          // nobody counts yet
 #ifndef SL_OCC_NOCOUNT
         if constexpr (PLANES) {
+            // Counting.  Every step: the cells that count -- alive, not agent / frozen / exit (advance_board.c:176-181)
+            // -- bump small bit-sliced counters that live in registers, one 4-bit counter per cell and colour slot
+            // (whole-row logic: a ripple of four half-adders per slot).  Every 15 counted steps the lanes walk the
+            // cells whose small counter is not zero and add it to the LDS counters: the walk visits live cells only
+            // (a handful per row), and it runs once per 15 steps instead of every step.
             const bool counting = live && going && s >= my_pre;
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
-                // alive, not agent / frozen / exit (advance_board.c:176-181)
-                u32 tick = counting ? (st.A.w[i] & ~st.G.w[i] & ~st.Z.w[i] & ~st.X.w[i] & pl::PG<W>::REAL) : 0u;
-                while (tick) {
-                    const int pos = __ffs((int)tick) - 1;
-                    tick &= tick - 1;
-                    u32 slot = ((st.C[0].w[i] >> pos) & 1u) | (((st.C[1].w[i] >> pos) & 1u) << 1) | (((st.C[2].w[i] >> pos) & 1u) << 2);
-                    if (SLOTS == 4) slot = (lut >> (2 * slot)) & 3u;
-                    const int x = NW == 2 ? 32 * i + pos : (pos < 16 ? pos - 1 : pos - 17 + WS);     // the cell's column
-                    __hip_atomic_fetch_add(cnt + x * Oc::CELL_DWORDS + slot / Oc::PER_DWORD,
-                                           1u << (Oc::CB * (slot % Oc::PER_DWORD)), __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_WAVEFRONT);
+                const u32 tick = counting ? (st.A.w[i] & ~st.G.w[i] & ~st.Z.w[i] & ~st.X.w[i] & pl::PG<W>::REAL) : 0u;
+#pragma unroll
+                for (int sl = 0; sl < SLOTS; ++sl) {
+                    u32 carry;
+                    if (SLOTS == 4) {       // slot = the colour's two used bits, compressed
+                        const u32 s0 = sel_lo == 0 ? st.C[0].w[i] : (sel_lo == 1 ? st.C[1].w[i] : (sel_lo == 2 ? st.C[2].w[i] : 0u));
+                        const u32 s1 = sel_hi == 1 ? st.C[1].w[i] : (sel_hi == 2 ? st.C[2].w[i] : 0u);
+                        carry = tick & ((sl & 1) ? s0 : ~s0) & ((sl & 2) ? s1 : ~s1);
+                    } else {
+                        carry = tick & ((sl & 1) ? st.C[0].w[i] : ~st.C[0].w[i]) & ((sl & 2) ? st.C[1].w[i] : ~st.C[1].w[i]) &
+                                ((sl & 4) ? st.C[2].w[i] : ~st.C[2].w[i]);
+                    }
+#pragma unroll
+                    for (int k = 0; k < MINI_BITS; ++k) {
+                        const u32 t = mini[sl][k][i] & carry;
+                        mini[sl][k][i] ^= carry;
+                        carry = t;
+                    }
                 }
+            }
+            if (++mini_steps == (1 << MINI_BITS) - 1) {
+                mini_steps = 0;
+                flush_mini();
             }
         } else if (live && going && s >= my_pre) {
 #pragma unroll
@@ -1204,6 +1310,7 @@ __global__ __launch_bounds__(64) void k_occupancy_rowlane(const u16 *__restrict_
             wave_sync();
         }
     }
+    if constexpr (PLANES) flush_mini();
     wave_sync();
     if (live) {
         if (Oc::CB == 8) {

@@ -137,7 +137,9 @@ class SafeLifeVectorEnv(object):
                                    ends (record + the board as the agent left it, taken before an auto-reset
                                    reloads the slot) and ``side_effects_flush()`` runs the episode-end pass of the
                                    reference's ``side_effect_score`` over the queue on the device -- see
-                                   ``SideEffectBatch``.  ``capacity``: episodes held between two flushes.
+                                   ``SideEffectBatch``.  ``capacity``: episodes held between two flushes; ``keep``
+                                   (default 2): output sets cycled -- a batch's tensors are overwritten by the
+                                   ``keep``-th flush after it.
     wrappers : dict or None        training-wrapper math of the reference's env_wrappers.py, fused into the
                                    step (stacked as training/env_factory.py:277-283 does); keys, all
                                    optional: ``movement_bonus``, ``movement_bonus_power``,
@@ -249,7 +251,8 @@ class SafeLifeVectorEnv(object):
         self._se = None
         if side_effects:
             self._se = dict(capacity=int(side_effects.get("capacity", 1024)),
-                            num_samples=int(side_effects.get("num_samples", 1000)))
+                            num_samples=int(side_effects.get("num_samples", 1000)),
+                            keep=max(1, int(side_effects.get("keep", 2))))
             self._se["queue"] = self._new_queue()
             s.finished = self._se["queue"][0]
         self._lib = _hip.lib()
@@ -507,14 +510,23 @@ class SafeLifeVectorEnv(object):
         H, W = self.pool.shape
         cap, K = se["capacity"], _hip.SL_SE_MAX_KEYS
         dev = self.device
-        out = dict(work_boards=torch.empty((2 * cap, H, W), dtype=torch.int16, device=dev),
-                   work_prob=torch.empty(2 * cap, dtype=torch.float32, device=dev),
-                   work_steps=torch.empty(2 * cap, dtype=torch.int32, device=dev),
-                   work_rng=torch.empty((2 * cap, 4), dtype=torch.int64, device=dev),
-                   counts=torch.empty((2, cap, H, W, 8), dtype=torch.int32, device=dev),
-                   keys=torch.empty((cap, K), dtype=torch.int16, device=dev),
-                   life_dist=torch.empty((cap, 2, 8, H, W), dtype=torch.float64, device=dev),
-                   type_masks=torch.zeros((cap, 2, K - 8, H, W), dtype=torch.uint8, device=dev))
+        # The pass's outputs are gigabytes at C5's size (life_dist alone: capacity x 2 x 8 x H x W float64): they are
+        # allocated once per output set and the sets are cycled -- a batch stays valid until `keep` further flushes
+        # (allocating them afresh stalled the stepping thread for milliseconds per flush).
+        sets = se.setdefault("outs", [])
+        if len(sets) < se.get("keep", 2):
+            sets.append(dict(work_boards=torch.empty((2 * cap, H, W), dtype=torch.int16, device=dev),
+                             work_prob=torch.empty(2 * cap, dtype=torch.float32, device=dev),
+                             work_steps=torch.empty(2 * cap, dtype=torch.int32, device=dev),
+                             work_rng=torch.empty((2 * cap, 4), dtype=torch.int64, device=dev),
+                             counts=torch.empty((2, cap, H, W, 8), dtype=torch.int32, device=dev),
+                             keys=torch.empty((cap, K), dtype=torch.int16, device=dev),
+                             life_dist=torch.empty((cap, 2, 8, H, W), dtype=torch.float64, device=dev),
+                             type_masks=torch.empty((cap, 2, K - 8, H, W), dtype=torch.uint8, device=dev)))
+            out = sets[-1]
+        else:
+            out = sets[se["flushes"] % len(sets)]
+        se["flushes"] = se.get("flushes", 0) + 1
         rc = self._lib.slhip_side_effects(self._sref, C.byref(q), se["num_samples"], 1,
                                           *[_hip.ptr(out[k]) for k in ("work_boards", "work_prob", "work_steps", "work_rng",
                                                                        "counts", "keys", "life_dist", "type_masks")],
