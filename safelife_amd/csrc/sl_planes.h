@@ -426,9 +426,11 @@ SL_PL_DEV Pl<NW> seen_twice(const VCtx<VERT> &vc, const Pl<NW> &q) {
 // draw:   SPAWN only; ok = draw(elig) makes the random draws of the flagged cells -- planes as NW words each; one
 //         word: bit 1+k = cell k, bit 17+k = cell WS+k; two words: cell 32 i + k at bit k of word i -- in row-major
 //         order and returns the cells whose draw succeeded
+// row_changed (optional): receives, per lane, the cells of its row that changed (non-zero = the row changed)
 // returns whether any cell of the wave changed (wave-uniform); if not, b is untouched
 template <int W, int VERT, bool SPAWN, class Draw>
-SL_PL_DEV bool ca_planes(V (&b)[(W + 1) / 2], const VCtx<VERT> &vc, const V &realm_word, const PConsts &c, Draw &&draw) {
+SL_PL_DEV bool ca_planes(V (&b)[(W + 1) / 2], const VCtx<VERT> &vc, const V &realm_word, const PConsts &c, Draw &&draw,
+                         V *row_changed = nullptr) {
     using G = PG<W>;
     constexpr int WS = G::WS, NE = G::NE, NW = G::NW;
     // -- entries of the transposition groups
@@ -475,6 +477,12 @@ SL_PL_DEV bool ca_planes(V (&b)[(W + 1) / 2], const VCtx<VERT> &vc, const V &rea
     }
     const Pl<NW> fresh = SPAWN ? (v.born | spawned) : v.born;
     const Pl<NW> gone = v.dies | fresh;                                      // cells whose old content goes
+    if (row_changed) {
+        V any = gone.w[0];
+#pragma unroll
+        for (int i = 1; i < NW; ++i) any = any | gone.w[i];
+        *row_changed = any;
+    }
     if (!qany(gone)) return false;
 
     // -- new cells: ALIVE + what they inherit (only if the wave has any)

@@ -656,7 +656,7 @@ constexpr bool use_planes() { return (W + 1) / 2 + 2 <= 16 || W == 64; }
 template <int H, int W, bool SPAWN, bool COLFIRST>
 __device__ __forceinline__ bool ca_step(RowWords<H, W> &b, bool mine, bool take, int up, int dn, const Consts &c,
                                         const pl::PConsts &pc, u64 *rng_lds, int g, double p,
-                                        const Jump *__restrict__ jump) {
+                                        const Jump *__restrict__ jump, u32 *row_changed = nullptr) {
     using Gm = Geom<H, W>;
     if constexpr (use_planes<H, W>()) {
         static_assert((int)pl::PV_BPERM == (int)V_BPERM && (int)pl::PV_SHIFT == (int)V_SHIFT && (int)pl::PV_ROTATE == (int)V_ROTATE, "");
@@ -665,13 +665,14 @@ __device__ __forceinline__ bool ca_step(RowWords<H, W> &b, bool mine, bool take,
         constexpr int NW = pl::PG<W>::NW;
         return pl::ca_planes<W, Gm::VERT, SPAWN>(b, vc, realm, pc, [&](const pl::Pl<NW> &elig) {
             return resolve_draws_planes<H, W, NW>(elig, rng_lds, g, p, jump);
-        });
+        }, row_changed);
     } else {
         Elig elig;
         RowWords<H, W> n;
         ca_rows<H, W, SPAWN, COLFIRST>(b, n, elig, up, dn, c);
         if (!mine) elig.clear();
         if (SPAWN && __ballot(elig.any())) resolve_draws<H, W>(b, n, elig, rng_lds, g, p, jump);
+        if (row_changed) *row_changed = 1u;              // (the word form does not know)
         if (take) {
 #pragma unroll
             for (int k = 0; k < Gm::WS; ++k) b[k] = n[k];
@@ -973,6 +974,30 @@ __device__ __forceinline__ void store_span(u16 *__restrict__ dst, const unsigned
     for (int i = 0; i < NVI; ++i) {
         const int slot = tid + 64 * WAVES * i;
         if (slot < nv) store16(d + (Gm::SWZ ? swz_chunk(slot) : slot), s[slot]);
+    }
+    const int rem = (bytes & 15) >> 1;
+    if (tid < rem) dst[nv * 8 + tid] = ((const u16 *)s)[nv * 8 + tid];
+}
+
+// The same for the fused step's boards, skipping the 16-byte chunks that lie entirely in boards whose mailbox says
+// "nothing changed" (the few cells the leaders touch in such a board they store themselves).
+template <int H, int W, class Box>
+__device__ __forceinline__ void store_span_dirty(u16 *__restrict__ dst, const unsigned char *region, int nbb, int tid,
+                                                 const Box *box) {
+    using Gm = Geom<H, W>;
+    static_assert(!Gm::SWZ, "row-major images only");
+    const int bytes = nbb * Gm::HW * 2;
+    const int nv = bytes >> 4;
+    u32x4 *d = (u32x4 *)dst;
+    const u32x4 *s = (const u32x4 *)(region + Gm::PAD);
+    constexpr int NVI = (Gm::SPAN / 16 + 64 * WAVES - 1) / (64 * WAVES);
+#pragma unroll
+    for (int i = 0; i < NVI; ++i) {
+        const int slot = tid + 64 * WAVES * i;
+        if (slot < nv) {
+            const int q0 = (slot * 8) / Gm::HW, q1 = min((slot * 8 + 7) / Gm::HW, nbb - 1);
+            if (box[q0].dirty | box[q1].dirty) store16(d + slot, s[slot]);
+        }
     }
     const int rem = (bytes & 15) >> 1;
     if (tid < rem) dst[nv * 8 + tid] = ((const u16 *)s)[nv * 8 + tid];
@@ -1741,7 +1766,7 @@ struct BoardBox {
     int qslot;          // leader -> rows: slot of the finished-episode queue that takes the board, or -1
     int score0;         // rows -> leader: score of the freshly loaded level
     int any;            // (box 0 only) bit 0: some board of the workgroup resets, bit 1: some board is queued
-    int pad;
+    int dirty;          // rows -> everyone: the CA changed a cell of the board in this launch (or a level was loaded)
 };
 static_assert(sizeof(BoardBox) == 32, "mailbox stride");
 
@@ -1806,6 +1831,15 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     constexpr bool LEADX = leadx<H, W, LEAN>();
     const bool lwave = wave == (LEADX ? WAVES : 0);    // the leader wave ...
     const bool rwave = !(LEADX && lwave);              // waves that hold rows
+    // SL_SPARSE_STORE (measured, off): single-step launches store only the boards the CA changed -- in a level of
+    // still lifes 57 % of the boards of a step are untouched apart from the agent's own cells, which the leaders then
+    // store themselves -- i.e. half the write traffic and half the dirty lines at the kernel boundary.  Bit-exact
+    // (suite + soak), and no faster: 8.01-8.09 vs 7.91 us per two-slice C3 step in one session (the per-chunk test
+    // and 14 more registers cost what the bytes save).
+#ifndef SL_SPARSE_STORE
+#define SL_SPARSE_STORE 0
+#endif
+    constexpr bool SPARSE_STORE = SL_SPARSE_STORE && ONE && use_planes<H, W>() && !Gm::SWZ;
     const bool lead = lwave && lane < nbb;             // ... whose lane q is the leader of board q
     const int lq = lead ? lane : 0;
     const unsigned e = e0b + (rowl ? gb : 0);          // the row lane's env
@@ -1995,6 +2029,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
             for (int k = r2; k < E; k += H)
                 env.exit_locs[(size_t)e * E + k] = env.pool_exit_locs[(size_t)level * E + k];
             *dirty_flag = 1;                             // (any wave that changes its goals raises the flag)
+            if (r2 == 0) box[gb].dirty = 1;              // (and the whole board is new)
         }
         wave_sync();
         if (mine) {
@@ -2086,6 +2121,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
         if (rwave) {
         const bool dyn = rowl && gstatic != 1;
         const int passes = __ballot(dyn) ? 2 : 1;
+        bool board_dirty = !SPARSE_STORE;
 #pragma nounroll
         for (int pass = 0; pass < passes; ++pass) {
             const bool has = rowl && (pass == 0 || dyn);     // row to advance (halo copies included)
@@ -2094,7 +2130,17 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
             if (has) read_row<H, W>(img, gb, r, b);
             bool changed = true;                             // (wave-uniform) some cell of the wave's rows changed
             if constexpr (use_planes<H, W>()) {
-                changed = ca_step<H, W, SPAWN, false>(b, mine, mine, up, dn, cst, pcst, rng_lds, live ? g : 0, p, jump);
+                u32 row_changed = 0;
+                changed = ca_step<H, W, SPAWN, false>(b, mine, mine, up, dn, cst, pcst, rng_lds, live ? g : 0, p, jump,
+                                                      &row_changed);
+                if (SPARSE_STORE && pass == 0) {             // which of the wave's boards changed
+                    const unsigned long long rows = __ballot(mine && row_changed != 0);
+#pragma unroll
+                    for (int q = 0; q < Gm::G; ++q) {
+                        const unsigned long long of_q = ((Gm::GL == 64 ? ~0ull : ((1ull << Gm::GL) - 1ull)) << (q * Gm::GL % 64));
+                        if (g == q) board_dirty = (rows & of_q) != 0;
+                    }
+                }
             } else {
                 // (column-first reduction where its three arrays fit beside the row: not at 15-16 words with 128 registers)
                 constexpr bool COLFIRST = LEAN && !SPAWN && (WS <= 13 || Gm::WAVES_PER_SIMD < 4);
@@ -2143,6 +2189,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
         if (rlead) {
             box[gb].score = score_rows;
             box[gb].gstat = gstatic;
+            box[gb].dirty = board_dirty ? 1 : 0;
         }
         }
         // the leaders: what does not depend on the scores is read before the barrier (in the LEADX kernels, under
@@ -2214,6 +2261,27 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
                 if (reward_t) reward_t[(size_t)t * B + el] = reward;
                 if (done_t) done_t[(size_t)t * B + el] = done;
 #endif
+                if (SPARSE_STORE && env.auto_reset && done) {
+                    box[lq].dirty = 1;      // a level is about to be loaded over this board: the span store takes it all
+                } else if (SPARSE_STORE && !box[lq].dirty) {
+                    // the rows changed nothing on this board: what the move and the repaint touched goes to global
+                    // memory cell by cell (the values are in registers: with the CA idle the move's cells are as
+                    // the move left them)
+                    u16 *gdst = env.board + (size_t)el * HW;
+                    if (pre_write) {
+                        gdst[pre_i[0]] = (u16)pre_c[0];
+                        gdst[pre_i[1]] = (u16)pre_c[1];
+                        gdst[pre_i[2]] = (u16)pre_c[2];
+                        gdst[pre_i[3]] = (u16)pre_c[3];
+                    }
+                    if (ly >= 0) gdst[Gm::cell(ly, lx)] = (u16)cell;
+                    const u16 paint = (u16)(FROZEN | EXIT | (w_open ? COLOR_R : 0u));
+                    if (exit0 >= 0) gdst[exit0] = paint;
+                    for (int k = 1; k < E; ++k) {
+                        const int ex = exits[k];
+                        if (ex >= 0) gdst[ex] = paint;
+                    }
+                }
                 if (hand_over) {
                     int slot = -1, next_level = -1, any = 0;
                     if (has_queue && ended) {
@@ -2295,7 +2363,8 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     asm volatile("" : "+v"(tid2));
     const int lane2 = tid2 & 63, wave2 = tid2 >> 6;
     if (rwave) {
-        store_span<H, W>(env.board + (size_t)e0b * HW, board, nbb, tid2);
+        if constexpr (SPARSE_STORE) store_span_dirty<H, W>(env.board + (size_t)e0b * HW, board, nbb, tid2, box);
+        else store_span<H, W>(env.board + (size_t)e0b * HW, board, nbb, tid2);
         if (dirty) store_span<H, W>(env.goals + (size_t)e0b * HW, goals, nbb, tid2);
     }
     if (lane2 < 4 * Gm::G && wave2 * Gm::G + (lane2 >> 2) < nbb)
