@@ -1065,6 +1065,90 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_ad
         ((u64 *)(rng + e0b + wave * Gm::G))[lane] = rng_lds[lane];
 }
 
+// Small batches (fewer workgroups of the kernel above than the chip has CUs: config C2's 1024 boards are 128): one
+// wavefront per workgroup, the row straight from and to global memory -- four times the workgroups, no LDS image, no
+// workgroup barrier -- and, for the shapes with a bit-plane form, the rows stay planes for all n steps.
+template <int H, int W>
+__global__ __launch_bounds__(64) void k_advance_small(const u16 *__restrict__ in, u16 *__restrict__ out, int B,
+                                                      const float *__restrict__ spawn_prob, int n_steps,
+                                                      const int32_t *__restrict__ n_each,
+                                                      const int32_t *__restrict__ n_valid, sl_pcg64 *rng,
+                                                      const Jump *__restrict__ jump) {
+    using Gm = Geom<H, W>;
+    constexpr int WS = Gm::WS;
+    __shared__ u64 rng_lds[4 * Gm::G];
+    const int lane = threadIdx.x;
+    if (n_valid) B = min(B, *n_valid);
+    const int e0b = blockIdx.x * Gm::G;
+    if (e0b >= B) return;
+    const int nbb = min(Gm::G, B - e0b);
+    const LaneMap<H, W> lm(lane);
+    const int g = lm.g, r = lm.r;
+    const bool rowl = lane < Gm::NL && g < nbb;
+    const bool live = rowl && lm.real;
+    const unsigned e = e0b + (rowl ? g : 0);
+    RowWords<H, W> b;
+    {
+        const u16 *row = in + ((size_t)e * H + r) * W;
+#pragma unroll
+        for (int k = 0; k < WS; ++k) {
+            const u32 lo = rowl ? row[k] : 0u;
+            const u32 hi = (rowl && !(Gm::ODD && k == WS - 1)) ? row[k + WS] : 0u;
+            b[k] = lo | (hi << 16);
+        }
+    }
+    if (lane < 4 * nbb) rng_lds[lane] = ((const u64 *)(rng + e0b))[lane];
+    const double p = live ? (double)spawn_prob[e] : 0.0;
+    const int my_n = n_each ? (rowl ? max(0, n_each[e]) : 0) : n_steps;
+    int wave_n = my_n;
+    if (n_each) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) wave_n = max(wave_n, __shfl_xor(wave_n, off));
+    }
+    const int partner = !rowl || lm.real ? lane : (r == 0 ? lane - H : lane + H);
+    const Consts cst = make_consts();
+    const pl::PConsts pcst = pl::make_pconsts();
+    wave_sync();
+    constexpr bool PLANES = use_planes<H, W>();
+    if constexpr (PLANES) {
+        constexpr int NW = pl::PG<W>::NW;
+        if (wave_n > 1) {               // many steps: one transposition at either end
+            pl::PState<NW> st;
+            const pl::VCtx<Gm::VERT> vctx = {lm.up, lm.dn, 4 * partner};
+            pl::planes_load<W>(b, pcst, st);
+            for (int s = 0; s < wave_n; ++s) {
+                const u32 realm = live && s < my_n ? vreg(pl::PG<W>::REAL) : 0u;
+                pl::planes_step<W, Gm::VERT, true>(st, vctx, realm, [&](const pl::Pl<NW> &elig) {
+                    return resolve_draws_planes<H, W, NW>(elig, rng_lds, rowl ? g : 0, p, jump);
+                });
+            }
+            pl::planes_store<W>(b, pcst, st);
+        } else if (wave_n == 1) {
+            ca_step<H, W, true, false>(b, live && my_n > 0, my_n > 0, lm.up, lm.dn, cst, pcst, rng_lds, rowl ? g : 0, p, jump);
+        }
+    } else {
+        for (int s = 0; s < wave_n; ++s) {
+            const bool going = s < my_n;
+            const bool changed = ca_step<H, W, true, false>(b, live && going, going, lm.up, lm.dn, cst, pcst, rng_lds,
+                                                            rowl ? g : 0, p, jump);
+            if (Gm::VERT == V_SHIFT && changed && s + 1 < wave_n) {
+#pragma unroll
+                for (int k = 0; k < WS; ++k) b[k] = bperm(4 * partner, b[k]);
+            }
+        }
+    }
+    if (live) {
+        u16 *row = out + ((size_t)e * H + r) * W;
+#pragma unroll
+        for (int k = 0; k < WS; ++k) {
+            row[k] = (u16)b[k];
+            if (!(Gm::ODD && k == WS - 1)) row[k + WS] = (u16)(b[k] >> 16);
+        }
+    }
+    wave_sync();
+    if (lane < 4 * nbb) ((u64 *)(rng + e0b))[lane] = rng_lds[lane];
+}
+
 // ---- life_occupancy ---------------------------------------------------------------------------------
 // (advance_board.c:153-189)  One wavefront per workgroup, G boards per wavefront, rows in registers for
 // all n steps.  After every step each lane bumps, for each of its cells that is ALIVE and not
@@ -1749,7 +1833,11 @@ __device__ __forceinline__ void write_policy_block(const sl_env_batch &env, unsi
         // still writes 1 KiB contiguously per channel.  (Chunks cut from the flat output run instead -- aligned
         // stores, but a division per chunk and per-element plane-crossing logic -- cost 55 us per C3 step, this
         // form 38; a divergent slow path for the one chunk in 39 that crosses a plane cost 77: some lane of
-        // nearly every wave has such a chunk.)
+        // nearly every wave has such a chunk.  Round 3, 35.6 us with this form: one 16-byte ALIGNED chunk of one
+        // plane per work item, its sixteen words re-read per channel: 64 us; nineteen words read once, a channel's
+        // bits collected into one integer and the store window moved up to the plane's next dword boundary
+        // (dword-aligned stores, bytes by multiply): 56 us.  The epilogue is bound by its instruction count, not by
+        // the split stores.)
         if (env.policy_dtype == 0) policy_planes<16>(env, stage, pnv, nb, nv, C, (size_t)(e0b + b0), tid);
         else policy_planes<4>(env, stage, pnv, nb, nv, C, (size_t)(e0b + b0), tid);
     }
@@ -2481,6 +2569,17 @@ hipError_t launch_advance_t(const u16 *in, u16 *out, int B, const float *spawn_p
                                    const int32_t *n_each, const int32_t *n_valid, sl_pcg64 *rng, const Jump *jump,
                                    hipStream_t stream) {
     using Gm = Geom<H, W>;
+    // batches that would leave CUs without a workgroup of the four-wave kernel: one wave per workgroup
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    if ((B + Gm::NB - 1) / Gm::NB < 2 * n_cu) {
+        hipLaunchKernelGGL((k_advance_small<H, W>), dim3((B + Gm::G - 1) / Gm::G), dim3(64), 0, stream, in, out, B, spawn_prob,
+                           n_steps, n_each, n_valid, rng, jump);
+        return hipGetLastError();
+    }
     auto fn = k_advance_rowlane<H, W>;
     hipError_t err = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, Gm::LDS_ADVANCE);
     if (err != hipSuccess) return err;
