@@ -1744,6 +1744,78 @@ __device__ __forceinline__ void write_obs_block(const sl_env_batch &env, const u
 
 // One round of write_policy_block: PER consecutive cells of a board's transposed view per work item (16 for
 // uint8, 4 for float32: 16 output bytes per channel either way, one store).
+// uint8 planes for the two standard channel lists (training: bits 0-11, 25-27; default: bits 0-15, 25-27), where
+// every channel is known at compile time: a thread's sixteen view words go through the 16 x 16 bit transposition of
+// sl_planes.h ONCE (plane j: low half = bit j of the sixteen cells, high half = bit 16 + j), and a channel's sixteen
+// output bytes are its sixteen bits spread out -- a field extract, a multiply and a mask per dword -- instead of
+// sixteen extracts and twelve packing operations per channel.
+template <int NCH>
+__device__ __forceinline__ void policy_planes_u8_std(const sl_env_batch &env, const u32 *stage, int pnv, int nb, int nv,
+                                                     size_t first_board, int tid, const pl::PConsts &pc) {
+    typedef u32 u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
+    constexpr int C = NCH;
+    const int cpb = (nv + 15) / 16;
+    const float inv_cpb = 1.0f / (float)cpb;
+    for (int it = tid; it < nb * cpb; it += 64 * WAVES) {
+        const int bq = div_small(it, cpb, inv_cpb), xy0 = (it - bq * cpb) * 16;
+        const u32 *view = stage + bq * pnv;
+        const int n_el = min(16, nv - xy0);
+        u32 v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int i0 = min(xy0 + q, nv - 1);
+            v[q] = view[i0 + (i0 >> 4)];
+        }
+        // transposition: 8-stage by byte permutes, then the 4-, 2- and 1-stages
+        u32 lo8[8], hi8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            lo8[i] = __builtin_amdgcn_perm(v[i + 8], v[i], 0x06020400u);
+            hi8[i] = __builtin_amdgcn_perm(v[i + 8], v[i], 0x07030501u);
+        }
+        u32 p[16];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const u32 *w = half ? hi8 : lo8;
+            u32 x[8], y[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                x[i] = pl::bf_lo(w[i], w[i + 4], 4, pc.m4);
+                x[i + 4] = pl::bf_hi(w[i], w[i + 4], 4, pc.m4);
+            }
+#pragma unroll
+            for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    y[4 * gq + i] = pl::bf_lo(x[4 * gq + i], x[4 * gq + i + 2], 2, pc.m2);
+                    y[4 * gq + i + 2] = pl::bf_hi(x[4 * gq + i], x[4 * gq + i + 2], 2, pc.m2);
+                }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                p[8 * half + 2 * j] = pl::bf_lo(y[2 * j], y[2 * j + 1], 1, pc.m1);
+                p[8 * half + 2 * j + 1] = pl::bf_hi(y[2 * j], y[2 * j + 1], 1, pc.m1);
+            }
+        }
+        // (the stores stay byte-aligned 16-byte vectors: moving the window up to the plane's next dword boundary --
+        //  three more words, dword-aligned stores -- measured 47 us against this form's 32.6)
+        const size_t o = (first_board + bq) * (size_t)C * nv + xy0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int bit = c < C - 3 ? c : 25 + (c - (C - 3));                 // both lists end with 25, 26, 27
+            const u32 sixteen = bit < 16 ? (p[bit] & 0xFFFFu) : (p[bit - 16] >> 16);
+            uint8_t *dst = (uint8_t *)env.policy_obs + o + (size_t)c * nv;
+            if (n_el == 16) {
+                u32 w4[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w4[k] = __umul24((sixteen >> (4 * k)) & 0xFu, 0x00204081u) & 0x01010101u;
+                *(u32x4_a1 *)dst = u32x4_a1{w4[0], w4[1], w4[2], w4[3]};
+            } else {
+                for (int q = 0; q < n_el; ++q) dst[q] = (uint8_t)((sixteen >> q) & 1u);
+            }
+        }
+    }
+}
+
 template <int PER>
 __device__ __forceinline__ void policy_planes(const sl_env_batch &env, const u32 *stage, int pnv, int nb, int nv, int C,
                                               size_t first_board, int tid) {
@@ -1811,6 +1883,11 @@ __device__ __forceinline__ void write_policy_block(const sl_env_batch &env, unsi
     // would put a whole wave on two LDS banks
     const int pnv = nv + (nv >> 4) + 1;
     const int per_round = ROOM / pnv;           // boards per round (the launcher guarantees >= 1)
+    // one of the two standard channel lists?  (wave-uniform: the channel list is a kernel argument)
+    int std_list = (C == 15 || C == 19) ? C : 0;
+    for (int c = 0; c < C && std_list; ++c)
+        if (env.channels[c] != (c < C - 3 ? c : 25 + (c - (C - 3)))) std_list = 0;
+    const pl::PConsts pcst = pl::make_pconsts();
     for (int b0 = 0; b0 < nbb; b0 += per_round) {
         const int nb = min(per_round, nbb - b0);
         __syncthreads();
@@ -1838,7 +1915,9 @@ __device__ __forceinline__ void write_policy_block(const sl_env_batch &env, unsi
         // bits collected into one integer and the store window moved up to the plane's next dword boundary
         // (dword-aligned stores, bytes by multiply): 56 us.  The epilogue is bound by its instruction count, not by
         // the split stores.)
-        if (env.policy_dtype == 0) policy_planes<16>(env, stage, pnv, nb, nv, C, (size_t)(e0b + b0), tid);
+        if (env.policy_dtype == 0 && std_list == 15) policy_planes_u8_std<15>(env, stage, pnv, nb, nv, (size_t)(e0b + b0), tid, pcst);
+        else if (env.policy_dtype == 0 && std_list == 19) policy_planes_u8_std<19>(env, stage, pnv, nb, nv, (size_t)(e0b + b0), tid, pcst);
+        else if (env.policy_dtype == 0) policy_planes<16>(env, stage, pnv, nb, nv, C, (size_t)(e0b + b0), tid);
         else policy_planes<4>(env, stage, pnv, nb, nv, C, (size_t)(e0b + b0), tid);
     }
 }
