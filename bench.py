@@ -310,8 +310,13 @@ def main():
     # rollouts exchanges once per rollout), so the hand-off -- ~30-70 us of host time -- falls where the host is
     # ahead of the device instead of in the middle of the launches
     shift = (every - (P + W + K) % every) % every
-    # (measured with the exchange forced on for one rank, K = 20: window closing at the last step 12.3 us per step,
-    #  five steps earlier 13.4 -- with busy queues the hand-off costs the stepping thread 35-80 us -- none 9.1)
+    # ... two steps ahead of the end: the exchange itself (RCCL's send / receive kernel and its hand-shake, ~25 us on
+    # the device) then runs under the last steps.  Measured with the exchange forced on for one rank, K = 20, the
+    # library's worker thread issuing it: window closing at the last step 10.4-11.8 us per step, two steps earlier
+    # 10.6-10.8, four 12.2-13.2, six 13-16 (the worker's runtime calls contend with the stepping thread's launches
+    # for as long as launches remain); without an exchange 9.1.
+    if K >= 8 and every >= 8:
+        shift = (shift + 2) % every
 
     def before(t):
         gather.before_step(t + shift)

@@ -25,6 +25,7 @@ EXPORTS = (
     "slhip_env_obs",
     "slhip_obs_to_policy", "slhip_side_effects",
     "slhip_gather_unique_id", "slhip_gather_init", "slhip_gather_window", "slhip_gather_destroy",
+    "slhip_gather_window_async", "slhip_gather_done", "slhip_gather_wait_streams",
 )
 SL_GATHER_ID_BYTES = 128
 SL_SE_MAX_KEYS = 24
@@ -47,7 +48,7 @@ ENV_SCALARS_HEAD = ("B", "H", "W", "E", "time_limit", "exit_points", "n_tables",
 ENV_STATE_PTRS = ("board", "goals", "exit_locs", "rng", "scalars", "points_table")
 ENV_POOL_PTRS = ("pool_board", "pool_goals", "pool_exit_locs", "pool_rng", "pool_scalars")
 ENV_OUT_PTRS = ("out", "obs", "score_lut")
-SL_ABI_VERSION = 5
+SL_ABI_VERSION = 6
 
 #: int32 column of each field inside `struct sl_env_scalars` (64 bytes = 16 columns)
 SCALAR_COLS = {"agent_row": 0, "agent_col": 1, "num_steps": 2, "old_value": 3, "required_points": 4,
@@ -143,6 +144,9 @@ def lib():
         L.slhip_gather_init.argtypes = [_p, C.c_int, C.c_int, C.POINTER(_p)]
         L.slhip_gather_window.argtypes = [_p, _p, _p, C.c_size_t, _p]
         L.slhip_gather_destroy.argtypes = [_p]
+        L.slhip_gather_window_async.argtypes = [_p, _p, _p, C.c_size_t, _p, C.c_int, _p, C.POINTER(C.c_longlong)]
+        L.slhip_gather_done.argtypes = [_p, C.c_longlong, C.c_int, C.POINTER(C.c_int)]
+        L.slhip_gather_wait_streams.argtypes = [_p, C.c_longlong, _p, C.c_int]
         for name in EXPORTS:
             getattr(L, name)  # AttributeError here means the .so is stale
         if L.slhip_abi_version() != SL_ABI_VERSION:

@@ -5,7 +5,10 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
+#include <deque>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 #include <dlfcn.h>
@@ -208,9 +211,32 @@ const Rccl &rccl() {
 int rccl_fail(const Rccl &r, int code, const char *what) {
     return fail(SL_E_HIP, std::string(what) + ": " + (r.GetErrorString ? r.GetErrorString(code) : "RCCL error"));
 }
+struct GatherRequest {
+    const void *send;
+    void *recv;
+    size_t bytes;
+    hipStream_t writers[8];
+    int n_writers;
+    hipStream_t stream;
+    long long ticket;
+};
 struct GatherComm {
     void *comm;
     int world, rank;
+    // asynchronous hand-off (slhip_gather_window_async): a worker thread of the library's own issues the stream
+    // ordering and the RCCL group, so the stepping thread pays for a queue push instead of ~20-80 us of runtime calls
+    int device = 0;
+    std::thread worker;
+    std::mutex m;
+    std::condition_variable cv, cv_done;
+    std::deque<GatherRequest> queue;
+    bool stop = false;
+    long long submitted = 0;                 // tickets handed out
+    std::atomic<long long> issued{0};        // tickets whose RCCL group has been enqueued (and done event recorded)
+    int error = 0;
+    static constexpr int RING = 8;
+    hipEvent_t order_ev[8] = {};             // writer stream -> gather stream
+    hipEvent_t done_ev[RING] = {};           // recorded behind ticket t's group: slot t % RING
 };
 }  // namespace
 
@@ -501,12 +527,16 @@ int slhip_gather_init(const void *id, int world, int rank, void **comm) {
     return SL_OK;
 }
 
+static int gather_issue(GatherComm *g, const void *send, void *recv, size_t bytes, hipStream_t st);
 int slhip_gather_window(void *comm, const void *send, void *recv, size_t bytes, void *stream) {
     GatherComm *g = (GatherComm *)comm;
     if (!g || !send || (g->rank == 0 && !recv)) return fail(SL_E_ARG, "bad gather arguments");
     if (bytes == 0) return SL_OK;
+    return gather_issue(g, send, recv, bytes, (hipStream_t)stream);
+}
+
+static int gather_issue(GatherComm *g, const void *send, void *recv, size_t bytes, hipStream_t st) {
     const Rccl &r = rccl();
-    hipStream_t st = (hipStream_t)stream;
     int rc = r.GroupStart();
     if (rc) return rccl_fail(r, rc, "ncclGroupStart");
     const int kChar = 0;                                            // ncclInt8
@@ -519,9 +549,120 @@ int slhip_gather_window(void *comm, const void *send, void *recv, size_t bytes, 
     return SL_OK;
 }
 
+static void gather_worker(GatherComm *g) {
+    (void)hipSetDevice(g->device);
+    for (;;) {
+        GatherRequest rq;
+        {
+            std::unique_lock<std::mutex> lock(g->m);
+            g->cv.wait(lock, [g] { return g->stop || !g->queue.empty(); });
+            if (g->queue.empty()) return;
+            rq = g->queue.front();
+            g->queue.pop_front();
+        }
+        int rc = SL_OK;
+        for (int i = 0; i < rq.n_writers && rc == SL_OK; ++i) {     // the exchange's stream waits for the window's writers
+            if (rq.writers[i] == rq.stream) continue;
+            hipError_t err = hipEventRecord(g->order_ev[i], rq.writers[i]);
+            if (err == hipSuccess) err = hipStreamWaitEvent(rq.stream, g->order_ev[i], 0);
+            if (err != hipSuccess) rc = SL_E_HIP;
+        }
+        if (rc == SL_OK) rc = gather_issue(g, rq.send, rq.recv, rq.bytes, rq.stream);
+        if (rc == SL_OK && hipEventRecord(g->done_ev[rq.ticket % GatherComm::RING], rq.stream) != hipSuccess) rc = SL_E_HIP;
+        {
+            std::lock_guard<std::mutex> lock(g->m);
+            if (rc != SL_OK && g->error == 0) g->error = rc;
+            g->issued.store(rq.ticket + 1, std::memory_order_release);
+        }
+        g->cv_done.notify_all();
+    }
+}
+
+int slhip_gather_window_async(void *comm, const void *send, void *recv, size_t bytes, void *const *writers, int n_writers,
+                              void *stream, long long *ticket) {
+    GatherComm *g = (GatherComm *)comm;
+    if (!g || !send || (g->rank == 0 && !recv) || n_writers < 0 || n_writers > 8 || (n_writers && !writers) || !ticket)
+        return fail(SL_E_ARG, "bad gather arguments");
+    std::lock_guard<std::mutex> lock(g->m);
+    if (g->error) return fail(g->error, "an earlier asynchronous gather failed");
+    if (!g->worker.joinable()) {                        // first use: events on this device, then the thread
+        hipError_t err = hipGetDevice(&g->device);
+        for (int i = 0; i < 8 && err == hipSuccess; ++i) err = hipEventCreateWithFlags(&g->order_ev[i], hipEventDisableTiming);
+        for (int i = 0; i < GatherComm::RING && err == hipSuccess; ++i) err = hipEventCreateWithFlags(&g->done_ev[i], hipEventDisableTiming);
+        if (err != hipSuccess) return hip_fail(err, "gather events");
+        g->worker = std::thread(gather_worker, g);
+    }
+    if (g->submitted - g->issued.load(std::memory_order_acquire) >= GatherComm::RING)
+        return fail(SL_E_ARG, "too many gather windows in flight");
+    GatherRequest rq;
+    rq.send = send, rq.recv = recv, rq.bytes = bytes, rq.n_writers = n_writers, rq.stream = (hipStream_t)stream;
+    for (int i = 0; i < n_writers; ++i) rq.writers[i] = (hipStream_t)writers[i];
+    rq.ticket = g->submitted++;
+    *ticket = rq.ticket;
+    g->queue.push_back(rq);
+    g->cv.notify_one();
+    return SL_OK;
+}
+
+int slhip_gather_done(void *comm, long long ticket, int block, int *done) {
+    GatherComm *g = (GatherComm *)comm;
+    if (!g || !done || ticket < 0) return fail(SL_E_ARG, "bad gather arguments");
+    *done = 0;
+    if (g->issued.load(std::memory_order_acquire) <= ticket) {
+        if (!block) return SL_OK;
+        std::unique_lock<std::mutex> lock(g->m);
+        g->cv_done.wait(lock, [g, ticket] { return g->issued.load(std::memory_order_acquire) > ticket || g->error; });
+    }
+    if (g->error) return fail(g->error, "asynchronous gather failed");
+    if (g->submitted - ticket > GatherComm::RING) {     // its event slot has been reused: long finished
+        *done = 1;
+        return SL_OK;
+    }
+    hipEvent_t ev = g->done_ev[ticket % GatherComm::RING];
+    if (block) {
+        hipError_t err = hipEventSynchronize(ev);
+        if (err != hipSuccess) return hip_fail(err, "hipEventSynchronize");
+        *done = 1;
+        return SL_OK;
+    }
+    *done = hipEventQuery(ev) == hipSuccess ? 1 : 0;
+    (void)hipGetLastError();
+    return SL_OK;
+}
+
+int slhip_gather_wait_streams(void *comm, long long ticket, void *const *streams, int n_streams) {
+    GatherComm *g = (GatherComm *)comm;
+    if (!g || ticket < 0 || n_streams < 0 || (n_streams && !streams)) return fail(SL_E_ARG, "bad gather arguments");
+    int done = 0;
+    {       // the group must have been enqueued before a stream can be made to wait for it
+        std::unique_lock<std::mutex> lock(g->m);
+        g->cv_done.wait(lock, [g, ticket] { return g->issued.load(std::memory_order_acquire) > ticket || g->error; });
+    }
+    if (g->error) return fail(g->error, "asynchronous gather failed");
+    (void)done;
+    if (g->submitted - ticket > GatherComm::RING) return SL_OK;        // slot reused: that window finished long ago
+    for (int i = 0; i < n_streams; ++i) {
+        hipError_t err = hipStreamWaitEvent((hipStream_t)streams[i], g->done_ev[ticket % GatherComm::RING], 0);
+        if (err != hipSuccess) return hip_fail(err, "hipStreamWaitEvent");
+    }
+    return SL_OK;
+}
+
 int slhip_gather_destroy(void *comm) {
     GatherComm *g = (GatherComm *)comm;
     if (!g) return SL_OK;
+    if (g->worker.joinable()) {
+        {
+            std::lock_guard<std::mutex> lock(g->m);
+            g->stop = true;
+        }
+        g->cv.notify_all();
+        g->worker.join();
+        for (auto &e : g->order_ev)
+            if (e) (void)hipEventDestroy(e);
+        for (auto &e : g->done_ev)
+            if (e) (void)hipEventDestroy(e);
+    }
     const Rccl &r = rccl();
     const int rc = r.ok ? r.CommDestroy(g->comm) : 0;
     delete g;

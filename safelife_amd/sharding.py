@@ -15,7 +15,9 @@ Two transports:
 * ``"rccl"`` (device tensors): the library's own ``slhip_gather_*`` entry points -- one RCCL group of
   ``ncclSend`` / ``ncclRecv`` per window on a side stream of this class, ordered against the streams that
   wrote the window by events only; the communicator is bootstrapped from a unique id that rank 0 broadcasts
-  over the existing ``torch.distributed`` process group.  The stepping thread never waits on the host.  (Round 2
+  over the existing ``torch.distributed`` process group.  The hand-off itself is asynchronous
+  (``slhip_gather_window_async``): a worker thread inside the library issues the event records, stream waits and
+  the RCCL group, so a window costs the stepping thread a queue push, and it never waits on the host.  (Round 2
   handed every window to ``torch.distributed.gather``: ~100 us of host time per window, 200-350 us for the
   first, against ~2.4 us of host slack per step.)
 * ``"torch"``: ``torch.distributed.gather`` -- CPU tensors over gloo (the CPU test-suite, ``bench.py
@@ -108,7 +110,7 @@ class RewardGather(object):
         self._comm = comm
         self._stream = torch.cuda.Stream(device=self.env.device)       # the exchange's own stream
         self._gptr = (C.c_void_p * 1)(self._stream.cuda_stream)
-        self._done_ev = [torch.cuda.Event(), torch.cuda.Event()]        # recorded behind each buffer's exchange
+        self._ticket = [-1, -1]                                         # the window each buffer was last handed off as
 
     def _order(self, before, after):
         """Streams of `after` wait for what is enqueued on the streams of `before` (events, no host wait)."""
@@ -139,11 +141,13 @@ class RewardGather(object):
         streams = self._writer_streams()
         self.windows += 1
         if self.backend == "rccl":
-            self._order(streams, [self._stream])
             recv = self.recv[which].data_ptr() if self.rank == 0 else None
-            _hip.check(self._lib.slhip_gather_window(self._comm, self.buf[which].data_ptr(), recv,
-                                                     self.buf[which].numel() * 4, self._gptr[0]))
-            self._done_ev[which].record(self._stream)
+            writers = (C.c_void_p * len(streams))(*[s_.cuda_stream for s_ in streams])
+            ticket = C.c_longlong(-1)
+            _hip.check(self._lib.slhip_gather_window_async(self._comm, self.buf[which].data_ptr(), recv,
+                                                           self.buf[which].numel() * 4, writers, len(streams),
+                                                           self._gptr[0], C.byref(ticket)))
+            self._ticket[which] = ticket.value
             self.busy[which] = True
             return None
         import torch.distributed as dist
@@ -162,10 +166,14 @@ class RewardGather(object):
     def _wait(self, which, streams):
         """`streams` wait (stream-level) for the exchange of buffer `which`."""
         if self.backend == "rccl":
-            # (a window later the exchange has long finished: one event query instead of an event record and a
-            #  stream wait per writer -- 1 us instead of ~13)
-            if self.busy[which] and streams and not self._done_ev[which].query():
-                self._order([self._stream], streams)
+            # (a window later the exchange has long finished: one query instead of a stream wait per writer)
+            if self.busy[which] and streams:
+                done = C.c_int(0)
+                from . import _hip
+                _hip.check(self._lib.slhip_gather_done(self._comm, self._ticket[which], 0, C.byref(done)))
+                if not done.value:
+                    arr = (C.c_void_p * len(streams))(*[s_.cuda_stream for s_ in streams])
+                    _hip.check(self._lib.slhip_gather_wait_streams(self._comm, self._ticket[which], arr, len(streams)))
             return
         work = self.work[which]
         if work is None:
