@@ -1742,80 +1742,111 @@ __device__ __forceinline__ void write_obs_block(const sl_env_batch &env, const u
     }
 }
 
-// One round of write_policy_block: PER consecutive cells of a board's transposed view per work item (16 for
-// uint8, 4 for float32: 16 output bytes per channel either way, one store).
 // uint8 planes for the two standard channel lists (training: bits 0-11, 25-27; default: bits 0-15, 25-27), where
-// every channel is known at compile time: a thread's sixteen view words go through the 16 x 16 bit transposition of
-// sl_planes.h ONCE (plane j: low half = bit j of the sixteen cells, high half = bit 16 + j), and a channel's sixteen
-// output bytes are its sixteen bits spread out -- a field extract, a multiply and a mask per dword -- instead of
-// sixteen extracts and twelve packing operations per channel.
-template <int NCH>
-__device__ __forceinline__ void policy_planes_u8_std(const sl_env_batch &env, const u32 *stage, int pnv, int nb, int nv,
-                                                     size_t first_board, int tid, const pl::PConsts &pc) {
+// every channel is known at compile time.  No staging: a work item is sixteen consecutive cells of one board's
+// TRANSPOSED view, i.e. a run down a column of the board image (wrapping into the next column), which it walks itself
+// -- two 16-bit LDS reads per cell (board word, goal word), the cursor kept incrementally.  The sixteen values are
+// byte-transposed four at a time (v_perm: low bytes, high bytes, the goal words' high bytes), after which a channel's
+// four output bytes are one shift and one mask of a dword: ~13 vector instructions per cell and ~8 per 16-byte
+// store, against ~35 per cell (fetch in view order, stage through LDS, two barriers per round) and ~13 per store
+// for the 16 x 16 bit transposition this replaces.
+template <int H, int W, int NCH>
+__device__ __forceinline__ void policy_direct_u8_std(const sl_env_batch &env, const unsigned char *smem, int e0b, int nbb,
+                                                     int tid) {
+    using Gm = Geom<H, W>;
     typedef u32 u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
     constexpr int C = NCH;
-    const int cpb = (nv + 15) / 16;
-    const float inv_cpb = 1.0f / (float)cpb;
-    for (int it = tid; it < nb * cpb; it += 64 * WAVES) {
-        const int bq = div_small(it, cpb, inv_cpb), xy0 = (it - bq * cpb) * 16;
-        const u32 *view = stage + bq * pnv;
-        const int n_el = min(16, nv - xy0);
-        u32 v[16];
+    const int vh = env.view_h, vw = env.view_w, nv = vh * vw;
+    const int cpb = (nv + 15) >> 4;
+    const float inv_cpb = 1.0f / (float)cpb, inv_vh = 1.0f / (float)vh, inv_vw = 1.0f / (float)vw;
+    const int n_exits = min(env.E, OBS_MAX_EXITS);
+    for (int it = tid; it < nbb * cpb; it += 64 * WAVES) {
+        const int bq = div_small(it, cpb, inv_cpb), i0 = (it - bq * cpb) * 16;
+        const int n_el = min(16, nv - i0);
+        const int *pp = (const int *)(smem + Gm::OFF_GSH) + bq * OBS_PAR_INTS;
+        const u16 *b16 = (const u16 *)(smem + Gm::OFF_BOARD + Gm::PAD) + bq * Gm::HW;
+        const u16 *g16 = (const u16 *)(smem + Gm::OFF_GOALS + Gm::PAD) + bq * Gm::HW;
+        const int oy = pp[0], ox = pp[1];
+        int vx = div_small(i0, vh, inv_vh), vy = i0 - vx * vh;
+        int sy = (int)((unsigned)(oy + vy) % (unsigned)H), sx = (int)((unsigned)(ox + vx) % (unsigned)W);
+        // first exit: where it is painted, as an offset into this run (transposed index - i0), and its board cell
+        int e_rel = -1, e_cell = 0;
+        if (n_exits > 0 && pp[2] >= 0) {
+            const int ty = div_small(pp[2], vw, inv_vw), tx = pp[2] - ty * vw;
+            e_rel = tx * vh + ty - i0;
+            e_cell = Gm::flat(pp[2 + OBS_MAX_EXITS]);
+        }
+        u32 bv[16], gv[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const int i0 = min(xy0 + q, nv - 1);
-            v[q] = view[i0 + (i0 >> 4)];
-        }
-        // transposition: 8-stage by byte permutes, then the 4-, 2- and 1-stages
-        u32 lo8[8], hi8[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            lo8[i] = __builtin_amdgcn_perm(v[i + 8], v[i], 0x06020400u);
-            hi8[i] = __builtin_amdgcn_perm(v[i + 8], v[i], 0x07030501u);
-        }
-        u32 p[16];
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const u32 *w = half ? hi8 : lo8;
-            u32 x[8], y[8];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                x[i] = pl::bf_lo(w[i], w[i + 4], 4, pc.m4);
-                x[i + 4] = pl::bf_hi(w[i], w[i + 4], 4, pc.m4);
+            int cell = Gm::cell(sy, sx);
+            if (q == e_rel) cell = e_cell;
+            bv[q] = b16[cell];
+            gv[q] = g16[cell];
+            ++vy;
+            sy = sy + 1 == H ? 0 : sy + 1;
+            if (vy == vh) {
+                vy = 0;
+                sy = oy;
+                sx = sx + 1 == W ? 0 : sx + 1;
             }
+        }
+        if (n_exits > 1) {                          // later exits overwrite earlier ones, as numpy does
+            for (int k = 1; k < n_exits; ++k) {
+                const int tv = pp[2 + k];
+                if (tv < 0) continue;
+                const int ty = div_small(tv, vw, inv_vw), tx = tv - ty * vw;
+                const int rel = tx * vh + ty - i0;
+                if (rel < 0 || rel >= 16) continue;
+                const int cell = Gm::flat(pp[2 + OBS_MAX_EXITS + k]);
+                const u32 bk = b16[cell], gk = g16[cell];
 #pragma unroll
-            for (int gq = 0; gq < 2; ++gq)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    y[4 * gq + i] = pl::bf_lo(x[4 * gq + i], x[4 * gq + i + 2], 2, pc.m2);
-                    y[4 * gq + i + 2] = pl::bf_hi(x[4 * gq + i], x[4 * gq + i + 2], 2, pc.m2);
+                for (int q = 0; q < 16; ++q) {
+                    bv[q] = q == rel ? bk : bv[q];
+                    gv[q] = q == rel ? gk : gv[q];
                 }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                p[8 * half + 2 * j] = pl::bf_lo(y[2 * j], y[2 * j + 1], 1, pc.m1);
-                p[8 * half + 2 * j + 1] = pl::bf_hi(y[2 * j], y[2 * j + 1], 1, pc.m1);
             }
         }
-        // (the stores stay byte-aligned 16-byte vectors: moving the window up to the plane's next dword boundary --
-        //  three more words, dword-aligned stores -- measured 47 us against this form's 32.6)
-        const size_t o = (first_board + bq) * (size_t)C * nv + xy0;
+        // byte transposition, four cells at a time: B0 / B1 = the board words' low / high bytes, G1 = the goal words'
+        // high bytes (goal colour = bits 9-11 of the word, bits 1-3 of that byte; channels 25-27 of the view word)
+        u32 B0[4], B1[4], G1[4];
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
+        for (int k = 0; k < 4; ++k) {
+            const u32 t = __builtin_amdgcn_perm(bv[4 * k + 1], bv[4 * k], 0x05010400u);
+            const u32 u = __builtin_amdgcn_perm(bv[4 * k + 3], bv[4 * k + 2], 0x05010400u);
+            B0[k] = __builtin_amdgcn_perm(u, t, 0x05040100u);
+            B1[k] = __builtin_amdgcn_perm(u, t, 0x07060302u);
+            const u32 tg = __builtin_amdgcn_perm(gv[4 * k + 1], gv[4 * k], 0x0C0C0501u);
+            const u32 ug = __builtin_amdgcn_perm(gv[4 * k + 3], gv[4 * k + 2], 0x0C0C0501u);
+            u32 g = __builtin_amdgcn_perm(ug, tg, 0x05040100u);
+            if (env.remove_white_goals) {           // all three colour bits set: no goal
+                const u32 m = g & (g >> 1) & (g >> 2) & 0x02020202u;
+                g &= ~(m | (m << 1) | (m << 2));
+            }
+            G1[k] = g;
+        }
+        uint8_t *dst = (uint8_t *)env.policy_obs + (size_t)(e0b + bq) * (size_t)C * nv + i0;
+#pragma unroll
+        for (int c = 0; c < C; ++c, dst += nv) {
             const int bit = c < C - 3 ? c : 25 + (c - (C - 3));                 // both lists end with 25, 26, 27
-            const u32 sixteen = bit < 16 ? (p[bit] & 0xFFFFu) : (p[bit - 16] >> 16);
-            uint8_t *dst = (uint8_t *)env.policy_obs + o + (size_t)c * nv;
-            if (n_el == 16) {
-                u32 w4[4];
+            const u32 *src = bit < 8 ? B0 : (bit < 16 ? B1 : G1);
+            const int sh = bit < 16 ? (bit & 7) : bit - 24;
+            u32 w4[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) w4[k] = __umul24((sixteen >> (4 * k)) & 0xFu, 0x00204081u) & 0x01010101u;
+            for (int k = 0; k < 4; ++k) w4[k] = (src[k] >> sh) & 0x01010101u;
+            // (byte-aligned 16-byte vectors: planes are nv bytes apart.  Stores rounded down to 16 bytes -- wrong
+            //  data, right count -- run no faster: the epilogue is bound by its instructions, not by split stores)
+            if (n_el == 16) {
                 *(u32x4_a1 *)dst = u32x4_a1{w4[0], w4[1], w4[2], w4[3]};
             } else {
-                for (int q = 0; q < n_el; ++q) dst[q] = (uint8_t)((sixteen >> q) & 1u);
+                for (int q = 0; q < n_el; ++q) dst[q] = (uint8_t)((w4[q >> 2] >> (8 * (q & 3))) & 1u);
             }
         }
     }
 }
 
+// One round of write_policy_block: PER consecutive cells of a board's transposed view per work item (16 for
+// uint8, 4 for float32: 16 output bytes per channel either way, one store).
 template <int PER>
 __device__ __forceinline__ void policy_planes(const sl_env_batch &env, const u32 *stage, int pnv, int nb, int nv, int C,
                                               size_t first_board, int tid) {
@@ -1883,11 +1914,13 @@ __device__ __forceinline__ void write_policy_block(const sl_env_batch &env, unsi
     // would put a whole wave on two LDS banks
     const int pnv = nv + (nv >> 4) + 1;
     const int per_round = ROOM / pnv;           // boards per round (the launcher guarantees >= 1)
-    // one of the two standard channel lists?  (wave-uniform: the channel list is a kernel argument)
+    // one of the two standard channel lists?  (wave-uniform: the channel list is a kernel argument) -- uint8 planes
+    // of those are written without staging
     int std_list = (C == 15 || C == 19) ? C : 0;
     for (int c = 0; c < C && std_list; ++c)
         if (env.channels[c] != (c < C - 3 ? c : 25 + (c - (C - 3)))) std_list = 0;
-    const pl::PConsts pcst = pl::make_pconsts();
+    if (env.policy_dtype == 0 && std_list == 15) return policy_direct_u8_std<H, W, 15>(env, smem, e0b, nbb, tid);
+    if (env.policy_dtype == 0 && std_list == 19) return policy_direct_u8_std<H, W, 19>(env, smem, e0b, nbb, tid);
     for (int b0 = 0; b0 < nbb; b0 += per_round) {
         const int nb = min(per_round, nbb - b0);
         __syncthreads();
@@ -1907,17 +1940,12 @@ __device__ __forceinline__ void write_policy_block(const sl_env_batch &env, unsi
         // view: its 16 words are read once and give a 16-element chunk of EVERY channel plane (one store per
         // channel, 16 uint8 or 4 float32 elements) -- the channel loop is wave-uniform, so the channel's bit
         // position is a scalar.  Planes are nv elements apart, i.e. the uint8 stores are only byte-aligned; a wave
-        // still writes 1 KiB contiguously per channel.  (Chunks cut from the flat output run instead -- aligned
-        // stores, but a division per chunk and per-element plane-crossing logic -- cost 55 us per C3 step, this
-        // form 38; a divergent slow path for the one chunk in 39 that crosses a plane cost 77: some lane of
-        // nearly every wave has such a chunk.  Round 3, 35.6 us with this form: one 16-byte ALIGNED chunk of one
-        // plane per work item, its sixteen words re-read per channel: 64 us; nineteen words read once, a channel's
-        // bits collected into one integer and the store window moved up to the plane's next dword boundary
-        // (dword-aligned stores, bytes by multiply): 56 us.  The epilogue is bound by its instruction count, not by
-        // the split stores.)
-        if (env.policy_dtype == 0 && std_list == 15) policy_planes_u8_std<15>(env, stage, pnv, nb, nv, (size_t)(e0b + b0), tid, pcst);
-        else if (env.policy_dtype == 0 && std_list == 19) policy_planes_u8_std<19>(env, stage, pnv, nb, nv, (size_t)(e0b + b0), tid, pcst);
-        else if (env.policy_dtype == 0) policy_planes<16>(env, stage, pnv, nb, nv, C, (size_t)(e0b + b0), tid);
+        // still writes 1 KiB contiguously per channel.  (uint8, measured per C3 step: chunks cut from the flat
+        // output run instead -- aligned stores, a division per chunk and per-element plane-crossing logic -- 55 us,
+        // this form 38; a divergent slow path for the one chunk in 39 that crosses a plane 77; one 16-byte ALIGNED
+        // chunk of one plane per work item, its words re-read per channel, 64; the store window moved up to the
+        // plane's next dword boundary, 56.  The standard channel lists no longer come here: policy_direct_u8_std.)
+        if (env.policy_dtype == 0) policy_planes<16>(env, stage, pnv, nb, nv, C, (size_t)(e0b + b0), tid);
         else policy_planes<4>(env, stage, pnv, nb, nv, C, (size_t)(e0b + b0), tid);
     }
 }
