@@ -92,7 +92,7 @@ class EnvBatch(C.Structure):
 
 _f64p = C.POINTER(C.c_double)
 
-WRAP_MOVEMENT, WRAP_AS_PENALTY, WRAP_EXIT_BONUS, WRAP_SIDE_EFFECT, WRAP_IGNORE_REWARD_CELLS = 1, 2, 4, 8, 16
+WRAP_MOVEMENT, WRAP_AS_PENALTY, WRAP_EXIT_BONUS, WRAP_SIDE_EFFECT, WRAP_IGNORE_REWARD_CELLS, WRAP_INACTION = 1, 2, 4, 8, 16, 32
 
 
 class Wrappers(C.Structure):
@@ -100,7 +100,7 @@ class Wrappers(C.Structure):
         ("flags", C.c_int32), ("move_period", C.c_int32), ("move_table_len", C.c_int32), ("reserved", C.c_int32),
         ("move_bonus", C.c_double), ("exit_bonus", C.c_double), ("penalty_coef", C.c_double),
         ("move_table", _f64p), ("n_prior", _i32p), ("prior", _i32p), ("last_side_effect", _i32p),
-        ("baseline", _u16p), ("shaped_reward", _f64p),
+        ("baseline", _u16p), ("shaped_reward", _f64p), ("inaction_rng", _pcgp),
     ]
 
 
@@ -353,14 +353,20 @@ class OracleEnv:
         s.obs = C.cast(_ptr(self.obs), _u8p) if self.obs is not None else None
 
     def set_wrappers(self, movement_bonus=None, movement_bonus_power=1e-100, movement_bonus_period=4,
-                     as_penalty=True, exit_bonus=None, penalty_coef=None, ignore_reward_cells=False):
-        """Training wrappers of env_factory.py:277-283 (None = wrapper absent)."""
+                     as_penalty=True, exit_bonus=None, penalty_coef=None, ignore_reward_cells=False,
+                     baseline="starting-state", inaction_rng=None):
+        """Training wrappers of env_factory.py:277-283 (None = wrapper absent).  baseline="inaction": the
+        baseline board advances once per step, spawners drawing from inaction_rng (uint64 [B,4] PCG64 words:
+        one stream per env where the reference has the process-wide generator)."""
+        assert baseline in ("starting-state", "inaction")
         B, H, W = self.s.B, self.s.H, self.s.W
         w = self.w = Wrappers()
         self.wa = wa = {
             "n_prior": np.zeros(B, np.int32), "prior": np.zeros((B, 8, 2), np.int32),
             "last_side_effect": np.zeros(B, np.int32), "baseline": np.zeros((B, H, W), np.uint16),
             "shaped_reward": np.zeros(B, np.float64),
+            "inaction_rng": (np.zeros((B, 4), np.uint64) if inaction_rng is None
+                             else np.ascontiguousarray(inaction_rng, dtype=np.uint64).reshape(B, 4).copy()),
             "move_table": movement_table(movement_bonus or 0.0, movement_bonus_period,
                                          movement_bonus_power, H + W + movement_bonus_period + 1),
         }
@@ -368,13 +374,14 @@ class OracleEnv:
                    | (WRAP_AS_PENALTY if as_penalty else 0)
                    | (WRAP_EXIT_BONUS if exit_bonus is not None else 0)
                    | (WRAP_SIDE_EFFECT if penalty_coef is not None else 0)
-                   | (WRAP_IGNORE_REWARD_CELLS if ignore_reward_cells else 0))
+                   | (WRAP_IGNORE_REWARD_CELLS if ignore_reward_cells else 0)
+                   | (WRAP_INACTION if baseline == "inaction" and penalty_coef is not None else 0))
         w.move_period = movement_bonus_period
         w.move_table_len = len(wa["move_table"])
         w.move_bonus = movement_bonus or 0.0
         w.exit_bonus = exit_bonus or 0.0
         w.penalty_coef = penalty_coef or 0.0
-        for k in ("move_table", "n_prior", "prior", "last_side_effect", "baseline", "shaped_reward"):
+        for k in ("move_table", "n_prior", "prior", "last_side_effect", "baseline", "shaped_reward", "inaction_rng"):
             setattr(w, k, C.cast(_ptr(wa[k]), dict(Wrappers._fields_)[k]))
 
     def reset(self, mask=None):

@@ -522,6 +522,10 @@ static void wrap_step_one(slo_env_batch *env, slo_wrappers *w, int e) {
     if ((w->flags & SLO_WRAP_EXIT_BONUS) && !env->times_up[e])     /* env_wrappers.py:124-128 */
         r = r + (double)(env->done[e] ? 1 : 0) * w->exit_bonus * (double)env->episode_reward[e];
     if (w->flags & SLO_WRAP_SIDE_EFFECT) {         /* env_wrappers.py:174-213 */
+        if (w->flags & SLO_WRAP_INACTION) {        /* :179-180, with the env's current spawn_prob */
+            slo_rng r1 = {&w->inaction_rng[e], slo_pcg64_next_double};
+            slo_advance_board(w->baseline + e * n, w->baseline + e * n, H, W, env->spawn_prob[e], 1, &r1);
+        }
         const uint16_t *board = env->board + e * n, *goals = env->goals + e * n;
         const uint16_t *base = w->baseline + e * n;
         const int32_t *exits = env->exit_locs + (size_t)e * E;

@@ -208,15 +208,25 @@ def level_record(game):
     return rec
 
 
-def run_trace(R, games, actions, env_kw, wrappers=None, min_perf_fraction=None):
+def run_trace(R, games, actions, env_kw, wrappers=None, min_perf_fraction=None, inaction_seed=None):
     """Drive the reference SafeLifeEnv over `games` (one episode each, in order) with the
     action stream; auto-reset on done like training/base_algo.py:231-236.
 
     `wrappers`: dict(movement=dict(...)|None, exit_bonus=float|None, side_effect=dict(...)|None):
     the reference's own env_wrappers stacked in the order of training/env_factory.py:277-283; the
     reward the outermost wrapper returns is recorded as `shaped_reward` (float64) next to the inner
-    SafeLifeEnv reward."""
+    SafeLifeEnv reward.
+
+    `inaction_seed`: seed of the process-wide generator (safelife/random.py:13) for the run -- the stream
+    SimpleSideEffectPenalty's "inaction" baseline draws its spawners from (env_wrappers.py:179-180: advance_board
+    outside any game method, i.e. after set_rng.__exit__ has put the global generator back)."""
     SafeLifeEnv = R.env.SafeLifeEnv
+    global_gen = None
+    if inaction_seed is not None:
+        import safelife.random as sl_random
+        global_gen = np.random.default_rng(inaction_seed)
+        sl_random.random_gen = global_gen
+        R.speedups.set_bit_generator(global_gen.bit_generator)
     it = iter(games)
     env = SafeLifeEnv(it, **env_kw)
     wrapped = env
@@ -240,7 +250,10 @@ def run_trace(R, games, actions, env_kw, wrappers=None, min_perf_fraction=None):
         wrapped = R.wrappers.MinPerformanceScheduler(wrapped, min_performance_fraction=min_perf_fraction)
     rec = {k: [] for k in ("obs", "reward", "done", "board", "goals", "agent_loc", "times_up",
                            "ep_length", "ep_reward", "success", "reset_obs", "reset_board",
-                           "reset_rng", "reset_required", "rng_after", "num_steps", "shaped_reward")}
+                           "reset_rng", "reset_required", "rng_after", "num_steps", "shaped_reward",
+                           "inaction_board", "inaction_rng_after")}
+    if global_gen is not None:
+        rec["inaction_rng0"] = words(global_gen.bit_generator)
 
     def note_reset(obs):
         rec["reset_obs"].append(obs.copy())
@@ -271,6 +284,12 @@ def run_trace(R, games, actions, env_kw, wrappers=None, min_perf_fraction=None):
         rec["success"].append(bool(info["episode"]["success"]))
         rec["rng_after"].append(words(env.game._rng.bit_generator))
         rec["num_steps"].append(env.game.num_steps)
+        if global_gen is not None:
+            w_ = wrapped
+            while not isinstance(w_, R.wrappers.SimpleSideEffectPenalty):
+                w_ = w_.env
+            rec["inaction_board"].append(w_.baseline_board.copy())
+            rec["inaction_rng_after"].append(words(global_gen.bit_generator))
         if done:
             try:
                 obs = wrapped.reset()
@@ -278,6 +297,8 @@ def run_trace(R, games, actions, env_kw, wrappers=None, min_perf_fraction=None):
                 break
             note_reset(obs)
             reset_at.append(t + 1)
+    if global_gen is None:
+        del rec["inaction_board"], rec["inaction_rng_after"]
     out = {k: np.array(v) for k, v in rec.items()}
     out["reset_at"] = np.array(reset_at)
     out["actions"] = np.array(actions[:len(rec["reward"])], np.int32)
@@ -350,10 +371,13 @@ def greedy_actions(R, game, rng, n, p_random=0.35):
     return acts
 
 
-def trace_blob(R, name, level_datas, seeds, actions, env_kw, min_perf_fraction=None, wrappers=None):
+def trace_blob(R, name, level_datas, seeds, actions, env_kw, min_perf_fraction=None, wrappers=None,
+               inaction_seed=None):
     Game = R.game.SafeLifeGame
     games = [seeded(Game.loaddata(d), s) for d, s in zip(level_datas, seeds)]
-    tr = run_trace(R, games, actions, env_kw, wrappers=wrappers, min_perf_fraction=min_perf_fraction)
+    tr = run_trace(R, games, actions, env_kw, wrappers=wrappers, min_perf_fraction=min_perf_fraction,
+                   inaction_seed=inaction_seed)
+    rng0 = tr.pop("inaction_rng0", None)
     games2 = [seeded(Game.loaddata(d), s) for d, s in zip(level_datas, seeds)]
     blob = {}
     for i, g in enumerate(games2):
@@ -375,15 +399,17 @@ def trace_blob(R, name, level_datas, seeds, actions, env_kw, min_perf_fraction=N
         if wrappers.get("exit_bonus") is not None:
             blob["wrap_exit_bonus"] = np.array(float(wrappers["exit_bonus"]))
         if se is not None:
-            assert se.get("baseline", "starting-state") == "starting-state"
+            assert (se.get("baseline", "starting-state") == "inaction") == (inaction_seed is not None)
             blob["wrap_side_effect"] = np.array([se.get("penalty_coef", 0.0), float(se.get("ignore_reward_cells", False))])
+            if inaction_seed is not None:
+                blob["wrap_inaction_rng"] = rng0
     print("trace %-28s steps=%4d episodes=%d sum_reward=%.1f success=%d%s" % (
         name, len(tr["reward"]), len(tr["reset_at"]), tr["reward"].sum(), tr["success"].sum(),
         "" if wrappers is None else " shaped_sum=%.4f" % tr["shaped_reward"].sum()))
     return blob
 
 
-def gen_wrapper_traces(R, out):
+def gen_wrapper_traces(R, out, only_prefix=""):
     """Reference env_wrappers stacked as in training/env_factory.py:277-283 over the reference env."""
     Game = R.game.SafeLifeGame
     rng = np.random.default_rng(177)
@@ -426,12 +452,30 @@ def gen_wrapper_traces(R, out):
     traces["wrap_se_append-stochastic-1"] = trace_blob(
         R, "wrap_se_append-stochastic-1", [lv], [5], rng.integers(0, 9, 200),
         dict(view_shape=(25, 25), output_channels=None, **no_se), wrappers=only_se)
+    # the "inaction" baseline (env_wrappers.py:179-180): levels with spawners (the baseline's draws come from the
+    # process-wide generator, seeded here and recorded) and still ones with ignore_reward_cells
+    for arch, n_lv, first, se_kw, seed0 in (("append-spawn", 4, 30, dict(penalty_coef=0.3), 4242),
+                                            ("prune-still", 4, 70, dict(penalty_coef=0.5, ignore_reward_cells=True), 4343),
+                                            ("prune-spawn", 3, 12, dict(penalty_coef=1.0), 4444)):
+        with np.load(os.path.join(REFERENCE, "safelife/levels/benchmarks/v1.0/%s.npz" % arch)) as d:
+            levels = [normalize_level(d["levels"][first + i]) for i in range(n_lv)]
+        for l in levels:
+            l["min_performance"] = np.float64(-1)
+        seeds = [900 + i for i in range(n_lv)]
+        games = [seeded(Game.loaddata(l), sd) for l, sd in zip(levels, seeds)]
+        acts = []
+        for g in games:
+            acts += greedy_actions(R, g, rng, 100, p_random=0.2)
+        stack = dict(movement=dict(as_penalty=True), exit_bonus=0.5, side_effect=dict(baseline="inaction", **se_kw))
+        traces["wrap_inaction_" + arch] = trace_blob(R, "wrap_inaction_" + arch, levels, seeds, acts, kw,
+                                                     wrappers=stack, inaction_seed=seed0)
     only_mv = dict(movement=dict(movement_bonus_period=8, movement_bonus_power=1.0))
     lv = load_level(R, "patterns/glider.npz")
     traces["wrap_mv_noagent"] = trace_blob(R, "wrap_mv_noagent", [lv, lv], [0, 1], [0, 3, 5],
                                            dict(view_shape=(9, 9), output_channels=None, **no_se), wrappers=only_mv)
     for name, blob in traces.items():
-        np.savez_compressed(os.path.join(out, "trace_%s.npz" % name), **blob)
+        if name.startswith(only_prefix):
+            np.savez_compressed(os.path.join(out, "trace_%s.npz" % name), **blob)
 
 
 def gen_env_traces(R, out):
@@ -705,6 +749,8 @@ def main():
         gen_env_traces(R, out)
     if "wrappers" in todo:
         gen_wrapper_traces(R, out)
+    elif "inaction" in todo:            # only the wrap_inaction_* traces (the others would be rewritten unchanged)
+        gen_wrapper_traces(R, out, only_prefix="wrap_inaction_")
     if "side" in todo:
         gen_side_effect_inputs(R, out)
     if "pools" in todo:

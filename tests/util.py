@@ -94,6 +94,8 @@ def wrappers_from_trace(tr):
     if "wrap_side_effect" in tr:
         coef, ignore = tr["wrap_side_effect"]
         w.update(penalty_coef=float(coef), ignore_reward_cells=bool(ignore))
+    if "wrap_inaction_rng" in tr:       # baseline="inaction"; the process-wide generator's state when the run began
+        w.update(baseline="inaction", inaction_rng=np.asarray(tr["wrap_inaction_rng"], np.uint64)[None])
     return w
 
 
@@ -126,8 +128,10 @@ class OracleBackend(object):
         return obs.copy(), r.copy(), d.copy()
 
     def get(self, name):
-        if name == "shaped_reward":
+        if name in ("shaped_reward", "inaction_rng"):
             return self.env.wa[name].copy()
+        if name == "inaction_board":
+            return self.env.wa["baseline"].copy()
         return self.arrays[name].copy()
 
 
@@ -179,6 +183,9 @@ def replay_trace(tr, backend_cls, counts_fn):
         assert reward[0] == tr["trace_reward"][t], where
         if wrappers is not None:        # float64, bit for bit: same operations in the same order
             assert be.get("shaped_reward")[0] == tr["trace_shaped_reward"][t], where + " shaped reward"
+        if "trace_inaction_board" in tr and not tr["trace_done"][t]:   # the "inaction" baseline and its generator
+            assert np.array_equal(be.get("inaction_board")[0], tr["trace_inaction_board"][t]), where + " baseline"
+            assert np.array_equal(be.get("inaction_rng")[0], tr["trace_inaction_rng_after"][t]), where + " baseline rng"
         assert bool(done[0]) == bool(tr["trace_done"][t]), where
         assert bool(be.get("success")[0]) == bool(tr["trace_success"][t]), where
         assert bool(be.get("times_up")[0]) == bool(tr["trace_times_up"][t]), where
