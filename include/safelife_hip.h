@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SL_ABI_VERSION 6
+#define SL_ABI_VERSION 7
 #define SL_MAX_CELLS 16384        /* H*W limit of one board */
 #define SL_MAX_CHANNELS 32
 
@@ -142,17 +142,24 @@ typedef struct sl_level_scalars {
  *   MovementBonusWrapper   :32-98   reward += movement_bonus * speed**power [- movement_bonus]
  *   ExtraExitBonus         :120-128 reward += done * bonus * episode_reward   (unless times_up)
  *   SimpleSideEffectPenalty:150-213 reward -= penalty_coef * (side_effect - last_side_effect),
- *                                   baseline = "starting-state" (the board right after reset)
+ *                                   baseline = "starting-state" (the board right after reset) or, with
+ *                                   SL_WRAP_INACTION, "inaction" (:179-180: that board advanced once per step)
  * (MinPerformanceScheduler :131-147 has no per-step arithmetic: sl_level_scalars.required_step.)
  * The wrapped reward is float64, as in the reference (np.float32 + np.float64), evaluated with the
  * same operations in the same order; speed**power comes from a host-built table so no pow() runs on
- * the device.  flags == 0 switches all of it off.  The "inaction" baseline draws from the
- * process-wide generator in the reference, has no per-env stream, and is not offered here. */
+ * the device.  flags == 0 switches all of it off.
+ * "inaction": the reference advances the baseline board outside any game method, so its spawners draw from the
+ * process-wide generator (safelife/random.py:13).  With many envs that is one generator per env, inaction_rng[e];
+ * an env whose generator starts in the state the process-wide one had reproduces the reference run exactly
+ * (tests/golden/trace_wrap_inaction_*).  Every slhip_env_step / slhip_env_step_slices call first advances the
+ * baselines (a launch of its own on the same stream; an env whose num_steps is 0 takes its current board as the
+ * baseline first, which is what the wrapper's reset() does); slhip_env_rollout with T > 1 refuses the flag. */
 #define SL_WRAP_MOVEMENT 1
 #define SL_WRAP_AS_PENALTY 2            /* MovementBonusWrapper.as_penalty */
 #define SL_WRAP_EXIT_BONUS 4
 #define SL_WRAP_SIDE_EFFECT 8
 #define SL_WRAP_IGNORE_REWARD_CELLS 16  /* SimpleSideEffectPenalty.ignore_reward_cells */
+#define SL_WRAP_INACTION 32             /* SimpleSideEffectPenalty.baseline == "inaction" (with SL_WRAP_SIDE_EFFECT) */
 #define SL_WRAP_MAX_PERIOD 8
 
 typedef struct sl_wrap_state {    /* per env, 48 bytes */
@@ -177,6 +184,10 @@ typedef struct sl_wrappers {
     uint32_t *pool_baseline;      /* workspace [L, H, (W+1)/2]: every pool level as it stands right after
                                      reset, player bits cleared, in the row kernels' register layout;
                                      filled by slhip_env_prepare() (needed with SL_WRAP_SIDE_EFFECT) */
+    uint16_t *inaction_board;     /* SL_WRAP_INACTION: [B,H,W] the baseline boards (state; 16-byte aligned) */
+    sl_pcg64 *inaction_rng;       /* SL_WRAP_INACTION: [B] the baselines' generators (state) */
+    uint32_t *inaction_rows;      /* SL_WRAP_INACTION: workspace [B, H, (W+1)/2], the baselines as the row kernels
+                                     read them (player bits cleared, register layout) */
 } sl_wrappers;
 
 /* Finished episodes, queued on the device by the step kernels for the side-effect pass (safelife_env.py:183-192

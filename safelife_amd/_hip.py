@@ -48,7 +48,7 @@ ENV_SCALARS_HEAD = ("B", "H", "W", "E", "time_limit", "exit_points", "n_tables",
 ENV_STATE_PTRS = ("board", "goals", "exit_locs", "rng", "scalars", "points_table")
 ENV_POOL_PTRS = ("pool_board", "pool_goals", "pool_exit_locs", "pool_rng", "pool_scalars")
 ENV_OUT_PTRS = ("out", "obs", "score_lut")
-SL_ABI_VERSION = 6
+SL_ABI_VERSION = 7
 
 #: int32 column of each field inside `struct sl_env_scalars` (64 bytes = 16 columns)
 SCALAR_COLS = {"agent_row": 0, "agent_col": 1, "num_steps": 2, "old_value": 3, "required_points": 4,
@@ -61,7 +61,7 @@ LEVEL_COLS = {"agent_row": 0, "agent_col": 1, "required_reset": 2, "required_ste
               "table_idx": 5, "spawn_prob": 6}
 
 
-WRAP_MOVEMENT, WRAP_AS_PENALTY, WRAP_EXIT_BONUS, WRAP_SIDE_EFFECT, WRAP_IGNORE_REWARD_CELLS = 1, 2, 4, 8, 16
+WRAP_MOVEMENT, WRAP_AS_PENALTY, WRAP_EXIT_BONUS, WRAP_SIDE_EFFECT, WRAP_IGNORE_REWARD_CELLS, WRAP_INACTION = 1, 2, 4, 8, 16, 32
 WRAP_MAX_PERIOD = 8
 
 
@@ -77,7 +77,7 @@ class Wrappers(C.Structure):
                 ("reserved", C.c_int32),
                 ("move_bonus", C.c_double), ("exit_bonus", C.c_double), ("penalty_coef", C.c_double),
                 ("move_table", _p), ("state", _p), ("shaped_reward", _p), ("shaped_reward_t", _p),
-                ("pool_baseline", _p)]
+                ("pool_baseline", _p), ("inaction_board", _p), ("inaction_rng", _p), ("inaction_rows", _p)]
 
 
 class EpisodeRecord(C.Structure):

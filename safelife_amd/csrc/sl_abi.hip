@@ -115,8 +115,12 @@ int check_env(const sl_env_batch *env) {
     const sl_wrappers &w = env->wrap;
     if (w.flags) {
         if (w.flags & ~(SL_WRAP_MOVEMENT | SL_WRAP_AS_PENALTY | SL_WRAP_EXIT_BONUS | SL_WRAP_SIDE_EFFECT |
-                        SL_WRAP_IGNORE_REWARD_CELLS))
+                        SL_WRAP_IGNORE_REWARD_CELLS | SL_WRAP_INACTION))
             return fail(SL_E_ARG, "unknown bit in wrap.flags");
+        if (w.flags & SL_WRAP_INACTION) {
+            if (!(w.flags & SL_WRAP_SIDE_EFFECT)) return fail(SL_E_ARG, "SL_WRAP_INACTION without SL_WRAP_SIDE_EFFECT");
+            if (!w.inaction_board || !w.inaction_rng) return fail(SL_E_ARG, "wrap.inaction_board / wrap.inaction_rng is null");
+        }
         if (!w.state || !w.shaped_reward) return fail(SL_E_ARG, "wrap.state / wrap.shaped_reward is null");
         if (w.flags & SL_WRAP_MOVEMENT) {
             if (w.move_period < 1 || w.move_period > SL_WRAP_MAX_PERIOD)
@@ -152,6 +156,10 @@ sl_env_batch env_slice(const sl_env_batch &env, int e0, int n) {
     if (env.wrap.flags) {
         s.wrap.state = env.wrap.state + e0;
         s.wrap.shaped_reward = env.wrap.shaped_reward + e0;
+        if (env.wrap.flags & SL_WRAP_INACTION) {
+            s.wrap.inaction_board = env.wrap.inaction_board + (size_t)e0 * hw;
+            s.wrap.inaction_rng = env.wrap.inaction_rng + e0;
+        }
     }
     return s;
 }
@@ -372,6 +380,9 @@ static bool use_rowlane(const sl_env_batch *env, int e_first) {
     else if (env->wrap.flags && (((env->wrap.flags & SL_WRAP_SIDE_EFFECT) && !env->wrap.pool_baseline) ||
                                  (((uintptr_t)env->wrap.state | (uintptr_t)env->wrap.move_table) & 15)))
         why = "wrapper workspace missing or unaligned";
+    else if ((env->wrap.flags & SL_WRAP_INACTION) &&
+             (!env->wrap.inaction_rows || (((uintptr_t)env->wrap.inaction_board | (uintptr_t)env->wrap.inaction_rng) & 15)))
+        why = "inaction-baseline workspace missing or unaligned";
     if (!why) return true;
     static std::atomic<bool> warned{false};
     if (!warned.exchange(true))
@@ -387,12 +398,20 @@ static int rollout_range(const sl_env_batch *env, int e_first, int e_count, cons
     int rc;
     if ((rc = jump_table(&jump))) return rc;
     hipError_t err;
+    const bool inaction = (env->wrap.flags & SL_WRAP_INACTION) != 0;
+    if (inaction && T > 1) return fail(SL_E_UNSUPPORTED, "the inaction baseline advances between steps: T must be 1");
     if (use_rowlane(env, e_first)) {
+        // (env_wrappers.py:179-180 advances the baseline after the env's step; the two do not touch each other's
+        //  state, and the step reads the result, so it goes first)
+        if (inaction && (err = sl::launch_inaction_rowlane(*env, e_first, e_count, jump, (hipStream_t)stream)) != hipSuccess)
+            return hip_fail(err, "inaction baseline launch");
         err = sl::launch_env_rollout_rowlane(*env, e_first, e_count, actions, T, tstride, reward_t, done_t, jump,
                                              (hipStream_t)stream);
     } else {
         if (T > 1 && e_count != env->B) return fail(SL_E_UNSUPPORTED, "T-step launches of a slice need the row kernels");
         const sl_env_batch s = env_slice(*env, e_first, e_count);
+        if (inaction && (err = sl::launch_inaction_generic(s, jump, (hipStream_t)stream)) != hipSuccess)
+            return hip_fail(err, "inaction baseline launch");
         err = sl::launch_env_rollout_generic(s, actions + e_first, T, reward_t ? reward_t + e_first : nullptr,
                                              done_t ? done_t + e_first : nullptr, jump, (hipStream_t)stream);
     }

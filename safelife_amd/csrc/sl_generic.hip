@@ -156,6 +156,24 @@ __global__ __launch_bounds__(GB) void k_advance_generic(const u16 *__restrict__ 
     if (tid < 4) ((u64 *)(rng + b))[tid] = l.rng[tid];
 }
 
+// SimpleSideEffectPenalty's "inaction" baseline (env_wrappers.py:179-180): every env's baseline board one CA step on,
+// with the baseline's own generator.  An env that has not stepped since its reset (num_steps == 0) starts from its
+// current board: the wrapper's reset() copies it (:168-172).
+__global__ __launch_bounds__(GB) void k_inaction_generic(sl_env_batch env, const Jump *__restrict__ jump) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int H = env.H, W = env.W, HW = H * W, b = blockIdx.x, tid = threadIdx.x;
+    GenericLds l = carve(smem, HW, 3);
+    const sl_env_scalars *sc = env.scalars + b;
+    u16 *base = env.wrap.inaction_board + (size_t)b * HW;
+    const u16 *src = sc->num_steps == 0 ? env.board + (size_t)b * HW : base;
+    for (int i = tid; i < HW; i += GB) l.buf[0][i] = src[i];
+    if (tid < 4) l.rng[tid] = ((const u64 *)(env.wrap.inaction_rng + b))[tid];
+    __syncthreads();
+    ca_step_block(l.buf[0], l.buf[1], l.buf[2], H, W, 1.0f / (float)W, (double)sc->spawn_prob, l.rng, jump, l.wave_tot);
+    for (int i = tid; i < HW; i += GB) base[i] = l.buf[2][i];
+    if (tid < 4) ((u64 *)(env.wrap.inaction_rng + b))[tid] = l.rng[tid];
+}
+
 // ------------------------------------------------------------------------------ alive_counts
 
 __global__ __launch_bounds__(GB) void k_alive_counts(const u16 *__restrict__ board,
@@ -465,12 +483,15 @@ __global__ __launch_bounds__(GB) void k_env_rollout_generic(sl_env_batch env,
                     if (exits[k] >= 0) rows[exits[k]] = 1;
                 __syncthreads();
                 const u16 *pb = env.pool_board + (size_t)sc->level_idx * HW;
+                // "inaction": the baseline board k_inaction_generic advanced just before this launch
+                const u16 *ib = (env.wrap.flags & SL_WRAP_INACTION) ? env.wrap.inaction_board + (size_t)e * HW : nullptr;
                 const bool open = sc->exit_open_at_reset != 0;
                 const bool ignore = (env.wrap.flags & SL_WRAP_IGNORE_REWARD_CELLS) != 0;
                 int mine = 0;
                 for (int i = tid; i < HW; i += GB)
                     if (!rows[i])
-                        mine += side_effect_cell(nxt[i] & 0xFFFFu & ~PLAYER, baseline_cell(pb[i], false, open),
+                        mine += side_effect_cell(nxt[i] & 0xFFFFu & ~PLAYER,
+                                                 ib ? (u32)ib[i] & ~PLAYER : baseline_cell(pb[i], false, open),
                                                  goals[i], ignore);
                 side = block_sum(mine, l.wave_tot);
             }
@@ -606,6 +627,14 @@ hipError_t launch_env_rollout_generic(const sl_env_batch &env, const int32_t *ac
     if (err != hipSuccess) return err;
     hipLaunchKernelGGL(k_env_rollout_generic, dim3(env.B), dim3(GB), lds, stream, env, actions, T,
                        reward_t, done_t, jump);
+    return hipGetLastError();
+}
+
+hipError_t launch_inaction_generic(const sl_env_batch &env, const Jump *jump, hipStream_t stream) {
+    size_t lds = generic_lds_bytes(env.H * env.W, 3);
+    hipError_t err = set_lds((const void *)k_inaction_generic, lds);
+    if (err != hipSuccess) return err;
+    hipLaunchKernelGGL(k_inaction_generic, dim3(env.B), dim3(GB), lds, stream, env, jump);
     return hipGetLastError();
 }
 

@@ -21,6 +21,8 @@ hipError_t launch_env_rollout_generic(const sl_env_batch &env, const int32_t *ac
                                       float *reward_t, uint8_t *done_t, const Jump *jump,
                                       hipStream_t stream);
 hipError_t launch_env_reset_generic(const sl_env_batch &env, const uint8_t *mask, hipStream_t stream);
+// SimpleSideEffectPenalty's "inaction" baseline, one CA step on (all envs of `env`)
+hipError_t launch_inaction_generic(const sl_env_batch &env, const Jump *jump, hipStream_t stream);
 hipError_t launch_env_obs_generic(const sl_env_batch &env, hipStream_t stream);
 struct sl_channel_list {
     int32_t c[SL_MAX_CHANNELS];
@@ -57,5 +59,8 @@ hipError_t launch_se_distributions(const sl_env_batch &env, const sl_episode_que
 hipError_t launch_env_rollout_rowlane(const sl_env_batch &env, int e_first, int e_count, const int32_t *actions,
                                       int T, int tstride, float *reward_t, uint8_t *done_t, const Jump *jump,
                                       hipStream_t stream);
+
+// the same for envs [e_first, e_first + e_count) on the row kernels (also writes wrap.inaction_rows)
+hipError_t launch_inaction_rowlane(const sl_env_batch &env, int e_first, int e_count, const Jump *jump, hipStream_t stream);
 
 }  // namespace sl

@@ -1065,6 +1065,67 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_ad
         ((u64 *)(rng + e0b + wave * Gm::G))[lane] = rng_lds[lane];
 }
 
+// SimpleSideEffectPenalty's "inaction" baseline (env_wrappers.py:179-180) for envs [e_first, e_first + e_count): each
+// env's baseline board one CA step on, with the baseline's own generator, written back as a board (the state) and as
+// rows in the register layout with the player bits cleared (what the fused step's wrapper epilogue compares with).
+// An env that has not stepped since its reset (num_steps == 0) starts from its current board -- the wrapper's reset()
+// copies it (:168-172) -- read row by row from global memory by the lanes concerned.
+template <int H, int W>
+__global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_inaction_rowlane(
+    const u16 *__restrict__ env_board, u16 *__restrict__ base_board, const sl_env_scalars *__restrict__ scalars,
+    sl_pcg64 *rng, u32 *__restrict__ rows_out, int e_first, int e_count, const Jump *__restrict__ jump) {
+    using Gm = Geom<H, W>;
+    constexpr int WS = Gm::WS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l0 = blockIdx.x * Gm::NB;                     // first board of the workgroup, within the range
+    if (l0 >= e_count) return;
+    const int nbb = min(Gm::NB, e_count - l0);
+    const int e0b = e_first + l0;
+    const LaneMap<H, W> lm(lane);
+    const int g = lm.g, r = lm.r, up = lm.up, dn = lm.dn;
+    const int gb = wave * Gm::G + g;
+    const bool rowl = lane < Gm::NL && gb < nbb;
+    const bool live = rowl && lm.real;
+    const unsigned e = e0b + (rowl ? gb : 0);
+    unsigned char *board = smem + Gm::OFF_BOARD;
+    u64 *rng_lds = (u64 *)(smem + Gm::OFF_RNG) + 4 * Gm::G * wave;
+
+    load_span<H, W>(base_board + (size_t)e0b * Gm::HW, board, nbb, lane, wave);
+    if (lane < 4 * Gm::G && wave * Gm::G + (lane >> 2) < nbb)
+        rng_lds[lane] = ((const u64 *)(rng + e0b + wave * Gm::G))[lane];
+    const bool fresh = rowl && scalars[e].num_steps == 0;
+    const double p = live ? (double)scalars[e].spawn_prob : 0.0;
+    __syncthreads();
+    const Consts cst = make_consts();
+    const pl::PConsts pcst = pl::make_pconsts();
+    RowWords<H, W> b;
+#pragma unroll
+    for (int k = 0; k < WS; ++k) b[k] = 0;
+    if (rowl) read_row<H, W>(board, gb, r, b);
+    if (fresh) {
+        const u16 *row = env_board + ((size_t)e * H + r) * W;
+#pragma unroll
+        for (int k = 0; k < WS; ++k) {
+            const u32 lo = row[k];
+            const u32 hi = (Gm::ODD && k == WS - 1) ? 0u : row[k + WS];
+            b[k] = lo | (hi << 16);
+        }
+    }
+    ca_step<H, W, true, false>(b, live, true, up, dn, cst, pcst, rng_lds, live ? g : 0, p, jump);
+    if (live) {
+        write_row<H, W>(board, gb, r, b);
+        u32 *out = rows_out + ((size_t)e * H + r) * WS;
+#pragma unroll
+        for (int k = 0; k < WS; ++k)
+            out[k] = b[k] & ~(PLAYER | (PLAYER << 16)) & ((Gm::ODD && k == WS - 1) ? 0xFFFFu : 0xFFFFFFFFu);
+    }
+    __syncthreads();
+    store_span<H, W>(base_board + (size_t)e0b * Gm::HW, board, nbb, tid);
+    if (lane < 4 * Gm::G && wave * Gm::G + (lane >> 2) < nbb)
+        ((u64 *)(rng + e0b + wave * Gm::G))[lane] = rng_lds[lane];
+}
+
 // Small batches (fewer workgroups of the kernel above than the chip has CUs: config C2's 1024 boards are 128): one
 // wavefront per workgroup, the row straight from and to global memory -- four times the workgroups, no LDS image, no
 // workgroup barrier -- and, for the shapes with a bit-plane form, the rows stay planes for all n steps.
@@ -2290,7 +2351,9 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
         if (t >= T) break;
         if (WRAP && (env.wrap.flags & SL_WRAP_SIDE_EFFECT)) {
             // baseline row (level, r) of every lane -> LDS, asynchronously; read after the CA pass
-            const u32 *src = env.wrap.pool_baseline + ((size_t)level * H + r) * WS;
+            // ("inaction": the env's own baseline, advanced by k_inaction_rowlane just before this launch)
+            const u32 *src = (env.wrap.flags & SL_WRAP_INACTION) ? env.wrap.inaction_rows + ((size_t)e * H + r) * WS
+                                                                 : env.wrap.pool_baseline + ((size_t)level * H + r) * WS;
 #pragma unroll
             for (int k = 0; k < WS; ++k)
                 __builtin_amdgcn_global_load_lds((glds_src_t)(src + k), (glds_dst_t)(base_rows + k * 256), 4, 0, 0);
@@ -2696,6 +2759,18 @@ hipError_t launch_advance_t(const u16 *in, u16 *out, int B, const float *spawn_p
 }
 
 template <int H, int W>
+hipError_t launch_inaction_t(const sl_env_batch &env, int e_first, int e_count, const Jump *jump, hipStream_t stream) {
+    using Gm = Geom<H, W>;
+    auto fn = k_inaction_rowlane<H, W>;
+    hipError_t err = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, Gm::LDS_ADVANCE);
+    if (err != hipSuccess) return err;
+    hipLaunchKernelGGL(fn, dim3((e_count + Gm::NB - 1) / Gm::NB), dim3(64 * WAVES), Gm::LDS_ADVANCE, stream,
+                       (const u16 *)env.board, env.wrap.inaction_board, (const sl_env_scalars *)env.scalars,
+                       env.wrap.inaction_rng, env.wrap.inaction_rows, e_first, e_count, jump);
+    return hipGetLastError();
+}
+
+template <int H, int W>
 hipError_t launch_occupancy_t(const u16 *in, int32_t *counts, size_t counts_stride, int B, const int32_t *n_valid,
                                      int valid_period, const int32_t *pre_steps, const float *spawn_prob, int n_steps,
                                      sl_pcg64 *rng, const Jump *jump, hipStream_t stream) {
@@ -2824,6 +2899,7 @@ hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, c
     PREFIX template hipError_t rl::launch_occupancy_t<h, w>(const u16 *, int32_t *, size_t, int, const int32_t *, int,    \
                                                             const int32_t *, const float *, int, sl_pcg64 *, const Jump *, \
                                                             hipStream_t);                                                  \
+    PREFIX template hipError_t rl::launch_inaction_t<h, w>(const sl_env_batch &, int, int, const Jump *, hipStream_t);     \
     PREFIX template hipError_t rl::launch_rollout_t<h, w>(const sl_env_batch &, int, int, const int32_t *, int, int,      \
                                                           float *, uint8_t *, const Jump *, hipStream_t);
 #ifdef SL_ROWLANE_PART
@@ -2882,6 +2958,13 @@ hipError_t launch_occupancy_rowlane(const u16 *in, int32_t *counts, size_t count
                                     int valid_period, const int32_t *pre_steps, int H, int W, const float *spawn_prob,
                                     int n_steps, sl_pcg64 *rng, const Jump *jump, hipStream_t stream) {
 #define X(h, w) if (H == h && W == w) return rl::launch_occupancy_t<h, w>(in, counts, counts_stride, B, n_valid, valid_period, pre_steps, spawn_prob, n_steps, rng, jump, stream);
+    SL_ROWLANE_SHAPES(X)
+#undef X
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_inaction_rowlane(const sl_env_batch &env, int e_first, int e_count, const Jump *jump, hipStream_t stream) {
+#define X(h, w) if (env.H == h && env.W == w) return rl::launch_inaction_t<h, w>(env, e_first, e_count, jump, stream);
     SL_ROWLANE_SHAPES(X)
 #undef X
     return hipErrorInvalidValue;

@@ -145,8 +145,12 @@ class SafeLifeVectorEnv(object):
                                    optional: ``movement_bonus``, ``movement_bonus_power``,
                                    ``movement_bonus_period``, ``as_penalty`` (MovementBonusWrapper),
                                    ``exit_bonus`` (ExtraExitBonus.bonus), ``penalty_coef``,
-                                   ``ignore_reward_cells`` (SimpleSideEffectPenalty, starting-state
-                                   baseline).  A wrapper is active when its coefficient is not None.
+                                   ``ignore_reward_cells``, ``baseline`` ("starting-state" or "inaction":
+                                   SimpleSideEffectPenalty; the inaction baseline's spawners draw from one
+                                   generator per env where the reference has the process-wide one --
+                                   ``inaction_seed``: a seed whose SeedSequence children seed them, or
+                                   ``inaction_rng``: PCG64 words uint64 [B,4]).  A wrapper is active when its
+                                   coefficient is not None.
                                    The wrapped float64 reward is ``env.shaped_reward`` after each step.
                                    (MinPerformanceScheduler = ``LevelPool(min_performance_fraction=...)``.)
     """
@@ -285,7 +289,7 @@ class SafeLifeVectorEnv(object):
     def _setup_wrappers(self, cfg):
         torch, t, s, dev = self.torch, self.t, self.struct, self.device
         known = {"movement_bonus", "movement_bonus_power", "movement_bonus_period", "as_penalty", "exit_bonus",
-                 "penalty_coef", "ignore_reward_cells"}
+                 "penalty_coef", "ignore_reward_cells", "baseline", "inaction_seed", "inaction_rng"}
         if set(cfg) - known:
             raise ValueError("unknown wrapper option(s): %s" % sorted(set(cfg) - known))
         B, (H, W) = self.num_envs, self.pool.shape
@@ -299,6 +303,11 @@ class SafeLifeVectorEnv(object):
                    | (_hip.WRAP_EXIT_BONUS if cfg.get("exit_bonus") is not None else 0)
                    | (_hip.WRAP_SIDE_EFFECT if cfg.get("penalty_coef") is not None else 0)
                    | (_hip.WRAP_IGNORE_REWARD_CELLS if cfg.get("ignore_reward_cells") else 0))
+        baseline = cfg.get("baseline", "starting-state")
+        if baseline not in ("starting-state", "inaction"):
+            raise ValueError('baseline must be "starting-state" or "inaction"')
+        if baseline == "inaction" and cfg.get("penalty_coef") is not None:
+            w.flags |= _hip.WRAP_INACTION
         if not w.flags & (_hip.WRAP_MOVEMENT | _hip.WRAP_EXIT_BONUS | _hip.WRAP_SIDE_EFFECT):
             w.flags = 0
             return
@@ -324,6 +333,24 @@ class SafeLifeVectorEnv(object):
         w.shaped_reward_t = None
         w.pool_baseline = t["pool_baseline"].data_ptr()
         self.shaped_reward = t["shaped_reward"]
+        if w.flags & _hip.WRAP_INACTION:
+            # env_wrappers.py:179-180: the baseline board advances once per step (a launch of its own in front of
+            # every step; slhip_env_rollout with T > 1 refuses the flag).  One generator per env.
+            words = cfg.get("inaction_rng")
+            if words is None:
+                seq = cfg.get("inaction_seed")
+                seq = seq if isinstance(seq, np.random.SeedSequence) else np.random.SeedSequence(seq)
+                words = np.zeros((B, 4), np.uint64)
+                for e, child in enumerate(seq.spawn(B)):
+                    st = np.random.PCG64(child).state["state"]
+                    words[e] = [st["state"] >> 64, st["state"] & (2 ** 64 - 1), st["inc"] >> 64, st["inc"] & (2 ** 64 - 1)]
+            words = np.ascontiguousarray(words, dtype=np.uint64).reshape(B, 4)
+            t["inaction_rng"] = torch.from_numpy(words.view(np.int64).copy()).to(dev)
+            t["inaction_board"] = torch.zeros((B, H, W), dtype=torch.int16, device=dev)
+            t["inaction_rows"] = torch.zeros((B, H, (W + 1) // 2), dtype=torch.int32, device=dev)
+            w.inaction_board = t["inaction_board"].data_ptr()
+            w.inaction_rng = t["inaction_rng"].data_ptr()
+            w.inaction_rows = t["inaction_rows"].data_ptr()
 
     # ------------------------------------------------------------------ gym-like surface
 
@@ -581,9 +608,9 @@ class SafeLifeVectorEnv(object):
         if name == "obs":
             a = self.obs.cpu().numpy()
             return a.view(np.uint32) if self.output_channels is None else a
-        if name in ("board", "goals", "pool_board", "pool_goals"):
+        if name in ("board", "goals", "pool_board", "pool_goals", "inaction_board"):
             return self.t[name].cpu().numpy().view(np.uint16)
-        if name in ("rng", "pool_rng"):
+        if name in ("rng", "pool_rng", "inaction_rng"):
             return self.t[name].cpu().numpy().view(np.uint64)
         if name == "agent_loc":
             return self.t["scalars"][:, 0:2].cpu().numpy()

@@ -285,6 +285,52 @@ def test_env_batch_wrappers_vs_oracle(pool_name, B, T, wrappers, kw):
     assert np.array_equal(dev.get("board"), cpu.get("board"))
 
 
+@pytest.mark.parametrize("pool_name,B,T,extra,kw", [
+    ("append_spawn_25", 300, 100, dict(), dict(time_limit=40)),
+    ("append_spawn_25", 200, 60, dict(), dict(time_limit=30, slices=2)),
+    ("prune_still_25", 200, 60, dict(ignore_reward_cells=True, penalty_coef=0.5), dict(time_limit=25)),
+    ("navigation_64", 40, 50, dict(), dict(time_limit=30)),
+])
+def test_env_batch_inaction_baseline_vs_oracle(pool_name, B, T, extra, kw):
+    """SimpleSideEffectPenalty(baseline="inaction") in the batch (env_wrappers.py:179-180): every env's baseline
+    board advanced once per step with its own generator -- shaped reward float64 bit for bit, baseline boards and
+    generators, across auto-resets (a fresh episode's baseline is the board its reset left)."""
+    pool, _ = util.pool_from_fixture(pool_name, _device_counts, min_performance_fraction=0.05)
+    words = np.random.default_rng(5).integers(0, 2 ** 63, (B, 4), dtype=np.uint64)
+    words[:, 3] |= 1                    # a PCG64 increment is odd
+    wrappers = dict(TRAINING_WRAPPERS, baseline="inaction", inaction_rng=words, **extra)
+    first = (np.arange(B) * 5) % len(pool)
+    common = dict(first_level=first, auto_reset=True, level_stride=3, view_shape=(15, 15), wrappers=wrappers, **kw)
+    dev = util.DeviceBackend(pool, B, **common)
+    cpu = util.OracleBackend(pool, B, **common)
+    assert np.array_equal(dev.reset(), cpu.reset())
+    rng = np.random.default_rng(14)
+    n_done = 0
+    for t in range(T):
+        a = rng.integers(0, 9, B).astype(np.int32)
+        if kw.get("slices", 1) > 1:
+            import torch
+            a_dev = torch.as_tensor(a, device=dev.env.device)
+            dev.env.step_async(a_dev)
+            r1, d1 = dev.env.numpy("reward"), dev.env.numpy("done")
+        else:
+            _, r1, d1 = dev.step(a)
+        _, r2, d2 = cpu.step(a)
+        assert np.array_equal(r1, r2) and np.array_equal(d1, d2), t
+        assert np.array_equal(dev.get("shaped_reward"), cpu.get("shaped_reward")), t
+        n_done += int(d1.sum())
+        if t % 10 == 0 or t == T - 1:
+            assert np.array_equal(dev.get("inaction_rng"), cpu.get("inaction_rng")), t
+            # (the oracle copies the board into the baseline when it resets an env, the library when the env next
+            #  steps: compare the envs that did not just finish)
+            keep = ~d1.astype(bool)
+            assert np.array_equal(dev.get("inaction_board")[keep], cpu.get("inaction_board")[keep]), t
+    assert n_done > B // 2
+    assert np.array_equal(dev.get("board"), cpu.get("board"))
+    with pytest.raises(Exception):      # the baseline advances between steps: no T-step launches
+        dev.env.rollout(rng.integers(0, 9, (3, B)).astype(np.int32))
+
+
 def test_generic_kernels_with_wrappers():
     """The size-generic kernels carry the same wrapper math: rerun the wrapper traces with the row
     kernels switched off (the switch is read once per process, hence the subprocess)."""
