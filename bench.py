@@ -538,13 +538,13 @@ def main():
                 t0 = time.perf_counter()
                 reps = 0
                 while time.perf_counter() - t0 < 1.0:
-                    for b in host_boards:
-                        ref.advance_board(b, 0.3)
+                    oracle.ref_advance_batch(ref, host_boards, 0.3, 1)
                     reps += 1
                 dt = time.perf_counter() - t0
                 extra["c2_cpu_reference_board_steps_per_s"] = 1024 * reps / dt
-                extra["c2_cpu_reference_note"] = ("safelife/speedups_src advance_board compiled with gcc -O3 (oracle/_ref), "
-                                                  "1 core of %s, called per board through its CPython wrapper" % cpu_model())
+                extra["c2_cpu_reference_note"] = ("safelife/speedups_src advance_board_nstep compiled with gcc -O3 (oracle/_ref), "
+                                                  "1 core of %s (the reference draws from one process-wide generator), "
+                                                  "called per board from a C loop: no interpreter or wrapper time" % cpu_model())
 
         # the same step with the training wrappers of env_factory.py:277-283 fused in (float64 shaped reward)
         us = time_steps(SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25), output_channels=TRAIN_CHANNELS,

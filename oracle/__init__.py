@@ -47,6 +47,22 @@ def load_ref():
     return mod
 
 
+def ref_advance_batch(ref_module, boards, spawn_prob=0.3, n_steps=1):
+    """The REFERENCE's compiled advance_board_nstep (advance_board.h:6-7) over uint16 [B,H,W] boards, looped in C
+    (no interpreter or wrapper time per board); it draws from whatever generator the module was last given
+    (``ref_module.set_bit_generator``).  Returns the advanced boards."""
+    so = C.CDLL(ref_module.__file__)          # the same mapping the interpreter imported: shares its generator pointer
+    fn = C.cast(so.advance_board_nstep, C.c_void_p)
+    boards = np.ascontiguousarray(boards, dtype=np.uint16)
+    out = np.empty_like(boards)
+    B, H, W = boards.shape
+    L = lib()
+    L.slo_ref_advance_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]
+    L.slo_ref_advance_batch.restype = None
+    L.slo_ref_advance_batch(fn, boards.ctypes.data, out.ctypes.data, B, H, W, spawn_prob, n_steps)
+    return out
+
+
 class Pcg64(C.Structure):
     _fields_ = [("state_hi", C.c_uint64), ("state_lo", C.c_uint64),
                 ("inc_hi", C.c_uint64), ("inc_lo", C.c_uint64)]

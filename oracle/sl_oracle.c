@@ -295,6 +295,12 @@ static int pick_threads(int n_threads) {
 #endif
 }
 
+void slo_ref_advance_batch(slo_ref_advance_fn fn, uint16_t *in, uint16_t *out, int B, int h, int w,
+                           float spawn_prob, int n_steps) {
+    size_t n = (size_t)h * w;
+    for (int b = 0; b < B; b++) fn(in + b * n, out + b * n, h, w, spawn_prob, n_steps);
+}
+
 int slo_advance_board_batch(const uint16_t *in, uint16_t *out, int B, int h, int w,
                             const float *spawn_prob, int n_steps, slo_pcg64 *rng,
                             int n_threads) {

@@ -96,6 +96,21 @@ def test_pcg64_matches_numpy():
     assert [g2.state_hi, g2.state_lo] == [int(x) for x in oracle.pcg64_state_words(bg2)[:2]]
 
 
+def test_reference_timing_harness():
+    """bench.py's C2 reference leg calls the reference's compiled advance_board_nstep from a C loop
+    (oracle.ref_advance_batch): same boards, same generator stream as its CPython wrapper board by board."""
+    ref = oracle.load_ref()
+    if ref is None:
+        pytest.skip("oracle/_ref not built (reference checkout absent)")
+    boards = util.random_boards(np.random.default_rng(4), 64, 25, 25, kind=0)
+    g1, g2 = np.random.PCG64(7), np.random.PCG64(7)
+    ref.set_bit_generator(g1)
+    got = oracle.ref_advance_batch(ref, boards, 0.3, 2)
+    ref.set_bit_generator(g2)
+    want = np.stack([ref.advance_board(b, 0.3, 2) for b in boards])
+    assert np.array_equal(got, want) and g1.state == g2.state
+
+
 def test_against_compiled_reference():
     """Random differential test against oracle/_ref (the reference C built from its own sources)."""
     ref = oracle.load_ref()
