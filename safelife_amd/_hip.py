@@ -26,6 +26,7 @@ EXPORTS = (
     "slhip_obs_to_policy", "slhip_side_effects",
     "slhip_gather_unique_id", "slhip_gather_init", "slhip_gather_window", "slhip_gather_destroy",
     "slhip_gather_window_async", "slhip_gather_done", "slhip_gather_wait_streams",
+    "slhip_aql_chain_open", "slhip_aql_step", "slhip_aql_sync", "slhip_aql_chain_close",
 )
 SL_GATHER_ID_BYTES = 128
 SL_SE_MAX_KEYS = 24
@@ -48,7 +49,7 @@ ENV_SCALARS_HEAD = ("B", "H", "W", "E", "time_limit", "exit_points", "n_tables",
 ENV_STATE_PTRS = ("board", "goals", "exit_locs", "rng", "scalars", "points_table")
 ENV_POOL_PTRS = ("pool_board", "pool_goals", "pool_exit_locs", "pool_rng", "pool_scalars")
 ENV_OUT_PTRS = ("out", "obs", "score_lut")
-SL_ABI_VERSION = 7
+SL_ABI_VERSION = 8
 
 #: int32 column of each field inside `struct sl_env_scalars` (64 bytes = 16 columns)
 SCALAR_COLS = {"agent_row": 0, "agent_col": 1, "num_steps": 2, "old_value": 3, "required_points": 4,
@@ -138,6 +139,11 @@ def lib():
         L.slhip_streams_order.argtypes = [_p, C.c_int, _p, C.c_int]
         L.slhip_env_rollout.argtypes = [C.POINTER(EnvBatch), _p, C.c_int, _p, _p, _p]
         L.slhip_env_obs.argtypes = [C.POINTER(EnvBatch), _p]
+        if hasattr(L, "slhip_aql_step"):
+            L.slhip_aql_chain_open.argtypes = [C.POINTER(EnvBatch), C.c_int, _p, C.POINTER(C.c_void_p)]
+            L.slhip_aql_step.argtypes = [C.c_void_p, C.POINTER(EnvBatch), _p, C.c_int]
+            L.slhip_aql_sync.argtypes = [C.c_void_p]
+            L.slhip_aql_chain_close.argtypes = [C.c_void_p]
         L.slhip_side_effects.argtypes = [C.POINTER(EnvBatch), C.POINTER(EpisodeQueue), C.c_int, C.c_int] + [_p] * 9
         L.slhip_obs_to_policy.argtypes = [_p, C.c_int, C.c_int, C.c_int, _p, C.c_int, _p, C.c_int, _p]
         L.slhip_gather_unique_id.argtypes = [_p]
@@ -147,9 +153,11 @@ def lib():
         L.slhip_gather_window_async.argtypes = [_p, _p, _p, C.c_size_t, _p, C.c_int, _p, C.POINTER(C.c_longlong)]
         L.slhip_gather_done.argtypes = [_p, C.c_longlong, C.c_int, C.POINTER(C.c_int)]
         L.slhip_gather_wait_streams.argtypes = [_p, C.c_longlong, _p, C.c_int]
+        foreign = bool(os.environ.get("SAFELIFE_HIP_LIB")) and os.environ.get("SAFELIFE_HIP_LIB_ANY_ABI") == "1"
         for name in EXPORTS:
-            getattr(L, name)  # AttributeError here means the .so is stale
-        if L.slhip_abi_version() != SL_ABI_VERSION:
+            if not foreign or hasattr(L, name):      # (A/B runs against an older build: tools/ab_libs.sh)
+                getattr(L, name)  # AttributeError here means the .so is stale
+        if L.slhip_abi_version() != SL_ABI_VERSION and not foreign:
             raise SafeLifeHipError("%s has ABI version %d, this package needs %d: rebuild it"
                                    % (LIB_PATH, L.slhip_abi_version(), SL_ABI_VERSION))
         _lib = L
