@@ -252,11 +252,6 @@ def main():
     ap.add_argument("--slices", type=int, default=2,
                     help="slices of the per-GPU batch, each stepped by its own launch on its own stream "
                          "(1 = one launch per step on one stream)")
-    ap.add_argument("--chain", choices=("auto", "on", "off"), default="off",
-                    help="step through the library's own AQL queues (slhip_aql_*: back-to-back steps without the kernel "
-                         "boundary, ordered per workgroup by tickets); auto: where the runtime offers such a queue, else "
-                         "the HIP-stream slices")
-    ap.add_argument("--chain-slices", type=int, default=1, help="AQL queues (dispatches per step) of the chain")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-steps", type=int, default=1001)
     ap.add_argument("--rollout", type=int, default=32,
@@ -296,16 +291,6 @@ def main():
                             auto_reset=True, level_stride=1, env_offset=rank * B, with_obs=bool(args.obs),
                             slices=args.slices)
     env.reset()
-    use_chain, chain_why = False, "switched off"
-    if args.chain != "off":
-        try:
-            env.chain_open(args.chain_slices)
-            use_chain, chain_why = True, None
-        except _hip.SafeLifeHipError as e:
-            if args.chain == "on":
-                raise
-            chain_why = str(e)
-            print("bench: AQL chain unavailable (%s): stepping through HIP streams" % chain_why, file=sys.stderr)
     gen = torch.Generator(device=dev)
     gen.manual_seed(7 + rank)
     # P checkpointed steps for the parity replay, then W warm-up steps, then the K timed ones
@@ -315,13 +300,12 @@ def main():
     forced = os.environ.get("SAFELIFE_FORCE_GATHER", "0") == "1"         # one rank, exchange on (RCCL to itself)
     every_used = gather_window(args.gather_every, K) if (world > 1 or forced) else args.gather_every
     gather = RewardGather(env, every=every_used, world=world, rank=rank)
-    gather.chained = use_chain
     gather.prime()
 
     # one step = every env stepped once = one launch per slice, each on the slice's own stream; the action
     # tensor is complete before the loop starts, so nothing has to be fenced per step (step_async)
     act_ptr = [actions[t].data_ptr() for t in range(P + W + K)]
-    step, every = (env.step_chain if use_chain else env.step_async), gather.every
+    step, every = env.step_async, gather.every
     # windows are counted from the END of the timed block: its last step closes one (a learner that consumes K-step
     # rollouts exchanges once per rollout), so the hand-off -- ~30-70 us of host time -- falls where the host is
     # ahead of the device instead of in the middle of the launches
@@ -379,8 +363,6 @@ def main():
     gc.disable()
     run(P, W)              # the W untimed warm-up steps, issued exactly like the timed ones
     gather.flush()
-    if use_chain:
-        env.chain_sync()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -405,8 +387,6 @@ def main():
     t_b = time.perf_counter()
     gather.flush()
     t_c = time.perf_counter()
-    if use_chain:
-        env.chain_sync()           # the chain's closing barrier packet (system-scope release), waited for here
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -424,8 +404,6 @@ def main():
     # device time per step: every slice stream runs its K launches back to back, all streams concurrently
     slice_ms = [e0.elapsed_time(e1) / K for e0, e1 in evs]
     kernel_ms = max(slice_ms)
-    if use_chain:      # (events on a HIP stream see nothing of the chained steps: filled in below)
-        kernel_ms = elapsed / K * 1e3
     per_rank = None
     if world > 1:
         # per-rank breakdown for the scaling run: wall time of the region, device time per step, host enqueue time
@@ -444,24 +422,6 @@ def main():
         # the state the timed launches left behind against a CPU replay of the same envs and actions
         threads = max(1, min(16, len(os.sched_getaffinity(0))))
         parity = parity_replay(pool, actions[:P + W + K].cpu().numpy(), B, env, checkpoints, threads)
-    if use_chain:
-        # the chained steps ran on the library's queues, not on a HIP stream.  The same kernel through the stream
-        # slices, K steps under HIP events, gives the per-launch device figure (roofline.launch_ms) next to the
-        # chain's wall clock.
-        torch.cuda.synchronize()
-        for t in range(P, P + W):
-            env.step_async(act_ptr[t])
-        env.join()
-        torch.cuda.synchronize()
-        evs[0][0].record(streams[0])
-        t_s0 = time.perf_counter()
-        for t in range(P + W, P + W + K):
-            env.step_async(act_ptr[t])
-        evs[0][1].record(streams[0])
-        env.join()
-        torch.cuda.synchronize()
-        stream_wall_ms = (time.perf_counter() - t_s0) / K * 1e3
-        kernel_ms = evs[0][0].elapsed_time(evs[0][1]) / K
 
     extra = {}
     if args.rollout > 0:
@@ -724,18 +684,11 @@ def main():
                            {0: ", no observation", 1: " + 25x25x15 u8 obs", 2: " + 25x25 u32 view"}[args.obs]),
                        "envs_per_gpu": B, "global_envs": world * B, "board": [H, Wd],
                        "level_pool": len(pool), "parallelism": "envs sharded %d-way, step records gathered "
-                                                               "to rank 0 every %d steps (%s); %s" % (
+                                                               "to rank 0 every %d steps (%s); %d slice(s) per GPU, one launch "
+                                                               "and one stream each" % (
                                                                    world, every_used,
                                                                    "RCCL send/recv on a side stream" if gather.collective
-                                                                   else "one rank: nothing to exchange",
-                                                                   ("steps dispatched back to back from %d AQL queue(s) of the "
-                                                                    "library's own: no kernel boundary, workgroup g of a step "
-                                                                    "waits for workgroup g of the step before (tickets)"
-                                                                    % env.chain_slices) if use_chain else
-                                                                   ("%d slice(s) per GPU, one launch and one stream each"
-                                                                    % env.slices)),
-                       "stepping": "aql-chain" if use_chain else "hip-streams",
-                       "chain_unavailable": chain_why},
+                                                                   else "one rank: nothing to exchange", env.slices)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "fused env step", "bytes_per_env_step": bytes_per_step,
@@ -745,10 +698,6 @@ def main():
                          # launches of a step run concurrently, each stream back to back, so a step costs one
                          # stream's launch-to-launch time
                          "launch_ms": kernel_ms, "launches_per_step": env.slices,
-                         "launch_ms_note": ("HIP events over %d steps of the SAME kernel issued through the %d stream "
-                                            "slice(s) right after the chained region (wall %.5f ms per step): the chained "
-                                            "steps overlap on queues HIP events cannot see" % (K, env.slices, stream_wall_ms))
-                         if use_chain else None,
                          "achieved_device": achieved_device, "frac_device": achieved_device / HBM_PEAK_GBS,
                          "host_enqueue_ms_per_step": (t_enqueued - t_start) / K * 1e3,
                          "measured_ceiling": ceiling,

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SL_ABI_VERSION 8
+#define SL_ABI_VERSION 7
 #define SL_MAX_CELLS 16384        /* H*W limit of one board */
 #define SL_MAX_CHANNELS 32
 
@@ -315,27 +315,6 @@ int slhip_streams_order(void *const *before, int n_before, void *const *after, i
  * envs so that every slice keeps the 16-byte alignment the row kernels' DMA needs. */
 int slhip_env_step_slices(const sl_env_batch *env, int n_slices, const int32_t *bounds, const int32_t *actions,
                           void *const *streams);
-
-/* Back-to-back steps WITHOUT the kernel boundary (round 3; no counterpart in the reference, whose envs step one at a
- * time on the CPU: this is how `for env in envs: env.step(a)` of training/base_algo.py:224-240 is issued when nothing
- * outside the envs looks at them between two steps).  Through a HIP stream, two dependent launches are ~2.2 us apart
- * (queue barrier, release, acquire) -- a quarter of a C3 step.  A chain dispatches the same step kernel from HSA queues
- * of the library's own (one per slice) with no barrier between consecutive steps; workgroup g of step t+1 waits for
- * workgroup g of step t through a ticket in device memory, the only dependence there is (csrc/sl_aql.hip).
- *   chain_open : slices as in slhip_env_step_slices; row-kernel shapes only, no "inaction" wrapper
- *                (SL_E_UNSUPPORTED otherwise, or when the HSA runtime offers no queue -- callers then keep to streams).
- *   step       : one step of every env.  head != 0 for the first step after anything OUTSIDE the chain wrote the envs'
- *                state or the actions through a HIP stream: the caller has synchronised those streams, the step is
- *                dispatched behind a queue barrier with a system-scope acquire.  actions: device int32 [B], complete
- *                when the call is made (or when the head's streams were synchronised).
- *   sync       : a system-scope release behind every step dispatched so far, waited for by the calling thread; only
- *                then may HIP streams or the host read what the steps wrote.  Reports a failed hand-over (a ticket
- *                that did not arrive; a workgroup that did not run on its predecessor's XCD, whose L2 holds the state)
- *                as SL_E_HIP: the state is then not valid. */
-int slhip_aql_chain_open(const sl_env_batch *env, int n_slices, const int32_t *bounds, void **chain);
-int slhip_aql_step(void *chain, const sl_env_batch *env, const int32_t *actions, int head);
-int slhip_aql_sync(void *chain);
-int slhip_aql_chain_close(void *chain);
 
 /* The episode-end pass of side_effect_score() (side_effects.py:103-130) for every episode in `queue` (what
  * safelife_env.py:183-192 runs inside the step that ends an episode), all on the device and without a host

@@ -521,110 +521,6 @@ int slhip_env_step_slices(const sl_env_batch *env, int n_slices, const int32_t *
     return SL_OK;
 }
 
-// ---- back-to-back steps on the library's own AQL queues (sl_aql.hip) -------------------------------------------------
-namespace {
-struct AqlChain {
-    int n_slices = 0, dev = 0;
-    int32_t bounds[9] = {};
-    uint32_t *tickets[8] = {};
-    uint32_t seq[8] = {};
-    int H = 0, W = 0, B = 0;
-};
-}  // namespace
-
-int slhip_aql_chain_open(const sl_env_batch *env, int n_slices, const int32_t *bounds, void **chain) {
-    int rc = check_env(env);
-    if (rc) return rc;
-    if (!chain || !bounds || n_slices < 1 || n_slices > 8) return fail(SL_E_ARG, "bad chain arguments (1 to 8 slices)");
-    if (bounds[0] != 0 || bounds[n_slices] != env->B) return fail(SL_E_ARG, "slice bounds must run from 0 to B");
-    for (int i = 0; i < n_slices; ++i) {
-        if (bounds[i + 1] < bounds[i]) return fail(SL_E_ARG, "slice bounds must not decrease");
-        if (!use_rowlane(env, bounds[i])) return fail(SL_E_UNSUPPORTED, "AQL stepping needs the row kernels");
-    }
-    if (env->wrap.flags & SL_WRAP_INACTION)
-        return fail(SL_E_UNSUPPORTED, "the inaction baseline is a launch of its own: HIP streams only");
-    if (const char *why = sl::aql_open(n_slices)) return fail(SL_E_UNSUPPORTED, std::string("AQL queues unavailable: ") + why);
-    if (const char *why = sl::aql_probe(sl::rowlane_probe_function())) return fail(SL_E_UNSUPPORTED, std::string("AQL queues unavailable: ") + why);
-    AqlChain *c = new AqlChain;
-    c->n_slices = n_slices;
-    c->H = env->H;
-    c->W = env->W;
-    c->B = env->B;
-    (void)hipGetDevice(&c->dev);
-    memcpy(c->bounds, bounds, sizeof(int32_t) * (n_slices + 1));
-    void *err_dev = nullptr;
-    hipError_t err = hipHostGetDevicePointer(&err_dev, (void *)sl::aql_error_word(), 0);
-    for (int i = 0; i < n_slices && err == hipSuccess; ++i) {
-        // (one workgroup holds at least one env: a word pair per env is always enough)
-        const size_t bytes = sizeof(uint32_t) * (2 + 2 * (size_t)(bounds[i + 1] - bounds[i] + 1));
-        err = hipMalloc((void **)&c->tickets[i], bytes);
-        if (err == hipSuccess) err = hipMemset(c->tickets[i], 0, bytes);
-        if (err == hipSuccess) err = hipMemcpy(c->tickets[i], &err_dev, sizeof(err_dev), hipMemcpyHostToDevice);
-    }
-    if (err == hipSuccess) err = hipDeviceSynchronize();
-    if (err != hipSuccess) {
-        for (int i = 0; i < n_slices; ++i)
-            if (c->tickets[i]) (void)hipFree(c->tickets[i]);
-        delete c;
-        return hip_fail(err, "AQL chain set-up");
-    }
-    *chain = c;
-    return SL_OK;
-}
-
-int slhip_aql_step(void *chain, const sl_env_batch *env, const int32_t *actions, int head) {
-    AqlChain *c = (AqlChain *)chain;
-    if (!c || !env || !actions) return fail(SL_E_ARG, "null pointer");
-    if (env->H != c->H || env->W != c->W || env->B != c->B) return fail(SL_E_ARG, "the chain was opened for another batch");
-    const sl::Jump *jump;
-    int rc;
-    if ((rc = jump_table(&jump))) return rc;
-    struct Batch {
-        Batch() { sl::aql_begin(); }
-        ~Batch() { sl::aql_commit(); }
-    } batch;
-    for (int i = 0; i < c->n_slices; ++i) {
-        const int n = c->bounds[i + 1] - c->bounds[i];
-        if (n == 0) continue;
-        sl::AqlLaunch a;
-        a.queue = i;
-        a.ticket = c->tickets[i];
-        a.seq = c->seq[i];
-        a.mode = head ? 2u : 3u;            // SL_TK_SIGN | (SL_TK_WAIT unless the queue barrier orders this step)
-        a.head = head != 0;
-        const hipError_t err = sl::launch_env_rollout_rowlane(*env, c->bounds[i], n, actions, 1, env->B, nullptr, nullptr,
-                                                              jump, nullptr, &a);
-        if (err != hipSuccess) return hip_fail(err, "AQL dispatch");
-        ++c->seq[i];
-    }
-    return SL_OK;
-}
-
-int slhip_aql_sync(void *chain) {
-    AqlChain *c = (AqlChain *)chain;
-    if (!c) return fail(SL_E_ARG, "null pointer");
-    const hipError_t err = sl::aql_fence(c->n_slices);
-    if (err != hipSuccess) return hip_fail(err, "AQL fence");
-    if (const volatile uint32_t *w = sl::aql_error_word()) {
-        const uint32_t code = *w;
-        if (code)
-            return fail(SL_E_HIP, std::string("AQL hand-over failed (") + ((code & 1) ? "ticket timeout " : "") +
-                                      ((code & 2) ? "workgroup changed XCD" : "") +
-                                      "): the steps since the chain's head are not valid; use the HIP-stream path");
-    }
-    return SL_OK;
-}
-
-int slhip_aql_chain_close(void *chain) {
-    AqlChain *c = (AqlChain *)chain;
-    if (!c) return SL_OK;
-    (void)sl::aql_fence(c->n_slices);
-    for (int i = 0; i < c->n_slices; ++i)
-        if (c->tickets[i]) (void)hipFree(c->tickets[i]);
-    delete c;
-    return SL_OK;
-}
-
 // ---- the records of every rank's envs -> rank 0 (RCCL point-to-point calls; helpers above) ----------------------
 int slhip_gather_unique_id(void *id_out) {
     if (!id_out) return fail(SL_E_ARG, "null pointer");

@@ -56,33 +56,9 @@ hipError_t launch_se_distributions(const sl_env_batch &env, const sl_episode_que
                                    hipStream_t stream);
 // envs [e_first, e_first + e_count) of the batch; actions / reward_t / done_t are indexed [t * tstride + e]
 // with the env's index in the whole batch
-// aql (optional): dispatch on one of the library's own AQL queues instead of `stream` (sl_aql.hip; T == 1 only)
-struct AqlLaunch {
-    int queue;              // index of the queue (one per slice)
-    u32 *ticket;            // the slice's tickets (layout: sl_rowlane.hip) ...
-    u32 seq, mode;          // ... the steps its chain has completed, SL_TK_WAIT | SL_TK_SIGN
-    bool head;              // first step of a chain: queue barrier + system-scope acquire instead of the ticket wait
-};
 hipError_t launch_env_rollout_rowlane(const sl_env_batch &env, int e_first, int e_count, const int32_t *actions,
                                       int T, int tstride, float *reward_t, uint8_t *done_t, const Jump *jump,
-                                      hipStream_t stream, const AqlLaunch *aql = nullptr);
-
-// sl_aql.hip : the library's own HSA queues next to HIP's streams
-// (null when usable, else why not)
-const char *aql_open(int n_queues);
-// can the kernel HIP knows as `f` be found in the HSA runtime's executables?  (null: yes)
-const char *aql_probe(hipFunction_t f);
-hipFunction_t rowlane_probe_function();      // any kernel of the library (sl_rowlane.hip)
-hipError_t aql_dispatch(const AqlLaunch &a, hipFunction_t f, unsigned grid, unsigned threads, unsigned lds,
-                        const void *args, size_t arg_bytes);
-// dispatches between begin and commit go out together (one flush of their argument blocks)
-void aql_begin();
-void aql_commit();
-// a barrier packet with a system-scope release behind everything dispatched on queues [0, n_queues), waited for
-// by the calling thread
-hipError_t aql_fence(int n_queues);
-// pinned host word the step kernels raise on a failed hand-over (SL_TK_ERR_*)
-volatile u32 *aql_error_word();
+                                      hipStream_t stream);
 
 // the same for envs [e_first, e_first + e_count) on the row kernels (also writes wrap.inaction_rows)
 hipError_t launch_inaction_rowlane(const sl_env_batch &env, int e_first, int e_count, const Jump *jump, hipStream_t stream);

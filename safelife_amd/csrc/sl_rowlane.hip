@@ -30,8 +30,6 @@
 #include <atomic>
 
 #include "sl_kernels.h"
-#include <type_traits>
-
 #include "sl_planes.h"
 
 // A/B knobs of the span moves (cache policy of the LDS DMA loads, flavour of the span stores)
@@ -54,22 +52,6 @@ namespace rl {
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WAVES = 4;
-
-// ---- state that an EARLIER LAUNCH's workgroup wrote, read without a kernel boundary in between --------------------
-// The library's own AQL queues (sl_aql.hip) dispatch back-to-back steps WITHOUT the queue barrier: workgroup g of step
-// t+1 waits for workgroup g of step t through a ticket in device memory instead of for the whole launch.  No
-// boundary means no cache invalidate between writer and reader, so everything the step kernel reads of the mutable
-// per-env state (boards, goals, generators, records, exit tables, wrapper state) goes past this CU's vector L1
-// (`sc1`: served by the L2 the writer's stores went through); read-only inputs keep plain loads.
-// Only launches of a chain pay for it (A/B on one box, C3 through HIP streams: sc1 on every launch's loads costs
-// 0.25 us per two-slice step): `chained` is a bit of a PRELOADED kernel argument, so the stream launches' prologue
-// neither waits for an argument fetch nor takes the sc1 forms.
-#define SL_MUT_AUX 16        /* the aux immediate of the DMA: sc1 */
-template <class T>
-__device__ __forceinline__ T ldm(const T *p, bool chained = true) {
-    return chained ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
-}
-
 
 // -DSL_TRACE: phase timestamps (s_memrealtime) of every wave are written to the `reward_t`
 // argument, reinterpreted as long long [grid * WAVES, 16] (profiling builds only).
@@ -919,7 +901,7 @@ __device__ __forceinline__ bool recolor_exits_lds(u16 *board, int ly, int lx, co
         nx = 1;
     }
     for (int k = 1; k < E; ++k) {
-        const int ex = ldm(exits + k);
+        const int ex = exits[k];
         if (ex >= 0) {
             const int i = Gm::flat(ex);
             board[i] = paint;
@@ -934,55 +916,6 @@ __device__ __forceinline__ bool recolor_exits_lds(u16 *board, int ly, int lx, co
 
 // ---- workgroup span <-> HBM -----------------------------------------------------------------------
 
-// Tickets (u32 words in device memory, one array per slice): [0..1] the address of a host-visible error word,
-// [2 + 2g] the signatures workgroup g has collected since the array was zeroed (every wave of every step signs once,
-// so "step n is complete" reads NWV * n; compared modulo 2^32), [3 + 2g] the XCD the workgroup's last step ran on.
-// The hand-over rests on one observed property of the dispatcher that nothing documents: workgroup g of every dispatch
-// of the same grid runs on the same XCD (g mod 8), so what step t left in that XCD's L2 is what step t+1 reads.  It is
-// therefore CHECKED at every hand-over: a reader whose XCD differs from its predecessor's, or whose ticket does not
-// arrive within the spin limit, raises the error word, and the host refuses the chain's results (sl_aql.hip).
-enum { SL_TK_WAIT = 1, SL_TK_SIGN = 2 };
-enum { SL_TK_ERR_TIMEOUT = 1, SL_TK_ERR_XCD = 2 };
-#ifndef SL_TK_SPIN_LIMIT
-#define SL_TK_SPIN_LIMIT (1 << 20)
-#endif
-__device__ __forceinline__ u32 xcc_id() { return __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u; }   // XCC_ID[3:0]
-
-__device__ __noinline__ void ticket_raise(u32 *ticket, u32 code) {
-    u32 *host_word = *(u32 *const *)ticket;
-    __hip_atomic_fetch_or(host_word, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// (one lane polls with a returning atomic: it executes in the L2, past every L1.)  Returns what the predecessor left in
-// the XCD word (wave 1 only; not waited for here: the caller compares it with xcc_id() + 1 once its loads are in).
-__device__ __forceinline__ u32 ticket_wait(u32 *ticket, u32 g, u32 want, int tid) {
-    u32 left = 0;
-    if ((tid & 63) == 0) {
-        u32 *cnt = ticket + 2 + 2 * g;
-        u32 v;
-        int spins = 0;
-        for (;;) {
-            asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(cnt), "v"(0u) : "memory");
-            if ((int)(v - want) >= 0) break;
-            if (++spins > SL_TK_SPIN_LIMIT) {
-                ticket_raise(ticket, SL_TK_ERR_TIMEOUT);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(2);
-        }
-        if (tid == 64) left = ldm(cnt + 1);
-    }
-    asm volatile("" ::: "memory");
-    return left;
-}
-
-__device__ __forceinline__ void ticket_sign(u32 *ticket, u32 g, int tid) {
-    u32 *cnt = ticket + 2 + 2 * g;
-    if (tid == 64) *(volatile u32 *)(cnt + 1) = xcc_id() + 1u;        // (wave 1 leaves the XCD behind for the successor)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if ((tid & 63) == 0) asm volatile("global_atomic_add %0, %1, off" ::"v"(cnt), "v"(1u) : "memory");
-}
-
 typedef __attribute__((address_space(1))) const void *glds_src_t;
 typedef __attribute__((address_space(3))) void *glds_dst_t;
 
@@ -993,7 +926,7 @@ typedef __attribute__((address_space(3))) void *glds_dst_t;
 __device__ __forceinline__ int swz_chunk(int s) { return s ^ ((s >> 4) & 7); }     // 8 chunks per row; key (row>>1)&7
 
 // NW: number of waves that share the move (wave = 0..NW-1 among them).
-template <int MAX_BYTES, bool SWZ = false, int NW = WAVES, int AUX = SL_LOAD_AUX>
+template <int MAX_BYTES, bool SWZ = false, int NW = WAVES>
 __device__ __forceinline__ void dma_to_lds(const unsigned char *__restrict__ src, unsigned char *dst, int bytes,
                                            int lane, int wave) {
     const int nv = bytes >> 4;
@@ -1004,17 +937,17 @@ __device__ __forceinline__ void dma_to_lds(const unsigned char *__restrict__ src
         const int s = c * 64 + lane;
         if (s < nv)
             __builtin_amdgcn_global_load_lds((glds_src_t)(src + (SWZ ? swz_chunk(s) : s) * 16),
-                                             (glds_dst_t)(dst + c * 1024), 16, 0, AUX);
+                                             (glds_dst_t)(dst + c * 1024), 16, 0, SL_LOAD_AUX);
     }
 }
 
-template <int H, int W, int NW = WAVES, int AUX = SL_LOAD_AUX>
+template <int H, int W, int NW = WAVES>
 __device__ __forceinline__ void load_span(const u16 *__restrict__ src, unsigned char *region, int nbb, int lane, int wave) {
     using Gm = Geom<H, W>;
     const int bytes = nbb * Gm::HW * 2;
-    dma_to_lds<Gm::SPAN, Gm::SWZ, NW, AUX>((const unsigned char *)src, region + Gm::PAD, bytes, lane, wave);
+    dma_to_lds<Gm::SPAN, Gm::SWZ, NW>((const unsigned char *)src, region + Gm::PAD, bytes, lane, wave);
     const int nv = bytes >> 4, rem = (bytes & 15) >> 1;          // leftover cells: tail workgroup only
-    if (wave == 0 && lane < rem) ((u16 *)(region + Gm::PAD))[nv * 8 + lane] = AUX ? ldm(src + nv * 8 + lane) : src[nv * 8 + lane];
+    if (wave == 0 && lane < rem) ((u16 *)(region + Gm::PAD))[nv * 8 + lane] = src[nv * 8 + lane];
 }
 
 __device__ __forceinline__ void store16(u32x4 *p, u32x4 v) {
@@ -2134,10 +2067,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     // critical path; kernel-argument loads are.)
     sl_env_batch env, int hot_E, int tstride, int T_arg, sl_step_out *__restrict__ out_rec,
     float *__restrict__ reward_t, uint8_t *__restrict__ done_t, double *__restrict__ shaped_t,
-    const Jump *__restrict__ jump,
-    // back-to-back steps on the library's own queue (sl_aql.hip): this slice's tickets, the number of steps the
-    // chain has completed, and what to do with them (SL_TK_*); null / 0 on every launch through a HIP stream
-    u32 *__restrict__ ticket, u32 tk_seq, u32 tk_mode) {
+    const Jump *__restrict__ jump) {
     using Gm = Geom<H, W>;
     constexpr int WS = Gm::WS, HW = Gm::HW;
     const int T = ONE ? 1 : T_arg;
@@ -2146,11 +2076,8 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     // envs [hot_first, hot_end) of the batch: one slice (slhip_env_step_slices) or all of it
     const unsigned B = tstride;                        // row pitch of the [T, B] per-step arrays
     const int E = hot_E;
-    // (the top bit of the preloaded range end: this launch belongs to a chain -- tickets, sc1 loads)
-    const bool chained = hot_end < 0;
-    const int e_end = hot_end & 0x7FFFFFFF;
     const int e0b = hot_first + blockIdx.x * Gm::NB;
-    const int nbb = min(Gm::NB, e_end - e0b);
+    const int nbb = min(Gm::NB, hot_end - e0b);
     const LaneMap<H, W> lm(lane);
     const int g = lm.g, r = lm.r, up = lm.up, dn = lm.dn;
     const int gb = wave * Gm::G + g;
@@ -2196,9 +2123,6 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     const u32 cell_mask = vreg(LDS_LUT ? (SCORE_CELL_MASK & 0x7FFF7FFFu) : SCORE_CELL_MASK), c100 = vreg(0x01000100u);
 
     SL_STAMP(0);
-    constexpr u32 NWV = WAVES + (leadx<H, W, LEAN>() ? 1 : 0);      // waves per workgroup: each signs the ticket once
-    u32 tk_left = 0;
-    if (chained && (tk_mode & SL_TK_WAIT)) tk_left = ticket_wait(ticket, blockIdx.x, tk_seq * NWV, tid);
     // Prologue.  The kernel arguments the loads need are fetched in one batch (the compiler otherwise sinks each
     // s_load next to its first use: dependent scalar-cache round trips in a row).
     const u16 *k_board = hot_board, *k_goals = hot_goals;
@@ -2208,9 +2132,9 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     // what the rows need of their board's record (every lane loads, unconditionally: a load inside a branch is
     // waited for at the end of that branch, in front of the DMA issue)
     const sl_env_scalars *const sc = hot_scalars + e;
-    int gstatic = ldm(&sc->goals_static, chained), level = ldm(&sc->level_idx, chained);
-    double p = (double)ldm(&sc->spawn_prob, chained);
-    u32 lut_base = (u32)ldm(&sc->table_idx, chained) * (u32)SCORE_LUT_BYTES;
+    int gstatic = sc->goals_static, level = sc->level_idx;
+    double p = (double)sc->spawn_prob;
+    u32 lut_base = (u32)sc->table_idx * (u32)SCORE_LUT_BYTES;
     // The leader lanes' view of their boards: the env records are copied to LDS by the DMA and worked on there (a
     // dozen per-board values held in registers for the whole launch cost every wave of the kernel those registers);
     // only the agent's location, which the move of step 0 needs before the copies have landed, is loaded directly.
@@ -2223,10 +2147,10 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     u32 pre_c[4] = {0u, 0u, 0u, 0u};
     bool pre_write = false;
     if (lwave) {
-        ly = ldm(&hot_scalars[el].agent_row, chained);
-        lx = ldm(&hot_scalars[el].agent_col, chained);
+        ly = hot_scalars[el].agent_row;
+        lx = hot_scalars[el].agent_col;
         action = actions[el];
-        exit0 = ldm(env.exit_locs + (size_t)el * E, chained);
+        exit0 = env.exit_locs[(size_t)el * E];
         if (T > 0 && lead && ly >= 0) {
             // safelife_env.py:151 for the first step of the launch: the four cells the move can touch are
             // fetched from global memory now (the previous launch's board); they are not waited for here --
@@ -2234,33 +2158,28 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
             int gi[4];
             act_cells<H, W>(ly, lx, action, pre_i, gi, pre_y1, pre_x1);
             const u16 *src = k_board + (size_t)el * HW;
-            pre_c[0] = ldm(src + gi[0], chained);
-            pre_c[1] = ldm(src + gi[1], chained);
-            pre_c[2] = ldm(src + gi[2], chained);
-            pre_c[3] = ldm(src + gi[3], chained);
+            pre_c[0] = src[gi[0]];
+            pre_c[1] = src[gi[1]];
+            pre_c[2] = src[gi[2]];
+            pre_c[3] = src[gi[3]];
         }
     } else {
-        // everything bulky goes through the LDS DMA, issued by the waves that are not the leader (the mutable state
-        // past the L1 when the launch is part of a chain)
+        // everything bulky goes through the LDS DMA, issued by the waves that are not the leader
         constexpr int DW = LEADX ? WAVES : WAVES - 1;
         const int dw = LEADX ? wave : wave - 1;
-        auto bulk = [&](auto aux) {
-            constexpr int AUX = decltype(aux)::value;
-            dma_to_lds<Gm::NB * 32, false, DW, AUX>((const unsigned char *)(k_rng + e0b), smem + Gm::OFF_RNG, nbb * 32, lane, dw);
-            dma_to_lds<Gm::NB * 64, false, DW, AUX>((const unsigned char *)(hot_scalars + e0b), smem + Gm::OFF_REC, nbb * 64, lane, dw);
-            if (LDS_LUT) dma_to_lds<4096, false, DW>((const unsigned char *)k_lut, smem + Gm::OFF_LUT, 4096, lane, dw);
-            load_span<H, W, DW, AUX>(k_board + (size_t)e0b * HW, board, nbb, lane, dw);
-            load_span<H, W, DW, AUX>(k_goals + (size_t)e0b * HW, goals, nbb, lane, dw);
-            if (WRAP)
-                dma_to_lds<Gm::NB * (int)sizeof(sl_wrap_state), false, DW, AUX>((const unsigned char *)(env.wrap.state + e0b),
-                                                                                smem + Gm::OFF_WST,
-                                                                                nbb * (int)sizeof(sl_wrap_state), lane, dw);
-        };
-        if (chained) bulk(std::integral_constant<int, SL_MUT_AUX>{});
-        else bulk(std::integral_constant<int, SL_LOAD_AUX>{});
-        if (WRAP && (env.wrap.flags & SL_WRAP_MOVEMENT))
-            dma_to_lds<Gm::MVT_N * 8, false, DW>((const unsigned char *)env.wrap.move_table, smem + Gm::OFF_MVT,
-                                                 min(env.wrap.move_table_len & ~1, Gm::MVT_N) * 8, lane, dw);
+        dma_to_lds<Gm::NB * 32, false, DW>((const unsigned char *)(k_rng + e0b), smem + Gm::OFF_RNG, nbb * 32, lane, dw);
+        dma_to_lds<Gm::NB * 64, false, DW>((const unsigned char *)(hot_scalars + e0b), smem + Gm::OFF_REC, nbb * 64, lane, dw);
+        if (LDS_LUT) dma_to_lds<4096, false, DW>((const unsigned char *)k_lut, smem + Gm::OFF_LUT, 4096, lane, dw);
+        load_span<H, W, DW>(k_board + (size_t)e0b * HW, board, nbb, lane, dw);
+        load_span<H, W, DW>(k_goals + (size_t)e0b * HW, goals, nbb, lane, dw);
+        if (WRAP) {
+            dma_to_lds<Gm::NB * (int)sizeof(sl_wrap_state), false, DW>((const unsigned char *)(env.wrap.state + e0b),
+                                                                       smem + Gm::OFF_WST,
+                                                                       nbb * (int)sizeof(sl_wrap_state), lane, dw);
+            if (env.wrap.flags & SL_WRAP_MOVEMENT)
+                dma_to_lds<Gm::MVT_N * 8, false, DW>((const unsigned char *)env.wrap.move_table, smem + Gm::OFF_MVT,
+                                                     min(env.wrap.move_table_len & ~1, Gm::MVT_N) * 8, lane, dw);
+        }
     }
     // Every kernel argument the rest of the kernel needs that did not arrive preloaded: fetched in ONE batch
     // here, in the shadow of the bulk loads.
@@ -2282,8 +2201,6 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     if (lwave) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else __syncthreads();
     SL_STAMP(2);
-    // (chained steps: the predecessor ran on this XCD -- its L2 is where the state just loaded came from)
-    if (chained && tk_left != 0u && tk_left != xcc_id() + 1u) ticket_raise(ticket, SL_TK_ERR_XCD);
 
     RowWords<H, W> b;
     Elig elig;
@@ -2619,7 +2536,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
                     const u16 paint = (u16)(FROZEN | EXIT | (w_open ? COLOR_R : 0u));
                     if (exit0 >= 0) gdst[exit0] = paint;
                     for (int k = 1; k < E; ++k) {
-                        const int ex = ldm(exits + k);
+                        const int ex = exits[k];
                         if (ex >= 0) gdst[ex] = paint;
                     }
                 }
@@ -2738,7 +2655,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
             pp[1] = pos_mod(x0 - vw / 2, W);
             for (int k = 0; k < OBS_MAX_EXITS; ++k) {
                 int tv = -1, xk = -1;
-                if (k < E) xk = k == 0 ? exit0 : ldm(obs_exits + k);
+                if (k < E) xk = k == 0 ? exit0 : obs_exits[k];
                 if (xk >= 0) {      // helper_utils.py:64-74: offset wrapped into [-H/2, H/2), clipped to the view
                     const int iy = xk / W, ix = xk - iy * W;
                     int jy = pos_mod(iy - y0 + H / 2, H) - H / 2 + vh / 2;
@@ -2759,9 +2676,6 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
         }
         if (env.policy_obs) write_policy_block<H, W>(env, smem, e0b, nbb, tid);
     }
-    // this wave's stores have reached the L2: sign the workgroup's ticket (the next step's workgroup of the same index
-    // waits for all NWV signatures)
-    if (chained && (tk_mode & SL_TK_SIGN)) ticket_sign(ticket, blockIdx.x, threadIdx.x);
 }
 
 #ifndef SL_ROWLANE_PART
@@ -2896,13 +2810,13 @@ hipError_t launch_occupancy_t(const u16 *in, int32_t *counts, size_t counts_stri
 template <int H, int W>
 hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, const int32_t *actions, int T,
                                    int tstride, float *reward_t, uint8_t *done_t, const Jump *jump,
-                                   hipStream_t stream, const AqlLaunch *aql) {
+                                   hipStream_t stream) {
     using Gm = Geom<H, W>;
     const bool lean = !env.wrap.flags && !env.obs && !env.policy_obs && env.finished.capacity == 0;
     const int variant = (env.n_tables == 1 ? 1 : 0) | (env.spawner_free ? 2 : 0) | (env.wrap.flags ? 4 : (lean ? 8 : 0));
     typedef void (*kernel_t)(const u16 *, const u16 *, const sl_pcg64 *, sl_env_scalars *, const int8_t *,
                              const int32_t *, int, int, sl_env_batch, int, int, int, sl_step_out *, float *,
-                             uint8_t *, double *, const Jump *, u32 *, u32, u32);
+                             uint8_t *, double *, const Jump *);
 #define SL_VARIANTS(ONE)                                                                                               \
     k_env_rollout_rowlane<H, W, false, true, false, false, ONE>, k_env_rollout_rowlane<H, W, true, true, false, false, ONE>,   \
     k_env_rollout_rowlane<H, W, false, false, false, false, ONE>, k_env_rollout_rowlane<H, W, true, false, false, false, ONE>, \
@@ -2957,23 +2871,15 @@ hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, c
             uint8_t *done_t;
             double *shaped_t;
             const Jump *jump;
-            u32 *ticket;
-            u32 tk_seq, tk_mode;
-        } args = {env.board, env.goals, env.rng, env.scalars, env.score_lut, actions, e_first,
-                  (int)((unsigned)(e_first + e_count) | (aql ? 0x80000000u : 0u)),        // (top bit: part of a chain)
-                  env,
-                  env.E, tstride, T, env.out, reward_t, done_t, env.wrap.shaped_reward_t, jump,
-                  aql ? aql->ticket : nullptr, aql ? aql->seq : 0u, aql ? aql->mode : 0u};
-        // the library's own queue instead of a HIP stream (sl_aql.hip): same kernel, same argument block
-        if (aql) return T == 1 ? aql_dispatch(*aql, f, grid, threads, (unsigned)lds, &args, sizeof(args)) : hipErrorInvalidValue;
+        } args = {env.board, env.goals, env.rng, env.scalars, env.score_lut, actions, e_first, e_first + e_count, env,
+                  env.E, tstride, T, env.out, reward_t, done_t, env.wrap.shaped_reward_t, jump};
         size_t size = sizeof(args);
         void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
         return hipModuleLaunchKernel(f, grid, 1, 1, threads, 1, 1, (unsigned)lds, stream, nullptr, extra);
     }
-    if (aql) return hipErrorNotSupported;
     hipLaunchKernelGGL(fn, dim3(grid), dim3(threads), lds, stream, env.board, env.goals, env.rng, env.scalars,
                        env.score_lut, actions, e_first, e_first + e_count, env, env.E, tstride, T, env.out, reward_t,
-                       done_t, env.wrap.shaped_reward_t, jump, (u32 *)nullptr, 0u, 0u);
+                       done_t, env.wrap.shaped_reward_t, jump);
     return hipGetLastError();
 }
 
@@ -2995,7 +2901,7 @@ hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, c
                                                             hipStream_t);                                                  \
     PREFIX template hipError_t rl::launch_inaction_t<h, w>(const sl_env_batch &, int, int, const Jump *, hipStream_t);     \
     PREFIX template hipError_t rl::launch_rollout_t<h, w>(const sl_env_batch &, int, int, const int32_t *, int, int,      \
-                                                          float *, uint8_t *, const Jump *, hipStream_t, const AqlLaunch *);
+                                                          float *, uint8_t *, const Jump *, hipStream_t);
 #ifdef SL_ROWLANE_PART
 #define X(h, w) SL_ROWLANE_LAUNCHERS(, h, w)
 #if SL_ROWLANE_PART == 1
@@ -3057,15 +2963,6 @@ hipError_t launch_occupancy_rowlane(const u16 *in, int32_t *counts, size_t count
     return hipErrorInvalidValue;
 }
 
-hipFunction_t rowlane_probe_function() {
-    hipFunction_t f = nullptr;
-    if (hipGetFuncBySymbol(&f, (const void *)rl::k_build_score_lut) != hipSuccess) {
-        (void)hipGetLastError();
-        return nullptr;
-    }
-    return f;
-}
-
 hipError_t launch_inaction_rowlane(const sl_env_batch &env, int e_first, int e_count, const Jump *jump, hipStream_t stream) {
 #define X(h, w) if (env.H == h && env.W == w) return rl::launch_inaction_t<h, w>(env, e_first, e_count, jump, stream);
     SL_ROWLANE_SHAPES(X)
@@ -3075,8 +2972,8 @@ hipError_t launch_inaction_rowlane(const sl_env_batch &env, int e_first, int e_c
 
 hipError_t launch_env_rollout_rowlane(const sl_env_batch &env, int e_first, int e_count, const int32_t *actions,
                                       int T, int tstride, float *reward_t, uint8_t *done_t, const Jump *jump,
-                                      hipStream_t stream, const AqlLaunch *aql) {
-#define X(h, w) if (env.H == h && env.W == w) return rl::launch_rollout_t<h, w>(env, e_first, e_count, actions, T, tstride, reward_t, done_t, jump, stream, aql);
+                                      hipStream_t stream) {
+#define X(h, w) if (env.H == h && env.W == w) return rl::launch_rollout_t<h, w>(env, e_first, e_count, actions, T, tstride, reward_t, done_t, jump, stream);
     SL_ROWLANE_SHAPES(X)
 #undef X
     return hipErrorInvalidValue;

@@ -15,8 +15,6 @@ libsafelife_hip.so.  Nothing here falls back to the CPU.
 """
 import ctypes as C
 
-import os
-
 import numpy as np
 
 from . import _hip
@@ -280,8 +278,6 @@ class SafeLifeVectorEnv(object):
         self._slice_streams = self._pick_streams(n_sl) if n_sl > 1 else []
         self._async_pending = False      # step_async() left work on the slice streams that the caller has not joined
         self._caller_ahead = True        # the caller's stream holds work the slice streams have not been fenced against
-        self._chain = None               # step_chain(): the library's own AQL queues (opened on first use)
-        self._chain_pending = False      # chained steps dispatched since the last chain_sync()
         self._stream_ptrs = (C.c_void_p * max(1, n_sl))(*[st.cuda_stream for st in self._slice_streams])
         self._primary_ptr = C.c_void_p(self._primary.cuda_stream)
         rc = self._lib.slhip_env_prepare(self._sref, _hip.current_stream_ptr())
@@ -433,78 +429,9 @@ class SafeLifeVectorEnv(object):
         self._async_pending = False
 
     def _settle(self):
-        """Before the env is touched on the caller's stream: join the slices if step_async() left work on them, and
-        wait for the chained steps if step_chain() dispatched any."""
+        """Before the env is touched on the caller's stream: join the slices if step_async() left work on them."""
         if self._async_pending:
             self.join()
-        if self._chain_pending:
-            # (what follows on the caller's stream -- even a read -- is not ordered against later chained steps: the
-            #  next one waits for the streams and starts a new chain)
-            self.chain_sync()
-            self._caller_ahead = True
-
-    # ---- chained stepping: back-to-back steps without the kernel boundary (csrc/sl_aql.hip, slhip_aql_*)
-
-    def chain_open(self, slices=None):
-        """Open the AQL chain (one queue per chain slice; default: SAFELIFE_AQL_SLICES or 1).  Raises
-        SafeLifeHipError when the batch or the runtime does not support it -- callers keep to step_async() then."""
-        if self._chain is not None:
-            return
-        B = self.num_envs
-        n = int(slices if slices is not None else os.environ.get("SAFELIFE_AQL_SLICES", "1"))
-        n = max(1, min(n, 8, (B + 63) // 64))
-        per = -(-(-(-B // n)) // 64) * 64
-        bounds = [min(B, i * per) for i in range(n)] + [B]
-        chain = C.c_void_p()
-        _hip.check(self._lib.slhip_aql_chain_open(self._sref, n, (C.c_int32 * (n + 1))(*bounds), C.byref(chain)))
-        self._chain, self.chain_slices = chain, n
-
-    def step_chain(self, actions):
-        """One step per env on the chain: no queue barrier, no cache flush between this step and the previous chained
-        one -- workgroup g waits for workgroup g of the step before through a ticket in device memory.  `actions` as
-        for step_async(), complete when the call is made.  Outputs and state may be read (by the host or by any
-        stream) only after ``chain_sync()``; every method of this class that touches the env does that itself."""
-        if isinstance(actions, int):
-            ptr = actions
-        else:
-            if (actions.dtype != self.torch.int32 or not actions.is_contiguous() or actions.numel() != self.num_envs
-                    or actions.device != self.device):
-                raise ValueError("step_chain() takes a contiguous int32 tensor [num_envs] on the env's device "
-                                 "(or its address); got %s %s on %s" % (actions.dtype, tuple(actions.shape), actions.device))
-            ptr = actions.data_ptr()
-        if self._chain is None:
-            self.chain_open()
-        head = 0
-        if self._caller_ahead or self._async_pending:
-            # HIP streams have touched the envs since the chain last ran (a reset, step(), rollout() ...): their work
-            # is waited for here, and the step goes out behind the queue barrier with a system-scope acquire
-            if self._async_pending:
-                self.join()
-            self.torch.cuda.synchronize(self.device)
-            self._caller_ahead = False
-            head = 1
-        rc = self._lib.slhip_aql_step(self._chain, self._sref, ptr, head)
-        if rc:
-            _hip.check(rc)
-        self._chain_pending = True
-
-    def chain_sync(self):
-        """Wait for every chained step dispatched so far (system-scope release behind them): afterwards their outputs
-        and the envs' state are visible to the host and to every HIP stream.  Raises if a hand-over failed."""
-        self._chain_pending = False
-        if self._chain is not None:
-            _hip.check(self._lib.slhip_aql_sync(self._chain))
-
-    def chain_close(self):
-        if self._chain is not None:
-            self._lib.slhip_aql_chain_close(self._chain)
-            self._chain, self._chain_pending = None, False
-
-    def __del__(self):
-        try:
-            self.chain_close()
-        except Exception:
-            pass
 
     def step_async(self, actions):
         """One step per env, one launch per slice on the slice's own stream; nothing is fenced.  `actions`:
