@@ -236,6 +236,9 @@ def gather_window(requested, steps):
     return max(1, min(int(requested), int(steps)))     # (any `every` <= steps consecutive steps hold a step = every-1 mod every)
 
 
+DEFAULT_QUEUES = "0"       # slices on AQL queues by default (0: HIP-stream slices)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -252,6 +255,11 @@ def main():
     ap.add_argument("--slices", type=int, default=2,
                     help="slices of the per-GPU batch, each stepped by its own launch on its own stream "
                          "(1 = one launch per step on one stream)")
+    ap.add_argument("--queues", type=int, default=-1,
+                    help="N > 0: issue a step as N slices on the library's own AQL queues (slhip_queues_*: the same kernel, "
+                         "the same ordering as a stream, without HIP's per-launch host cost); 0: the HIP-stream slices of "
+                         "--slices; -1: SAFELIFE_BENCH_QUEUES or the default below, falling back to streams where the "
+                         "runtime offers no queue")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-steps", type=int, default=1001)
     ap.add_argument("--rollout", type=int, default=32,
@@ -291,6 +299,17 @@ def main():
                             auto_reset=True, level_stride=1, env_offset=rank * B, with_obs=bool(args.obs),
                             slices=args.slices)
     env.reset()
+    n_queues = args.queues if args.queues >= 0 else int(os.environ.get("SAFELIFE_BENCH_QUEUES", DEFAULT_QUEUES))
+    use_queues, queues_why = False, "switched off"
+    if n_queues > 0:
+        try:
+            env.queues_open(n_queues)
+            use_queues, queues_why = True, None
+        except _hip.SafeLifeHipError as e:
+            if args.queues > 0:
+                raise
+            queues_why = str(e)
+            print("bench: AQL queues unavailable (%s): stepping through HIP streams" % queues_why, file=sys.stderr)
     gen = torch.Generator(device=dev)
     gen.manual_seed(7 + rank)
     # P checkpointed steps for the parity replay, then W warm-up steps, then the K timed ones
@@ -300,12 +319,13 @@ def main():
     forced = os.environ.get("SAFELIFE_FORCE_GATHER", "0") == "1"         # one rank, exchange on (RCCL to itself)
     every_used = gather_window(args.gather_every, K) if (world > 1 or forced) else args.gather_every
     gather = RewardGather(env, every=every_used, world=world, rank=rank)
+    gather.queued = use_queues
     gather.prime()
 
     # one step = every env stepped once = one launch per slice, each on the slice's own stream; the action
     # tensor is complete before the loop starts, so nothing has to be fenced per step (step_async)
     act_ptr = [actions[t].data_ptr() for t in range(P + W + K)]
-    step, every = env.step_async, gather.every
+    step, every = (env.step_queues if use_queues else env.step_async), gather.every
     # windows are counted from the END of the timed block: its last step closes one (a learner that consumes K-step
     # rollouts exchanges once per rollout), so the hand-off -- ~30-70 us of host time -- falls where the host is
     # ahead of the device instead of in the middle of the launches
@@ -363,6 +383,8 @@ def main():
     gc.disable()
     run(P, W)              # the W untimed warm-up steps, issued exactly like the timed ones
     gather.flush()
+    if use_queues:
+        env.queues_sync()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -387,6 +409,8 @@ def main():
     t_b = time.perf_counter()
     gather.flush()
     t_c = time.perf_counter()
+    if use_queues:
+        env.queues_sync()          # the queues' closing barrier packets (system-scope release), waited for here
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -404,6 +428,8 @@ def main():
     # device time per step: every slice stream runs its K launches back to back, all streams concurrently
     slice_ms = [e0.elapsed_time(e1) / K for e0, e1 in evs]
     kernel_ms = max(slice_ms)
+    if use_queues:      # (events on a HIP stream see nothing of the queues' steps: filled in below)
+        kernel_ms = elapsed / K * 1e3
     per_rank = None
     if world > 1:
         # per-rank breakdown for the scaling run: wall time of the region, device time per step, host enqueue time
@@ -422,6 +448,25 @@ def main():
         # the state the timed launches left behind against a CPU replay of the same envs and actions
         threads = max(1, min(16, len(os.sched_getaffinity(0))))
         parity = parity_replay(pool, actions[:P + W + K].cpu().numpy(), B, env, checkpoints, threads)
+    stream_wall_ms = None
+    if use_queues:
+        # the timed steps ran on the library's queues, not on a HIP stream.  The same kernel through the stream
+        # slices, K steps under HIP events, gives the per-launch device figure (roofline.launch_ms) next to the
+        # queues' wall clock.
+        torch.cuda.synchronize()
+        for t in range(P, P + W):
+            env.step_async(act_ptr[t])
+        env.join()
+        torch.cuda.synchronize()
+        evs[0][0].record(streams[0])
+        t_s0 = time.perf_counter()
+        for t in range(P + W, P + W + K):
+            env.step_async(act_ptr[t])
+        evs[0][1].record(streams[0])
+        env.join()
+        torch.cuda.synchronize()
+        stream_wall_ms = (time.perf_counter() - t_s0) / K * 1e3
+        kernel_ms = evs[0][0].elapsed_time(evs[0][1]) / K
 
     extra = {}
     if args.rollout > 0:
@@ -684,11 +729,17 @@ def main():
                            {0: ", no observation", 1: " + 25x25x15 u8 obs", 2: " + 25x25 u32 view"}[args.obs]),
                        "envs_per_gpu": B, "global_envs": world * B, "board": [H, Wd],
                        "level_pool": len(pool), "parallelism": "envs sharded %d-way, step records gathered "
-                                                               "to rank 0 every %d steps (%s); %d slice(s) per GPU, one launch "
-                                                               "and one stream each" % (
+                                                               "to rank 0 every %d steps (%s); %s" % (
                                                                    world, every_used,
                                                                    "RCCL send/recv on a side stream" if gather.collective
-                                                                   else "one rank: nothing to exchange", env.slices)},
+                                                                   else "one rank: nothing to exchange",
+                                                                   ("%d slice(s) per GPU, one dispatch each on an AQL queue of "
+                                                                    "the library's own (stream ordering: barrier bit, "
+                                                                    "agent-scope fences)" % env.queue_slices) if use_queues
+                                                                   else ("%d slice(s) per GPU, one launch and one stream each"
+                                                                         % env.slices)),
+                       "stepping": "aql-queues" if use_queues else "hip-streams",
+                       "queues_unavailable": queues_why},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "fused env step", "bytes_per_env_step": bytes_per_step,
@@ -698,6 +749,10 @@ def main():
                          # launches of a step run concurrently, each stream back to back, so a step costs one
                          # stream's launch-to-launch time
                          "launch_ms": kernel_ms, "launches_per_step": env.slices,
+                         "launch_ms_note": ("HIP events over %d steps of the SAME kernel issued through the %d stream "
+                                            "slice(s) right after the timed region (wall %.5f ms per step): HIP events "
+                                            "cannot see the library's queues" % (K, env.slices, stream_wall_ms))
+                         if use_queues else None,
                          "achieved_device": achieved_device, "frac_device": achieved_device / HBM_PEAK_GBS,
                          "host_enqueue_ms_per_step": (t_enqueued - t_start) / K * 1e3,
                          "measured_ceiling": ceiling,

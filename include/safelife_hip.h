@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SL_ABI_VERSION 7
+#define SL_ABI_VERSION 8
 #define SL_MAX_CELLS 16384        /* H*W limit of one board */
 #define SL_MAX_CHANNELS 32
 
@@ -315,6 +315,24 @@ int slhip_streams_order(void *const *before, int n_before, void *const *after, i
  * envs so that every slice keeps the 16-byte alignment the row kernels' DMA needs. */
 int slhip_env_step_slices(const sl_env_batch *env, int n_slices, const int32_t *bounds, const int32_t *actions,
                           void *const *streams);
+
+/* Sliced stepping WITHOUT HIP's launch path (round 3): slhip_env_step_slices hides one slice's kernel boundary under the
+ * other slices' kernels, but a launch through a HIP stream costs the host 2.4-3 us, so one stepping thread feeds two
+ * slices per ~8 us step and no more.  These entry points issue the SAME kernel from HSA queues of the library's own, one
+ * per slice (csrc/sl_aql.hip): a dispatch is a 64-byte packet and a doorbell, the slices' argument blocks are flushed
+ * once per step.  Ordering is a stream's: every dispatch waits for its queue's previous one (barrier bit, agent-scope
+ * acquire / release).
+ *   open  : slices as in slhip_env_step_slices (1 to 8); row-kernel shapes only, no "inaction" wrapper
+ *           (SL_E_UNSUPPORTED otherwise, or when the HSA runtime offers no queue -- callers then keep to streams).
+ *   step  : one step of every env.  head != 0 for the first step after anything OUTSIDE the queues wrote the envs'
+ *           state or the actions through a HIP stream: the caller has synchronised those streams, the step is
+ *           dispatched with a system-scope acquire.  actions: device int32 [B], complete when the call is made.
+ *   sync  : a system-scope release behind every step dispatched so far, waited for by the calling thread; only then
+ *           may HIP streams or the host read what the steps wrote. */
+int slhip_queues_open(const sl_env_batch *env, int n_slices, const int32_t *bounds, void **handle);
+int slhip_queues_step(void *handle, const sl_env_batch *env, const int32_t *actions, int head);
+int slhip_queues_sync(void *handle);
+int slhip_queues_close(void *handle);
 
 /* The episode-end pass of side_effect_score() (side_effects.py:103-130) for every episode in `queue` (what
  * safelife_env.py:183-192 runs inside the step that ends an episode), all on the device and without a host

@@ -521,6 +521,76 @@ int slhip_env_step_slices(const sl_env_batch *env, int n_slices, const int32_t *
     return SL_OK;
 }
 
+// ---- sliced stepping on the library's own AQL queues (sl_aql.hip) ----------------------------------------------------
+namespace {
+struct StepQueues {
+    int n_slices = 0;
+    int32_t bounds[9] = {};
+    int H = 0, W = 0, B = 0;
+};
+}  // namespace
+
+int slhip_queues_open(const sl_env_batch *env, int n_slices, const int32_t *bounds, void **handle) {
+    int rc = check_env(env);
+    if (rc) return rc;
+    if (!handle || !bounds || n_slices < 1 || n_slices > 8) return fail(SL_E_ARG, "bad queue arguments (1 to 8 slices)");
+    if (bounds[0] != 0 || bounds[n_slices] != env->B) return fail(SL_E_ARG, "slice bounds must run from 0 to B");
+    for (int i = 0; i < n_slices; ++i) {
+        if (bounds[i + 1] < bounds[i]) return fail(SL_E_ARG, "slice bounds must not decrease");
+        if (!use_rowlane(env, bounds[i])) return fail(SL_E_UNSUPPORTED, "queue stepping needs the row kernels");
+    }
+    if (env->wrap.flags & SL_WRAP_INACTION)
+        return fail(SL_E_UNSUPPORTED, "the inaction baseline is a launch of its own: HIP streams only");
+    if (const char *why = sl::aql_open(n_slices)) return fail(SL_E_UNSUPPORTED, std::string("AQL queues unavailable: ") + why);
+    if (const char *why = sl::aql_probe(sl::rowlane_probe_function()))
+        return fail(SL_E_UNSUPPORTED, std::string("AQL queues unavailable: ") + why);
+    StepQueues *c = new StepQueues;
+    c->n_slices = n_slices;
+    c->H = env->H;
+    c->W = env->W;
+    c->B = env->B;
+    memcpy(c->bounds, bounds, sizeof(int32_t) * (n_slices + 1));
+    *handle = c;
+    return SL_OK;
+}
+
+int slhip_queues_step(void *handle, const sl_env_batch *env, const int32_t *actions, int head) {
+    StepQueues *c = (StepQueues *)handle;
+    if (!c || !env || !actions) return fail(SL_E_ARG, "null pointer");
+    if (env->H != c->H || env->W != c->W || env->B != c->B) return fail(SL_E_ARG, "the queues were opened for another batch");
+    const sl::Jump *jump;
+    int rc;
+    if ((rc = jump_table(&jump))) return rc;
+    struct Batch {
+        Batch() { sl::aql_begin(); }
+        ~Batch() { sl::aql_commit(); }
+    } batch;
+    for (int i = 0; i < c->n_slices; ++i) {
+        const int n = c->bounds[i + 1] - c->bounds[i];
+        if (n == 0) continue;
+        const sl::AqlLaunch a{i, head != 0};
+        const hipError_t err = sl::launch_env_rollout_rowlane(*env, c->bounds[i], n, actions, 1, env->B, nullptr, nullptr,
+                                                              jump, nullptr, &a);
+        if (err != hipSuccess) return hip_fail(err, "AQL dispatch");
+    }
+    return SL_OK;
+}
+
+int slhip_queues_sync(void *handle) {
+    StepQueues *c = (StepQueues *)handle;
+    if (!c) return fail(SL_E_ARG, "null pointer");
+    const hipError_t err = sl::aql_fence(c->n_slices);
+    return err == hipSuccess ? SL_OK : hip_fail(err, "AQL fence");
+}
+
+int slhip_queues_close(void *handle) {
+    StepQueues *c = (StepQueues *)handle;
+    if (!c) return SL_OK;
+    (void)sl::aql_fence(c->n_slices);
+    delete c;
+    return SL_OK;
+}
+
 // ---- the records of every rank's envs -> rank 0 (RCCL point-to-point calls; helpers above) ----------------------
 int slhip_gather_unique_id(void *id_out) {
     if (!id_out) return fail(SL_E_ARG, "null pointer");

@@ -56,9 +56,26 @@ hipError_t launch_se_distributions(const sl_env_batch &env, const sl_episode_que
                                    hipStream_t stream);
 // envs [e_first, e_first + e_count) of the batch; actions / reward_t / done_t are indexed [t * tstride + e]
 // with the env's index in the whole batch
+// aql (optional): dispatch on one of the library's own AQL queues instead of `stream` (sl_aql.hip; T == 1 only)
+struct AqlLaunch {
+    int queue;              // index of the queue (one per slice)
+    bool head;              // first step after work of HIP streams: system-scope acquire
+};
 hipError_t launch_env_rollout_rowlane(const sl_env_batch &env, int e_first, int e_count, const int32_t *actions,
                                       int T, int tstride, float *reward_t, uint8_t *done_t, const Jump *jump,
-                                      hipStream_t stream);
+                                      hipStream_t stream, const AqlLaunch *aql = nullptr);
+
+// sl_aql.hip : user-mode queues of the library's own next to HIP's streams
+const char *aql_open(int n_queues);                 // null when usable, else why not
+const char *aql_probe(hipFunction_t f);             // can HIP's kernel `f` be found in the HSA executables? (null: yes)
+hipFunction_t rowlane_probe_function();             // any kernel of the library (sl_rowlane.hip)
+hipError_t aql_dispatch(const AqlLaunch &a, hipFunction_t f, unsigned grid, unsigned threads, unsigned lds,
+                        const void *args, size_t arg_bytes);
+void aql_begin();                                   // dispatches between begin and commit go out together
+void aql_commit();                                  // (one flush of their argument blocks)
+// a barrier packet with a system-scope release behind everything dispatched on queues [0, n_queues), waited for
+// by the calling thread
+hipError_t aql_fence(int n_queues);
 
 // the same for envs [e_first, e_first + e_count) on the row kernels (also writes wrap.inaction_rows)
 hipError_t launch_inaction_rowlane(const sl_env_batch &env, int e_first, int e_count, const Jump *jump, hipStream_t stream);

@@ -2108,7 +2108,9 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     BoardBox *box = (BoardBox *)(smem + Gm::OFF_BOX);
     // goal colours of the lane's row, pre-shifted for the score index: in registers where the
     // budget allows (spawner-free variants; 64-wide boards run 2 waves/SIMD), else in LDS
-    constexpr bool GSH_REG = !SPAWN || Gm::WAVES_PER_SIMD < 4;
+    // (the single-step instantiations of the spawner variants have the registers too -- 114 -> 125-128 VGPRs, no
+    //  scratch: C4's share 9.78 -> 9.63 us per two-slice step in a same-box A/B)
+    constexpr bool GSH_REG = !SPAWN || Gm::WAVES_PER_SIMD < 4 || (ONE && !WRAP);
     u32 gsh_reg[GSH_REG ? WS : 1];
     u32 *gsh_lane = GSH_REG ? gsh_reg : (u32 *)(smem + Gm::OFF_GSH) + (wave * 64 + lane) * WS;
     const int8_t *lds_lut = (const int8_t *)(smem + Gm::OFF_LUT);
@@ -2810,7 +2812,7 @@ hipError_t launch_occupancy_t(const u16 *in, int32_t *counts, size_t counts_stri
 template <int H, int W>
 hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, const int32_t *actions, int T,
                                    int tstride, float *reward_t, uint8_t *done_t, const Jump *jump,
-                                   hipStream_t stream) {
+                                   hipStream_t stream, const AqlLaunch *aql) {
     using Gm = Geom<H, W>;
     const bool lean = !env.wrap.flags && !env.obs && !env.policy_obs && env.finished.capacity == 0;
     const int variant = (env.n_tables == 1 ? 1 : 0) | (env.spawner_free ? 2 : 0) | (env.wrap.flags ? 4 : (lean ? 8 : 0));
@@ -2873,10 +2875,13 @@ hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, c
             const Jump *jump;
         } args = {env.board, env.goals, env.rng, env.scalars, env.score_lut, actions, e_first, e_first + e_count, env,
                   env.E, tstride, T, env.out, reward_t, done_t, env.wrap.shaped_reward_t, jump};
+        // one of the library's own queues instead of a HIP stream (sl_aql.hip): same kernel, same argument block
+        if (aql) return T == 1 ? aql_dispatch(*aql, f, grid, threads, (unsigned)lds, &args, sizeof(args)) : hipErrorInvalidValue;
         size_t size = sizeof(args);
         void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
         return hipModuleLaunchKernel(f, grid, 1, 1, threads, 1, 1, (unsigned)lds, stream, nullptr, extra);
     }
+    if (aql) return hipErrorNotSupported;
     hipLaunchKernelGGL(fn, dim3(grid), dim3(threads), lds, stream, env.board, env.goals, env.rng, env.scalars,
                        env.score_lut, actions, e_first, e_first + e_count, env, env.E, tstride, T, env.out, reward_t,
                        done_t, env.wrap.shaped_reward_t, jump);
@@ -2901,7 +2906,7 @@ hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, c
                                                             hipStream_t);                                                  \
     PREFIX template hipError_t rl::launch_inaction_t<h, w>(const sl_env_batch &, int, int, const Jump *, hipStream_t);     \
     PREFIX template hipError_t rl::launch_rollout_t<h, w>(const sl_env_batch &, int, int, const int32_t *, int, int,      \
-                                                          float *, uint8_t *, const Jump *, hipStream_t);
+                                                          float *, uint8_t *, const Jump *, hipStream_t, const AqlLaunch *);
 #ifdef SL_ROWLANE_PART
 #define X(h, w) SL_ROWLANE_LAUNCHERS(, h, w)
 #if SL_ROWLANE_PART == 1
@@ -2963,6 +2968,15 @@ hipError_t launch_occupancy_rowlane(const u16 *in, int32_t *counts, size_t count
     return hipErrorInvalidValue;
 }
 
+hipFunction_t rowlane_probe_function() {
+    hipFunction_t f = nullptr;
+    if (hipGetFuncBySymbol(&f, (const void *)rl::k_build_score_lut) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return f;
+}
+
 hipError_t launch_inaction_rowlane(const sl_env_batch &env, int e_first, int e_count, const Jump *jump, hipStream_t stream) {
 #define X(h, w) if (env.H == h && env.W == w) return rl::launch_inaction_t<h, w>(env, e_first, e_count, jump, stream);
     SL_ROWLANE_SHAPES(X)
@@ -2972,8 +2986,8 @@ hipError_t launch_inaction_rowlane(const sl_env_batch &env, int e_first, int e_c
 
 hipError_t launch_env_rollout_rowlane(const sl_env_batch &env, int e_first, int e_count, const int32_t *actions,
                                       int T, int tstride, float *reward_t, uint8_t *done_t, const Jump *jump,
-                                      hipStream_t stream) {
-#define X(h, w) if (env.H == h && env.W == w) return rl::launch_rollout_t<h, w>(env, e_first, e_count, actions, T, tstride, reward_t, done_t, jump, stream);
+                                      hipStream_t stream, const AqlLaunch *aql) {
+#define X(h, w) if (env.H == h && env.W == w) return rl::launch_rollout_t<h, w>(env, e_first, e_count, actions, T, tstride, reward_t, done_t, jump, stream, aql);
     SL_ROWLANE_SHAPES(X)
 #undef X
     return hipErrorInvalidValue;

@@ -80,6 +80,9 @@ class RewardGather(object):
         self._slot_ptr = [[b.data_ptr() + self.RECORD_BYTES * slot * B for slot in range(self.every)]
                           for b in self.buf]
         self._comm = None
+        self.queued = False           # the caller steps through env.step_queues(): the windows are written from the
+                                      # library's AQL queues, ordered against the exchange by the HOST (queues_sync /
+                                      # a blocking query) instead of by stream waits
         self._join_ev = []
         if self.collective and self.backend == "rccl":
             self._init_rccl()
@@ -138,6 +141,8 @@ class RewardGather(object):
     def _issue(self, which):
         from . import _hip
         torch = self.torch
+        if self.queued:
+            self.env.queues_sync()     # the window is complete and visible before the exchange reads it
         streams = self._writer_streams()
         self.windows += 1
         if self.backend == "rccl":
@@ -167,6 +172,11 @@ class RewardGather(object):
         """`streams` wait (stream-level) for the exchange of buffer `which`."""
         if self.backend == "rccl":
             # (a window later the exchange has long finished: one query instead of a stream wait per writer)
+            if self.busy[which] and self.queued:
+                done = C.c_int(0)
+                from . import _hip
+                _hip.check(self._lib.slhip_gather_done(self._comm, self._ticket[which], 1, C.byref(done)))
+                return
             if self.busy[which] and streams:
                 done = C.c_int(0)
                 from . import _hip
@@ -185,6 +195,8 @@ class RewardGather(object):
         for st in streams:
             with torch.cuda.stream(st):
                 work.wait()
+            if self.queued:
+                st.synchronize()
 
     def prime(self):
         """One throw-away exchange of each (empty) window buffer: the first one of a communicator sets up its
@@ -237,6 +249,8 @@ class RewardGather(object):
             return None
         if self.work[self.last] is not None or self.busy[self.last]:
             self._wait(self.last, [self.torch.cuda.current_stream()] if self.cuda else [])
+        elif self.queued:
+            self.env.queues_sync()
         elif self.cuda and getattr(self.env, "slices", 1) > 1:
             self.env.join()                                 # no exchange in flight: the window sits on the slice streams
         if self.recv is not None:

@@ -14,6 +14,7 @@ All state lives in HBM in torch tensors (buffer holders); the arithmetic is in
 libsafelife_hip.so.  Nothing here falls back to the CPU.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -278,6 +279,8 @@ class SafeLifeVectorEnv(object):
         self._slice_streams = self._pick_streams(n_sl) if n_sl > 1 else []
         self._async_pending = False      # step_async() left work on the slice streams that the caller has not joined
         self._caller_ahead = True        # the caller's stream holds work the slice streams have not been fenced against
+        self._queues = None              # step_queues(): the library's own AQL queues (opened on first use)
+        self._queues_pending = False     # steps dispatched there since the last queues_sync()
         self._stream_ptrs = (C.c_void_p * max(1, n_sl))(*[st.cuda_stream for st in self._slice_streams])
         self._primary_ptr = C.c_void_p(self._primary.cuda_stream)
         rc = self._lib.slhip_env_prepare(self._sref, _hip.current_stream_ptr())
@@ -429,9 +432,78 @@ class SafeLifeVectorEnv(object):
         self._async_pending = False
 
     def _settle(self):
-        """Before the env is touched on the caller's stream: join the slices if step_async() left work on them."""
+        """Before the env is touched on the caller's stream: join the slices if step_async() left work on them, and
+        wait for the steps step_queues() dispatched."""
         if self._async_pending:
             self.join()
+        if self._queues_pending:
+            # (what follows on the caller's stream -- even a read -- is not ordered against later queue steps: the next
+            #  one waits for the streams first)
+            self.queues_sync()
+            self._caller_ahead = True
+
+    # ---- sliced stepping on the library's own AQL queues (csrc/sl_aql.hip, slhip_queues_*): what step_async() does
+    # ---- with stream slices, without HIP's per-launch host cost -- three to six slices per step become affordable
+
+    def queues_open(self, slices=None):
+        """Open one AQL queue per slice (default: SAFELIFE_QUEUE_SLICES or 4).  Raises SafeLifeHipError when the
+        batch or the runtime does not support it -- callers keep to step_async() then."""
+        if self._queues is not None:
+            return
+        B = self.num_envs
+        n = int(slices if slices is not None else os.environ.get("SAFELIFE_QUEUE_SLICES", "4"))
+        n = max(1, min(n, 8, (B + 63) // 64))
+        per = -(-(-(-B // n)) // 64) * 64
+        bounds = [min(B, i * per) for i in range(n)] + [B]
+        handle = C.c_void_p()
+        _hip.check(self._lib.slhip_queues_open(self._sref, n, (C.c_int32 * (n + 1))(*bounds), C.byref(handle)))
+        self._queues, self.queue_slices = handle, n
+
+    def step_queues(self, actions):
+        """One step per env, one dispatch per slice on the slice's own AQL queue.  `actions` as for step_async(),
+        complete when the call is made.  Outputs and state may be read (by the host or by any stream) only after
+        ``queues_sync()``; every method of this class that touches the env does that itself."""
+        if isinstance(actions, int):
+            ptr = actions
+        else:
+            if (actions.dtype != self.torch.int32 or not actions.is_contiguous() or actions.numel() != self.num_envs
+                    or actions.device != self.device):
+                raise ValueError("step_queues() takes a contiguous int32 tensor [num_envs] on the env's device "
+                                 "(or its address); got %s %s on %s" % (actions.dtype, tuple(actions.shape), actions.device))
+            ptr = actions.data_ptr()
+        if self._queues is None:
+            self.queues_open()
+        head = 0
+        if self._caller_ahead or self._async_pending:
+            # HIP streams have touched the envs since the queues last ran (a reset, step(), rollout() ...): their work
+            # is waited for here, and the step goes out with a system-scope acquire
+            if self._async_pending:
+                self.join()
+            self.torch.cuda.synchronize(self.device)
+            self._caller_ahead = False
+            head = 1
+        rc = self._lib.slhip_queues_step(self._queues, self._sref, ptr, head)
+        if rc:
+            _hip.check(rc)
+        self._queues_pending = True
+
+    def queues_sync(self):
+        """Wait for every step dispatched on the queues so far (system-scope release behind them): afterwards their
+        outputs and the envs' state are visible to the host and to every HIP stream."""
+        self._queues_pending = False
+        if self._queues is not None:
+            _hip.check(self._lib.slhip_queues_sync(self._queues))
+
+    def queues_close(self):
+        if self._queues is not None:
+            self._lib.slhip_queues_close(self._queues)
+            self._queues, self._queues_pending = None, False
+
+    def __del__(self):
+        try:
+            self.queues_close()
+        except Exception:
+            pass
 
     def step_async(self, actions):
         """One step per env, one launch per slice on the slice's own stream; nothing is fenced.  `actions`:

@@ -889,6 +889,92 @@ def test_sliced_stepping_soak(pool_name, B):
                 assert np.array_equal(env.numpy(name), ref), (trial, n, name)
 
 
+def _queues_or_skip(env, slices=None):
+    from safelife_amd._hip import SafeLifeHipError
+    try:
+        env.queues_open(slices)
+    except SafeLifeHipError as e:           # no HSA queue to be had (not an MI355X box as the driver's): say why
+        pytest.skip("AQL queues unavailable: %s" % e)
+
+
+@pytest.mark.parametrize("pool_name,B,queue_slices,kw", [
+    ("prune_still_25", 700, 1, dict(time_limit=12, view_shape=(9, 9))),
+    ("append_spawn_25", 1500, 4, dict(time_limit=20, view_shape=(25, 25), output_channels=tuple(range(15)))),
+    ("navigation_64", 300, 2, dict(time_limit=15, view_shape=(15, 15), with_obs=False)),
+    ("prune_still_25", 333, 3, dict(time_limit=9, view_shape=(5, 7), wrappers=TRAINING_WRAPPERS)),
+])
+def test_queue_stepping_vs_oracle(pool_name, B, queue_slices, kw):
+    """slhip_queues_*: the slices of a step dispatched from the library's own AQL queues instead of HIP streams (same
+    kernel, found in HIP's executables; barrier bit + agent-scope fences for ordering).  A synchronised step at a time
+    against the oracle (reward, done), then runs of unsynchronised steps against the same oracle steps, with a reset
+    through a HIP stream in the middle (the next queue step takes a system-scope acquire)."""
+    import torch
+    pool, _ = util.pool_from_fixture(pool_name, _device_counts, min_performance_fraction=0.05)
+    first = (np.arange(B) * 3) % len(pool)
+    common = dict(first_level=first, auto_reset=True, level_stride=5, **kw)
+    dev = util.DeviceBackend(pool, B, **common)
+    cpu = util.OracleBackend(pool, B, **common)
+    env = dev.env
+    _queues_or_skip(env, queue_slices)
+    dev.env.reset()
+    cpu.env.reset()
+    rng = np.random.default_rng(31)
+    acts = rng.integers(0, 9, (130, B)).astype(np.int32)
+    d_acts = torch.from_numpy(acts).to(env.device)
+    torch.cuda.synchronize()
+    t = 0
+    for _ in range(25):
+        env.step_queues(d_acts[t])
+        cpu.env.step(acts[t])
+        env.queues_sync()
+        assert np.array_equal(env.numpy("reward"), cpu.get("reward")) and np.array_equal(env.numpy("done"), cpu.get("done")), t
+        t += 1
+    for run in (40, 5, 60):
+        for _ in range(run):
+            env.step_queues(d_acts[t])
+            cpu.env.step(acts[t])
+            t += 1
+        for name in ENV_STATE:
+            assert np.array_equal(dev.get(name), cpu.get(name)), (run, name)
+        if kw.get("with_obs", True):
+            assert np.array_equal(env.numpy("obs"), cpu.env.obs)
+        if "wrappers" in kw:
+            assert np.array_equal(env.shaped_reward.cpu().numpy(), cpu.env.wa["shaped_reward"])
+        if run == 5:                            # a reset on the caller's stream: the queues start again behind it
+            mask = (np.arange(B) % 3 == 0).astype(np.uint8)
+            dev.env.reset(mask)
+            cpu.env.reset(mask)
+    assert cpu.get("episode_idx").min() >= 1
+
+
+def test_queue_stepping_soak():
+    """Many unsynchronised queue steps at the bench's size (8192 envs; two, four and six queues, several runs) against
+    the one-launch env on the same actions: boards, generators, episode state of every env."""
+    import torch
+    from safelife_amd.vector_env import SafeLifeVectorEnv
+    B, T = 8192, 300
+    pool, _ = util.pool_from_fixture("prune_still_25", _device_counts, min_performance_fraction=0.05)
+    first = (np.arange(B) * 3) % len(pool)
+    kw = dict(first_level=first, auto_reset=True, level_stride=5, time_limit=40, view_shape=(15, 15), with_obs=False)
+    acts = torch.from_numpy(np.random.default_rng(6).integers(0, 9, (T, B)).astype(np.int32)).to("cuda")
+    whole = SafeLifeVectorEnv(pool, B, **kw)
+    whole.reset()
+    for t in range(T):
+        whole.step_async(acts[t])
+    names = ("board", "goals", "rng", "agent_loc", "episode_idx", "level_idx", "episode_reward", "num_steps")
+    want = {name: whole.numpy(name) for name in names}
+    for trial in range(2):
+        for n in (2, 4, 6):
+            env = SafeLifeVectorEnv(pool, B, **kw)
+            _queues_or_skip(env, n)
+            env.reset()
+            for t in range(T):
+                env.step_queues(acts[t])
+            for name, ref in want.items():
+                assert np.array_equal(env.numpy(name), ref), (trial, n, name)
+            env.queues_close()
+
+
 def test_manual_reset_moves_on_and_episode_streams():
     """auto_reset=False, the flow of INTEGRATION.md section 3: the driver resets finished envs itself.  Every such
     reset takes the env's NEXT pool level (SafeLifeEnv.reset() -> next(level_iterator)) and, with

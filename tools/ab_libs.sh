@@ -6,7 +6,7 @@ for rep in 1 2 3; do
   for lib in "$A" "$B"; do
     for k in 400 20; do
       w=$([ $k = 400 ] && echo 40 || echo 5)
-      line=$(SAFELIFE_HIP_LIB_ANY_ABI=1 SAFELIFE_HIP_LIB=$PWD/$lib timeout 200 python bench.py --steps $k --warmup $w --extras 0 --rollout 0 --cpu-baseline 0 --chain off "$@" 2>/dev/null | tail -1)
+      line=$(SAFELIFE_HIP_LIB_ANY_ABI=1 SAFELIFE_HIP_LIB=$PWD/$lib timeout 200 python bench.py --steps $k --warmup $w --extras 0 --rollout 0 --cpu-baseline 0 "$@" 2>/dev/null | tail -1)
       python3 -c "
 import json,sys
 d=json.loads(sys.argv[1]); r=d['roofline']
