@@ -411,6 +411,7 @@ def main():
     t_c = time.perf_counter()
     if use_queues:
         env.queues_sync()          # the queues' closing barrier packets (system-scope release), waited for here
+    t_d = time.perf_counter()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -422,9 +423,9 @@ def main():
         print("per-step host us (t, before, step, after):", " ".join("%d:%.0f/%.0f/%.0f" % x for x in step_host[-K:]),
               file=sys.stderr)
     if dbg:
-        print("timeline us: enqueue loop %.1f | e1 record %.1f | flush %.1f | synchronize %.1f | total %.1f"
-              % ((t_enqueued - t_start) * 1e6, (t_b - t_enqueued) * 1e6, (t_c - t_b) * 1e6,
-                 (t_start + elapsed - t_c) * 1e6, elapsed * 1e6), file=sys.stderr)
+        print("timeline us: enqueue loop %.1f | e1 record %.1f | flush %.1f | queues_sync %.1f | synchronize %.1f | total %.1f"
+              % ((t_enqueued - t_start) * 1e6, (t_b - t_enqueued) * 1e6, (t_c - t_b) * 1e6, (t_d - t_c) * 1e6,
+                 (t_start + elapsed - t_d) * 1e6, elapsed * 1e6), file=sys.stderr)
     # device time per step: every slice stream runs its K launches back to back, all streams concurrently
     slice_ms = [e0.elapsed_time(e1) / K for e0, e1 in evs]
     kernel_ms = max(slice_ms)
