@@ -545,10 +545,12 @@ __device__ pl::Pl<NW> resolve_draws_planes(const pl::Pl<NW> &elig, u64 *rng_lds,
     for (int i = 0; i < NW; ++i) mine += __popc(elig.w[i]);
     const int incl = wave_scan(mine);
     int before = 0, total = 0;
+    int tot_q[Gm::G];                   // (wave-uniform) draws of each of the wave's boards
 #pragma unroll
     for (int q = 0; q < Gm::G; ++q) {
         const int lo = q ? __builtin_amdgcn_readlane(incl, LaneMap<H, W>::first_lane(q) - 1) : 0;
         const int hi = __builtin_amdgcn_readlane(incl, LaneMap<H, W>::last_lane(q));
+        tot_q[q] = hi - lo;
         if (g == q) {
             before = lo;
             total = hi - lo;
@@ -556,6 +558,14 @@ __device__ pl::Pl<NW> resolve_draws_planes(const pl::Pl<NW> &elig, u64 *rng_lds,
     }
     const int excl = incl - mine - before;
     const U128 st = {rng_lds[4 * g + 0], rng_lds[4 * g + 1]}, inc = {rng_lds[4 * g + 2], rng_lds[4 * g + 3]};
+    // two boards per wave: lanes 0-31 make the draws of board 0, lanes 32-63 those of board 1 (below), whatever
+    // rows they hold
+    const int wq = Gm::G == 2 ? (int)(__lane_id() >> 5) : 0;
+    U128 wst = st, winc = inc;
+    if constexpr (Gm::G == 2) {
+        wst = {rng_lds[4 * wq + 0], rng_lds[4 * wq + 1]};
+        winc = {rng_lds[4 * wq + 2], rng_lds[4 * wq + 3]};
+    }
     wave_sync();     // every lane has read the old state before a leader replaces it
     pl::Pl<NW> ok;
 #pragma unroll
@@ -598,6 +608,69 @@ __device__ pl::Pl<NW> resolve_draws_planes(const pl::Pl<NW> &elig, u64 *rng_lds,
             const int log2per = 5 - log2c;
             const u32 d0 = bperm(4 * min(63, w0 << log2per), v), d1 = bperm(4 * min(63, (w0 + 1) << log2per), v);
             const u32 d2 = bperm(4 * min(63, (w0 + 2) << log2per), v);
+            u64 R = (((u64)d1 << 32) | d0) >> sh;
+            if (sh) R |= (u64)d2 << (64 - sh);
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                u32 todo = elig.w[i], got = 0;
+                while (todo) {
+                    const u32 bit = todo & (0u - todo);
+                    got |= (R & 1ull) ? bit : 0u;
+                    R >>= 1;
+                    todo ^= bit;
+                }
+                ok.w[i] = got;
+            }
+            wave_sync();
+            return ok;
+        }
+    }
+    if constexpr (Gm::G == 2) {
+        // Two boards per wave (25x25, 26x26): the same even deal, each board's draws over a 32-lane half of the wave
+        // -- the cells that draw sit around a few spawner clusters, i.e. in a few rows, and row by row the wave would
+        // loop as often as its busiest row has such cells.  Lane j of half q makes draws [j c, (j + 1) c) of board
+        // q (one c for both boards); the xor swizzles stay inside a half; a row's lane pulls its dwords from the
+        // half of its OWN board.
+        const int tmax = max(tot_q[0], tot_q[1]);
+        if (tmax <= 32 * 32) {
+            const int lane = (int)__lane_id(), j = lane & 31;
+            const int need = (tmax + 31) >> 5;
+            const int log2c = need <= 1 ? 0 : 32 - __clz(need - 1);            // c = 2^log2c >= tmax / 32
+            const int total_w = wq ? tot_q[1] : tot_q[0];
+            const int first = j << log2c;
+            const int n_here = min(max(total_w - first, 0), 1 << log2c);
+            // (the threshold is the BOARD's: taken from a lane that holds one of its rows)
+            const u32 tl0 = __builtin_amdgcn_readlane((u32)thr, LaneMap<H, W>::first_lane(0) + 1);
+            const u32 th0 = __builtin_amdgcn_readlane((u32)(thr >> 32), LaneMap<H, W>::first_lane(0) + 1);
+            const u32 tl1 = __builtin_amdgcn_readlane((u32)thr, LaneMap<H, W>::first_lane(1) + 1);
+            const u32 th1 = __builtin_amdgcn_readlane((u32)(thr >> 32), LaneMap<H, W>::first_lane(1) + 1);
+            const u64 wthr = wq ? (((u64)th1 << 32) | tl1) : (((u64)th0 << 32) | tl0);
+            u32 bits = 0;
+            if (n_here > 0) {
+                U128 cur = pcg_jump(jump, first, wst, winc);
+                for (int i = 0; i < n_here; ++i) {
+                    cur = pcg_step(cur, winc);
+                    bits |= (pcg_output_u53(cur) < wthr ? 1u : 0u) << i;        // advance_board.c:115
+                }
+                if (first + n_here == total_w) {    // the lane that made the board's last draw holds its new state
+                    rng_lds[4 * wq + 0] = cur.hi;
+                    rng_lds[4 * wq + 1] = cur.lo;
+                }
+            }
+            const int per = 32 >> log2c;                                        // lanes per dword of outcomes
+            u32 v = bits << ((lane & (per - 1)) << log2c);
+            if (per > 1) v |= (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x041F);      // xor 1
+            if (per > 2) v |= (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x081F);      // xor 2
+            if (per > 4) v |= (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x101F);      // xor 4
+            if (per > 8) v |= (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x201F);      // xor 8
+            if (per > 16) v |= (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);     // xor 16
+            // dword d of board q's outcome string sits in lanes [32 q + d per, 32 q + (d + 1) per)
+            const int w0 = excl >> 5, sh = excl & 31;
+            const int log2per = 5 - log2c;
+            const int base = 32 * g;
+            const u32 d0 = bperm(4 * (base + min(31, w0 << log2per)), v);
+            const u32 d1 = bperm(4 * (base + min(31, (w0 + 1) << log2per)), v);
+            const u32 d2 = bperm(4 * (base + min(31, (w0 + 2) << log2per)), v);
             u64 R = (((u64)d1 << 32) | d0) >> sh;
             if (sh) R |= (u64)d2 << (64 - sh);
 #pragma unroll
@@ -2108,9 +2181,10 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     BoardBox *box = (BoardBox *)(smem + Gm::OFF_BOX);
     // goal colours of the lane's row, pre-shifted for the score index: in registers where the
     // budget allows (spawner-free variants; 64-wide boards run 2 waves/SIMD), else in LDS
-    // (the single-step instantiations of the spawner variants have the registers too -- 114 -> 125-128 VGPRs, no
-    //  scratch: C4's share 9.78 -> 9.63 us per two-slice step in a same-box A/B)
-    constexpr bool GSH_REG = !SPAWN || Gm::WAVES_PER_SIMD < 4 || (ONE && !WRAP);
+    // (and the LEAN single-step instantiation of the spawner variant where it fits: 114 -> 125 VGPRs at 25x25, C4's
+    //  share 9.6 -> 9.25 us per two-slice step on top of the even deal of the draws; the non-LEAN one and 26x26 tip
+    //  into 8 bytes of scratch with it and keep the words in LDS)
+    constexpr bool GSH_REG = !SPAWN || Gm::WAVES_PER_SIMD < 4 || (ONE && LEAN && W <= 25);
     u32 gsh_reg[GSH_REG ? WS : 1];
     u32 *gsh_lane = GSH_REG ? gsh_reg : (u32 *)(smem + Gm::OFF_GSH) + (wave * 64 + lane) * WS;
     const int8_t *lds_lut = (const int8_t *)(smem + Gm::OFF_LUT);
