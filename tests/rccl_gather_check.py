@@ -2,7 +2,8 @@
 SafeLifeVectorEnv (two slices) + RewardGather with the exchange forced on for a single rank -- the library's own
 RCCL entry points (slhip_gather_*: rank 0 sends to and receives from itself inside one RCCL group, on the gather's
 side stream).  Two phases: step_async() (the windows are written on the slice streams) and step() on the SAME
-sliced env (one launch on the caller's stream: the gather has to follow the writer)."""
+sliced env (one launch on the caller's stream: the gather has to follow the writer), then step_queues() (the
+library's AQL queues: host-side ordering)."""
 import os
 import sys
 
@@ -64,6 +65,32 @@ for t in range(T, 2 * T):
         rw, dn = gather.latest()
         assert np.array_equal(rw[0].cpu().numpy(), np.stack(want_r[-every:])), t
         assert np.array_equal(dn[0].cpu().numpy(), np.stack(want_d[-every:])), t
+# phase 3: the same env stepped from the library's own AQL queues (slhip_queues_*): the windows are ordered against
+# the exchange by the host (queues_sync before a window is handed over, a blocking query before it is reused)
+gather.flush()
+torch.cuda.synchronize()
+try:
+    env.queues_open(3)
+    queued = True
+except _hip.SafeLifeHipError as e:
+    print("queues unavailable:", e)
+    queued = False
+if queued:
+    gather.queued = True
+    for t in range(2 * T, 3 * T):
+        a = torch.from_numpy(rng.integers(0, 9, B).astype(np.int32)).to(dev)
+        torch.cuda.synchronize()
+        gather.before_step(t)
+        env.step_queues(a)
+        gather.after_step(t)
+        ref.step(a)
+        want_r.append(ref.numpy("reward"))
+        want_d.append(ref.numpy("done"))
+        if t % every == every - 1:
+            rw, dn = gather.latest()
+            assert np.array_equal(rw[0].cpu().numpy(), np.stack(want_r[-every:])), t
+            assert np.array_equal(dn[0].cpu().numpy(), np.stack(want_d[-every:])), t
+    gather.queued = False
 gather.flush()
 torch.cuda.synchronize()
 assert np.array_equal(env.numpy("board"), ref.numpy("board"))
