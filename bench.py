@@ -236,7 +236,7 @@ def gather_window(requested, steps):
     return max(1, min(int(requested), int(steps)))     # (any `every` <= steps consecutive steps hold a step = every-1 mod every)
 
 
-DEFAULT_QUEUES = "0"       # slices on AQL queues by default (0: HIP-stream slices)
+DEFAULT_QUEUES = "4"       # slices on AQL queues by default (0: HIP-stream slices); see DESIGN 4.1c
 
 
 def main():
@@ -260,6 +260,9 @@ def main():
                          "the same ordering as a stream, without HIP's per-launch host cost); 0: the HIP-stream slices of "
                          "--slices; -1: SAFELIFE_BENCH_QUEUES or the default below, falling back to streams where the "
                          "runtime offers no queue")
+    ap.add_argument("--stream-leg", type=int, default=1,
+                    help="queue stepping only: 1 = also run K steps of the same kernel through the stream slices under HIP "
+                         "events (roofline.launch_ms); 0 = leave it out (profiling runs: only the queues' launches in the trace)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-steps", type=int, default=1001)
     ap.add_argument("--rollout", type=int, default=32,
@@ -398,12 +401,17 @@ def main():
     dbg = os.environ.get("SL_BENCH_DEBUG") == "1"
     # (the start event is enqueued on the idle stream just ahead of the wall clock: the event interval then
     #  covers the whole timed region, and its ~3 us of host time stays out of it)
-    evs[0][0].record(streams[0])
+    # (queue stepping: nothing of the timed region runs on a HIP stream, so no event pair goes onto one -- a marker
+    #  on an otherwise idle stream costs the closing synchronize ~20 us; the pair is used further down, around the
+    #  stream-path run of the same kernel)
+    if not use_queues:
+        evs[0][0].record(streams[0])
     windows0, exposed0 = gather.windows, gather.exposed_s
     t_start = time.perf_counter()
     run(P + W, K)
     t_enqueued = time.perf_counter()
-    evs[0][1].record(streams[0])
+    if not use_queues:
+        evs[0][1].record(streams[0])
     # (completion is left to the synchronize below: polling hipStreamQuery / hipEventQuery first was measured
     #  10-25 us slower over the region -- the polls contend with the runtime's own completion handling)
     t_b = time.perf_counter()
@@ -427,10 +435,11 @@ def main():
               % ((t_enqueued - t_start) * 1e6, (t_b - t_enqueued) * 1e6, (t_c - t_b) * 1e6, (t_d - t_c) * 1e6,
                  (t_start + elapsed - t_d) * 1e6, elapsed * 1e6), file=sys.stderr)
     # device time per step: every slice stream runs its K launches back to back, all streams concurrently
-    slice_ms = [e0.elapsed_time(e1) / K for e0, e1 in evs]
-    kernel_ms = max(slice_ms)
     if use_queues:      # (events on a HIP stream see nothing of the queues' steps: filled in below)
         kernel_ms = elapsed / K * 1e3
+    else:
+        slice_ms = [e0.elapsed_time(e1) / K for e0, e1 in evs]
+        kernel_ms = max(slice_ms)
     per_rank = None
     if world > 1:
         # per-rank breakdown for the scaling run: wall time of the region, device time per step, host enqueue time
@@ -450,7 +459,7 @@ def main():
         threads = max(1, min(16, len(os.sched_getaffinity(0))))
         parity = parity_replay(pool, actions[:P + W + K].cpu().numpy(), B, env, checkpoints, threads)
     stream_wall_ms = None
-    if use_queues:
+    if use_queues and args.stream_leg:
         # the timed steps ran on the library's queues, not on a HIP stream.  The same kernel through the stream
         # slices, K steps under HIP events, gives the per-launch device figure (roofline.launch_ms) next to the
         # queues' wall clock.
@@ -712,7 +721,7 @@ def main():
         try:    # HBM bytes per launch from the committed PMC passes (tools/pmc_run.sh), if they match this run
             with open(os.path.join(REPO, "profiles", "traffic_latest.json")) as f:
                 tj = json.load(f)
-            if tj.get("envs_per_gpu") == B and tj.get("obs") == args.obs and tj.get("slices", 1) == env.slices:
+            if tj.get("envs_per_gpu") == B and tj.get("obs") == args.obs and tj.get("slices", 1) in (env.slices, getattr(env, "queue_slices", 0)):
                 traffic = tj.get("hbm_bytes_per_step", tj["hbm_bytes_per_launch"])      # all launches of one step
         except (OSError, ValueError, KeyError):
             pass
@@ -749,11 +758,11 @@ def main():
                          # device time of one step (HIP events on slice 0's stream over the same region): the slice
                          # launches of a step run concurrently, each stream back to back, so a step costs one
                          # stream's launch-to-launch time
-                         "launch_ms": kernel_ms, "launches_per_step": env.slices,
+                         "launch_ms": kernel_ms, "launches_per_step": env.queue_slices if use_queues else env.slices,
                          "launch_ms_note": ("HIP events over %d steps of the SAME kernel issued through the %d stream "
                                             "slice(s) right after the timed region (wall %.5f ms per step): HIP events "
                                             "cannot see the library's queues" % (K, env.slices, stream_wall_ms))
-                         if use_queues else None,
+                         if stream_wall_ms is not None else None,
                          "achieved_device": achieved_device, "frac_device": achieved_device / HBM_PEAK_GBS,
                          "host_enqueue_ms_per_step": (t_enqueued - t_start) / K * 1e3,
                          "measured_ceiling": ceiling,
