@@ -550,7 +550,26 @@ def main():
             env3.join()
             e1.record()
             torch.cuda.synchronize()
-            return e0.elapsed_time(e1) / n * 1e3
+            us_streams = e0.elapsed_time(e1) / n * 1e3
+            # the same steps through the library's AQL queues (wall clock around n steps + their fence), where the
+            # timed region ran on them
+            env3.last_queues_us = None
+            if use_queues:
+                try:
+                    env3.queues_open(n_queues)
+                    for t in range(20):
+                        env3.step_queues(acts[t])
+                    env3.queues_sync()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for t in range(20, 20 + n):
+                        env3.step_queues(acts[t])
+                    env3.queues_sync()
+                    env3.last_queues_us = (time.perf_counter() - t0) / n * 1e6
+                    env3.queues_close()
+                except _hip.SafeLifeHipError:
+                    pass
+            return us_streams
 
         # C2 (BASELINE configs[1]): advance_board alone on 1024 random 25x25 boards (SURVEY 8d palette-like)
         from safelife_amd import speedups
@@ -602,10 +621,14 @@ def main():
                                                   "called per board from a C loop: no interpreter or wrapper time" % cpu_model())
 
         # the same step with the training wrappers of env_factory.py:277-283 fused in (float64 shaped reward)
-        us = time_steps(SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25), output_channels=TRAIN_CHANNELS,
-                                          auto_reset=True, with_obs=False, slices=args.slices,
-                                          wrappers=dict(movement_bonus=0.1, exit_bonus=0.5, penalty_coef=0.3)), B)
+        envw = SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25), output_channels=TRAIN_CHANNELS,
+                                 auto_reset=True, with_obs=False, slices=args.slices,
+                                 wrappers=dict(movement_bonus=0.1, exit_bonus=0.5, penalty_coef=0.3))
+        us = time_steps(envw, B)
         extra["training_wrappers_us_per_step"] = us
+        if envw.last_queues_us:
+            extra["training_wrappers_queues_us_per_step"] = envw.last_queues_us
+        del envw
         # ... with SimpleSideEffectPenalty's "inaction" baseline (env_wrappers.py:179-180): one more launch per slice
         # and step, a CA step of every env's baseline board
         us = time_steps(SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25), output_channels=TRAIN_CHANNELS,
@@ -618,10 +641,15 @@ def main():
             if not os.path.exists(os.path.join(REPO, "tests", "golden", "pool_%s.npz" % pname)):
                 continue
             p2 = load_pool(pname, _device_counts)
-            us = time_steps(SafeLifeVectorEnv(p2, n_envs, time_limit=1000, view_shape=(25, 25), slices=args.slices,
-                                              output_channels=TRAIN_CHANNELS, auto_reset=True, with_obs=False), n_envs)
+            envc = SafeLifeVectorEnv(p2, n_envs, time_limit=1000, view_shape=(25, 25), slices=args.slices,
+                                     output_channels=TRAIN_CHANNELS, auto_reset=True, with_obs=False)
+            us = time_steps(envc, n_envs)
             extra[tag + "_us_per_step"] = us
             extra[tag + "_env_steps_per_s_per_gpu"] = n_envs / (us * 1e-6)
+            if envc.last_queues_us:
+                extra[tag + "_queues_us_per_step"] = envc.last_queues_us
+                extra[tag + "_queues_env_steps_per_s_per_gpu"] = n_envs / (envc.last_queues_us * 1e-6)
+            del envc
             if pname == "navigation_64":
                 # side_effects.py:109-111 runs life_occupancy(board, n_step=1000) twice at every episode end
                 from safelife_amd import speedups
