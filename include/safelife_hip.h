@@ -328,7 +328,15 @@ int slhip_env_step_slices(const sl_env_batch *env, int n_slices, const int32_t *
  *           state or the actions through a HIP stream: the caller has synchronised those streams, the step is
  *           dispatched with a system-scope acquire.  actions: device int32 [B], complete when the call is made.
  *   sync  : a system-scope release behind every step dispatched so far, waited for by the calling thread; only then
- *           may HIP streams or the host read what the steps wrote. */
+ *           may HIP streams or the host read what the steps wrote.
+ * Fences between the steps of a queue (environment, read by open): SAFELIFE_QUEUE_FENCES=agent gives every step an
+ * agent-scope acquire AND release, exactly a HIP stream's, independent of where workgroups run.  The default leaves the
+ * RELEASE out (it alone costs ~0.9 us of a 7.5 us step of 8192 25x25 envs): what a step wrote then stays in the L2 of
+ * the XCD its workgroups ran on, and the next step's workgroup of the same index reads it there -- which holds as long
+ * as a workgroup index always runs on the same XCD.  That is observed on MI355X but documented nowhere, so it is
+ * RECORDED (every step ORs its XCD into a per-workgroup word, system scope) and CHECKED by a kernel in front of every
+ * sync's fence: a workgroup index that has seen two XCDs makes sync (and every later sync of the handle) return
+ * SL_E_HIP -- the state is then not valid and the caller must start over with SAFELIFE_QUEUE_FENCES=agent. */
 int slhip_queues_open(const sl_env_batch *env, int n_slices, const int32_t *bounds, void **handle);
 int slhip_queues_step(void *handle, const sl_env_batch *env, const int32_t *actions, int head);
 int slhip_queues_sync(void *handle);

@@ -522,11 +522,28 @@ int slhip_env_step_slices(const sl_env_batch *env, int n_slices, const int32_t *
 }
 
 // ---- sliced stepping on the library's own AQL queues (sl_aql.hip) ----------------------------------------------------
+namespace sl {
+// The placement record of release-free stepping (sl_rowlane.hip: every step ORs the XCD it ran on into its workgroup's
+// word): a workgroup index that has seen more than one XCD read state another XCD's L2 still held.
+__global__ void k_xcd_check(const u32 *__restrict__ seen, int n, u32 *__restrict__ flag) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const u32 v = __hip_atomic_load(seen + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (v & (v - 1u)) (void)__hip_atomic_fetch_or(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace sl
+
 namespace {
 struct StepQueues {
     int n_slices = 0;
     int32_t bounds[9] = {};
     int H = 0, W = 0, B = 0;
+    // SAFELIFE_QUEUE_FENCES=agent: every step with agent-scope acquire AND release, as a HIP stream (placement-
+    // independent).  Default: no release between steps, with the placement recorded by the kernels and checked at
+    // every sync (the release alone costs ~0.9 us of a 7.5 us C3 step).
+    bool lite = false;
+    uint32_t *seen = nullptr, *flag = nullptr;
+    hipFunction_t check = nullptr;
 };
 }  // namespace
 
@@ -550,6 +567,28 @@ int slhip_queues_open(const sl_env_batch *env, int n_slices, const int32_t *boun
     c->W = env->W;
     c->B = env->B;
     memcpy(c->bounds, bounds, sizeof(int32_t) * (n_slices + 1));
+    const char *mode = getenv("SAFELIFE_QUEUE_FENCES");
+    c->lite = !(mode && !strcmp(mode, "agent"));
+    if (c->lite) {
+        // (one word per workgroup; a workgroup holds at least one env, and slice i's words start at bounds[i])
+        hipError_t err = hipMalloc((void **)&c->seen, sizeof(uint32_t) * (size_t)(env->B + 1));
+        if (err == hipSuccess) err = hipMemset(c->seen, 0, sizeof(uint32_t) * (size_t)(env->B + 1));
+        // (SAFELIFE_QUEUE_FENCES_SELFTEST=1: the first word starts out with two XCDs in it -- the next sync must refuse)
+        if (err == hipSuccess && getenv("SAFELIFE_QUEUE_FENCES_SELFTEST")) err = hipMemset(c->seen, 3, 1);
+        if (err == hipSuccess) err = hipHostMalloc((void **)&c->flag, 64, hipHostMallocDefault);
+        if (err == hipSuccess) err = hipDeviceSynchronize();
+        if (err == hipSuccess && hipGetFuncBySymbol(&c->check, (const void *)sl::k_xcd_check) != hipSuccess) err = hipErrorNotFound;
+        if (err == hipSuccess && sl::aql_probe(c->check)) err = hipErrorNotFound;
+        if (err != hipSuccess) {
+            (void)hipGetLastError();
+            if (c->seen) (void)hipFree(c->seen);
+            if (c->flag) (void)hipHostFree(c->flag);
+            c->seen = c->flag = nullptr;
+            c->lite = false;                 // (no record, no shortcut)
+        } else {
+            *c->flag = 0;
+        }
+    }
     *handle = c;
     return SL_OK;
 }
@@ -568,7 +607,7 @@ int slhip_queues_step(void *handle, const sl_env_batch *env, const int32_t *acti
     for (int i = 0; i < c->n_slices; ++i) {
         const int n = c->bounds[i + 1] - c->bounds[i];
         if (n == 0) continue;
-        const sl::AqlLaunch a{i, head != 0};
+        const sl::AqlLaunch a{i, head != 0, c->lite ? c->seen + c->bounds[i] : nullptr};
         const hipError_t err = sl::launch_env_rollout_rowlane(*env, c->bounds[i], n, actions, 1, env->B, nullptr, nullptr,
                                                               jump, nullptr, &a);
         if (err != hipSuccess) return hip_fail(err, "AQL dispatch");
@@ -579,14 +618,22 @@ int slhip_queues_step(void *handle, const sl_env_batch *env, const int32_t *acti
 int slhip_queues_sync(void *handle) {
     StepQueues *c = (StepQueues *)handle;
     if (!c) return fail(SL_E_ARG, "null pointer");
-    const hipError_t err = sl::aql_fence(c->n_slices);
-    return err == hipSuccess ? SL_OK : hip_fail(err, "AQL fence");
+    sl::AqlCheck check{c->check, c->seen, c->B, c->flag};
+    const hipError_t err = sl::aql_fence(c->n_slices, c->lite ? &check : nullptr);
+    if (err != hipSuccess) return hip_fail(err, "AQL fence");
+    if (c->lite && *(volatile uint32_t *)c->flag)
+        return fail(SL_E_HIP, "queue stepping: a workgroup index ran on more than one XCD, so a step without a release "
+                              "fence may have read stale state -- the envs' state since the queues were opened is not "
+                              "valid; set SAFELIFE_QUEUE_FENCES=agent");
+    return SL_OK;
 }
 
 int slhip_queues_close(void *handle) {
     StepQueues *c = (StepQueues *)handle;
     if (!c) return SL_OK;
     (void)sl::aql_fence(c->n_slices);
+    if (c->seen) (void)hipFree(c->seen);
+    if (c->flag) (void)hipHostFree(c->flag);
     delete c;
     return SL_OK;
 }

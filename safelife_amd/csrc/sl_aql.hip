@@ -128,6 +128,8 @@ struct Device {
     std::unordered_map<hipFunction_t, KernelInfo> kernels;
     hsa_ven_amd_loader_1_03_pfn_t loader{};
     int readback = 1;       // SL_AQL_READBACK=0 (A/B only): no read-back after writing arguments into device memory
+    int step_acquire = HSA_FENCE_SCOPE_AGENT, step_release = HSA_FENCE_SCOPE_AGENT;   // SL_AQL_STEP_ACQUIRE / _RELEASE
+                            // (A/B only: anything below agent scope makes the results depend on where workgroups run)
     std::mutex mu;
     // dispatches of one step, written but not yet published (aql_begin ... aql_commit): their argument blocks are
     // flushed together, then the packets go out
@@ -258,6 +260,8 @@ void open_device(Device &d, int dev) {
         return;
     }
     d.readback = env_int("SL_AQL_READBACK", 1);
+    d.step_acquire = env_int("SL_AQL_STEP_ACQUIRE", HSA_FENCE_SCOPE_AGENT);
+    d.step_release = env_int("SL_AQL_STEP_RELEASE", HSA_FENCE_SCOPE_AGENT);
     d.ok = true;
 }
 
@@ -406,16 +410,14 @@ const char *aql_probe(hipFunction_t f) {
     return kernel_info(*d, f) ? nullptr : "HIP's kernels were not found in the HSA runtime's executables";
 }
 
-hipError_t aql_dispatch(const AqlLaunch &a, hipFunction_t f, unsigned grid, unsigned threads, unsigned lds,
-                        const void *args, size_t arg_bytes) {
-    Device *d = current();
-    if (!d || !d->ok || a.queue < 0 || a.queue >= d->n_queues) return hipErrorNotInitialized;
-    const Hsa &h = hsa();
-    std::lock_guard<std::mutex> lock(d->mu);
-    const KernelInfo *k = kernel_info(*d, f);
+namespace {
+// one kernel dispatch packet on `queue` (the caller holds d.mu); hd: the packet header, completion: its signal or {0}
+hipError_t emit(Device &d, const Hsa &h, int queue, hipFunction_t f, unsigned grid, unsigned threads, unsigned lds,
+                const void *args, size_t arg_bytes, uint16_t hd, hsa_signal_t completion, bool may_batch) {
+    const KernelInfo *k = kernel_info(d, f);
     if (!k) return hipErrorNotFound;
     if (arg_bytes > k->kernarg || k->kernarg > KARG_SLOT || k->priv != 0) return hipErrorInvalidValue;
-    Queue &q = d->queues[a.queue];
+    Queue &q = d.queues[queue];
     // the argument block: explicit arguments, zeros where hidden ones would follow (the step kernels have none)
     unsigned char *slot = q.karg + (q.karg_next++ % KARG_SLOTS) * KARG_SLOT;
     alignas(64) unsigned char block[KARG_SLOT];
@@ -423,7 +425,7 @@ hipError_t aql_dispatch(const AqlLaunch &a, hipFunction_t f, unsigned grid, unsi
     memcpy(block, args, arg_bytes);
     memset(block + arg_bytes, 0, total - arg_bytes);
     memcpy(slot, block, total);
-    d->last_tail = slot + total - 1;
+    d.last_tail = slot + total - 1;
     uint64_t idx;
     hsa_kernel_dispatch_packet_t *p = (hsa_kernel_dispatch_packet_t *)claim(h, q.q, &idx);
     p->workgroup_size_x = (uint16_t)threads;
@@ -438,20 +440,46 @@ hipError_t aql_dispatch(const AqlLaunch &a, hipFunction_t f, unsigned grid, unsi
     p->kernel_object = k->object;
     p->kernarg_address = slot;
     p->reserved2 = 0;
-    p->completion_signal.handle = 0;
-    const uint16_t hd = header(HSA_PACKET_TYPE_KERNEL_DISPATCH, true, a.head ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT,
-                               HSA_FENCE_SCOPE_AGENT);
+    p->completion_signal = completion;
     const uint16_t setup = 3 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
     q.dirty = true;
     const uint32_t head_word = (uint32_t)hd | ((uint32_t)setup << 16);
-    if (d->batching && d->n_pending < MAX_QUEUES) {
-        d->pending[d->n_pending++] = {a.queue, (uint32_t *)p, head_word, idx};
+    if (may_batch && d.batching && d.n_pending < MAX_QUEUES) {
+        d.pending[d.n_pending++] = {queue, (uint32_t *)p, head_word, idx};
         return hipSuccess;
     }
-    publish(*d, h);
+    publish(d, h);
     __atomic_store_n((uint32_t *)p, head_word, __ATOMIC_RELEASE);
     h.hsa_signal_store_screlease(q.q->doorbell_signal, (hsa_signal_value_t)idx);
     return hipSuccess;
+}
+
+// a barrier-AND packet on `queue`: waits for the queue's earlier packets (barrier bit) and for `deps`
+void barrier(Device &d, const Hsa &h, int queue, const hsa_signal_t *deps, int n_deps, int release, hsa_signal_t completion) {
+    Queue &q = d.queues[queue];
+    uint64_t idx;
+    hsa_barrier_and_packet_t *p = (hsa_barrier_and_packet_t *)claim(h, q.q, &idx);
+    memset((unsigned char *)p + 4, 0, 60);
+    for (int i = 0; i < n_deps && i < 5; ++i) p->dep_signal[i] = deps[i];
+    p->completion_signal = completion;
+    const uint16_t hd = header(HSA_PACKET_TYPE_BARRIER_AND, true, HSA_FENCE_SCOPE_NONE, release);
+    __atomic_store_n((uint32_t *)p, (uint32_t)hd, __ATOMIC_RELEASE);
+    h.hsa_signal_store_screlease(q.q->doorbell_signal, (hsa_signal_value_t)idx);
+}
+}  // namespace
+
+hipError_t aql_dispatch(const AqlLaunch &a, hipFunction_t f, unsigned grid, unsigned threads, unsigned lds,
+                        const void *args, size_t arg_bytes) {
+    Device *d = current();
+    if (!d || !d->ok || a.queue < 0 || a.queue >= d->n_queues) return hipErrorNotInitialized;
+    const Hsa &h = hsa();
+    std::lock_guard<std::mutex> lock(d->mu);
+    // a step that records its workgroups' XCDs goes without a release fence: what it wrote stays in the L2 of the XCD
+    // its workgroups ran on, which is where the next step's workgroups of the same index read it -- as long as the
+    // record shows ONE XCD per workgroup (aql_fence's check); otherwise agent scope on both sides, as a HIP stream
+    const int release = a.xcd_seen ? HSA_FENCE_SCOPE_NONE : d->step_release;
+    const uint16_t hd = header(HSA_PACKET_TYPE_KERNEL_DISPATCH, true, a.head ? HSA_FENCE_SCOPE_SYSTEM : d->step_acquire, release);
+    return emit(*d, h, a.queue, f, grid, threads, lds, args, arg_bytes, hd, hsa_signal_t{0}, true);
 }
 
 void aql_begin() {
@@ -470,25 +498,45 @@ void aql_commit() {
     d->batching = false;
 }
 
-hipError_t aql_fence(int n_queues) {
+hipError_t aql_fence(int n_queues, const AqlCheck *check) {
     Device *d = current();
     if (!d || !d->ok) return hipErrorNotInitialized;
     const Hsa &h = hsa();
     std::lock_guard<std::mutex> lock(d->mu);
+    publish(*d, h);
     if (n_queues > d->n_queues) n_queues = d->n_queues;
+    bool any = false;
+    for (int i = 0; i < n_queues; ++i) any = any || d->queues[i].dirty;
+    if (!any) return hipSuccess;
     bool waiting[MAX_QUEUES] = {};
-    for (int i = 0; i < n_queues; ++i) {
+    hsa_signal_t deps[MAX_QUEUES];
+    int n_deps = 0;
+    // queues 1..: a barrier packet with a system-scope release behind their steps; queue 0 last -- with a check, its
+    // barrier waits for the others' as well, the check kernel follows, and its completion is the fence
+    for (int i = n_queues - 1; i >= 0; --i) {
         Queue &q = d->queues[i];
-        if (!q.dirty) continue;
+        const bool carries_check = i == 0 && check && check->f;
+        if (!q.dirty && !carries_check) continue;
         h.hsa_signal_store_relaxed(q.fence, 1);
-        uint64_t idx;
-        hsa_barrier_and_packet_t *p = (hsa_barrier_and_packet_t *)claim(h, q.q, &idx);
-        memset((unsigned char *)p + 4, 0, 60);
-        p->completion_signal = q.fence;
-        const uint16_t hd = header(HSA_PACKET_TYPE_BARRIER_AND, true, HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_SYSTEM);
-        __atomic_store_n((uint32_t *)p, (uint32_t)hd, __ATOMIC_RELEASE);
-        h.hsa_signal_store_screlease(q.q->doorbell_signal, (hsa_signal_value_t)idx);
         waiting[i] = true;
+        q.dirty = false;
+        if (!carries_check) {
+            // (with a check, the release that makes everything visible is the check dispatch's: it comes last)
+            barrier(*d, h, i, nullptr, 0, check && check->f ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_SYSTEM, q.fence);
+            if (i > 0) deps[n_deps++] = q.fence;
+            continue;
+        }
+        for (int k = 0; k < n_deps; k += 5)
+            barrier(*d, h, 0, deps + k, n_deps - k < 5 ? n_deps - k : 5, HSA_FENCE_SCOPE_NONE, hsa_signal_t{0});
+        struct {
+            const u32 *seen;
+            int n;
+            u32 *flag;
+        } args = {check->seen, check->n, check->flag};
+        const uint16_t hd = header(HSA_PACKET_TYPE_KERNEL_DISPATCH, true, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_SYSTEM);
+        const hipError_t err = emit(*d, h, 0, check->f, (unsigned)((check->n + 255) / 256), 256, 0, &args, sizeof(args), hd,
+                                    q.fence, false);
+        if (err != hipSuccess) return err;
         q.dirty = false;
     }
     // (bounded: a queue that cannot finish must not take the calling thread with it)

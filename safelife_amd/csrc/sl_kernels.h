@@ -60,6 +60,8 @@ hipError_t launch_se_distributions(const sl_env_batch &env, const sl_episode_que
 struct AqlLaunch {
     int queue;              // index of the queue (one per slice)
     bool head;              // first step after work of HIP streams: system-scope acquire
+    u32 *xcd_seen;          // non-null: no release fence behind this step; the kernel records where its workgroups
+                            // ran (one word per workgroup of the slice) and aql_fence() has the record checked
 };
 hipError_t launch_env_rollout_rowlane(const sl_env_batch &env, int e_first, int e_count, const int32_t *actions,
                                       int T, int tstride, float *reward_t, uint8_t *done_t, const Jump *jump,
@@ -75,7 +77,15 @@ void aql_begin();                                   // dispatches between begin 
 void aql_commit();                                  // (one flush of their argument blocks)
 // a barrier packet with a system-scope release behind everything dispatched on queues [0, n_queues), waited for
 // by the calling thread
-hipError_t aql_fence(int n_queues);
+// check (optional): a kernel `void(const u32 *seen, int n, u32 *flag)` dispatched on queue 0 behind every queue's
+// steps and in front of the fence (how the placement record of release-free stepping is verified)
+struct AqlCheck {
+    hipFunction_t f;
+    const u32 *seen;
+    int n;
+    u32 *flag;
+};
+hipError_t aql_fence(int n_queues, const AqlCheck *check = nullptr);
 
 // the same for envs [e_first, e_first + e_count) on the row kernels (also writes wrap.inaction_rows)
 hipError_t launch_inaction_rowlane(const sl_env_batch &env, int e_first, int e_count, const Jump *jump, hipStream_t stream);

@@ -2140,7 +2140,10 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     // critical path; kernel-argument loads are.)
     sl_env_batch env, int hot_E, int tstride, int T_arg, sl_step_out *__restrict__ out_rec,
     float *__restrict__ reward_t, uint8_t *__restrict__ done_t, double *__restrict__ shaped_t,
-    const Jump *__restrict__ jump) {
+    const Jump *__restrict__ jump,
+    // queue stepping without a release fence between steps (sl_aql.hip): one word per workgroup of this slice that
+    // collects the XCDs the workgroup has ever run on; null on every other launch
+    u32 *__restrict__ xcd_seen) {
     using Gm = Geom<H, W>;
     constexpr int WS = Gm::WS, HW = Gm::HW;
     const int T = ONE ? 1 : T_arg;
@@ -2752,6 +2755,10 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
         }
         if (env.policy_obs) write_policy_block<H, W>(env, smem, e0b, nbb, tid);
     }
+    // (fire and forget, system scope: the host's check kernel reads the words when the queues are synchronised)
+    if (xcd_seen && threadIdx.x == 64)
+        (void)__hip_atomic_fetch_or(xcd_seen + blockIdx.x, 1u << (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u),
+                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 #ifndef SL_ROWLANE_PART
@@ -2892,7 +2899,7 @@ hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, c
     const int variant = (env.n_tables == 1 ? 1 : 0) | (env.spawner_free ? 2 : 0) | (env.wrap.flags ? 4 : (lean ? 8 : 0));
     typedef void (*kernel_t)(const u16 *, const u16 *, const sl_pcg64 *, sl_env_scalars *, const int8_t *,
                              const int32_t *, int, int, sl_env_batch, int, int, int, sl_step_out *, float *,
-                             uint8_t *, double *, const Jump *);
+                             uint8_t *, double *, const Jump *, u32 *);
 #define SL_VARIANTS(ONE)                                                                                               \
     k_env_rollout_rowlane<H, W, false, true, false, false, ONE>, k_env_rollout_rowlane<H, W, true, true, false, false, ONE>,   \
     k_env_rollout_rowlane<H, W, false, false, false, false, ONE>, k_env_rollout_rowlane<H, W, true, false, false, false, ONE>, \
@@ -2947,8 +2954,10 @@ hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, c
             uint8_t *done_t;
             double *shaped_t;
             const Jump *jump;
+            u32 *xcd_seen;
         } args = {env.board, env.goals, env.rng, env.scalars, env.score_lut, actions, e_first, e_first + e_count, env,
-                  env.E, tstride, T, env.out, reward_t, done_t, env.wrap.shaped_reward_t, jump};
+                  env.E, tstride, T, env.out, reward_t, done_t, env.wrap.shaped_reward_t, jump,
+                  aql ? aql->xcd_seen : nullptr};
         // one of the library's own queues instead of a HIP stream (sl_aql.hip): same kernel, same argument block
         if (aql) return T == 1 ? aql_dispatch(*aql, f, grid, threads, (unsigned)lds, &args, sizeof(args)) : hipErrorInvalidValue;
         size_t size = sizeof(args);
@@ -2958,7 +2967,7 @@ hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, c
     if (aql) return hipErrorNotSupported;
     hipLaunchKernelGGL(fn, dim3(grid), dim3(threads), lds, stream, env.board, env.goals, env.rng, env.scalars,
                        env.score_lut, actions, e_first, e_first + e_count, env, env.E, tstride, T, env.out, reward_t,
-                       done_t, env.wrap.shaped_reward_t, jump);
+                       done_t, env.wrap.shaped_reward_t, jump, (u32 *)nullptr);
     return hipGetLastError();
 }
 

@@ -947,7 +947,43 @@ def test_queue_stepping_vs_oracle(pool_name, B, queue_slices, kw):
     assert cpu.get("episode_idx").min() >= 1
 
 
-def test_queue_stepping_soak():
+def test_queue_stepping_refuses_a_workgroup_seen_on_two_xcds(monkeypatch):
+    """Release-free queue stepping rests on a workgroup index always running on the same XCD; the kernels record
+    where they ran and every sync has the record checked.  With a record that starts out with two XCDs in one word
+    (SAFELIFE_QUEUE_FENCES_SELFTEST) the first sync must refuse; with SAFELIFE_QUEUE_FENCES=agent there is no record
+    and nothing to refuse."""
+    import torch
+    from safelife_amd._hip import SafeLifeHipError
+    from safelife_amd.vector_env import SafeLifeVectorEnv
+    pool, _ = util.pool_from_fixture("prune_still_25", _device_counts, n=8, min_performance_fraction=0.05)
+    B = 256
+    acts = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    kw = dict(auto_reset=True, time_limit=20, view_shape=(9, 9), with_obs=False)
+    monkeypatch.setenv("SAFELIFE_QUEUE_FENCES_SELFTEST", "1")
+    env = SafeLifeVectorEnv(pool, B, **kw)
+    _queues_or_skip(env, 2)
+    env.reset()
+    env.step_queues(acts)
+    with pytest.raises(SafeLifeHipError, match="more than one XCD"):
+        env.queues_sync()
+    env.queues_close()
+    monkeypatch.setenv("SAFELIFE_QUEUE_FENCES", "agent")
+    env = SafeLifeVectorEnv(pool, B, **kw)
+    env.queues_open(2)
+    env.reset()
+    env.step_queues(acts)
+    env.queues_sync()
+    env.queues_close()
+
+
+@pytest.mark.parametrize("fences", ["default", "agent"])
+def test_queue_stepping_soak(fences, monkeypatch):
+    if fences == "agent":
+        monkeypatch.setenv("SAFELIFE_QUEUE_FENCES", "agent")
+    _queue_stepping_soak()
+
+
+def _queue_stepping_soak():
     """Many unsynchronised queue steps at the bench's size (8192 envs; two, four and six queues, several runs) against
     the one-launch env on the same actions: boards, generators, episode state of every env."""
     import torch
