@@ -304,6 +304,26 @@ def main():
     env.reset()
     n_queues = args.queues if args.queues >= 0 else int(os.environ.get("SAFELIFE_BENCH_QUEUES", DEFAULT_QUEUES))
     use_queues, queues_why = False, "switched off"
+    if n_queues > 0 and os.environ.get("SAFELIFE_QUEUE_FENCES") != "agent" and not os.environ.get("SL_BENCH_NO_PROBE"):
+        # Release-free queue stepping is valid only where a workgroup index always runs on the same XCD; the library
+        # checks that at every sync and refuses otherwise.  Probe it on a scratch batch of the same shape first: where
+        # the check fails, this process steps with a stream's fences instead (SAFELIFE_QUEUE_FENCES=agent).
+        try:
+            probe = SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25), output_channels=TRAIN_CHANNELS,
+                                      auto_reset=True, level_stride=1, with_obs=False)
+            probe.reset()
+            probe.queues_open(n_queues)
+            pa = torch.zeros((B,), dtype=torch.int32, device=dev)
+            for _ in range(32):
+                probe.step_queues(pa)
+            probe.queues_sync()
+            probe.queues_close()
+        except _hip.SafeLifeHipError as e:
+            if "more than one XCD" in str(e):
+                print("bench: %s" % e, file=sys.stderr)
+                os.environ["SAFELIFE_QUEUE_FENCES"] = "agent"
+        finally:
+            probe = None
     if n_queues > 0:
         try:
             env.queues_open(n_queues)
@@ -777,6 +797,8 @@ def main():
                                                                    else ("%d slice(s) per GPU, one launch and one stream each"
                                                                          % env.slices)),
                        "stepping": "aql-queues" if use_queues else "hip-streams",
+                       "queue_fences": (os.environ.get("SAFELIFE_QUEUE_FENCES") or "no release between steps; placement "
+                                        "recorded by the kernels and checked at every sync") if use_queues else None,
                        "queues_unavailable": queues_why},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -823,4 +845,12 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except Exception as e:      # a placement check that fails in the middle of the run: once more with a stream's fences
+        if ("more than one XCD" in str(e) and os.environ.get("SAFELIFE_QUEUE_FENCES") != "agent"
+                and int(os.environ.get("WORLD_SIZE", "1")) == 1):
+            print("bench: %s -- starting over with SAFELIFE_QUEUE_FENCES=agent" % e, file=sys.stderr)
+            os.environ["SAFELIFE_QUEUE_FENCES"] = "agent"
+            os.execv(sys.executable, [sys.executable] + sys.argv)
+        raise
