@@ -260,6 +260,12 @@ def main():
                          "the same ordering as a stream, without HIP's per-launch host cost); 0: the HIP-stream slices of "
                          "--slices; -1: SAFELIFE_BENCH_QUEUES or the default below, falling back to streams where the "
                          "runtime offers no queue")
+    ap.add_argument("--queue-fences", choices=("none", "agent"), default=os.environ.get("SAFELIFE_QUEUE_FENCES") or "none",
+                    help="queue stepping: 'agent' = every step with a stream's agent-scope acquire AND release (the "
+                         "library's default); 'none' = this bench OPTS IN to release-free stepping "
+                         "(SL_QUEUES_RELEASE_FREE: ~0.9 us per step faster; valid only while a workgroup index keeps its "
+                         "XCD, which the library probes at open and every step verifies -- on a violation the run is "
+                         "repeated with 'agent', on every rank).  config.queue_fences says which mode produced the line")
     ap.add_argument("--stream-leg", type=int, default=1,
                     help="queue stepping only: 1 = also run K steps of the same kernel through the stream slices under HIP "
                          "events (roofline.launch_ms); 0 = leave it out (profiling runs: only the queues' launches in the trace)")
@@ -301,159 +307,156 @@ def main():
                             output_channels=None if args.obs == 2 else TRAIN_CHANNELS,
                             auto_reset=True, level_stride=1, env_offset=rank * B, with_obs=bool(args.obs),
                             slices=args.slices)
-    env.reset()
     n_queues = args.queues if args.queues >= 0 else int(os.environ.get("SAFELIFE_BENCH_QUEUES", DEFAULT_QUEUES))
-    use_queues, queues_why = False, "switched off"
-    if n_queues > 0 and os.environ.get("SAFELIFE_QUEUE_FENCES") != "agent" and not os.environ.get("SL_BENCH_NO_PROBE"):
-        # Release-free queue stepping is valid only where a workgroup index always runs on the same XCD; the library
-        # checks that at every sync and refuses otherwise.  Probe it on a scratch batch of the same shape first: where
-        # the check fails, this process steps with a stream's fences instead (SAFELIFE_QUEUE_FENCES=agent).
-        try:
-            probe = SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25), output_channels=TRAIN_CHANNELS,
-                                      auto_reset=True, level_stride=1, with_obs=False)
-            probe.reset()
-            probe.queues_open(n_queues)
-            pa = torch.zeros((B,), dtype=torch.int32, device=dev)
-            for _ in range(32):
-                probe.step_queues(pa)
-            probe.queues_sync()
-            probe.queues_close()
-        except _hip.SafeLifeHipError as e:
-            if "more than one XCD" in str(e):
-                print("bench: %s" % e, file=sys.stderr)
-                os.environ["SAFELIFE_QUEUE_FENCES"] = "agent"
-        finally:
-            probe = None
-    if n_queues > 0:
-        try:
-            env.queues_open(n_queues)
-            use_queues, queues_why = True, None
-        except _hip.SafeLifeHipError as e:
-            if args.queues > 0:
-                raise
-            queues_why = str(e)
-            print("bench: AQL queues unavailable (%s): stepping through HIP streams" % queues_why, file=sys.stderr)
     gen = torch.Generator(device=dev)
     gen.manual_seed(7 + rank)
     # P checkpointed steps for the parity replay, then W warm-up steps, then the K timed ones
     P = 8 if (args.cpu_baseline and world == 1) else 0
     actions = torch.randint(0, 9, (P + W + K, B), generator=gen, device=dev, dtype=torch.int32)
+    act_ptr = [actions[t].data_ptr() for t in range(P + W + K)]
     # N > 1: the window is cut so that at least one closes -- one RCCL exchange is issued -- inside the timed steps
     forced = os.environ.get("SAFELIFE_FORCE_GATHER", "0") == "1"         # one rank, exchange on (RCCL to itself)
     every_used = gather_window(args.gather_every, K) if (world > 1 or forced) else args.gather_every
     gather = RewardGather(env, every=every_used, world=world, rank=rank)
-    gather.queued = use_queues
     gather.prime()
-
-    # one step = every env stepped once = one launch per slice, each on the slice's own stream; the action
-    # tensor is complete before the loop starts, so nothing has to be fenced per step (step_async)
-    act_ptr = [actions[t].data_ptr() for t in range(P + W + K)]
-    step, every = (env.step_queues if use_queues else env.step_async), gather.every
+    every = gather.every
     # windows are counted from the END of the timed block: its last step closes one (a learner that consumes K-step
-    # rollouts exchanges once per rollout), so the hand-off -- ~30-70 us of host time -- falls where the host is
-    # ahead of the device instead of in the middle of the launches
+    # rollouts exchanges once per rollout), so the hand-off falls where the host is ahead of the device instead of
+    # in the middle of the launches
     shift = (every - (P + W + K) % every) % every
     # ... two steps ahead of the end: the exchange itself (RCCL's send / receive kernel and its hand-shake, ~25 us on
-    # the device) then runs under the last steps.  Measured with the exchange forced on for one rank, K = 20, the
-    # library's worker thread issuing it: window closing at the last step 10.4-11.8 us per step, two steps earlier
-    # 10.6-10.8, four 12.2-13.2, six 13-16 (the worker's runtime calls contend with the stepping thread's launches
-    # for as long as launches remain); without an exchange 9.1.
+    # the device) then runs under the last steps.
     if K >= 8 and every >= 8:
         shift = (shift + 2) % every
-
-    def before(t):
-        gather.before_step(t + shift)
-
-    def after(t):
-        gather.after_step(t + shift)
-
-    step_host = []
-
-    def run(t0, n):
-        if os.environ.get("SL_BENCH_DEBUG") == "2":      # per-call host times (slows the loop down)
-            for t in range(t0, t0 + n):
-                a = time.perf_counter()
-                before(t)
-                b = time.perf_counter()
-                step(act_ptr[t])
-                c = time.perf_counter()
-                if (t + shift) % every == every - 1:
-                    after(t)
-                step_host.append((t, (b - a) * 1e6, (c - b) * 1e6, (time.perf_counter() - c) * 1e6))
-            return
-        if not gather.collective:        # one rank: records stay in the env's own tensor, no windows to rotate
-            for t in range(t0, t0 + n):
-                step(act_ptr[t])
-            return
-        for t in range(t0, t0 + n):
-            before(t)
-            step(act_ptr[t])
-            if (t + shift) % every == every - 1:
-                after(t)
-
-    # the first steps since the reset run one at a time, with a snapshot of the device state after each
-    # (untimed; the CPU replay of the cpu_baseline leg compares every one of them)
-    checkpoints = {}
-    n_check = P
-    for t in range(n_check):
-        run(t, 1)
-        checkpoints[t + 1] = env.snapshot()     # device-side copies: nothing crosses to the host before the timed region
-    # (no garbage-collector pass inside the timed region: with ~20 steps in it, one young-generation pass of the
-    #  interpreter -- whose position depends on how many objects the set-up happened to allocate -- shows up as
-    #  +1 us per step; timeit does the same)
-    import gc
-    gc.collect()
-    gc.disable()
-    run(P, W)              # the W untimed warm-up steps, issued exactly like the timed ones
-    gather.flush()
-    if use_queues:
-        env.queues_sync()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-    # HIP events on the stream the kernels are launched on.  With slices, every slice stream runs the same K
-    # launches concurrently; the pair sits on slice 0's stream only: an event record as the LAST command of a
-    # stream makes the closing synchronize ~15 us slower for that stream (ROCm retires a trailing marker
-    # through its blocking path even when the GPU is long done), and one such stream is enough
-    streams = env._slice_streams or [torch.cuda.current_stream()]
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))]
     dbg = os.environ.get("SL_BENCH_DEBUG") == "1"
-    # (the start event is enqueued on the idle stream just ahead of the wall clock: the event interval then
-    #  covers the whole timed region, and its ~3 us of host time stays out of it)
-    # (queue stepping: nothing of the timed region runs on a HIP stream, so no event pair goes onto one -- a marker
-    #  on an otherwise idle stream costs the closing synchronize ~20 us; the pair is used further down, around the
-    #  stream-path run of the same kernel)
-    if not use_queues:
-        evs[0][0].record(streams[0])
-    windows0, exposed0 = gather.windows, gather.exposed_s
-    t_start = time.perf_counter()
-    run(P + W, K)
-    t_enqueued = time.perf_counter()
-    if not use_queues:
-        evs[0][1].record(streams[0])
-    # (completion is left to the synchronize below: polling hipStreamQuery / hipEventQuery first was measured
-    #  10-25 us slower over the region -- the polls contend with the runtime's own completion handling)
-    t_b = time.perf_counter()
-    gather.flush()
-    t_c = time.perf_counter()
-    if use_queues:
-        env.queues_sync()          # the queues' closing barrier packets (system-scope release), waited for here
-    t_d = time.perf_counter()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    import gc
+
+    def attempt(fences):
+        """Reset, P checkpointed steps, W warm-up steps, the K timed steps.  Returns the measurements, or None when
+        release-free queue stepping was refused by its placement check on ANY rank (the caller repeats with 'agent')."""
+        res = {"use_queues": False, "queues_why": "switched off", "fences": None}
+        env.queues_close()
+        env.reset()
+        if n_queues > 0:
+            try:
+                env.queues_open(n_queues, release_free=(fences == "none"))
+                res["use_queues"], res["queues_why"] = True, None
+                res["fences"] = "none" if env.queue_release_free else "agent"
+                if fences == "none" and not env.queue_release_free:
+                    print("bench: release-free queue stepping not granted (%s): agent-scope fences" % env.queue_mode_note,
+                          file=sys.stderr)
+            except _hip.SafeLifeHipError as e:
+                if args.queues > 0:
+                    raise
+                res["queues_why"] = str(e)
+                print("bench: AQL queues unavailable (%s): stepping through HIP streams" % e, file=sys.stderr)
+        use_queues = res["use_queues"]
+        gather.queued = use_queues
+        refused = [False]
+
+        def guarded_sync():
+            try:
+                env.queues_sync()
+            except _hip.SafeLifeHipError as e:
+                if "another XCD" not in str(e):
+                    raise
+                print("bench: %s" % e, file=sys.stderr)
+                refused[0] = True
+
+        def run(t0, n):
+            # one step = every env stepped once = one dispatch per slice; the action tensor is complete before the
+            # loop starts, so nothing has to be fenced per step
+            if use_queues:
+                # ALL n steps (and their windows) are enqueued by the library in one call per window: the stepping
+                # thread is out of the loop (slhip_queues_steps)
+                gather.run_queued(t0, n, act_ptr[t0], B, shift, assume_ordered=True)
+                return
+            if not gather.collective:        # one rank: records stay in the env's own tensor, no windows to rotate
+                for t in range(t0, t0 + n):
+                    env.step_async(act_ptr[t])
+                return
+            for t in range(t0, t0 + n):
+                gather.before_step(t + shift)
+                env.step_async(act_ptr[t])
+                if (t + shift) % every == every - 1:
+                    gather.after_step(t + shift)
+
+        # the first steps since the reset run one at a time, with a snapshot of the device state after each
+        # (untimed; the CPU replay of the cpu_baseline leg compares every one of them)
+        checkpoints = {}
         torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t_start
-    gather_windows, gather_exposed = gather.windows - windows0, gather.exposed_s - exposed0
-    gc.enable()
-    if step_host:
-        print("per-step host us (t, before, step, after):", " ".join("%d:%.0f/%.0f/%.0f" % x for x in step_host[-K:]),
-              file=sys.stderr)
-    if dbg:
-        print("timeline us: enqueue loop %.1f | e1 record %.1f | flush %.1f | queues_sync %.1f | synchronize %.1f | total %.1f"
-              % ((t_enqueued - t_start) * 1e6, (t_b - t_enqueued) * 1e6, (t_c - t_b) * 1e6, (t_d - t_c) * 1e6,
-                 (t_start + elapsed - t_d) * 1e6, elapsed * 1e6), file=sys.stderr)
+        for t in range(P):
+            run(t, 1)
+            if use_queues:
+                guarded_sync()
+            checkpoints[t + 1] = env.snapshot()     # device-side copies: nothing crosses to the host before the timed region
+        # (no garbage-collector pass inside the timed region: with ~20 steps in it, one young-generation pass of the
+        #  interpreter shows up as +1 us per step; timeit does the same)
+        gc.collect()
+        gc.disable()
+        torch.cuda.synchronize()
+        run(P, W)              # the W untimed warm-up steps, issued exactly like the timed ones
+        gather.flush()
+        if use_queues:
+            guarded_sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        # HIP events on the stream the kernels are launched on.  With slices, every slice stream runs the same K
+        # launches concurrently; the pair sits on slice 0's stream only: an event record as the LAST command of a
+        # stream makes the closing synchronize ~15 us slower for that stream, and one such stream is enough.
+        # (queue stepping: nothing of the timed region runs on a HIP stream, so no event pair goes onto one -- a marker
+        #  on an otherwise idle stream costs the closing synchronize ~20 us; the pair is used further down, around the
+        #  stream-path run of the same kernel)
+        streams = env._slice_streams or [torch.cuda.current_stream()]
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))]
+        if not use_queues:
+            evs[0][0].record(streams[0])
+        windows0, exposed0 = gather.windows, gather.exposed_s
+        t_start = time.perf_counter()
+        run(P + W, K)
+        t_enqueued = time.perf_counter()
+        if not use_queues:
+            evs[0][1].record(streams[0])
+        # (completion is left to the synchronize below: polling hipStreamQuery / hipEventQuery first was measured
+        #  10-25 us slower over the region -- the polls contend with the runtime's own completion handling)
+        t_b = time.perf_counter()
+        gather.flush()
+        t_c = time.perf_counter()
+        if use_queues:
+            guarded_sync()         # the queues' closing barrier packets (system-scope release), waited for here
+        t_d = time.perf_counter()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t_start
+        gc.enable()
+        if world > 1:
+            bad = torch.tensor([1 if refused[0] else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+            refused[0] = bool(bad.item())
+        if refused[0]:
+            return None
+        if dbg:
+            print("timeline us: enqueue %.1f | e1 record %.1f | flush %.1f | queues_sync %.1f | synchronize %.1f | total %.1f"
+                  % ((t_enqueued - t_start) * 1e6, (t_b - t_enqueued) * 1e6, (t_c - t_b) * 1e6, (t_d - t_c) * 1e6,
+                     (t_start + elapsed - t_d) * 1e6, elapsed * 1e6), file=sys.stderr)
+        res.update(elapsed=elapsed, t_start=t_start, t_enqueued=t_enqueued, checkpoints=checkpoints, evs=evs, streams=streams,
+                   gather_windows=gather.windows - windows0, gather_exposed=gather.exposed_s - exposed0)
+        return res
+
+    res = attempt(args.queue_fences)
+    if res is None:
+        print("bench: repeating the run with agent-scope fences", file=sys.stderr)
+        res = attempt("agent")
+        if res is None:
+            raise SystemExit("bench: placement check failed with agent-scope fences -- cannot happen")
+    use_queues, queues_why = res["use_queues"], res["queues_why"]
+    elapsed, t_start, t_enqueued = res["elapsed"], res["t_start"], res["t_enqueued"]
+    checkpoints, evs, streams = res["checkpoints"], res["evs"], res["streams"]
+    gather_windows, gather_exposed = res["gather_windows"], res["gather_exposed"]
     # device time per step: every slice stream runs its K launches back to back, all streams concurrently
     if use_queues:      # (events on a HIP stream see nothing of the queues' steps: filled in below)
         kernel_ms = elapsed / K * 1e3
@@ -576,7 +579,7 @@ def main():
             env3.last_queues_us = None
             if use_queues:
                 try:
-                    env3.queues_open(n_queues)
+                    env3.queues_open(n_queues, release_free=(res["fences"] == "none"))
                     for t in range(20):
                         env3.step_queues(acts[t])
                     env3.queues_sync()
@@ -769,7 +772,10 @@ def main():
         try:    # HBM bytes per launch from the committed PMC passes (tools/pmc_run.sh), if they match this run
             with open(os.path.join(REPO, "profiles", "traffic_latest.json")) as f:
                 tj = json.load(f)
-            if tj.get("envs_per_gpu") == B and tj.get("obs") == args.obs and tj.get("slices", 1) in (env.slices, getattr(env, "queue_slices", 0)):
+            # (only a PMC run of the SAME stepping mode counts: launches per step and, for the queues, the fences)
+            same = (tj.get("slices", 1) == (env.queue_slices if use_queues else env.slices)
+                    and tj.get("queue_fences") == (res["fences"] if use_queues else None))
+            if tj.get("envs_per_gpu") == B and tj.get("obs") == args.obs and same:
                 traffic = tj.get("hbm_bytes_per_step", tj["hbm_bytes_per_launch"])      # all launches of one step
         except (OSError, ValueError, KeyError):
             pass
@@ -792,13 +798,18 @@ def main():
                                                                    "RCCL send/recv on a side stream" if gather.collective
                                                                    else "one rank: nothing to exchange",
                                                                    ("%d slice(s) per GPU, one dispatch each on an AQL queue of "
-                                                                    "the library's own (stream ordering: barrier bit, "
-                                                                    "agent-scope fences)" % env.queue_slices) if use_queues
+                                                                    "the library's own (barrier bit; fences: see "
+                                                                    "queue_fences), all K steps enqueued by one C call"
+                                                                    % env.queue_slices) if use_queues
                                                                    else ("%d slice(s) per GPU, one launch and one stream each"
                                                                          % env.slices)),
                        "stepping": "aql-queues" if use_queues else "hip-streams",
-                       "queue_fences": (os.environ.get("SAFELIFE_QUEUE_FENCES") or "no release between steps; placement "
-                                        "recorded by the kernels and checked at every sync") if use_queues else None,
+                       "queue_fences": ({"none": "none: bench opted in to release-free stepping (SL_QUEUES_RELEASE_FREE) -- "
+                                                 "agent-scope acquire, NO release between the steps of a queue; placement "
+                                                 "probed at open and verified by every step",
+                                         "agent": "agent: agent-scope acquire and release on every step (a stream's "
+                                                  "fences; the library's default)"}[res["fences"]]) if use_queues else None,
+                       "queue_fences_requested": args.queue_fences if use_queues else None,
                        "queues_unavailable": queues_why},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -845,12 +856,4 @@ def main():
 
 
 if __name__ == "__main__":
-    try:
-        main()
-    except Exception as e:      # a placement check that fails in the middle of the run: once more with a stream's fences
-        if ("more than one XCD" in str(e) and os.environ.get("SAFELIFE_QUEUE_FENCES") != "agent"
-                and int(os.environ.get("WORLD_SIZE", "1")) == 1):
-            print("bench: %s -- starting over with SAFELIFE_QUEUE_FENCES=agent" % e, file=sys.stderr)
-            os.environ["SAFELIFE_QUEUE_FENCES"] = "agent"
-            os.execv(sys.executable, [sys.executable] + sys.argv)
-        raise
+    main()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SL_ABI_VERSION 8
+#define SL_ABI_VERSION 9
 #define SL_MAX_CELLS 16384        /* H*W limit of one board */
 #define SL_MAX_CHANNELS 32
 
@@ -316,31 +316,56 @@ int slhip_streams_order(void *const *before, int n_before, void *const *after, i
 int slhip_env_step_slices(const sl_env_batch *env, int n_slices, const int32_t *bounds, const int32_t *actions,
                           void *const *streams);
 
-/* Sliced stepping WITHOUT HIP's launch path (round 3): slhip_env_step_slices hides one slice's kernel boundary under the
- * other slices' kernels, but a launch through a HIP stream costs the host 2.4-3 us, so one stepping thread feeds two
- * slices per ~8 us step and no more.  These entry points issue the SAME kernel from HSA queues of the library's own, one
- * per slice (csrc/sl_aql.hip): a dispatch is a 64-byte packet and a doorbell, the slices' argument blocks are flushed
- * once per step.  Ordering is a stream's: every dispatch waits for its queue's previous one (barrier bit, agent-scope
- * acquire / release).
- *   open  : slices as in slhip_env_step_slices (1 to 8); row-kernel shapes only, no "inaction" wrapper
- *           (SL_E_UNSUPPORTED otherwise, or when the HSA runtime offers no queue -- callers then keep to streams).
- *   step  : one step of every env.  head != 0 for the first step after anything OUTSIDE the queues wrote the envs'
- *           state or the actions through a HIP stream: the caller has synchronised those streams, the step is
- *           dispatched with a system-scope acquire.  actions: device int32 [B], complete when the call is made.
- *   sync  : a system-scope release behind every step dispatched so far, waited for by the calling thread; only then
- *           may HIP streams or the host read what the steps wrote.
- * Fences between the steps of a queue (environment, read by open): SAFELIFE_QUEUE_FENCES=agent gives every step an
- * agent-scope acquire AND release, exactly a HIP stream's, independent of where workgroups run.  The default leaves the
- * RELEASE out (it alone costs ~0.9 us of a 7.5 us step of 8192 25x25 envs): what a step wrote then stays in the L2 of
- * the XCD its workgroups ran on, and the next step's workgroup of the same index reads it there -- which holds as long
- * as a workgroup index always runs on the same XCD.  That is observed on MI355X but documented nowhere, so it is
- * RECORDED (every step ORs its XCD into a per-workgroup word, system scope) and CHECKED by a kernel in front of every
- * sync's fence: a workgroup index that has seen two XCDs makes sync (and every later sync of the handle) return
- * SL_E_HIP -- the state is then not valid and the caller must start over with SAFELIFE_QUEUE_FENCES=agent. */
-int slhip_queues_open(const sl_env_batch *env, int n_slices, const int32_t *bounds, void **handle);
+/* Sliced stepping WITHOUT HIP's launch path: slhip_env_step_slices hides one slice's kernel boundary under the other
+ * slices' kernels, but a launch through a HIP stream costs the host 2.4-3 us, so one stepping thread feeds two slices per
+ * ~8 us step and no more.  These entry points issue the SAME kernel from HSA queues of the library's own, one per slice
+ * (csrc/sl_aql.hip): a dispatch is a 64-byte packet and a doorbell, and the packets and argument blocks of MANY steps
+ * are written by one call.  Ordering is a stream's: every dispatch waits for its queue's previous one (barrier bit) with
+ * agent-scope acquire / release fences -- independent of where workgroups run.
+ *   open   : slices as in slhip_env_step_slices (1 to 8); row-kernel shapes only, no "inaction" wrapper
+ *            (SL_E_UNSUPPORTED otherwise, or when the HSA runtime offers no queue -- callers then keep to streams).
+ *   steps  : n_steps consecutive steps of every env, all enqueued by this call (the queue rings give back-pressure: the
+ *            call blocks while they are full).  Step t takes its actions from actions + t * action_stride (int32
+ *            elements; device int32 [B] each, complete when the call is made) and writes its sl_step_out records to
+ *            env->out + t * out_stride (records; 0: every step overwrites env->out).  head != 0 for the first step
+ *            after anything OUTSIDE the queues wrote the envs' state or the actions through a HIP stream: the caller
+ *            has synchronised those streams, and step 0 is dispatched with a system-scope acquire.
+ *   step   : steps(handle, env, actions, 0, 0, 1, head).
+ *   marker : a system-scope release behind every step dispatched so far, with a completion signal; returns at once
+ *            (*ticket = -1: nothing was outstanding).  wait: the calling thread -- any thread -- waits for it.  Only then
+ *            may HIP streams or the host read what the steps in front of the marker wrote.
+ *   sync   : marker + wait.
+ *   mode   : the flags in effect (why_not, optional: why SL_QUEUES_RELEASE_FREE was asked for and not granted, or NULL).
+ *
+ * SL_QUEUES_RELEASE_FREE (open's flags; OPT-IN, never the default): the steps of a queue go without the RELEASE fence
+ * (it alone costs ~0.9 us of a 7.5 us step of 8192 25x25 envs: the write-back of the XCDs' L2s).  What a step wrote then
+ * stays in the L2 of the XCD its workgroups ran on, and the next step's workgroup of the same index reads it there --
+ * which is valid ONLY while a workgroup index keeps running on the same XCD.  MI355X in SPX mode deals the workgroups
+ * of every dispatch round-robin over its XCDs, but no programming guide promises it, so
+ *   - open probes it (a probe kernel, three dispatches per queue) and falls back to the fenced mode where it does not
+ *     hold (slhip_queues_mode reports that), and
+ *   - EVERY step verifies it: a workgroup ORs its XCD into the word of its first env (one returning atomic, in flight
+ *     under the loads) and raises a host-visible flag if a predecessor ran elsewhere; wait / sync then -- and from then
+ *     on -- return SL_E_HIP: the envs' state since the queues were opened is not valid, and the caller starts over
+ *     without the flag.  Use it where losing a run to that is acceptable (benchmarks, restartable roll-outs).
+ *
+ * selftest (tests only): SL_QUEUES_SELFTEST_PLANT puts two XCDs into the record of env 0's workgroup;
+ * SL_QUEUES_SELFTEST_SHIFT moves the interior slice bounds up by `arg` envs on every other step, so that the envs next
+ * to a bound are stepped by workgroups of another index than the step before -- harmless with a stream's fences, a real
+ * misplacement for release-free stepping (tests/test_hip_parity.py shows both). */
+#define SL_QUEUES_RELEASE_FREE 1
+#define SL_QUEUES_SELFTEST_PLANT 1
+#define SL_QUEUES_SELFTEST_SHIFT 2
+int slhip_queues_open(const sl_env_batch *env, int n_slices, const int32_t *bounds, int flags, void **handle);
+int slhip_queues_mode(void *handle, const char **why_not);
+int slhip_queues_steps(void *handle, const sl_env_batch *env, const int32_t *actions, long long action_stride,
+                       long long out_stride, int n_steps, int head);
 int slhip_queues_step(void *handle, const sl_env_batch *env, const int32_t *actions, int head);
+int slhip_queues_marker(void *handle, long long *ticket);
+int slhip_queues_wait(void *handle, long long ticket);
 int slhip_queues_sync(void *handle);
 int slhip_queues_close(void *handle);
+int slhip_queues_selftest(void *handle, int what, int arg);
 
 /* The episode-end pass of side_effect_score() (side_effects.py:103-130) for every episode in `queue` (what
  * safelife_env.py:183-192 runs inside the step that ends an episode), all on the device and without a host
@@ -406,6 +431,12 @@ int slhip_gather_window_async(void *comm, const void *send, void *recv, size_t b
                               void *stream, long long *ticket);
 int slhip_gather_done(void *comm, long long ticket, int block, int *done);
 int slhip_gather_wait_streams(void *comm, long long ticket, void *const *streams, int n_streams);
+/* A window that was written from the library's AQL queues (slhip_queues_steps): the call puts a marker behind the steps
+ * dispatched so far on `queues` (the handle of slhip_queues_open) and returns; the worker thread waits for the marker
+ * -- not the stepping thread, which goes on enqueuing the next window's steps -- and then issues the RCCL group on
+ * `stream`.  Tickets as above. */
+int slhip_gather_window_queued(void *comm, const void *send, void *recv, size_t bytes, void *queues, void *stream,
+                               long long *ticket);
 
 /* SafeLifeEnv.get_obs() for the current state. */
 int slhip_env_obs(const sl_env_batch *env, void *stream);

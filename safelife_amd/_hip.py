@@ -26,8 +26,12 @@ EXPORTS = (
     "slhip_obs_to_policy", "slhip_side_effects",
     "slhip_gather_unique_id", "slhip_gather_init", "slhip_gather_window", "slhip_gather_destroy",
     "slhip_gather_window_async", "slhip_gather_done", "slhip_gather_wait_streams",
-    "slhip_queues_open", "slhip_queues_step", "slhip_queues_sync", "slhip_queues_close",
+    "slhip_gather_window_queued",
+    "slhip_queues_open", "slhip_queues_mode", "slhip_queues_steps", "slhip_queues_step", "slhip_queues_marker",
+    "slhip_queues_wait", "slhip_queues_sync", "slhip_queues_close", "slhip_queues_selftest",
 )
+QUEUES_RELEASE_FREE = 1
+QUEUES_SELFTEST_PLANT, QUEUES_SELFTEST_SHIFT = 1, 2
 SL_GATHER_ID_BYTES = 128
 SL_SE_MAX_KEYS = 24
 
@@ -49,7 +53,7 @@ ENV_SCALARS_HEAD = ("B", "H", "W", "E", "time_limit", "exit_points", "n_tables",
 ENV_STATE_PTRS = ("board", "goals", "exit_locs", "rng", "scalars", "points_table")
 ENV_POOL_PTRS = ("pool_board", "pool_goals", "pool_exit_locs", "pool_rng", "pool_scalars")
 ENV_OUT_PTRS = ("out", "obs", "score_lut")
-SL_ABI_VERSION = 8
+SL_ABI_VERSION = 9
 
 #: int32 column of each field inside `struct sl_env_scalars` (64 bytes = 16 columns)
 SCALAR_COLS = {"agent_row": 0, "agent_col": 1, "num_steps": 2, "old_value": 3, "required_points": 4,
@@ -140,10 +144,17 @@ def lib():
         L.slhip_env_rollout.argtypes = [C.POINTER(EnvBatch), _p, C.c_int, _p, _p, _p]
         L.slhip_env_obs.argtypes = [C.POINTER(EnvBatch), _p]
         if hasattr(L, "slhip_queues_step"):
-            L.slhip_queues_open.argtypes = [C.POINTER(EnvBatch), C.c_int, _p, C.POINTER(C.c_void_p)]
+            L.slhip_queues_open.argtypes = [C.POINTER(EnvBatch), C.c_int, _p, C.c_int, C.POINTER(C.c_void_p)]
             L.slhip_queues_step.argtypes = [C.c_void_p, C.POINTER(EnvBatch), _p, C.c_int]
             L.slhip_queues_sync.argtypes = [C.c_void_p]
             L.slhip_queues_close.argtypes = [C.c_void_p]
+        if hasattr(L, "slhip_queues_steps"):
+            L.slhip_queues_mode.argtypes = [C.c_void_p, C.POINTER(C.c_char_p)]
+            L.slhip_queues_steps.argtypes = [C.c_void_p, C.POINTER(EnvBatch), _p, C.c_longlong, C.c_longlong, C.c_int, C.c_int]
+            L.slhip_queues_marker.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+            L.slhip_queues_wait.argtypes = [C.c_void_p, C.c_longlong]
+            L.slhip_queues_selftest.argtypes = [C.c_void_p, C.c_int, C.c_int]
+            L.slhip_gather_window_queued.argtypes = [_p, _p, _p, C.c_size_t, C.c_void_p, _p, C.POINTER(C.c_longlong)]
         L.slhip_side_effects.argtypes = [C.POINTER(EnvBatch), C.POINTER(EpisodeQueue), C.c_int, C.c_int] + [_p] * 9
         L.slhip_obs_to_policy.argtypes = [_p, C.c_int, C.c_int, C.c_int, _p, C.c_int, _p, C.c_int, _p]
         L.slhip_gather_unique_id.argtypes = [_p]

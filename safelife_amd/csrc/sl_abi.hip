@@ -227,6 +227,8 @@ struct GatherRequest {
     int n_writers;
     hipStream_t stream;
     long long ticket;
+    long long marker;       // >= 0: the window was written from the library's AQL queues; the worker waits for this
+                            // marker of theirs (slhip_queues_marker) instead of ordering streams
 };
 struct GatherComm {
     void *comm;
@@ -523,13 +525,9 @@ int slhip_env_step_slices(const sl_env_batch *env, int n_slices, const int32_t *
 
 // ---- sliced stepping on the library's own AQL queues (sl_aql.hip) ----------------------------------------------------
 namespace sl {
-// The placement record of release-free stepping (sl_rowlane.hip: every step ORs the XCD it ran on into its workgroup's
-// word): a workgroup index that has seen more than one XCD read state another XCD's L2 still held.
-__global__ void k_xcd_check(const u32 *__restrict__ seen, int n, u32 *__restrict__ flag) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const u32 v = __hip_atomic_load(seen + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (v & (v - 1u)) (void)__hip_atomic_fetch_or(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+// The placement probe of release-free stepping: where does workgroup i of a dispatch run?
+__global__ void k_xcd_probe(u32 *__restrict__ out) {
+    if (threadIdx.x == 0) out[blockIdx.x] = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u;      // XCC_ID
 }
 }  // namespace sl
 
@@ -538,27 +536,72 @@ struct StepQueues {
     int n_slices = 0;
     int32_t bounds[9] = {};
     int H = 0, W = 0, B = 0;
-    // SAFELIFE_QUEUE_FENCES=agent: every step with agent-scope acquire AND release, as a HIP stream (placement-
-    // independent).  Default: no release between steps, with the placement recorded by the kernels and checked at
-    // every sync (the release alone costs ~0.9 us of a 7.5 us C3 step).
-    bool lite = false;
+    // SL_QUEUES_RELEASE_FREE (opt-in): no release fence between the steps of a queue; the placement this rests on is
+    // probed when the queues are opened and verified by every step (sl_rowlane.hip: xcd_seen / xcd_flag).
+    bool release_free = false;
     uint32_t *seen = nullptr, *flag = nullptr;
-    hipFunction_t check = nullptr;
+    bool pending = false;           // steps dispatched since this handle last waited for a marker of its own
+    int shift = 0;                  // self-test: interior slice bounds move by this many envs on every other step
+    long long steps = 0;
+    std::string downgraded;         // why release-free stepping was asked for and not granted
 };
+
+// Release-free stepping is only sound where a workgroup index keeps its XCD from dispatch to dispatch.  Probe it: the
+// same grid three times on every queue; every run must put workgroup i where the first run put it.
+bool placement_is_stable(int n_queues, int grid, std::string *why) {
+    hipFunction_t f = nullptr;
+    if (hipGetFuncBySymbol(&f, (const void *)sl::k_xcd_probe) != hipSuccess || sl::aql_probe(f)) {
+        (void)hipGetLastError();
+        *why = "the placement probe kernel was not found";
+        return false;
+    }
+    const int runs = 3 * n_queues;
+    uint32_t *out = nullptr;
+    if (hipMalloc((void **)&out, sizeof(uint32_t) * (size_t)grid * runs) != hipSuccess) {
+        (void)hipGetLastError();
+        *why = "no memory for the placement probe";
+        return false;
+    }
+    bool ok = hipMemset(out, 0xFF, sizeof(uint32_t) * (size_t)grid * runs) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+    for (int r = 0; r < runs && ok; ++r) {
+        struct {
+            uint32_t *out;
+        } args = {out + (size_t)r * grid};
+        const sl::AqlLaunch a{r % n_queues, true, false, nullptr, nullptr};
+        ok = sl::aql_dispatch(a, f, (unsigned)grid, 256, 0, &args, sizeof(args)) == hipSuccess;
+    }
+    ok = ok && sl::aql_fence(n_queues) == hipSuccess;
+    std::vector<uint32_t> host((size_t)grid * runs);
+    ok = ok && hipMemcpy(host.data(), out, sizeof(uint32_t) * host.size(), hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(out);
+    if (!ok) {
+        (void)hipGetLastError();
+        *why = "the placement probe could not be run";
+        return false;
+    }
+    for (int r = 1; r < runs; ++r)
+        for (int i = 0; i < grid; ++i)
+            if (host[(size_t)r * grid + i] != host[i] || host[i] > 15u) {
+                *why = "workgroup " + std::to_string(i) + " ran on XCD " + std::to_string(host[i]) + " in one dispatch and on XCD " +
+                       std::to_string(host[(size_t)r * grid + i]) + " in another";
+                return false;
+            }
+    return true;
+}
 }  // namespace
 
-int slhip_queues_open(const sl_env_batch *env, int n_slices, const int32_t *bounds, void **handle) {
+int slhip_queues_open(const sl_env_batch *env, int n_slices, const int32_t *bounds, int flags, void **handle) {
     int rc = check_env(env);
     if (rc) return rc;
     if (!handle || !bounds || n_slices < 1 || n_slices > 8) return fail(SL_E_ARG, "bad queue arguments (1 to 8 slices)");
+    if (flags & ~SL_QUEUES_RELEASE_FREE) return fail(SL_E_ARG, "unknown queue flags");
     if (bounds[0] != 0 || bounds[n_slices] != env->B) return fail(SL_E_ARG, "slice bounds must run from 0 to B");
     for (int i = 0; i < n_slices; ++i) {
         if (bounds[i + 1] < bounds[i]) return fail(SL_E_ARG, "slice bounds must not decrease");
         if (!use_rowlane(env, bounds[i])) return fail(SL_E_UNSUPPORTED, "queue stepping needs the row kernels");
     }
-    if (env->wrap.flags & SL_WRAP_INACTION)
-        return fail(SL_E_UNSUPPORTED, "the inaction baseline is a launch of its own: HIP streams only");
     if (const char *why = sl::aql_open(n_slices)) return fail(SL_E_UNSUPPORTED, std::string("AQL queues unavailable: ") + why);
+    if (sl::aql_poisoned()) return fail(SL_E_HIP, "AQL queues: an earlier wait timed out on this device");
     if (const char *why = sl::aql_probe(sl::rowlane_probe_function()))
         return fail(SL_E_UNSUPPORTED, std::string("AQL queues unavailable: ") + why);
     StepQueues *c = new StepQueues;
@@ -567,75 +610,173 @@ int slhip_queues_open(const sl_env_batch *env, int n_slices, const int32_t *boun
     c->W = env->W;
     c->B = env->B;
     memcpy(c->bounds, bounds, sizeof(int32_t) * (n_slices + 1));
-    const char *mode = getenv("SAFELIFE_QUEUE_FENCES");
-    c->lite = !(mode && !strcmp(mode, "agent"));
-    if (c->lite) {
-        // (one word per workgroup; a workgroup holds at least one env, and slice i's words start at bounds[i])
-        hipError_t err = hipMalloc((void **)&c->seen, sizeof(uint32_t) * (size_t)(env->B + 1));
-        if (err == hipSuccess) err = hipMemset(c->seen, 0, sizeof(uint32_t) * (size_t)(env->B + 1));
-        // (SAFELIFE_QUEUE_FENCES_SELFTEST=1: the first word starts out with two XCDs in it -- the next sync must refuse)
-        if (err == hipSuccess && getenv("SAFELIFE_QUEUE_FENCES_SELFTEST")) err = hipMemset(c->seen, 3, 1);
-        if (err == hipSuccess) err = hipHostMalloc((void **)&c->flag, 64, hipHostMallocDefault);
-        if (err == hipSuccess) err = hipDeviceSynchronize();
-        if (err == hipSuccess && hipGetFuncBySymbol(&c->check, (const void *)sl::k_xcd_check) != hipSuccess) err = hipErrorNotFound;
-        if (err == hipSuccess && sl::aql_probe(c->check)) err = hipErrorNotFound;
-        if (err != hipSuccess) {
-            (void)hipGetLastError();
-            if (c->seen) (void)hipFree(c->seen);
-            if (c->flag) (void)hipHostFree(c->flag);
-            c->seen = c->flag = nullptr;
-            c->lite = false;                 // (no record, no shortcut)
+    if (flags & SL_QUEUES_RELEASE_FREE) {
+        int grid = 1;
+        for (int i = 0; i < n_slices; ++i) grid = std::max(grid, bounds[i + 1] - bounds[i]);    // (>= workgroups of a slice)
+        grid = std::min(grid, 4096);
+        std::string why;
+        hipError_t err = hipSuccess;
+        if (!placement_is_stable(n_slices, grid, &why)) {
+            c->downgraded = why;
         } else {
-            *c->flag = 0;
+            // (one word per env of the batch: a workgroup uses the word of its first env)
+            err = hipMalloc((void **)&c->seen, sizeof(uint32_t) * (size_t)(env->B + 1));
+            if (err == hipSuccess) err = hipMemset(c->seen, 0, sizeof(uint32_t) * (size_t)(env->B + 1));
+            if (err == hipSuccess) err = hipHostMalloc((void **)&c->flag, 64, hipHostMallocDefault);
+            if (err == hipSuccess) err = hipDeviceSynchronize();
+            if (err != hipSuccess) {
+                (void)hipGetLastError();
+                if (c->seen) (void)hipFree(c->seen);
+                if (c->flag) (void)hipHostFree(c->flag);
+                c->seen = c->flag = nullptr;
+                c->downgraded = "no memory for the placement record";
+            } else {
+                *c->flag = 0;
+                c->release_free = true;
+            }
         }
     }
     *handle = c;
     return SL_OK;
 }
 
-int slhip_queues_step(void *handle, const sl_env_batch *env, const int32_t *actions, int head) {
+int slhip_queues_mode(void *handle, const char **why_not) {
+    StepQueues *c = (StepQueues *)handle;
+    if (!c) return fail(SL_E_ARG, "null pointer");
+    if (why_not) *why_not = c->downgraded.empty() ? nullptr : c->downgraded.c_str();
+    return c->release_free ? SL_QUEUES_RELEASE_FREE : 0;
+}
+
+int slhip_queues_selftest(void *handle, int what, int arg) {
+    StepQueues *c = (StepQueues *)handle;
+    if (!c) return fail(SL_E_ARG, "null pointer");
+    if (what == SL_QUEUES_SELFTEST_PLANT) {
+        // the record of env 0's workgroup starts out with two XCDs in it: the next step must raise the flag
+        if (!c->release_free) return fail(SL_E_UNSUPPORTED, "no placement record in this mode");
+        if (hipMemset(c->seen, 3, 1) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return hip_fail(hipGetLastError(), "selftest");
+        return SL_OK;
+    }
+    if (what == SL_QUEUES_SELFTEST_SHIFT) {
+        // every other step moves the interior slice bounds up by `arg` envs: the envs around a bound are then stepped
+        // by workgroups of another index -- i.e., where placement follows the index, on another XCD -- than the step
+        // before.  With a stream's fences that changes nothing; without a release it must trip the placement check.
+        if (arg < 0 || (arg && c->n_slices < 2)) return fail(SL_E_ARG, "bad shift");
+        for (int i = 1; i < c->n_slices; ++i)
+            if (c->bounds[i] + arg > c->bounds[i + 1]) return fail(SL_E_ARG, "shift larger than a slice");
+        c->shift = arg;
+        return SL_OK;
+    }
+    return fail(SL_E_ARG, "unknown self-test");
+}
+
+int slhip_queues_steps(void *handle, const sl_env_batch *env, const int32_t *actions, long long action_stride,
+                       long long out_stride, int n_steps, int head) {
     StepQueues *c = (StepQueues *)handle;
     if (!c || !env || !actions) return fail(SL_E_ARG, "null pointer");
+    if (n_steps < 0) return fail(SL_E_ARG, "n_steps < 0");
     if (env->H != c->H || env->W != c->W || env->B != c->B) return fail(SL_E_ARG, "the queues were opened for another batch");
+    if (env->wrap.flags & SL_WRAP_INACTION)
+        return fail(SL_E_UNSUPPORTED, "the inaction baseline is a launch of its own: HIP streams only");
+    if (n_steps == 0) return SL_OK;
     const sl::Jump *jump;
     int rc;
     if ((rc = jump_table(&jump))) return rc;
+    // one prepared launch per slice (and per bound set of the self-test); per step only the action and output
+    // pointers are patched into its argument block
+    sl::PreparedStep ps[2][8];
+    const int n_sets = c->shift ? 2 : 1;
+    for (int s = 0; s < n_sets; ++s)
+        for (int i = 0; i < c->n_slices; ++i) {
+            const int lo = c->bounds[i] + (s && i > 0 ? c->shift : 0);
+            const int hi = c->bounds[i + 1] + (s && i + 1 < c->n_slices ? c->shift : 0);
+            ps[s][i].grid = 0;
+            if (hi <= lo) continue;
+            if (!use_rowlane(env, lo)) return fail(SL_E_UNSUPPORTED, "queue stepping needs the row kernels");
+            const hipError_t err = sl::launch_env_rollout_rowlane(*env, lo, hi - lo, actions, 1, env->B, nullptr, nullptr, jump,
+                                                                  nullptr, &ps[s][i]);
+            if (err != hipSuccess) return hip_fail(err, "AQL dispatch (prepare)");
+            memcpy(ps[s][i].args + ps[s][i].off_seen, &c->seen, sizeof(void *));
+            memcpy(ps[s][i].args + ps[s][i].off_flag, &c->flag, sizeof(void *));
+        }
     struct Batch {
         Batch() { sl::aql_begin(); }
         ~Batch() { sl::aql_commit(); }
     } batch;
-    for (int i = 0; i < c->n_slices; ++i) {
-        const int n = c->bounds[i + 1] - c->bounds[i];
-        if (n == 0) continue;
-        const sl::AqlLaunch a{i, head != 0, c->lite ? c->seen + c->bounds[i] : nullptr};
-        const hipError_t err = sl::launch_env_rollout_rowlane(*env, c->bounds[i], n, actions, 1, env->B, nullptr, nullptr,
-                                                              jump, nullptr, &a);
-        if (err != hipSuccess) return hip_fail(err, "AQL dispatch");
+    c->pending = true;
+    for (int t = 0; t < n_steps; ++t) {
+        const int32_t *a_t = actions + (long long)t * action_stride;
+        sl_step_out *o_t = env->out + (long long)t * out_stride;
+        const int s = c->shift ? (int)(c->steps & 1) : 0;
+        ++c->steps;
+        for (int i = 0; i < c->n_slices; ++i) {
+            sl::PreparedStep &p = ps[s][i];
+            if (!p.grid) continue;
+            memcpy(p.args + p.off_actions, &a_t, sizeof(void *));
+            memcpy(p.args + p.off_out, &o_t, sizeof(void *));
+            const sl::AqlLaunch a{i, head != 0 && t == 0, c->release_free, c->seen, c->flag};
+            const hipError_t err = sl::aql_dispatch(a, p.f, p.grid, p.threads, p.lds, p.args, p.arg_bytes);
+            if (err != hipSuccess) return hip_fail(err, "AQL dispatch");
+        }
+        // the first step goes out at once (the device starts while the rest is being written), the others in
+        // batches of eight steps: one flush of the argument ring (sfence + read-back, ~1 us) per batch
+        if (t == 0 || (t & 7) == 0) sl::aql_flush();
     }
     return SL_OK;
+}
+
+int slhip_queues_step(void *handle, const sl_env_batch *env, const int32_t *actions, int head) {
+    return slhip_queues_steps(handle, env, actions, 0, 0, 1, head);
+}
+
+static int queues_flag(StepQueues *c) {
+    if (c->release_free && *(volatile uint32_t *)c->flag)
+        return fail(SL_E_HIP, "queue stepping: envs were stepped by a workgroup on another XCD than the step before, so a step "
+                              "without a release fence may have read stale state -- the envs' state since the queues were "
+                              "opened is not valid; open the queues without SL_QUEUES_RELEASE_FREE");
+    return SL_OK;
+}
+
+int slhip_queues_marker(void *handle, long long *ticket) {
+    StepQueues *c = (StepQueues *)handle;
+    if (!c || !ticket) return fail(SL_E_ARG, "null pointer");
+    const hipError_t err = sl::aql_marker(c->n_slices, c->pending, ticket);
+    if (err != hipSuccess) return hip_fail(err, "AQL marker");
+    return SL_OK;
+}
+
+int slhip_queues_wait(void *handle, long long ticket) {
+    StepQueues *c = (StepQueues *)handle;
+    if (!c) return fail(SL_E_ARG, "null pointer");
+    const hipError_t err = sl::aql_wait(ticket);
+    if (err != hipSuccess) return hip_fail(err, "AQL wait");
+    return queues_flag(c);
 }
 
 int slhip_queues_sync(void *handle) {
     StepQueues *c = (StepQueues *)handle;
     if (!c) return fail(SL_E_ARG, "null pointer");
-    sl::AqlCheck check{c->check, c->seen, c->B, c->flag};
-    const hipError_t err = sl::aql_fence(c->n_slices, c->lite ? &check : nullptr);
+    long long ticket = -1;
+    hipError_t err = sl::aql_marker(c->n_slices, c->pending, &ticket);
+    if (err == hipSuccess) err = sl::aql_wait(ticket);
     if (err != hipSuccess) return hip_fail(err, "AQL fence");
-    if (c->lite && *(volatile uint32_t *)c->flag)
-        return fail(SL_E_HIP, "queue stepping: a workgroup index ran on more than one XCD, so a step without a release "
-                              "fence may have read stale state -- the envs' state since the queues were opened is not "
-                              "valid; set SAFELIFE_QUEUE_FENCES=agent");
-    return SL_OK;
+    c->pending = false;
+    return queues_flag(c);
 }
 
 int slhip_queues_close(void *handle) {
     StepQueues *c = (StepQueues *)handle;
     if (!c) return SL_OK;
-    (void)sl::aql_fence(c->n_slices);
-    if (c->seen) (void)hipFree(c->seen);
-    if (c->flag) (void)hipHostFree(c->flag);
+    long long ticket = -1;
+    hipError_t err = sl::aql_marker(c->n_slices, c->pending, &ticket);
+    if (err == hipSuccess) err = sl::aql_wait(ticket);
+    // (a fence that failed or timed out leaves step kernels in flight that still write the record and the flag:
+    //  those few kilobytes are leaked rather than freed under them)
+    if (err == hipSuccess && !sl::aql_poisoned()) {
+        if (c->seen) (void)hipFree(c->seen);
+        if (c->flag) (void)hipHostFree(c->flag);
+    }
     delete c;
-    return SL_OK;
+    return err == hipSuccess ? SL_OK : hip_fail(err, "AQL fence (close)");
 }
 
 // ---- the records of every rank's envs -> rank 0 (RCCL point-to-point calls; helpers above) ----------------------
@@ -697,6 +838,9 @@ static void gather_worker(GatherComm *g) {
             g->queue.pop_front();
         }
         int rc = SL_OK;
+        // a window written from the AQL queues: their marker (system-scope release behind the window's last step) is
+        // waited for HERE, on this thread -- the stepping thread keeps dispatching the next window's steps meanwhile
+        if (rq.marker >= 0 && sl::aql_wait(rq.marker) != hipSuccess) rc = SL_E_HIP;
         for (int i = 0; i < rq.n_writers && rc == SL_OK; ++i) {     // the exchange's stream waits for the window's writers
             if (rq.writers[i] == rq.stream) continue;
             hipError_t err = hipEventRecord(g->order_ev[i], rq.writers[i]);
@@ -714,8 +858,25 @@ static void gather_worker(GatherComm *g) {
     }
 }
 
+static int gather_submit(void *comm, const void *send, void *recv, size_t bytes, void *const *writers, int n_writers,
+                         void *stream, long long marker, long long *ticket);
 int slhip_gather_window_async(void *comm, const void *send, void *recv, size_t bytes, void *const *writers, int n_writers,
                               void *stream, long long *ticket) {
+    return gather_submit(comm, send, recv, bytes, writers, n_writers, stream, -1, ticket);
+}
+
+int slhip_gather_window_queued(void *comm, const void *send, void *recv, size_t bytes, void *queues, void *stream,
+                               long long *ticket) {
+    // the marker is put behind the window's steps now, by the stepping thread (a few packets); the wait is the worker's
+    long long marker = -1;
+    if (!queues) return fail(SL_E_ARG, "null pointer");
+    const int rc = slhip_queues_marker(queues, &marker);
+    if (rc) return rc;
+    return gather_submit(comm, send, recv, bytes, nullptr, 0, stream, marker, ticket);
+}
+
+static int gather_submit(void *comm, const void *send, void *recv, size_t bytes, void *const *writers, int n_writers,
+                         void *stream, long long marker, long long *ticket) {
     GatherComm *g = (GatherComm *)comm;
     if (!g || !send || (g->rank == 0 && !recv) || n_writers < 0 || n_writers > 8 || (n_writers && !writers) || !ticket)
         return fail(SL_E_ARG, "bad gather arguments");
@@ -733,6 +894,7 @@ int slhip_gather_window_async(void *comm, const void *send, void *recv, size_t b
     GatherRequest rq;
     rq.send = send, rq.recv = recv, rq.bytes = bytes, rq.n_writers = n_writers, rq.stream = (hipStream_t)stream;
     for (int i = 0; i < n_writers; ++i) rq.writers[i] = (hipStream_t)writers[i];
+    rq.marker = marker;
     rq.ticket = g->submitted++;
     *ticket = rq.ticket;
     g->queue.push_back(rq);

@@ -9,10 +9,13 @@
 // device-memory ring and flushed ONCE, and three to six slices become affordable.
 //
 // Ordering is the queue's own, exactly what a HIP stream gives: every dispatch carries the barrier bit (it starts when
-// its queue's previous packet has completed) with agent-scope acquire and release fences -- nothing here relies on
-// where a workgroup runs.  The kernel is the one HIP loaded: its descriptor is looked up in the runtime's executables
-// (HSA loader extension) under the name HIP reports for the hipFunction_t, so streams and queues run the same code
-// object with the same argument block.
+// its queue's previous packet has completed) with agent-scope acquire and release fences -- in that (default) mode
+// nothing here relies on where a workgroup runs.  The one exception is OPT-IN (AqlLaunch::release_free, asked for
+// through slhip_queues_open's SL_QUEUES_RELEASE_FREE): steps without a release fence, valid only while a workgroup
+// index keeps running on the same XCD, which the step kernels themselves verify at every step (sl_rowlane.hip).
+// The kernel is the one HIP loaded: its descriptor is looked up in the runtime's executables (HSA loader extension)
+// under the name HIP reports for the hipFunction_t, so streams and queues run the same code object with the same
+// argument block.
 //
 // What stays with the caller (vector_env.py): a first step after work of HIP streams (resets, the policy's actions) is
 // dispatched with a system-scope acquire once the caller has synchronised those streams; before anything outside the
@@ -114,7 +117,18 @@ struct Queue {
     hsa_signal_t fence{0};
     unsigned char *karg = nullptr;
     uint64_t karg_next = 0;
-    bool dirty = false;             // dispatched since the last fence
+    bool dirty = false;             // dispatched since the last marker
+};
+
+// A marker: one barrier packet per queue (system-scope release, completion signal) behind everything dispatched so
+// far.  Issued without waiting; whoever needs the results waits for its signals (the stepping thread in
+// slhip_queues_sync, the gather's worker thread before it hands a window to RCCL).
+constexpr int MARKERS = 16;
+struct Marker {
+    hsa_signal_t sig[MAX_QUEUES];
+    bool have[MAX_QUEUES] = {};     // signal created
+    bool waiting[MAX_QUEUES] = {};  // a barrier packet of this marker will set sig[i] to 0
+    long long ticket = -1;
 };
 
 struct Device {
@@ -139,10 +153,14 @@ struct Device {
         uint32_t head_word;
         uint64_t index;
     };
-    Pending pending[MAX_QUEUES];
+    static constexpr int MAX_PENDING = 64;
+    Pending pending[MAX_PENDING];
     int n_pending = 0;
     bool batching = false;
     const volatile unsigned char *last_tail = nullptr;
+    Marker markers[MARKERS];
+    long long next_ticket = 0;
+    bool poisoned = false;          // a marker timed out: work may still be in flight, nothing of the queues' is freed
 };
 
 Device g_dev[64];
@@ -444,7 +462,8 @@ hipError_t emit(Device &d, const Hsa &h, int queue, hipFunction_t f, unsigned gr
     const uint16_t setup = 3 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
     q.dirty = true;
     const uint32_t head_word = (uint32_t)hd | ((uint32_t)setup << 16);
-    if (may_batch && d.batching && d.n_pending < MAX_QUEUES) {
+    if (may_batch && d.batching) {
+        if (d.n_pending == Device::MAX_PENDING) publish(d, h);
         d.pending[d.n_pending++] = {queue, (uint32_t *)p, head_word, idx};
         return hipSuccess;
     }
@@ -474,10 +493,11 @@ hipError_t aql_dispatch(const AqlLaunch &a, hipFunction_t f, unsigned grid, unsi
     if (!d || !d->ok || a.queue < 0 || a.queue >= d->n_queues) return hipErrorNotInitialized;
     const Hsa &h = hsa();
     std::lock_guard<std::mutex> lock(d->mu);
-    // a step that records its workgroups' XCDs goes without a release fence: what it wrote stays in the L2 of the XCD
-    // its workgroups ran on, which is where the next step's workgroups of the same index read it -- as long as the
-    // record shows ONE XCD per workgroup (aql_fence's check); otherwise agent scope on both sides, as a HIP stream
-    const int release = a.xcd_seen ? HSA_FENCE_SCOPE_NONE : d->step_release;
+    // release-free (opt-in): the step goes without a release fence, so what it wrote stays in the L2 of the XCD its
+    // workgroups ran on, which is where the next step's workgroups of the same index read it -- valid as long as a
+    // workgroup index keeps its XCD, which every step verifies itself against the record of the steps before it
+    // (a.xcd_seen / a.xcd_flag).  Otherwise agent scope on both sides, as a HIP stream.
+    const int release = a.release_free ? HSA_FENCE_SCOPE_NONE : d->step_release;
     const uint16_t hd = header(HSA_PACKET_TYPE_KERNEL_DISPATCH, true, a.head ? HSA_FENCE_SCOPE_SYSTEM : d->step_acquire, release);
     return emit(*d, h, a.queue, f, grid, threads, lds, args, arg_bytes, hd, hsa_signal_t{0}, true);
 }
@@ -498,55 +518,84 @@ void aql_commit() {
     d->batching = false;
 }
 
-hipError_t aql_fence(int n_queues, const AqlCheck *check) {
+void aql_flush() {
+    Device *d = current();
+    if (!d || !d->ok) return;
+    const Hsa &h = hsa();
+    std::lock_guard<std::mutex> lock(d->mu);
+    publish(*d, h);
+}
+
+hipError_t aql_marker(int n_queues, bool force, long long *ticket) {
     Device *d = current();
     if (!d || !d->ok) return hipErrorNotInitialized;
     const Hsa &h = hsa();
     std::lock_guard<std::mutex> lock(d->mu);
     publish(*d, h);
     if (n_queues > d->n_queues) n_queues = d->n_queues;
-    bool any = false;
+    *ticket = -1;
+    bool any = force;
     for (int i = 0; i < n_queues; ++i) any = any || d->queues[i].dirty;
-    if (!any) return hipSuccess;
-    bool waiting[MAX_QUEUES] = {};
-    hsa_signal_t deps[MAX_QUEUES];
-    int n_deps = 0;
-    // queues 1..: a barrier packet with a system-scope release behind their steps; queue 0 last -- with a check, its
-    // barrier waits for the others' as well, the check kernel follows, and its completion is the fence
-    for (int i = n_queues - 1; i >= 0; --i) {
-        Queue &q = d->queues[i];
-        const bool carries_check = i == 0 && check && check->f;
-        if (!q.dirty && !carries_check) continue;
-        h.hsa_signal_store_relaxed(q.fence, 1);
-        waiting[i] = true;
-        q.dirty = false;
-        if (!carries_check) {
-            // (with a check, the release that makes everything visible is the check dispatch's: it comes last)
-            barrier(*d, h, i, nullptr, 0, check && check->f ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_SYSTEM, q.fence);
-            if (i > 0) deps[n_deps++] = q.fence;
-            continue;
-        }
-        for (int k = 0; k < n_deps; k += 5)
-            barrier(*d, h, 0, deps + k, n_deps - k < 5 ? n_deps - k : 5, HSA_FENCE_SCOPE_NONE, hsa_signal_t{0});
-        struct {
-            const u32 *seen;
-            int n;
-            u32 *flag;
-        } args = {check->seen, check->n, check->flag};
-        const uint16_t hd = header(HSA_PACKET_TYPE_KERNEL_DISPATCH, true, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_SYSTEM);
-        const hipError_t err = emit(*d, h, 0, check->f, (unsigned)((check->n + 255) / 256), 256, 0, &args, sizeof(args), hd,
-                                    q.fence, false);
-        if (err != hipSuccess) return err;
-        q.dirty = false;
-    }
-    // (bounded: a queue that cannot finish must not take the calling thread with it)
-    const auto t0 = std::chrono::steady_clock::now();
+    if (!any) return hipSuccess;                    // nothing dispatched since the last marker: nothing to wait for
+    Marker &m = d->markers[d->next_ticket % MARKERS];
+    // (a slot comes round after MARKERS - 1 younger markers; every queue is in-order, so its packets retired long ago)
+    for (int i = 0; i < MAX_QUEUES; ++i)
+        if (m.waiting[i] && h.hsa_signal_load_relaxed(m.sig[i]) != 0) return hipErrorNotReady;
+    m.ticket = d->next_ticket++;
+    for (int i = 0; i < MAX_QUEUES; ++i) m.waiting[i] = false;
     for (int i = 0; i < n_queues; ++i) {
-        if (!waiting[i]) continue;
-        while (h.hsa_signal_wait_scacquire(d->queues[i].fence, HSA_SIGNAL_CONDITION_EQ, 0, 1000000, HSA_WAIT_STATE_ACTIVE) != 0)
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) return hipErrorLaunchTimeOut;
+        Queue &q = d->queues[i];
+        if (!q.dirty && !force) continue;
+        if (!m.have[i]) {
+            if (h.hsa_signal_create(0, 0, nullptr, &m.sig[i]) != HSA_STATUS_SUCCESS) return hipErrorOutOfMemory;
+            m.have[i] = true;
+        }
+        h.hsa_signal_store_relaxed(m.sig[i], 1);
+        m.waiting[i] = true;
+        q.dirty = false;
+        barrier(*d, h, i, nullptr, 0, HSA_FENCE_SCOPE_SYSTEM, m.sig[i]);
     }
+    *ticket = m.ticket;
     return hipSuccess;
+}
+
+hipError_t aql_wait(long long ticket) {
+    if (ticket < 0) return hipSuccess;
+    Device *d = current();
+    if (!d || !d->ok) return hipErrorNotInitialized;
+    const Hsa &h = hsa();
+    hsa_signal_t sig[MAX_QUEUES];
+    int n = 0;
+    {
+        std::lock_guard<std::mutex> lock(d->mu);
+        if (d->poisoned) return hipErrorLaunchTimeOut;
+        Marker &m = d->markers[ticket % MARKERS];
+        if (m.ticket != ticket) return hipSuccess;          // the slot has been reused: that marker was passed long ago
+        for (int i = 0; i < MAX_QUEUES; ++i)
+            if (m.waiting[i]) sig[n++] = m.sig[i];
+    }
+    // (outside the lock: the stepping thread keeps dispatching while a worker thread waits here; bounded: a queue
+    //  that cannot finish must not take the calling thread with it)
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < n; ++i)
+        while (h.hsa_signal_wait_scacquire(sig[i], HSA_SIGNAL_CONDITION_EQ, 0, 1000000, HSA_WAIT_STATE_ACTIVE) != 0)
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) {
+                std::lock_guard<std::mutex> lock(d->mu);
+                d->poisoned = true;
+                return hipErrorLaunchTimeOut;
+            }
+    return hipSuccess;
+}
+
+hipError_t aql_fence(int n_queues) {
+    long long ticket = -1;
+    const hipError_t err = aql_marker(n_queues, false, &ticket);
+    return err != hipSuccess ? err : aql_wait(ticket);
+}
+
+bool aql_poisoned() {
+    Device *d = current();
+    return d && d->poisoned;
 }
 
 }  // namespace sl

@@ -56,16 +56,29 @@ hipError_t launch_se_distributions(const sl_env_batch &env, const sl_episode_que
                                    hipStream_t stream);
 // envs [e_first, e_first + e_count) of the batch; actions / reward_t / done_t are indexed [t * tstride + e]
 // with the env's index in the whole batch
-// aql (optional): dispatch on one of the library's own AQL queues instead of `stream` (sl_aql.hip; T == 1 only)
+// (sl_aql.hip dispatches the same kernel from queues of the library's own: PreparedStep below)
 struct AqlLaunch {
     int queue;              // index of the queue (one per slice)
     bool head;              // first step after work of HIP streams: system-scope acquire
-    u32 *xcd_seen;          // non-null: no release fence behind this step; the kernel records where its workgroups
-                            // ran (one word per workgroup of the slice) and aql_fence() has the record checked
+    bool release_free;      // opt-in: no release fence behind this step (valid while a workgroup index keeps its XCD)
+    u32 *xcd_seen;          // release-free stepping: the placement record, one word per env of the BATCH (a workgroup
+                            // uses the word of its first env): the XCDs the workgroup that steps these envs has run on
+    u32 *xcd_flag;          // ... and the host-visible word a step raises when its workgroup finds another XCD there
 };
+// A single-step launch of the fused kernel that is not issued but handed back: kernel handle, geometry and the packed
+// argument block with the offsets of the fields that change from step to step -- what the queues dispatch, any number
+// of times, with those fields patched in.
+struct PreparedStep {
+    hipFunction_t f;
+    unsigned grid, threads, lds;
+    size_t arg_bytes;
+    size_t off_actions, off_out, off_seen, off_flag;
+    alignas(16) unsigned char args[1024];
+};
+// prepared (optional, T == 1 only): fill it instead of launching
 hipError_t launch_env_rollout_rowlane(const sl_env_batch &env, int e_first, int e_count, const int32_t *actions,
                                       int T, int tstride, float *reward_t, uint8_t *done_t, const Jump *jump,
-                                      hipStream_t stream, const AqlLaunch *aql = nullptr);
+                                      hipStream_t stream, PreparedStep *prepared = nullptr);
 
 // sl_aql.hip : user-mode queues of the library's own next to HIP's streams
 const char *aql_open(int n_queues);                 // null when usable, else why not
@@ -73,19 +86,17 @@ const char *aql_probe(hipFunction_t f);             // can HIP's kernel `f` be f
 hipFunction_t rowlane_probe_function();             // any kernel of the library (sl_rowlane.hip)
 hipError_t aql_dispatch(const AqlLaunch &a, hipFunction_t f, unsigned grid, unsigned threads, unsigned lds,
                         const void *args, size_t arg_bytes);
-void aql_begin();                                   // dispatches between begin and commit go out together
-void aql_commit();                                  // (one flush of their argument blocks)
-// a barrier packet with a system-scope release behind everything dispatched on queues [0, n_queues), waited for
-// by the calling thread
-// check (optional): a kernel `void(const u32 *seen, int n, u32 *flag)` dispatched on queue 0 behind every queue's
-// steps and in front of the fence (how the placement record of release-free stepping is verified)
-struct AqlCheck {
-    hipFunction_t f;
-    const u32 *seen;
-    int n;
-    u32 *flag;
-};
-hipError_t aql_fence(int n_queues, const AqlCheck *check = nullptr);
+void aql_begin();                                   // dispatches between begin and commit go out in batches: their
+void aql_flush();                                   // argument blocks are flushed once per batch (flush: hand over what
+void aql_commit();                                  // has been written so far; commit: flush and leave batch mode)
+// marker: a barrier packet with a system-scope release and a completion signal behind everything dispatched so far on
+// queues [0, n_queues) that have work since their last marker (force: on every one of them); returns at once.
+// *ticket = -1 when there was nothing to mark.  wait: the calling thread spins on the marker's signals (any thread; the
+// queues stay usable meanwhile).  fence = marker + wait.
+hipError_t aql_marker(int n_queues, bool force, long long *ticket);
+hipError_t aql_wait(long long ticket);
+hipError_t aql_fence(int n_queues);
+bool aql_poisoned();                                // a wait timed out: work may still be in flight
 
 // the same for envs [e_first, e_first + e_count) on the row kernels (also writes wrap.inaction_rows)
 hipError_t launch_inaction_rowlane(const sl_env_batch &env, int e_first, int e_count, const Jump *jump, hipStream_t stream);

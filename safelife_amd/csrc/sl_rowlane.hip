@@ -28,6 +28,8 @@
 // safelife_env.py:105-146 + helper_utils.py:42-75 (observation), env_wrappers.py:32-213 (wrappers).
 #include "sl_device.h"
 #include <atomic>
+#include <cstddef>
+#include <cstring>
 
 #include "sl_kernels.h"
 #include "sl_planes.h"
@@ -2141,9 +2143,10 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     sl_env_batch env, int hot_E, int tstride, int T_arg, sl_step_out *__restrict__ out_rec,
     float *__restrict__ reward_t, uint8_t *__restrict__ done_t, double *__restrict__ shaped_t,
     const Jump *__restrict__ jump,
-    // queue stepping without a release fence between steps (sl_aql.hip): one word per workgroup of this slice that
-    // collects the XCDs the workgroup has ever run on; null on every other launch
-    u32 *__restrict__ xcd_seen) {
+    // queue stepping without a release fence between steps (sl_aql.hip, opt-in): the placement record -- word e of the
+    // batch collects the XCDs that workgroups whose first env is e have run on -- and the host-visible word a workgroup
+    // raises when it finds an XCD other than its own there; both null on every other launch
+    u32 *__restrict__ xcd_seen, u32 *__restrict__ xcd_flag) {
     using Gm = Geom<H, W>;
     constexpr int WS = Gm::WS, HW = Gm::HW;
     const int T = ONE ? 1 : T_arg;
@@ -2225,6 +2228,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     int pre_i[4] = {0, 0, 0, 0}, pre_y1 = 0, pre_x1 = 0;   // the move of step 0, on cells taken from global memory
     u32 pre_c[4] = {0u, 0u, 0u, 0u};
     bool pre_write = false;
+    u32 xcd_old = 0, xcd_bit = 0;
     if (lwave) {
         ly = hot_scalars[el].agent_row;
         lx = hot_scalars[el].agent_col;
@@ -2243,6 +2247,14 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
             pre_c[3] = src[gi[3]];
         }
     } else {
+        // Release-free queue stepping: the state this workgroup is about to load was left in the L2 of the XCD its
+        // predecessor (same first env, previous step) ran on.  One returning atomic -- in flight under the bulk loads,
+        // looked at behind the load barrier -- ORs this workgroup's XCD into the record and brings back where the
+        // predecessors ran.
+        if (xcd_seen && wave == 1) {
+            xcd_bit = 1u << (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u);        // XCC_ID
+            if (lane == 0) xcd_old = __hip_atomic_fetch_or(xcd_seen + e0b, xcd_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         // everything bulky goes through the LDS DMA, issued by the waves that are not the leader
         constexpr int DW = LEADX ? WAVES : WAVES - 1;
         const int dw = LEADX ? wave : wave - 1;
@@ -2280,6 +2292,9 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     if (lwave) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else __syncthreads();
     SL_STAMP(2);
+    // (a predecessor ran on another XCD: what the loads above brought may be stale -- say so where the host looks at
+    //  every sync; the word only ever goes from 0 to 1)
+    if (xcd_old & ~xcd_bit) __hip_atomic_store(xcd_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 
     RowWords<H, W> b;
     Elig elig;
@@ -2755,10 +2770,6 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
         }
         if (env.policy_obs) write_policy_block<H, W>(env, smem, e0b, nbb, tid);
     }
-    // (fire and forget, system scope: the host's check kernel reads the words when the queues are synchronised)
-    if (xcd_seen && threadIdx.x == 64)
-        (void)__hip_atomic_fetch_or(xcd_seen + blockIdx.x, 1u << (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u),
-                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 #ifndef SL_ROWLANE_PART
@@ -2890,16 +2901,37 @@ hipError_t launch_occupancy_t(const u16 *in, int32_t *counts, size_t counts_stri
     return hipGetLastError();
 }
 
+// The fused kernel's argument block, packed once per launch: the runtime copies ONE buffer instead of walking eighteen
+// arguments (a step is two ~2.5 us launches through streams; the host must keep ahead of a ~8 us device step), and the
+// library's own queues write it into their argument ring as it is.  Mirrors the kernel's parameter list (natural
+// alignment == the kernel-argument layout).
+struct RolloutArgs {
+    const u16 *board, *goals;
+    const sl_pcg64 *rng;
+    sl_env_scalars *scalars;
+    const int8_t *lut;
+    const int32_t *actions;
+    int first, end;
+    sl_env_batch env;
+    int E, tstride, T;
+    sl_step_out *out;
+    float *reward_t;
+    uint8_t *done_t;
+    double *shaped_t;
+    const Jump *jump;
+    u32 *xcd_seen, *xcd_flag;
+};
+static_assert(sizeof(RolloutArgs) <= sizeof(PreparedStep::args), "argument block of a prepared step");
+
+// variant selection, LDS size and the module-level handle of the kernel that steps `env` (T steps per launch)
 template <int H, int W>
-hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, const int32_t *actions, int T,
-                                   int tstride, float *reward_t, uint8_t *done_t, const Jump *jump,
-                                   hipStream_t stream, const AqlLaunch *aql) {
+hipError_t pick_rollout_t(const sl_env_batch &env, int T, void **kernel, hipFunction_t *f_out, unsigned *threads_out, int *lds_out) {
     using Gm = Geom<H, W>;
     const bool lean = !env.wrap.flags && !env.obs && !env.policy_obs && env.finished.capacity == 0;
     const int variant = (env.n_tables == 1 ? 1 : 0) | (env.spawner_free ? 2 : 0) | (env.wrap.flags ? 4 : (lean ? 8 : 0));
     typedef void (*kernel_t)(const u16 *, const u16 *, const sl_pcg64 *, sl_env_scalars *, const int8_t *,
                              const int32_t *, int, int, sl_env_batch, int, int, int, sl_step_out *, float *,
-                             uint8_t *, double *, const Jump *, u32 *);
+                             uint8_t *, double *, const Jump *, u32 *, u32 *);
 #define SL_VARIANTS(ONE)                                                                                               \
     k_env_rollout_rowlane<H, W, false, true, false, false, ONE>, k_env_rollout_rowlane<H, W, true, true, false, false, ONE>,   \
     k_env_rollout_rowlane<H, W, false, false, false, false, ONE>, k_env_rollout_rowlane<H, W, true, false, false, false, ONE>, \
@@ -2910,7 +2942,7 @@ hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, c
     static const kernel_t table[24] = {SL_VARIANTS(false), SL_VARIANTS(true)};
 #undef SL_VARIANTS
     const int slot = variant + (T == 1 ? 12 : 0);
-    const unsigned threads = 64 * (WAVES + ((variant & 8) && Gm::LEADX_OK ? 1 : 0));     // LEAN: a fifth, leader wave
+    *threads_out = 64 * (WAVES + ((variant & 8) && Gm::LEADX_OK ? 1 : 0));     // LEAN: a fifth, leader wave
     const kernel_t fn = table[slot];
     const bool spawn = !(variant & 2), base_in_gsh = !spawn && Gm::WAVES_PER_SIMD == 4;
     const int lds = !(variant & 4) ? Gm::LDS_BYTES : (base_in_gsh ? Gm::LDS_WRAP_GSHREG : Gm::LDS_WRAP_GSHLDS);
@@ -2934,41 +2966,51 @@ hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, c
         ce.fn.store(f, std::memory_order_relaxed);
         ce.ready.store(true, std::memory_order_release);
     }
+    *kernel = (void *)fn;
+    *f_out = ce.fn.load(std::memory_order_relaxed);
+    *lds_out = lds;
+    return hipSuccess;
+}
+
+template <int H, int W>
+hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, const int32_t *actions, int T,
+                                   int tstride, float *reward_t, uint8_t *done_t, const Jump *jump,
+                                   hipStream_t stream, PreparedStep *prepared) {
+    using Gm = Geom<H, W>;
+    void *kernel = nullptr;
+    hipFunction_t f = nullptr;
+    unsigned threads = 0;
+    int lds = 0;
+    hipError_t err = pick_rollout_t<H, W>(env, T, &kernel, &f, &threads, &lds);
+    if (err != hipSuccess) return err;
     const unsigned grid = (unsigned)((e_count + Gm::NB - 1) / Gm::NB);
-    if (hipFunction_t f = ce.fn.load(std::memory_order_relaxed)) {
-        // Launch through the module API with the argument block already packed: the runtime copies ONE buffer
-        // instead of walking eighteen arguments (a step is two ~2.5 us launches; the host must keep ahead of a
-        // ~8 us device step).  The struct mirrors the kernel's parameter list (natural alignment == the
-        // kernel-argument layout).
-        struct Args {
-            const u16 *board, *goals;
-            const sl_pcg64 *rng;
-            sl_env_scalars *scalars;
-            const int8_t *lut;
-            const int32_t *actions;
-            int first, end;
-            sl_env_batch env;
-            int E, tstride, T;
-            sl_step_out *out;
-            float *reward_t;
-            uint8_t *done_t;
-            double *shaped_t;
-            const Jump *jump;
-            u32 *xcd_seen;
-        } args = {env.board, env.goals, env.rng, env.scalars, env.score_lut, actions, e_first, e_first + e_count, env,
-                  env.E, tstride, T, env.out, reward_t, done_t, env.wrap.shaped_reward_t, jump,
-                  aql ? aql->xcd_seen : nullptr};
-        // one of the library's own queues instead of a HIP stream (sl_aql.hip): same kernel, same argument block
-        if (aql) return T == 1 ? aql_dispatch(*aql, f, grid, threads, (unsigned)lds, &args, sizeof(args)) : hipErrorInvalidValue;
+    RolloutArgs args = {env.board, env.goals, env.rng, env.scalars, env.score_lut, actions, e_first, e_first + e_count, env,
+                        env.E, tstride, T, env.out, reward_t, done_t, env.wrap.shaped_reward_t, jump, nullptr, nullptr};
+    if (prepared) {
+        // not launched: the argument block and the launch geometry, for the library's own queues (sl_aql.hip) to
+        // dispatch any number of times with the per-step fields patched in
+        if (!f || T != 1) return hipErrorNotSupported;
+        prepared->f = f;
+        prepared->grid = grid;
+        prepared->threads = threads;
+        prepared->lds = (unsigned)lds;
+        prepared->arg_bytes = sizeof(args);
+        memcpy(prepared->args, &args, sizeof(args));
+        prepared->off_actions = offsetof(RolloutArgs, actions);
+        prepared->off_out = offsetof(RolloutArgs, out);
+        prepared->off_seen = offsetof(RolloutArgs, xcd_seen);
+        prepared->off_flag = offsetof(RolloutArgs, xcd_flag);
+        return hipSuccess;
+    }
+    if (f) {
         size_t size = sizeof(args);
         void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
         return hipModuleLaunchKernel(f, grid, 1, 1, threads, 1, 1, (unsigned)lds, stream, nullptr, extra);
     }
-    if (aql) return hipErrorNotSupported;
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(threads), lds, stream, env.board, env.goals, env.rng, env.scalars,
-                       env.score_lut, actions, e_first, e_first + e_count, env, env.E, tstride, T, env.out, reward_t,
-                       done_t, env.wrap.shaped_reward_t, jump, (u32 *)nullptr);
-    return hipGetLastError();
+    void *params[] = {&args.board, &args.goals, &args.rng, &args.scalars, &args.lut, &args.actions, &args.first, &args.end,
+                      &args.env, &args.E, &args.tstride, &args.T, &args.out, &args.reward_t, &args.done_t, &args.shaped_t,
+                      &args.jump, &args.xcd_seen, &args.xcd_flag};
+    return hipLaunchKernel(kernel, dim3(grid), dim3(threads), params, (size_t)lds, stream);
 }
 
 }  // namespace rl
@@ -2989,7 +3031,7 @@ hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, c
                                                             hipStream_t);                                                  \
     PREFIX template hipError_t rl::launch_inaction_t<h, w>(const sl_env_batch &, int, int, const Jump *, hipStream_t);     \
     PREFIX template hipError_t rl::launch_rollout_t<h, w>(const sl_env_batch &, int, int, const int32_t *, int, int,      \
-                                                          float *, uint8_t *, const Jump *, hipStream_t, const AqlLaunch *);
+                                                          float *, uint8_t *, const Jump *, hipStream_t, PreparedStep *);
 #ifdef SL_ROWLANE_PART
 #define X(h, w) SL_ROWLANE_LAUNCHERS(, h, w)
 #if SL_ROWLANE_PART == 1
@@ -3069,8 +3111,8 @@ hipError_t launch_inaction_rowlane(const sl_env_batch &env, int e_first, int e_c
 
 hipError_t launch_env_rollout_rowlane(const sl_env_batch &env, int e_first, int e_count, const int32_t *actions,
                                       int T, int tstride, float *reward_t, uint8_t *done_t, const Jump *jump,
-                                      hipStream_t stream, const AqlLaunch *aql) {
-#define X(h, w) if (env.H == h && env.W == w) return rl::launch_rollout_t<h, w>(env, e_first, e_count, actions, T, tstride, reward_t, done_t, jump, stream, aql);
+                                      hipStream_t stream, PreparedStep *prepared) {
+#define X(h, w) if (env.H == h && env.W == w) return rl::launch_rollout_t<h, w>(env, e_first, e_count, actions, T, tstride, reward_t, done_t, jump, stream, prepared);
     SL_ROWLANE_SHAPES(X)
 #undef X
     return hipErrorInvalidValue;

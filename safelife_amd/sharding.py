@@ -141,10 +141,21 @@ class RewardGather(object):
     def _issue(self, which):
         from . import _hip
         torch = self.torch
+        self.windows += 1
+        if self.queued and self.backend == "rccl" and getattr(self.env, "_queues", None) is not None:
+            # the window was written from the library's AQL queues: a marker goes behind its last step now, and the
+            # library's worker thread -- not this one -- waits for it before it hands the window to RCCL
+            recv = self.recv[which].data_ptr() if self.rank == 0 else None
+            ticket = C.c_longlong(-1)
+            _hip.check(self._lib.slhip_gather_window_queued(self._comm, self.buf[which].data_ptr(), recv,
+                                                            self.buf[which].numel() * 4, self.env._queues,
+                                                            self._gptr[0], C.byref(ticket)))
+            self._ticket[which] = ticket.value
+            self.busy[which] = True
+            return None
         if self.queued:
             self.env.queues_sync()     # the window is complete and visible before the exchange reads it
         streams = self._writer_streams()
-        self.windows += 1
         if self.backend == "rccl":
             recv = self.recv[which].data_ptr() if self.rank == 0 else None
             writers = (C.c_void_p * len(streams))(*[s_.cuda_stream for s_ in streams])
@@ -228,6 +239,35 @@ class RewardGather(object):
             t0 = time.perf_counter()
             self.work[which] = self._issue(which)
             self.exposed_s += time.perf_counter() - t0
+
+    def run_queued(self, t0, n, action_ptr, action_stride, shift=0, assume_ordered=False):
+        """Steps t0 .. t0+n-1 through ``env.step_queues_many``: whole windows (or what is left of one) per call to the
+        library, the records of step t going to slot (t + shift) % every of its window, and a window handed to the
+        exchange right behind the call that completes it.  `action_ptr`: device address of step t0's actions, steps
+        `action_stride` int32 elements apart.  ``assume_ordered``: as ``SafeLifeVectorEnv.step_queues``."""
+        env, B = self.env, self.B
+        if not self.collective:             # one rank: the records stay in the env's own tensor
+            env.step_queues_many(action_ptr, n, action_stride, assume_ordered=assume_ordered)
+            return
+        t = t0
+        while t < t0 + n:
+            tt = t + shift
+            slot, which = tt % self.every, (tt // self.every) % 2
+            seg = min(self.every - slot, t0 + n - t)
+            if slot == 0 and (self.work[which] is not None or self.busy[which]):
+                w0 = time.perf_counter()
+                self._wait(which, [])                       # the buffer is free again (the exchange of two windows ago)
+                self.work[which], self.busy[which] = None, False
+                self.exposed_s += time.perf_counter() - w0
+            env.set_step_outputs(self._slot_ptr[which][slot])
+            env.step_queues_many(action_ptr + 4 * action_stride * (t - t0), seg, action_stride, out_stride=B,
+                                 assume_ordered=assume_ordered)
+            if slot + seg == self.every:
+                self.last = which
+                w0 = time.perf_counter()
+                self.work[which] = self._issue(which)
+                self.exposed_s += time.perf_counter() - w0
+            t += seg
 
     def flush(self):
         """Wait (stream-level, on the caller's current stream and the writers') for outstanding exchanges and hand

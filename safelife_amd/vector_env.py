@@ -281,6 +281,7 @@ class SafeLifeVectorEnv(object):
         self._caller_ahead = True        # the caller's stream holds work the slice streams have not been fenced against
         self._queues = None              # step_queues(): the library's own AQL queues (opened on first use)
         self._queues_pending = False     # steps dispatched there since the last queues_sync()
+        self._queue_refs = []            # action tensors of those steps (kept alive until the sync)
         self._stream_ptrs = (C.c_void_p * max(1, n_sl))(*[st.cuda_stream for st in self._slice_streams])
         self._primary_ptr = C.c_void_p(self._primary.cuda_stream)
         rc = self._lib.slhip_env_prepare(self._sref, _hip.current_stream_ptr())
@@ -438,16 +439,21 @@ class SafeLifeVectorEnv(object):
             self.join()
         if self._queues_pending:
             # (what follows on the caller's stream -- even a read -- is not ordered against later queue steps: the next
-            #  one waits for the streams first)
+            #  one waits for the streams first; queues_sync() notes that)
             self.queues_sync()
-            self._caller_ahead = True
 
     # ---- sliced stepping on the library's own AQL queues (csrc/sl_aql.hip, slhip_queues_*): what step_async() does
     # ---- with stream slices, without HIP's per-launch host cost -- three to six slices per step become affordable
 
-    def queues_open(self, slices=None):
+    def queues_open(self, slices=None, release_free=None):
         """Open one AQL queue per slice (default: SAFELIFE_QUEUE_SLICES or 4).  Raises SafeLifeHipError when the
-        batch or the runtime does not support it -- callers keep to step_async() then."""
+        batch or the runtime does not support it -- callers keep to step_async() then.
+
+        ``release_free`` (default: True only if SAFELIFE_QUEUE_FENCES=none): OPT-IN to steps without a release fence
+        (include/safelife_hip.h, SL_QUEUES_RELEASE_FREE) -- ~0.9 us faster per C3 step, valid only while a workgroup
+        index keeps its XCD; the library probes that when the queues are opened (``queue_release_free`` tells whether
+        it was granted, ``queue_mode_note`` why not) and every step verifies it: a violation makes ``queues_sync()``
+        raise, and the envs' state since the queues were opened is then lost.  The default keeps a stream's fences."""
         if self._queues is not None:
             return
         B = self.num_envs
@@ -455,49 +461,106 @@ class SafeLifeVectorEnv(object):
         n = max(1, min(n, 8, (B + 63) // 64))
         per = -(-(-(-B // n)) // 64) * 64
         bounds = [min(B, i * per) for i in range(n)] + [B]
+        if release_free is None:
+            release_free = os.environ.get("SAFELIFE_QUEUE_FENCES", "agent") == "none"
         handle = C.c_void_p()
-        _hip.check(self._lib.slhip_queues_open(self._sref, n, (C.c_int32 * (n + 1))(*bounds), C.byref(handle)))
+        _hip.check(self._lib.slhip_queues_open(self._sref, n, (C.c_int32 * (n + 1))(*bounds),
+                                               _hip.QUEUES_RELEASE_FREE if release_free else 0, C.byref(handle)))
+        why = C.c_char_p()
+        mode = self._lib.slhip_queues_mode(handle, C.byref(why))
         self._queues, self.queue_slices = handle, n
+        self.queue_release_free = bool(mode & _hip.QUEUES_RELEASE_FREE)
+        self.queue_mode_note = why.value.decode() if why.value else None
+        if release_free and not self.queue_release_free:
+            import warnings
+            warnings.warn("safelife_amd: release-free queue stepping was asked for and not granted (%s); stepping with "
+                          "agent-scope fences" % self.queue_mode_note, RuntimeWarning, stacklevel=2)
 
-    def step_queues(self, actions):
+    def _queue_head(self, assume_ordered):
+        """1 if the next queue step must take a system-scope acquire behind a device synchronize: HIP streams have
+        touched the envs (reset, step(), rollout() ...) or may hold work on the actions / outputs (anything after a
+        queues_sync()) since the queues last ran."""
+        if not (self._caller_ahead or self._async_pending):
+            return 0
+        if self._async_pending:
+            self.join()
+        if not assume_ordered:
+            self.torch.cuda.synchronize(self.device)
+        self._caller_ahead = False
+        return 1
+
+    def step_queues(self, actions, assume_ordered=False):
         """One step per env, one dispatch per slice on the slice's own AQL queue.  `actions` as for step_async(),
-        complete when the call is made.  Outputs and state may be read (by the host or by any stream) only after
-        ``queues_sync()``; every method of this class that touches the env does that itself."""
+        complete when the call is made; the env keeps a reference to the tensor until the next ``queues_sync()`` (an
+        address passed as int must stay valid that long).  Outputs and state may be read (by the host or by any stream)
+        only after ``queues_sync()``; every method of this class that touches the env does that itself.
+        ``assume_ordered``: the caller vouches that no HIP stream holds unfinished work on the envs, the actions or
+        the outputs (e.g. it has just synchronised the device itself): the first step after stream work then skips
+        the device synchronize it would otherwise make."""
+        self.step_queues_many(actions, 1, assume_ordered=assume_ordered)
+
+    def step_queues_many(self, actions, n_steps=None, action_stride=None, out_stride=0, assume_ordered=False):
+        """``n_steps`` consecutive steps, ALL enqueued by this one call (``slhip_queues_steps``: the packets and
+        argument blocks of every step and slice are written on the C side, the device starts on the first step while
+        the rest is being written; the call blocks only while the queue rings are full).  `actions`: int32 device
+        tensor [T, B] (or [B] with n_steps=1), complete when the call is made -- or its address with ``n_steps`` and
+        ``action_stride`` (int32 elements between consecutive steps).  ``out_stride``: sl_step_out records between
+        the outputs of consecutive steps (0: every step overwrites the env's own record tensor; sharding.RewardGather
+        points it at a window).  Keeps a reference to `actions` until the next ``queues_sync()``."""
         if isinstance(actions, int):
             ptr = actions
+            if n_steps is None:
+                raise ValueError("n_steps is needed with an address")
+            stride = int(action_stride if action_stride is not None else self.num_envs)
         else:
-            if (actions.dtype != self.torch.int32 or not actions.is_contiguous() or actions.numel() != self.num_envs
-                    or actions.device != self.device):
-                raise ValueError("step_queues() takes a contiguous int32 tensor [num_envs] on the env's device "
-                                 "(or its address); got %s %s on %s" % (actions.dtype, tuple(actions.shape), actions.device))
-            ptr = actions.data_ptr()
+            t = actions
+            if n_steps is None:
+                n_steps = 1 if t.dim() == 1 else int(t.shape[0])
+            if (t.dtype != self.torch.int32 or not t.is_contiguous() or t.device != self.device
+                    or t.numel() < n_steps * self.num_envs or (t.dim() > 1 and t.shape[-1] != self.num_envs)):
+                raise ValueError("step_queues() takes a contiguous int32 tensor [num_envs] (or [T, num_envs]) on the env's "
+                                 "device (or its address); got %s %s on %s" % (t.dtype, tuple(t.shape), t.device))
+            ptr = t.data_ptr()
+            stride = int(action_stride if action_stride is not None else self.num_envs)
+            self._queue_refs.append(t)
         if self._queues is None:
             self.queues_open()
-        head = 0
-        if self._caller_ahead or self._async_pending:
-            # HIP streams have touched the envs since the queues last ran (a reset, step(), rollout() ...): their work
-            # is waited for here, and the step goes out with a system-scope acquire
-            if self._async_pending:
-                self.join()
-            self.torch.cuda.synchronize(self.device)
-            self._caller_ahead = False
-            head = 1
-        rc = self._lib.slhip_queues_step(self._queues, self._sref, ptr, head)
+        head = self._queue_head(assume_ordered)
+        rc = self._lib.slhip_queues_steps(self._queues, self._sref, ptr, stride, int(out_stride), int(n_steps), head)
         if rc:
             _hip.check(rc)
         self._queues_pending = True
 
+    def queues_marker(self):
+        """A system-scope release behind every queue step dispatched so far; returns a ticket at once (-1: nothing was
+        outstanding).  ``queues_wait(ticket)`` waits for it.  The pair is ``queues_sync()`` split in two, for callers
+        that have something else to do in between (or another thread to do the waiting: sharding.RewardGather)."""
+        ticket = C.c_longlong(-1)
+        if self._queues is not None:
+            _hip.check(self._lib.slhip_queues_marker(self._queues, C.byref(ticket)))
+        return ticket.value
+
+    def queues_wait(self, ticket):
+        if self._queues is not None:
+            _hip.check(self._lib.slhip_queues_wait(self._queues, int(ticket)))
+
     def queues_sync(self):
         """Wait for every step dispatched on the queues so far (system-scope release behind them): afterwards their
-        outputs and the envs' state are visible to the host and to every HIP stream."""
+        outputs and the envs' state are visible to the host and to every HIP stream.  Whatever the caller then does on
+        HIP streams is not ordered against LATER queue steps: the next one synchronises the device first (see
+        ``assume_ordered``)."""
         self._queues_pending = False
         if self._queues is not None:
-            _hip.check(self._lib.slhip_queues_sync(self._queues))
+            try:
+                _hip.check(self._lib.slhip_queues_sync(self._queues))
+            finally:
+                self._queue_refs = []
+                self._caller_ahead = True
 
     def queues_close(self):
         if self._queues is not None:
             self._lib.slhip_queues_close(self._queues)
-            self._queues, self._queues_pending = None, False
+            self._queues, self._queues_pending, self._queue_refs = None, False, []
 
     def __del__(self):
         try:
@@ -517,6 +580,8 @@ class SafeLifeVectorEnv(object):
                 raise ValueError("step_async() takes a contiguous int32 tensor [num_envs] on the env's device "
                                  "(or its address); got %s %s on %s" % (actions.dtype, tuple(actions.shape), actions.device))
             ptr = actions.data_ptr()
+        if self._queues_pending:        # steps still running on the AQL queues: their writes are not visible to streams yet
+            self._settle()
         if self.slices > 1:
             if self._caller_ahead:      # a reset / step() / rollout() on the caller's stream since the last fence
                 self.fence()

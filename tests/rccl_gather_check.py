@@ -3,7 +3,8 @@ SafeLifeVectorEnv (two slices) + RewardGather with the exchange forced on for a 
 RCCL entry points (slhip_gather_*: rank 0 sends to and receives from itself inside one RCCL group, on the gather's
 side stream).  Two phases: step_async() (the windows are written on the slice streams) and step() on the SAME
 sliced env (one launch on the caller's stream: the gather has to follow the writer), then step_queues() (the
-library's AQL queues: host-side ordering)."""
+library's AQL queues: a marker behind each window, waited for by the library's worker thread), one call per step
+and whole windows per call (RewardGather.run_queued -> slhip_queues_steps with one record slot per step)."""
 import os
 import sys
 
@@ -65,8 +66,9 @@ for t in range(T, 2 * T):
         rw, dn = gather.latest()
         assert np.array_equal(rw[0].cpu().numpy(), np.stack(want_r[-every:])), t
         assert np.array_equal(dn[0].cpu().numpy(), np.stack(want_d[-every:])), t
-# phase 3: the same env stepped from the library's own AQL queues (slhip_queues_*): the windows are ordered against
-# the exchange by the host (queues_sync before a window is handed over, a blocking query before it is reused)
+# phase 3: the same env stepped from the library's own AQL queues (slhip_queues_*): a window is handed over with a
+# marker behind its last step (slhip_gather_window_queued: the worker thread waits for it, then issues the RCCL group);
+# a blocking query before a buffer is reused
 gather.flush()
 torch.cuda.synchronize()
 try:
@@ -90,6 +92,25 @@ if queued:
             rw, dn = gather.latest()
             assert np.array_equal(rw[0].cpu().numpy(), np.stack(want_r[-every:])), t
             assert np.array_equal(dn[0].cpu().numpy(), np.stack(want_d[-every:])), t
+    # phase 4: whole windows per library call (two and a half windows at a time: the split at window ends is
+    # run_queued's), every step's records in their own slot
+    t, keep = 3 * T, []
+    for chunk in (2 * every + every // 2, every - every // 2, 3 * every):
+        acts = torch.from_numpy(rng.integers(0, 9, (chunk, B)).astype(np.int32)).to(dev)
+        torch.cuda.synchronize()
+        gather.run_queued(t, chunk, acts.data_ptr(), B)
+        for k in range(chunk):
+            ref.step(acts[k])
+            want_r.append(ref.numpy("reward"))
+            want_d.append(ref.numpy("done"))
+        t += chunk
+        keep.append(acts)                       # (addresses were handed over: the tensors live until the queues are synced)
+        if t % every == 0:
+            rw, dn = gather.latest()
+            assert np.array_equal(rw[0].cpu().numpy(), np.stack(want_r[-every:])), t
+            assert np.array_equal(dn[0].cpu().numpy(), np.stack(want_d[-every:])), t
+    gather.flush()
+    env.queues_sync()
     gather.queued = False
 gather.flush()
 torch.cuda.synchronize()

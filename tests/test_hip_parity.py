@@ -889,24 +889,28 @@ def test_sliced_stepping_soak(pool_name, B):
                 assert np.array_equal(env.numpy(name), ref), (trial, n, name)
 
 
-def _queues_or_skip(env, slices=None):
+def _queues_or_skip(env, slices=None, release_free=False):
     from safelife_amd._hip import SafeLifeHipError
     try:
-        env.queues_open(slices)
+        env.queues_open(slices, release_free=release_free)
     except SafeLifeHipError as e:           # no HSA queue to be had (not an MI355X box as the driver's): say why
         pytest.skip("AQL queues unavailable: %s" % e)
+    if release_free and not env.queue_release_free:
+        pytest.skip("release-free stepping not granted on this box: %s" % env.queue_mode_note)
 
 
+@pytest.mark.parametrize("release_free", [False, True], ids=["agent-fences", "release-free"])
 @pytest.mark.parametrize("pool_name,B,queue_slices,kw", [
     ("prune_still_25", 700, 1, dict(time_limit=12, view_shape=(9, 9))),
     ("append_spawn_25", 1500, 4, dict(time_limit=20, view_shape=(25, 25), output_channels=tuple(range(15)))),
     ("navigation_64", 300, 2, dict(time_limit=15, view_shape=(15, 15), with_obs=False)),
     ("prune_still_25", 333, 3, dict(time_limit=9, view_shape=(5, 7), wrappers=TRAINING_WRAPPERS)),
 ])
-def test_queue_stepping_vs_oracle(pool_name, B, queue_slices, kw):
+def test_queue_stepping_vs_oracle(pool_name, B, queue_slices, kw, release_free):
     """slhip_queues_*: the slices of a step dispatched from the library's own AQL queues instead of HIP streams (same
-    kernel, found in HIP's executables; barrier bit + agent-scope fences for ordering).  A synchronised step at a time
-    against the oracle (reward, done), then runs of unsynchronised steps against the same oracle steps, with a reset
+    kernel, found in HIP's executables; barrier bit + agent-scope fences for ordering, or -- opt-in -- no release
+    between steps).  A synchronised step at a time against the oracle (reward, done), then runs of unsynchronised steps
+    -- one call per step, and many steps per call (slhip_queues_steps) -- against the same oracle steps, with a reset
     through a HIP stream in the middle (the next queue step takes a system-scope acquire)."""
     import torch
     pool, _ = util.pool_from_fixture(pool_name, _device_counts, min_performance_fraction=0.05)
@@ -915,7 +919,8 @@ def test_queue_stepping_vs_oracle(pool_name, B, queue_slices, kw):
     dev = util.DeviceBackend(pool, B, **common)
     cpu = util.OracleBackend(pool, B, **common)
     env = dev.env
-    _queues_or_skip(env, queue_slices)
+    _queues_or_skip(env, queue_slices, release_free)
+    assert env.queue_release_free == release_free
     dev.env.reset()
     cpu.env.reset()
     rng = np.random.default_rng(31)
@@ -930,10 +935,16 @@ def test_queue_stepping_vs_oracle(pool_name, B, queue_slices, kw):
         assert np.array_equal(env.numpy("reward"), cpu.get("reward")) and np.array_equal(env.numpy("done"), cpu.get("done")), t
         t += 1
     for run in (40, 5, 60):
-        for _ in range(run):
-            env.step_queues(d_acts[t])
-            cpu.env.step(acts[t])
-            t += 1
+        if run == 5:
+            for _ in range(run):
+                env.step_queues(d_acts[t])
+                cpu.env.step(acts[t])
+                t += 1
+        else:                                   # one call for the whole run
+            env.step_queues_many(d_acts[t:t + run])
+            for _ in range(run):
+                cpu.env.step(acts[t])
+                t += 1
         for name in ENV_STATE:
             assert np.array_equal(dev.get(name), cpu.get(name)), (run, name)
         if kw.get("with_obs", True):
@@ -947,68 +958,187 @@ def test_queue_stepping_vs_oracle(pool_name, B, queue_slices, kw):
     assert cpu.get("episode_idx").min() >= 1
 
 
-def test_queue_stepping_refuses_a_workgroup_seen_on_two_xcds(monkeypatch):
-    """Release-free queue stepping rests on a workgroup index always running on the same XCD; the kernels record
-    where they ran and every sync has the record checked.  With a record that starts out with two XCDs in one word
-    (SAFELIFE_QUEUE_FENCES_SELFTEST) the first sync must refuse; with SAFELIFE_QUEUE_FENCES=agent there is no record
-    and nothing to refuse."""
+def test_queue_steps_write_one_record_set_per_step():
+    """slhip_queues_steps with out_stride: step t's sl_step_out records land in slot t of a caller-owned window (what
+    sharding.RewardGather hands to RCCL), against the oracle's reward / done of every step."""
     import torch
-    from safelife_amd._hip import SafeLifeHipError
+    B, T = 512, 24
+    pool, _ = util.pool_from_fixture("prune_still_25", _device_counts, min_performance_fraction=0.05)
+    common = dict(first_level=np.arange(B) % len(pool), auto_reset=True, level_stride=3, time_limit=10, view_shape=(9, 9),
+                  with_obs=False)
+    dev = util.DeviceBackend(pool, B, **common)
+    cpu = util.OracleBackend(pool, B, **common)
+    env = dev.env
+    _queues_or_skip(env, 3)
+    env.reset()
+    cpu.env.reset()
+    acts = np.random.default_rng(8).integers(0, 9, (T, B)).astype(np.int32)
+    d_acts = torch.from_numpy(acts).to(env.device)
+    window = torch.zeros((T, B, 4), dtype=torch.int32, device=env.device)
+    torch.cuda.synchronize()
+    env.set_step_outputs(window.data_ptr())
+    env.step_queues_many(d_acts, out_stride=B)
+    env.queues_sync()
+    env.set_step_outputs(None)
+    rec = window.cpu().numpy()
+    for t in range(T):
+        cpu.env.step(acts[t])
+        assert np.array_equal(rec[t, :, 0].view(np.float32), cpu.get("reward")), t
+        assert np.array_equal(rec[t, :, 1].astype(np.uint32) & 0xFF, cpu.get("done").astype(np.uint32)), t
+
+
+def test_queue_stepping_refuses_a_planted_placement_record():
+    """Release-free queue stepping (opt-in) rests on a workgroup index always running on the same XCD; every step ORs
+    its XCD into the record of its envs and raises a flag when it finds another one there.  With a record that starts
+    out with two XCDs in one word (self-test hook) the next sync must refuse, and keep refusing."""
+    import torch
+    from safelife_amd import _hip
     from safelife_amd.vector_env import SafeLifeVectorEnv
     pool, _ = util.pool_from_fixture("prune_still_25", _device_counts, n=8, min_performance_fraction=0.05)
     B = 256
     acts = torch.zeros((B,), dtype=torch.int32, device="cuda")
     kw = dict(auto_reset=True, time_limit=20, view_shape=(9, 9), with_obs=False)
-    monkeypatch.setenv("SAFELIFE_QUEUE_FENCES_SELFTEST", "1")
     env = SafeLifeVectorEnv(pool, B, **kw)
-    _queues_or_skip(env, 2)
+    _queues_or_skip(env, 2, release_free=True)
     env.reset()
     env.step_queues(acts)
-    with pytest.raises(SafeLifeHipError, match="more than one XCD"):
+    env.queues_sync()                       # an honest record: nothing to refuse
+    _hip.check(env._lib.slhip_queues_selftest(env._queues, _hip.QUEUES_SELFTEST_PLANT, 0))
+    env.step_queues(acts)
+    with pytest.raises(_hip.SafeLifeHipError, match="another XCD"):
+        env.queues_sync()
+    env.step_queues(acts)
+    with pytest.raises(_hip.SafeLifeHipError, match="another XCD"):
         env.queues_sync()
     env.queues_close()
-    monkeypatch.setenv("SAFELIFE_QUEUE_FENCES", "agent")
+    # the default mode has no record and nothing to plant
     env = SafeLifeVectorEnv(pool, B, **kw)
     env.queues_open(2)
+    assert not env.queue_release_free
+    assert env._lib.slhip_queues_selftest(env._queues, _hip.QUEUES_SELFTEST_PLANT, 0) == _hip.SL_E_UNSUPPORTED
     env.reset()
     env.step_queues(acts)
     env.queues_sync()
     env.queues_close()
 
 
-@pytest.mark.parametrize("fences", ["default", "agent"])
-def test_queue_stepping_soak(fences, monkeypatch):
-    if fences == "agent":
-        monkeypatch.setenv("SAFELIFE_QUEUE_FENCES", "agent")
-    _queue_stepping_soak()
+def test_queue_stepping_with_misplaced_workgroups():
+    """A REAL misplacement, not a planted word: on every other step the interior slice bounds move up by one workgroup's
+    envs (self-test hook), so most envs are stepped by a workgroup of another index -- on MI355X: on another XCD --
+    than the step before.
+      * with a stream's fences (the default) that is harmless: bit exact against the oracle;
+      * release-free, the placement check must fire (sync raises), and the state it refuses really is wrong: boards
+        differ from the oracle's, because steps read what another XCD's L2 had not written back."""
+    import torch
+    from safelife_amd import _hip
+    B, T = 8192, 60
+    pool, _ = util.pool_from_fixture("prune_still_25", _device_counts, min_performance_fraction=0.05)
+    common = dict(first_level=np.arange(B) % len(pool), auto_reset=True, level_stride=3, time_limit=25, view_shape=(9, 9),
+                  with_obs=False)
+    cpu = util.OracleBackend(pool, B, **common)
+    cpu.env.reset()
+    acts = np.random.default_rng(12).integers(0, 9, (T, B)).astype(np.int32)
+    for t in range(T):
+        cpu.env.step(acts[t], n_threads=8)
+    names = ("board", "goals", "rng", "agent_loc", "episode_idx", "num_steps")
+    want = {name: cpu.get(name).copy() for name in names}
+    d_acts = torch.from_numpy(acts).to("cuda")
+    torch.cuda.synchronize()
+
+    dev = util.DeviceBackend(pool, B, **common)
+    env = dev.env
+    _queues_or_skip(env, 4)
+    _hip.check(env._lib.slhip_queues_selftest(env._queues, _hip.QUEUES_SELFTEST_SHIFT, 8))
+    env.reset()
+    env.step_queues_many(d_acts)
+    env.queues_sync()
+    for name in names:
+        assert np.array_equal(dev.get(name), want[name]), ("agent fences, shifted bounds", name)
+    env.queues_close()
+
+    dev = util.DeviceBackend(pool, B, **common)
+    env = dev.env
+    _queues_or_skip(env, 4, release_free=True)
+    _hip.check(env._lib.slhip_queues_selftest(env._queues, _hip.QUEUES_SELFTEST_SHIFT, 8))
+    env.reset()
+    env.step_queues_many(d_acts)
+    with pytest.raises(_hip.SafeLifeHipError, match="another XCD"):
+        env.queues_sync()
+    # what the check refused (the fence itself completed: everything is visible): compare it anyway
+    env._queues_pending = False
+    wrong = int((dev.get("board") != want["board"]).any(axis=(1, 2)).sum())
+    print("release-free stepping with misplaced workgroups: %d of %d boards differ from the oracle" % (wrong, B))
+    assert wrong > 0
+    env.queues_close()
 
 
-def _queue_stepping_soak():
-    """Many unsynchronised queue steps at the bench's size (8192 envs; two, four and six queues, several runs) against
-    the one-launch env on the same actions: boards, generators, episode state of every env."""
+@pytest.mark.parametrize("release_free", [False, True], ids=["agent-fences", "release-free"])
+def test_queue_stepping_soak(release_free):
+    """Many unsynchronised queue steps at the bench's size (8192 envs; two, four and six queues; one call per step and
+    one call for all of them) against the ORACLE on the same actions: boards, generators, episode state of every env."""
     import torch
     from safelife_amd.vector_env import SafeLifeVectorEnv
     B, T = 8192, 300
     pool, _ = util.pool_from_fixture("prune_still_25", _device_counts, min_performance_fraction=0.05)
     first = (np.arange(B) * 3) % len(pool)
     kw = dict(first_level=first, auto_reset=True, level_stride=5, time_limit=40, view_shape=(15, 15), with_obs=False)
-    acts = torch.from_numpy(np.random.default_rng(6).integers(0, 9, (T, B)).astype(np.int32)).to("cuda")
-    whole = SafeLifeVectorEnv(pool, B, **kw)
-    whole.reset()
+    host_acts = np.random.default_rng(6).integers(0, 9, (T, B)).astype(np.int32)
+    cpu = util.OracleBackend(pool, B, **kw)
+    cpu.env.reset()
     for t in range(T):
-        whole.step_async(acts[t])
+        cpu.env.step(host_acts[t], n_threads=8)
     names = ("board", "goals", "rng", "agent_loc", "episode_idx", "level_idx", "episode_reward", "num_steps")
-    want = {name: whole.numpy(name) for name in names}
+    want = {name: cpu.get(name).copy() for name in names}
+    acts = torch.from_numpy(host_acts).to("cuda")
     for trial in range(2):
         for n in (2, 4, 6):
             env = SafeLifeVectorEnv(pool, B, **kw)
-            _queues_or_skip(env, n)
+            _queues_or_skip(env, n, release_free)
             env.reset()
-            for t in range(T):
-                env.step_queues(acts[t])
+            if trial == 0:
+                for t in range(T):
+                    env.step_queues(acts[t])
+            else:
+                env.step_queues_many(acts)
             for name, ref in want.items():
                 assert np.array_equal(env.numpy(name), ref), (trial, n, name)
             env.queues_close()
+
+
+def test_queue_steps_then_stream_steps_are_ordered():
+    """step_queues() followed by step_async() / step() / a direct queues_sync() and more queue steps: the env settles
+    the queues before anything goes onto a HIP stream and takes a system-scope acquire behind a device synchronize
+    when it comes back."""
+    import torch
+    B, T = 640, 40
+    pool, _ = util.pool_from_fixture("append_spawn_25", _device_counts, min_performance_fraction=0.05)
+    common = dict(first_level=np.arange(B) % len(pool), auto_reset=True, level_stride=3, time_limit=15, view_shape=(9, 9),
+                  with_obs=False)
+    dev = util.DeviceBackend(pool, B, slices=2, **common)
+    cpu = util.OracleBackend(pool, B, **common)
+    env = dev.env
+    _queues_or_skip(env, 2)
+    env.reset()
+    cpu.env.reset()
+    acts = np.random.default_rng(3).integers(0, 9, (T, B)).astype(np.int32)
+    d_acts = torch.from_numpy(acts).to(env.device)
+    torch.cuda.synchronize()
+    for t in range(T):
+        kind = t % 5
+        if kind in (0, 1):
+            env.step_queues(d_acts[t])
+        elif kind == 2:
+            env.step_async(d_acts[t])           # (queues pending: settled first)
+        elif kind == 3:
+            env.step(d_acts[t])
+        else:
+            env.queues_sync()                   # a direct sync, then actions made on a stream right before the step
+            fresh = (d_acts[t] + 0).contiguous()
+            env.step_queues(fresh)
+            del fresh                           # (the env holds on to the tensor until its next sync)
+        cpu.env.step(acts[t])
+    for name in ENV_STATE:
+        assert np.array_equal(dev.get(name), cpu.get(name)), name
 
 
 def test_manual_reset_moves_on_and_episode_streams():
