@@ -363,13 +363,15 @@ def main():
                 print("bench: %s" % e, file=sys.stderr)
                 refused[0] = True
 
-        def run(t0, n):
+        def run(t0, n, ordered=True):
             # one step = every env stepped once = one dispatch per slice; the action tensor is complete before the
             # loop starts, so nothing has to be fenced per step
             if use_queues:
                 # ALL n steps (and their windows) are enqueued by the library in one call per window: the stepping
-                # thread is out of the loop (slhip_queues_steps)
-                gather.run_queued(t0, n, act_ptr[t0], B, shift, assume_ordered=True)
+                # thread is out of the loop (slhip_queues_steps).  ordered: the device has just been synchronised and
+                # no stream holds work on the envs (the warm-up and the timed region); the checkpointed steps are
+                # not -- their snapshots are still being copied on a stream -- and wait for the device themselves
+                gather.run_queued(t0, n, act_ptr[t0], B, shift, assume_ordered=ordered)
                 return
             if not gather.collective:        # one rank: records stay in the env's own tensor, no windows to rotate
                 for t in range(t0, t0 + n):
@@ -386,7 +388,7 @@ def main():
         checkpoints = {}
         torch.cuda.synchronize()
         for t in range(P):
-            run(t, 1)
+            run(t, 1, ordered=False)
             if use_queues:
                 guarded_sync()
             checkpoints[t + 1] = env.snapshot()     # device-side copies: nothing crosses to the host before the timed region

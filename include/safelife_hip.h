@@ -340,8 +340,10 @@ int slhip_env_step_slices(const sl_env_batch *env, int n_slices, const int32_t *
  * SL_QUEUES_RELEASE_FREE (open's flags; OPT-IN, never the default): the steps of a queue go without the RELEASE fence
  * (it alone costs ~0.9 us of a 7.5 us step of 8192 25x25 envs: the write-back of the XCDs' L2s).  What a step wrote then
  * stays in the L2 of the XCD its workgroups ran on, and the next step's workgroup of the same index reads it there --
- * which is valid ONLY while a workgroup index keeps running on the same XCD.  MI355X in SPX mode deals the workgroups
- * of every dispatch round-robin over its XCDs, but no programming guide promises it, so
+ * which is valid ONLY while a workgroup index of a QUEUE keeps running on the same XCD.  MI355X runs workgroup i of
+ * every dispatch of a queue on XCD (q + i) mod 8, q a constant of the queue (tools/ubench/xcd_place.hip,
+ * profiles/round4_a_xcd_placement.txt: whatever the grid, the kernel, the queue's history and the other queues are
+ * doing), but no programming guide promises it, so
  *   - open probes it (a probe kernel, three dispatches per queue) and falls back to the fenced mode where it does not
  *     hold (slhip_queues_mode reports that), and
  *   - EVERY step verifies it: a workgroup ORs its XCD into the word of its first env (one returning atomic, in flight
@@ -350,12 +352,13 @@ int slhip_env_step_slices(const sl_env_batch *env, int n_slices, const int32_t *
  *     without the flag.  Use it where losing a run to that is acceptable (benchmarks, restartable roll-outs).
  *
  * selftest (tests only): SL_QUEUES_SELFTEST_PLANT puts two XCDs into the record of env 0's workgroup;
- * SL_QUEUES_SELFTEST_SHIFT moves the interior slice bounds up by `arg` envs on every other step, so that the envs next
- * to a bound are stepped by workgroups of another index than the step before -- harmless with a stream's fences, a real
- * misplacement for release-free stepping (tests/test_hip_parity.py shows both). */
+ * SL_QUEUES_SELFTEST_SWAP (arg 1 / 0: on / off) dispatches step t's slice i on queue (i + t) mod n behind a host-side
+ * drain of all queues that carries no release, so that every env is stepped -- in order -- by a workgroup of another
+ * QUEUE than the step before, which on MI355X means another XCD -- harmless with a stream's fences, a real misplacement
+ * for release-free stepping (tests/test_hip_parity.py shows both). */
 #define SL_QUEUES_RELEASE_FREE 1
 #define SL_QUEUES_SELFTEST_PLANT 1
-#define SL_QUEUES_SELFTEST_SHIFT 2
+#define SL_QUEUES_SELFTEST_SWAP 2
 int slhip_queues_open(const sl_env_batch *env, int n_slices, const int32_t *bounds, int flags, void **handle);
 int slhip_queues_mode(void *handle, const char **why_not);
 int slhip_queues_steps(void *handle, const sl_env_batch *env, const int32_t *actions, long long action_stride,

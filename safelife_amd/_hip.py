@@ -31,7 +31,7 @@ EXPORTS = (
     "slhip_queues_wait", "slhip_queues_sync", "slhip_queues_close", "slhip_queues_selftest",
 )
 QUEUES_RELEASE_FREE = 1
-QUEUES_SELFTEST_PLANT, QUEUES_SELFTEST_SHIFT = 1, 2
+QUEUES_SELFTEST_PLANT, QUEUES_SELFTEST_SWAP = 1, 2
 SL_GATHER_ID_BYTES = 128
 SL_SE_MAX_KEYS = 24
 

@@ -541,13 +541,21 @@ struct StepQueues {
     bool release_free = false;
     uint32_t *seen = nullptr, *flag = nullptr;
     bool pending = false;           // steps dispatched since this handle last waited for a marker of its own
-    int shift = 0;                  // self-test: interior slice bounds move by this many envs on every other step
+    bool swap = false;              // self-test: slice i goes to queue (i + step) mod n, behind a release-less drain
+    // what every slice's argument block looked like the last time round (the per-step pointers aside): as long as it
+    // stays the same, the blocks already in the queues' argument rings are patched instead of rewritten
+    uint32_t serial = 0, version[8] = {};
+    unsigned char last_args[8][sizeof(sl::PreparedStep::args)] = {};
+    size_t last_bytes[8] = {};
     long long steps = 0;
     std::string downgraded;         // why release-free stepping was asked for and not granted
 };
 
-// Release-free stepping is only sound where a workgroup index keeps its XCD from dispatch to dispatch.  Probe it: the
-// same grid three times on every queue; every run must put workgroup i where the first run put it.
+// Release-free stepping is only sound where a workgroup index keeps its XCD from dispatch to dispatch OF ITS QUEUE
+// (slice i is always stepped from queue i).  Probe it: three grids on every queue -- the slice's, one workgroup, and
+// the slice's again; every run must put workgroup i where the queue's first run put it.  (Measured with
+// tools/ubench/xcd_place.hip, profiles/round4_a_xcd_placement.txt: workgroup i of a dispatch runs on XCD (q + i) mod 8
+// with q a constant of the queue, whatever the grid, the kernel, the queue's history and the other queues are doing.)
 bool placement_is_stable(int n_queues, int grid, std::string *why) {
     hipFunction_t f = nullptr;
     if (hipGetFuncBySymbol(&f, (const void *)sl::k_xcd_probe) != hipSuccess || sl::aql_probe(f)) {
@@ -555,7 +563,7 @@ bool placement_is_stable(int n_queues, int grid, std::string *why) {
         *why = "the placement probe kernel was not found";
         return false;
     }
-    const int runs = 3 * n_queues;
+    const int runs = 4 * n_queues;                  // queue = r % n_queues; a queue's run 2 is the one-workgroup grid
     uint32_t *out = nullptr;
     if (hipMalloc((void **)&out, sizeof(uint32_t) * (size_t)grid * runs) != hipSuccess) {
         (void)hipGetLastError();
@@ -568,7 +576,7 @@ bool placement_is_stable(int n_queues, int grid, std::string *why) {
             uint32_t *out;
         } args = {out + (size_t)r * grid};
         const sl::AqlLaunch a{r % n_queues, true, false, nullptr, nullptr};
-        ok = sl::aql_dispatch(a, f, (unsigned)grid, 256, 0, &args, sizeof(args)) == hipSuccess;
+        ok = sl::aql_dispatch(a, f, (unsigned)(r / n_queues == 2 ? 1 : grid), 256, 0, &args, sizeof(args)) == hipSuccess;
     }
     ok = ok && sl::aql_fence(n_queues) == hipSuccess;
     std::vector<uint32_t> host((size_t)grid * runs);
@@ -579,13 +587,15 @@ bool placement_is_stable(int n_queues, int grid, std::string *why) {
         *why = "the placement probe could not be run";
         return false;
     }
-    for (int r = 1; r < runs; ++r)
-        for (int i = 0; i < grid; ++i)
-            if (host[(size_t)r * grid + i] != host[i] || host[i] > 15u) {
-                *why = "workgroup " + std::to_string(i) + " ran on XCD " + std::to_string(host[i]) + " in one dispatch and on XCD " +
-                       std::to_string(host[(size_t)r * grid + i]) + " in another";
+    for (int r = n_queues; r < runs; ++r) {
+        const uint32_t *first = host.data() + (size_t)(r % n_queues) * grid, *mine = host.data() + (size_t)r * grid;
+        for (int i = 0; i < (r / n_queues == 2 ? 1 : grid); ++i)
+            if (mine[i] != first[i] || first[i] > 15u) {
+                *why = "workgroup " + std::to_string(i) + " of queue " + std::to_string(r % n_queues) + " ran on XCD " +
+                       std::to_string(first[i]) + " in one dispatch and on XCD " + std::to_string(mine[i]) + " in another";
                 return false;
             }
+    }
     return true;
 }
 }  // namespace
@@ -605,6 +615,8 @@ int slhip_queues_open(const sl_env_batch *env, int n_slices, const int32_t *boun
     if (const char *why = sl::aql_probe(sl::rowlane_probe_function()))
         return fail(SL_E_UNSUPPORTED, std::string("AQL queues unavailable: ") + why);
     StepQueues *c = new StepQueues;
+    static std::atomic<uint32_t> serials{0};
+    c->serial = ++serials;
     c->n_slices = n_slices;
     c->H = env->H;
     c->W = env->W;
@@ -656,14 +668,13 @@ int slhip_queues_selftest(void *handle, int what, int arg) {
         if (hipMemset(c->seen, 3, 1) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return hip_fail(hipGetLastError(), "selftest");
         return SL_OK;
     }
-    if (what == SL_QUEUES_SELFTEST_SHIFT) {
-        // every other step moves the interior slice bounds up by `arg` envs: the envs around a bound are then stepped
-        // by workgroups of another index -- i.e., where placement follows the index, on another XCD -- than the step
-        // before.  With a stream's fences that changes nothing; without a release it must trip the placement check.
-        if (arg < 0 || (arg && c->n_slices < 2)) return fail(SL_E_ARG, "bad shift");
-        for (int i = 1; i < c->n_slices; ++i)
-            if (c->bounds[i] + arg > c->bounds[i + 1]) return fail(SL_E_ARG, "shift larger than a slice");
-        c->shift = arg;
+    if (what == SL_QUEUES_SELFTEST_SWAP) {
+        // from now on step t dispatches slice i on queue (i + t) mod n, behind a drain of all queues that carries NO
+        // release: the envs of a slice are then stepped, in order, by the same workgroup indices of ANOTHER queue --
+        // i.e., where placement is (queue constant + index) mod 8, on another XCD -- than the step before.  With a
+        // stream's fences that changes nothing; without a release it must trip the placement check.
+        if (arg < 0 || arg > 1 || (arg && c->n_slices < 2)) return fail(SL_E_ARG, "swap needs two slices");
+        c->swap = arg != 0;
         return SL_OK;
     }
     return fail(SL_E_ARG, "unknown self-test");
@@ -681,23 +692,27 @@ int slhip_queues_steps(void *handle, const sl_env_batch *env, const int32_t *act
     const sl::Jump *jump;
     int rc;
     if ((rc = jump_table(&jump))) return rc;
-    // one prepared launch per slice (and per bound set of the self-test); per step only the action and output
-    // pointers are patched into its argument block
-    sl::PreparedStep ps[2][8];
-    const int n_sets = c->shift ? 2 : 1;
-    for (int s = 0; s < n_sets; ++s)
-        for (int i = 0; i < c->n_slices; ++i) {
-            const int lo = c->bounds[i] + (s && i > 0 ? c->shift : 0);
-            const int hi = c->bounds[i + 1] + (s && i + 1 < c->n_slices ? c->shift : 0);
-            ps[s][i].grid = 0;
-            if (hi <= lo) continue;
-            if (!use_rowlane(env, lo)) return fail(SL_E_UNSUPPORTED, "queue stepping needs the row kernels");
-            const hipError_t err = sl::launch_env_rollout_rowlane(*env, lo, hi - lo, actions, 1, env->B, nullptr, nullptr, jump,
-                                                                  nullptr, &ps[s][i]);
-            if (err != hipSuccess) return hip_fail(err, "AQL dispatch (prepare)");
-            memcpy(ps[s][i].args + ps[s][i].off_seen, &c->seen, sizeof(void *));
-            memcpy(ps[s][i].args + ps[s][i].off_flag, &c->flag, sizeof(void *));
+    // one prepared launch per slice; per step only the action and output pointers are patched into its argument block
+    sl::PreparedStep ps[8];
+    for (int i = 0; i < c->n_slices; ++i) {
+        const int lo = c->bounds[i], hi = c->bounds[i + 1];
+        ps[i].grid = 0;
+        if (hi <= lo) continue;
+        const hipError_t err = sl::launch_env_rollout_rowlane(*env, lo, hi - lo, actions, 1, env->B, nullptr, nullptr, jump,
+                                                              nullptr, &ps[i]);
+        if (err != hipSuccess) return hip_fail(err, "AQL dispatch (prepare)");
+        memcpy(ps[i].args + ps[i].off_seen, &c->seen, sizeof(void *));
+        memcpy(ps[i].args + ps[i].off_flag, &c->flag, sizeof(void *));
+        // (compared with the per-step fields blanked: they are patched into every dispatch anyway)
+        const void *none = nullptr;
+        memcpy(ps[i].args + ps[i].off_actions, &none, sizeof(void *));
+        memcpy(ps[i].args + ps[i].off_out, &none, sizeof(void *));
+        if (c->last_bytes[i] != ps[i].arg_bytes || memcmp(c->last_args[i], ps[i].args, ps[i].arg_bytes)) {
+            memcpy(c->last_args[i], ps[i].args, ps[i].arg_bytes);
+            c->last_bytes[i] = ps[i].arg_bytes;
+            ++c->version[i];
         }
+    }
     struct Batch {
         Batch() { sl::aql_begin(); }
         ~Batch() { sl::aql_commit(); }
@@ -706,20 +721,32 @@ int slhip_queues_steps(void *handle, const sl_env_batch *env, const int32_t *act
     for (int t = 0; t < n_steps; ++t) {
         const int32_t *a_t = actions + (long long)t * action_stride;
         sl_step_out *o_t = env->out + (long long)t * out_stride;
-        const int s = c->shift ? (int)(c->steps & 1) : 0;
-        ++c->steps;
+        if (c->swap) {
+            const hipError_t err = sl::aql_drain(c->n_slices);
+            if (err != hipSuccess) return hip_fail(err, "AQL drain (self-test)");
+        }
         for (int i = 0; i < c->n_slices; ++i) {
-            sl::PreparedStep &p = ps[s][i];
+            sl::PreparedStep &p = ps[i];
             if (!p.grid) continue;
             memcpy(p.args + p.off_actions, &a_t, sizeof(void *));
             memcpy(p.args + p.off_out, &o_t, sizeof(void *));
-            const sl::AqlLaunch a{i, head != 0 && t == 0, c->release_free, c->seen, c->flag};
-            const hipError_t err = sl::aql_dispatch(a, p.f, p.grid, p.threads, p.lds, p.args, p.arg_bytes);
+            const int queue = c->swap ? (int)((i + c->steps) % c->n_slices) : i;
+            const sl::AqlLaunch a{queue, head != 0 && t == 0, c->release_free, c->seen, c->flag};
+            sl::AqlPatch patch{c->serial * 8u + (uint32_t)i, c->version[i], 2, {p.off_actions, p.off_out}};
+#ifdef SL_TRACE
+            if (g_trace_base && g_trace_next < g_trace_slots) {
+                float *trace = (float *)(g_trace_base + g_trace_bytes * g_trace_next++);
+                memcpy(p.args + p.off_trace, &trace, sizeof(void *));
+            }
+            patch.owner = 0;                        // (profiling build: every block is written in full)
+#endif
+            const hipError_t err = sl::aql_dispatch(a, p.f, p.grid, p.threads, p.lds, p.args, p.arg_bytes, &patch);
             if (err != hipSuccess) return hip_fail(err, "AQL dispatch");
         }
+        ++c->steps;
         // the first step goes out at once (the device starts while the rest is being written), the others in
         // batches of eight steps: one flush of the argument ring (sfence + read-back, ~1 us) per batch
-        if (t == 0 || (t & 7) == 0) sl::aql_flush();
+        if (t == 0 || (t & 7) == 0 || c->swap) sl::aql_flush();
     }
     return SL_OK;
 }

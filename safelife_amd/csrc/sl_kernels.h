@@ -72,7 +72,7 @@ struct PreparedStep {
     hipFunction_t f;
     unsigned grid, threads, lds;
     size_t arg_bytes;
-    size_t off_actions, off_out, off_seen, off_flag;
+    size_t off_actions, off_out, off_seen, off_flag, off_trace;
     alignas(16) unsigned char args[1024];
 };
 // prepared (optional, T == 1 only): fill it instead of launching
@@ -84,8 +84,15 @@ hipError_t launch_env_rollout_rowlane(const sl_env_batch &env, int e_first, int 
 const char *aql_open(int n_queues);                 // null when usable, else why not
 const char *aql_probe(hipFunction_t f);             // can HIP's kernel `f` be found in the HSA executables? (null: yes)
 hipFunction_t rowlane_probe_function();             // any kernel of the library (sl_rowlane.hip)
+// patch (optional): the argument block is `version` of `owner`'s (any non-zero ids the caller keeps unique); where the
+// queue's next argument slot already holds exactly that, only the 8-byte words at `offset[0..n)` are written again
+struct AqlPatch {
+    uint32_t owner, version;
+    int n;
+    size_t offset[4];
+};
 hipError_t aql_dispatch(const AqlLaunch &a, hipFunction_t f, unsigned grid, unsigned threads, unsigned lds,
-                        const void *args, size_t arg_bytes);
+                        const void *args, size_t arg_bytes, const AqlPatch *patch = nullptr);
 void aql_begin();                                   // dispatches between begin and commit go out in batches: their
 void aql_flush();                                   // argument blocks are flushed once per batch (flush: hand over what
 void aql_commit();                                  // has been written so far; commit: flush and leave batch mode)
@@ -96,6 +103,7 @@ void aql_commit();                                  // has been written so far; 
 hipError_t aql_marker(int n_queues, bool force, long long *ticket);
 hipError_t aql_wait(long long ticket);
 hipError_t aql_fence(int n_queues);
+hipError_t aql_drain(int n_queues);                // (self-test) every queue idle, no cache action
 bool aql_poisoned();                                // a wait timed out: work may still be in flight
 
 // the same for envs [e_first, e_first + e_count) on the row kernels (also writes wrap.inaction_rows)

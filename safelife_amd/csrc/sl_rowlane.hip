@@ -3000,6 +3000,7 @@ hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, c
         prepared->off_out = offsetof(RolloutArgs, out);
         prepared->off_seen = offsetof(RolloutArgs, xcd_seen);
         prepared->off_flag = offsetof(RolloutArgs, xcd_flag);
+        prepared->off_trace = offsetof(RolloutArgs, reward_t);
         return hipSuccess;
     }
     if (f) {

@@ -1023,9 +1023,10 @@ def test_queue_stepping_refuses_a_planted_placement_record():
 
 
 def test_queue_stepping_with_misplaced_workgroups():
-    """A REAL misplacement, not a planted word: on every other step the interior slice bounds move up by one workgroup's
-    envs (self-test hook), so most envs are stepped by a workgroup of another index -- on MI355X: on another XCD --
-    than the step before.
+    """A REAL misplacement, not a planted word: step t dispatches slice i on queue (i + t) mod n (self-test hook; the
+    host drains the queues between steps WITHOUT any cache action, so the steps of an env stay in order).  A workgroup
+    index of another queue runs -- on MI355X -- on another XCD (profiles/round4_a_xcd_placement.txt), so every env is
+    stepped on another XCD than the step before.
       * with a stream's fences (the default) that is harmless: bit exact against the oracle;
       * release-free, the placement check must fire (sync raises), and the state it refuses really is wrong: boards
         differ from the oracle's, because steps read what another XCD's L2 had not written back."""
@@ -1048,24 +1049,25 @@ def test_queue_stepping_with_misplaced_workgroups():
     dev = util.DeviceBackend(pool, B, **common)
     env = dev.env
     _queues_or_skip(env, 4)
-    _hip.check(env._lib.slhip_queues_selftest(env._queues, _hip.QUEUES_SELFTEST_SHIFT, 8))
+    _hip.check(env._lib.slhip_queues_selftest(env._queues, _hip.QUEUES_SELFTEST_SWAP, 1))
     env.reset()
     env.step_queues_many(d_acts)
     env.queues_sync()
     for name in names:
-        assert np.array_equal(dev.get(name), want[name]), ("agent fences, shifted bounds", name)
+        assert np.array_equal(dev.get(name), want[name]), ("agent fences, queues swapped", name)
     env.queues_close()
 
     dev = util.DeviceBackend(pool, B, **common)
     env = dev.env
     _queues_or_skip(env, 4, release_free=True)
-    _hip.check(env._lib.slhip_queues_selftest(env._queues, _hip.QUEUES_SELFTEST_SHIFT, 8))
     env.reset()
-    env.step_queues_many(d_acts)
+    env.step_queues_many(d_acts[:10])       # honest placement first: nothing to refuse
+    env.queues_sync()
+    _hip.check(env._lib.slhip_queues_selftest(env._queues, _hip.QUEUES_SELFTEST_SWAP, 1))
+    env.step_queues_many(d_acts[10:])
     with pytest.raises(_hip.SafeLifeHipError, match="another XCD"):
         env.queues_sync()
     # what the check refused (the fence itself completed: everything is visible): compare it anyway
-    env._queues_pending = False
     wrong = int((dev.get("board") != want["board"]).any(axis=(1, 2)).sum())
     print("release-free stepping with misplaced workgroups: %d of %d boards differ from the oracle" % (wrong, B))
     assert wrong > 0
