@@ -427,9 +427,16 @@ def main():
         gather.flush()
         t_c = time.perf_counter()
         if use_queues:
-            guarded_sync()         # the queues' closing barrier packets (system-scope release), waited for here
+            # The closing bracket is BOTH waits: torch.cuda.synchronize() (HIP's streams: idle in queue mode, apart from
+            # the exchange's) and the queues' fence (a system-scope release behind the last step, waited for on its
+            # completion signals).  The clock stops when both have returned, i.e. every step has completed and is
+            # visible; the stream-side wait -- ~5 us of runtime time even when there is nothing to wait for -- comes
+            # first so that it passes while the queues are still stepping.
+            torch.cuda.synchronize()
+            guarded_sync()
+        else:
+            torch.cuda.synchronize()
         t_d = time.perf_counter()
-        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
@@ -442,7 +449,7 @@ def main():
         if refused[0]:
             return None
         if dbg:
-            print("timeline us: enqueue %.1f | e1 record %.1f | flush %.1f | queues_sync %.1f | synchronize %.1f | total %.1f"
+            print("timeline us: enqueue %.1f | e1 record %.1f | flush %.1f | synchronize + queues_sync %.1f | barrier %.1f | total %.1f"
                   % ((t_enqueued - t_start) * 1e6, (t_b - t_enqueued) * 1e6, (t_c - t_b) * 1e6, (t_d - t_c) * 1e6,
                      (t_start + elapsed - t_d) * 1e6, elapsed * 1e6), file=sys.stderr)
         res.update(elapsed=elapsed, t_start=t_start, t_enqueued=t_enqueued, checkpoints=checkpoints, evs=evs, streams=streams,

@@ -38,6 +38,8 @@
 #include <mutex>
 #include <string>
 #include <unordered_map>
+#include <vector>
+#include <cstdio>
 
 #include "sl_kernels.h"
 
@@ -49,10 +51,11 @@ constexpr uint32_t QUEUE_PACKETS = 1024;
 constexpr size_t KARG_SLOT = 1024;              // bytes per argument block
 // Argument blocks per queue: a short ring.  A slot is written again only when the packet that used it last has
 // COMPLETED (the read index has passed the packet behind it: every step packet carries the barrier bit), so the host
-// runs at most KARG_SLOTS - 2 dispatches ahead of a queue -- and after the first lap every slot already holds the block
-// of the same slice of the same batch: only the words that change from step to step cross the PCIe aperture again
-// (AqlPatch: two pointers instead of ~600 bytes, 0.6 us of a dispatch's 0.7 us of host time).
-constexpr size_t KARG_SLOTS = 16;
+// runs at most KARG_SLOTS - 2 dispatches ahead of a queue.  A slot that already holds the block of the same slice of
+// the same batch (AqlPatch; aql_warm() writes it into every idle slot when a batch first steps) only has the words that
+// change from step to step sent across the PCIe aperture again: two pointers instead of ~600 bytes, i.e. 0.6 us of a
+// dispatch's 0.7 us of host time.
+constexpr size_t KARG_SLOTS = 64;
 
 struct Hsa {
     bool ok = false;
@@ -64,7 +67,9 @@ struct Hsa {
     X(hsa_queue_add_write_index_relaxed) X(hsa_queue_load_read_index_scacquire) X(hsa_system_get_major_extension_table) \
     X(hsa_executable_get_symbol_by_name) X(hsa_executable_symbol_get_info) X(hsa_amd_agent_iterate_memory_pools)        \
     X(hsa_amd_memory_pool_get_info) X(hsa_amd_memory_pool_allocate) X(hsa_amd_agents_allow_access)                      \
-    X(hsa_amd_agent_memory_pool_get_info) X(hsa_status_string)
+    X(hsa_amd_agent_memory_pool_get_info) X(hsa_status_string) X(hsa_system_get_info)                                   \
+    X(hsa_amd_profiling_set_profiler_enabled) X(hsa_amd_profiling_get_dispatch_time)                                   \
+    X(hsa_amd_profiling_convert_tick_to_system_domain)
 #define X(n) decltype(&::n) n = nullptr;
     SL_HSA_FNS(X)
 #undef X
@@ -171,6 +176,17 @@ struct Device {
     Marker markers[MARKERS];
     long long next_ticket = 0;
     bool poisoned = false;          // a marker timed out: work may still be in flight, nothing of the queues' is freed
+    // SL_AQL_TIMELINE=1 (debugging): the queues run with dispatch profiling on, every dispatch carries a completion
+    // signal, and aql_timeline_dump() prints when the host rang which doorbell and when the device started and ended
+    // what, all on the HSA system clock
+    bool timeline = false;
+    struct TlEvent {
+        const char *what;
+        int queue;
+        uint64_t host_tick;
+        hsa_signal_t sig;       // {0}: a host-side mark
+    };
+    std::vector<TlEvent> tl;
 };
 
 Device g_dev[64];
@@ -287,6 +303,7 @@ void open_device(Device &d, int dev) {
         d.why = "no memory pool for kernel arguments";
         return;
     }
+    d.timeline = env_int("SL_AQL_TIMELINE", 0) != 0;
     d.readback = env_int("SL_AQL_READBACK", 1);
     d.step_acquire = env_int("SL_AQL_STEP_ACQUIRE", HSA_FENCE_SCOPE_AGENT);
     d.step_release = env_int("SL_AQL_STEP_RELEASE", HSA_FENCE_SCOPE_AGENT);
@@ -300,6 +317,7 @@ bool open_queue(Device &d, Queue &q) {
         d.why = hsa_err("hsa_queue_create", st);
         return false;
     }
+    if (d.timeline) (void)h.hsa_amd_profiling_set_profiler_enabled(q.q, 1);
     st = h.hsa_signal_create(0, 0, nullptr, &q.fence);
     if (st != HSA_STATUS_SUCCESS) {
         d.why = hsa_err("hsa_signal_create", st);
@@ -382,6 +400,15 @@ void *claim(const Hsa &h, hsa_queue_t *q, uint64_t *index) {
     return (unsigned char *)q->base_address + (idx & (q->size - 1)) * 64;
 }
 
+uint64_t sys_tick(const Hsa &h) {
+    uint64_t t = 0;
+    h.hsa_system_get_info(HSA_SYSTEM_INFO_TIMESTAMP, &t);
+    return t;
+}
+void tl_mark(Device &d, const Hsa &h, const char *what, int queue = -1, hsa_signal_t sig = hsa_signal_t{0}) {
+    if (d.timeline && d.tl.size() < 4096) d.tl.push_back({what, queue, sys_tick(h), sig});
+}
+
 // Argument blocks written since the last call have landed in device memory (posted writes through the aperture:
 // drained from the CPU's write-combining buffers, then -- as the runtime does for device-resident arguments -- one
 // byte read back: a read does not pass the writes in front of it); then the pending packets are handed to the queues.
@@ -391,6 +418,7 @@ void publish(Device &d, const Hsa &h) {
         if (d.readback) (void)*d.last_tail;
     }
     d.last_tail = nullptr;
+    if (d.n_pending) tl_mark(d, h, "doorbells");
     for (int i = 0; i < d.n_pending; ++i) {
         const Device::Pending &p = d.pending[i];
         __atomic_store_n(p.packet, p.head_word, __ATOMIC_RELEASE);
@@ -485,6 +513,9 @@ hipError_t emit(Device &d, const Hsa &h, int queue, hipFunction_t f, unsigned gr
     p->kernel_object = k->object;
     p->kernarg_address = slot;
     p->reserved2 = 0;
+    if (d.timeline && !completion.handle && d.tl.size() < 4096 &&
+        h.hsa_signal_create(1, 0, nullptr, &completion) == HSA_STATUS_SUCCESS)
+        tl_mark(d, h, "dispatch", queue, completion);
     p->completion_signal = completion;
     const uint16_t setup = 3 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
     q.dirty = true;
@@ -527,6 +558,29 @@ hipError_t aql_dispatch(const AqlLaunch &a, hipFunction_t f, unsigned grid, unsi
     const int release = a.release_free ? HSA_FENCE_SCOPE_NONE : d->step_release;
     const uint16_t hd = header(HSA_PACKET_TYPE_KERNEL_DISPATCH, true, a.head ? HSA_FENCE_SCOPE_SYSTEM : d->step_acquire, release);
     return emit(*d, h, a.queue, f, grid, threads, lds, args, arg_bytes, hd, hsa_signal_t{0}, true, patch);
+}
+
+void aql_warm(int queue, hipFunction_t f, const void *args, size_t arg_bytes, const AqlPatch &patch) {
+    Device *d = current();
+    if (!d || !d->ok || queue < 0 || queue >= d->n_queues || !patch.owner) return;
+    const Hsa &h = hsa();
+    std::lock_guard<std::mutex> lock(d->mu);
+    const KernelInfo *k = kernel_info(*d, f);
+    if (!k || arg_bytes > k->kernarg || k->kernarg > KARG_SLOT) return;
+    Queue &q = d->queues[queue];
+    const size_t total = (k->kernarg + 63) & ~(size_t)63;
+    const uint64_t read = h.hsa_queue_load_read_index_scacquire(q.q);
+    for (size_t si = 0; si < KARG_SLOTS; ++si) {
+        Queue::Slot &sl = q.slots[si];
+        if (sl.used && read < sl.packet + 2) continue;          // still (possibly) being read: rewritten when its turn comes
+        if (sl.owner == patch.owner && sl.version == patch.version) continue;
+        unsigned char *slot = q.karg + si * KARG_SLOT;
+        memcpy(slot, args, arg_bytes);
+        if (total > arg_bytes) memset(slot + arg_bytes, 0, total - arg_bytes);
+        d->last_tail = slot + total - 1;
+        sl.owner = patch.owner;
+        sl.version = patch.version;
+    }
 }
 
 void aql_begin() {
@@ -581,6 +635,7 @@ hipError_t aql_marker(int n_queues, bool force, long long *ticket) {
         m.waiting[i] = true;
         q.dirty = false;
         barrier(*d, h, i, nullptr, 0, HSA_FENCE_SCOPE_SYSTEM, m.sig[i]);
+        tl_mark(*d, h, "marker", i, m.sig[i]);
     }
     *ticket = m.ticket;
     return hipSuccess;
@@ -640,6 +695,40 @@ hipError_t aql_fence(int n_queues) {
     long long ticket = -1;
     const hipError_t err = aql_marker(n_queues, false, &ticket);
     return err != hipSuccess ? err : aql_wait(ticket);
+}
+
+void aql_timeline_mark(const char *what) {
+    Device *d = current();
+    if (!d || !d->ok || !d->timeline) return;
+    std::lock_guard<std::mutex> lock(d->mu);
+    tl_mark(*d, hsa(), what);
+}
+
+void aql_timeline_dump() {
+    Device *d = current();
+    if (!d || !d->ok || !d->timeline) return;
+    const Hsa &h = hsa();
+    std::lock_guard<std::mutex> lock(d->mu);
+    if (d->tl.empty()) return;
+    uint64_t freq = 0;
+    h.hsa_system_get_info(HSA_SYSTEM_INFO_TIMESTAMP_FREQUENCY, &freq);
+    const double us = freq ? 1e6 / (double)freq : 0.0;
+    const uint64_t t0 = d->tl[0].host_tick;
+    fprintf(stderr, "aql timeline (us since the first mark; host = when the host did it, device = start .. end on the device)\n");
+    for (const Device::TlEvent &e : d->tl) {
+        if (!e.sig.handle) {
+            fprintf(stderr, "  host %9.2f  %s\n", (double)(int64_t)(e.host_tick - t0) * us, e.what);
+            continue;
+        }
+        hsa_amd_profiling_dispatch_time_t dt{};
+        uint64_t a = 0, b = 0;
+        const bool ok = h.hsa_amd_profiling_get_dispatch_time(d->gpu, e.sig, &dt) == HSA_STATUS_SUCCESS &&
+                        h.hsa_amd_profiling_convert_tick_to_system_domain(d->gpu, dt.start, &a) == HSA_STATUS_SUCCESS &&
+                        h.hsa_amd_profiling_convert_tick_to_system_domain(d->gpu, dt.end, &b) == HSA_STATUS_SUCCESS;
+        fprintf(stderr, "  host %9.2f  %-8s queue %d   device %9.2f .. %9.2f%s\n", (double)(int64_t)(e.host_tick - t0) * us, e.what,
+                e.queue, (double)(int64_t)(a - t0) * us, (double)(int64_t)(b - t0) * us, ok ? "" : "  (no timestamps)");
+    }
+    d->tl.clear();          // (the dispatches' signals are leaked: debugging only)
 }
 
 bool aql_poisoned() {

@@ -93,6 +93,8 @@ struct AqlPatch {
 };
 hipError_t aql_dispatch(const AqlLaunch &a, hipFunction_t f, unsigned grid, unsigned threads, unsigned lds,
                         const void *args, size_t arg_bytes, const AqlPatch *patch = nullptr);
+// write `owner`'s argument block into every idle slot of the queue's argument ring (dispatches then only patch)
+void aql_warm(int queue, hipFunction_t f, const void *args, size_t arg_bytes, const AqlPatch &patch);
 void aql_begin();                                   // dispatches between begin and commit go out in batches: their
 void aql_flush();                                   // argument blocks are flushed once per batch (flush: hand over what
 void aql_commit();                                  // has been written so far; commit: flush and leave batch mode)
@@ -104,6 +106,8 @@ hipError_t aql_marker(int n_queues, bool force, long long *ticket);
 hipError_t aql_wait(long long ticket);
 hipError_t aql_fence(int n_queues);
 hipError_t aql_drain(int n_queues);                // (self-test) every queue idle, no cache action
+void aql_timeline_mark(const char *what);           // SL_AQL_TIMELINE=1 (debugging): a host-side mark ...
+void aql_timeline_dump();                           // ... and the timeline since the last dump, on stderr
 bool aql_poisoned();                                // a wait timed out: work may still be in flight
 
 // the same for envs [e_first, e_first + e_count) on the row kernels (also writes wrap.inaction_rows)
