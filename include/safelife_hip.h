@@ -344,14 +344,15 @@ int slhip_env_step_slices(const sl_env_batch *env, int n_slices, const int32_t *
  * every dispatch of a queue on XCD (q + i) mod 8, q a constant of the queue (tools/ubench/xcd_place.hip,
  * profiles/round4_a_xcd_placement.txt: whatever the grid, the kernel, the queue's history and the other queues are
  * doing), but no programming guide promises it, so
- *   - open probes it (a probe kernel, three dispatches per queue) and falls back to the fenced mode where it does not
- *     hold (slhip_queues_mode reports that), and
- *   - EVERY step verifies it: a workgroup ORs its XCD into the word of its first env (one returning atomic, in flight
- *     under the loads) and raises a host-visible flag if a predecessor ran elsewhere; wait / sync then -- and from then
- *     on -- return SL_E_HIP: the envs' state since the queues were opened is not valid, and the caller starts over
- *     without the flag.  Use it where losing a run to that is acceptable (benchmarks, restartable roll-outs).
+ *   - open probes it (a probe kernel, three dispatches per queue: q of every queue, and that every workgroup follows
+ *     the formula) and falls back to the fenced mode where it does not hold (slhip_queues_mode reports that), and
+ *   - EVERY step verifies it: every workgroup compares the XCD it runs on with (q + i) mod 8 of its slice's queue --
+ *     scalar code, no memory access -- and raises a host-visible flag if it finds itself anywhere else; wait / sync
+ *     then -- and from then on -- return SL_E_HIP: the envs' state since the queues were opened is not valid, and the
+ *     caller starts over without the flag.  Use it where losing a run to that is acceptable (benchmarks, restartable
+ *     roll-outs).
  *
- * selftest (tests only): SL_QUEUES_SELFTEST_PLANT puts two XCDs into the record of env 0's workgroup;
+ * selftest (tests only): SL_QUEUES_SELFTEST_PLANT tells slice 0 to expect its workgroups one XCD further on than they run;
  * SL_QUEUES_SELFTEST_SWAP (arg 1 / 0: on / off) dispatches step t's slice i on queue (i + t) mod n behind a host-side
  * drain of all queues that carries no release, so that every env is stepped -- in order -- by a workgroup of another
  * QUEUE than the step before, which on MI355X means another XCD -- harmless with a stream's fences, a real misplacement

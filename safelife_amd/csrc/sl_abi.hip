@@ -537,9 +537,10 @@ struct StepQueues {
     int32_t bounds[9] = {};
     int H = 0, W = 0, B = 0;
     // SL_QUEUES_RELEASE_FREE (opt-in): no release fence between the steps of a queue; the placement this rests on is
-    // probed when the queues are opened and verified by every step (sl_rowlane.hip: xcd_seen / xcd_flag).
+    // probed when the queues are opened and verified by every step (sl_rowlane.hip: xcd_base / xcd_flag).
     bool release_free = false;
-    uint32_t *seen = nullptr, *flag = nullptr;
+    int base[8] = {};               // queue i runs workgroup w of a dispatch on XCD (base[i] + w) mod 8 (probed at open)
+    uint32_t *flag = nullptr;       // host memory: raised by a step kernel that finds itself on another XCD
     bool pending = false;           // steps dispatched since this handle last waited for a marker of its own
     bool swap = false;              // self-test: slice i goes to queue (i + step) mod n, behind a release-less drain
     // what every slice's argument block looked like the last time round (the per-step pointers aside): as long as it
@@ -551,19 +552,20 @@ struct StepQueues {
     std::string downgraded;         // why release-free stepping was asked for and not granted
 };
 
-// Release-free stepping is only sound where a workgroup index keeps its XCD from dispatch to dispatch OF ITS QUEUE
-// (slice i is always stepped from queue i).  Probe it: three grids on every queue -- the slice's, one workgroup, and
-// the slice's again; every run must put workgroup i where the queue's first run put it.  (Measured with
-// tools/ubench/xcd_place.hip, profiles/round4_a_xcd_placement.txt: workgroup i of a dispatch runs on XCD (q + i) mod 8
-// with q a constant of the queue, whatever the grid, the kernel, the queue's history and the other queues are doing.)
-bool placement_is_stable(int n_queues, int grid, std::string *why) {
+// Release-free stepping is only sound where workgroup w of a dispatch of queue i always runs on the same XCD (slice i is
+// always stepped from queue i).  MI355X runs it on XCD (q_i + w) mod 8, q_i a constant of the queue, whatever the grid,
+// the kernel, the queue's history and the other queues are doing (tools/ubench/xcd_place.hip,
+// profiles/round4_a_xcd_placement.txt).  Probed here: three grids on every queue -- the slice's, one workgroup, the
+// slice's again; every run must follow that formula with the queue's q_i, which the step kernels then check themselves
+// against at every step.
+bool probe_placement(int n_queues, int grid, int *base, std::string *why) {
     hipFunction_t f = nullptr;
     if (hipGetFuncBySymbol(&f, (const void *)sl::k_xcd_probe) != hipSuccess || sl::aql_probe(f)) {
         (void)hipGetLastError();
         *why = "the placement probe kernel was not found";
         return false;
     }
-    const int runs = 4 * n_queues;                  // queue = r % n_queues; a queue's run 2 is the one-workgroup grid
+    const int runs = 3 * n_queues;                  // queue = r % n_queues; a queue's second run is the one-workgroup grid
     uint32_t *out = nullptr;
     if (hipMalloc((void **)&out, sizeof(uint32_t) * (size_t)grid * runs) != hipSuccess) {
         (void)hipGetLastError();
@@ -575,8 +577,8 @@ bool placement_is_stable(int n_queues, int grid, std::string *why) {
         struct {
             uint32_t *out;
         } args = {out + (size_t)r * grid};
-        const sl::AqlLaunch a{r % n_queues, true, false, nullptr, nullptr};
-        ok = sl::aql_dispatch(a, f, (unsigned)(r / n_queues == 2 ? 1 : grid), 256, 0, &args, sizeof(args)) == hipSuccess;
+        const sl::AqlLaunch a{r % n_queues, true, false};
+        ok = sl::aql_dispatch(a, f, (unsigned)(r / n_queues == 1 ? 1 : grid), 256, 0, &args, sizeof(args)) == hipSuccess;
     }
     ok = ok && sl::aql_fence(n_queues) == hipSuccess;
     std::vector<uint32_t> host((size_t)grid * runs);
@@ -587,12 +589,14 @@ bool placement_is_stable(int n_queues, int grid, std::string *why) {
         *why = "the placement probe could not be run";
         return false;
     }
-    for (int r = n_queues; r < runs; ++r) {
-        const uint32_t *first = host.data() + (size_t)(r % n_queues) * grid, *mine = host.data() + (size_t)r * grid;
-        for (int i = 0; i < (r / n_queues == 2 ? 1 : grid); ++i)
-            if (mine[i] != first[i] || first[i] > 15u) {
-                *why = "workgroup " + std::to_string(i) + " of queue " + std::to_string(r % n_queues) + " ran on XCD " +
-                       std::to_string(first[i]) + " in one dispatch and on XCD " + std::to_string(mine[i]) + " in another";
+    for (int r = 0; r < runs; ++r) {
+        const int q = r % n_queues;
+        const uint32_t *mine = host.data() + (size_t)r * grid;
+        if (r < n_queues) base[q] = (int)mine[0];
+        for (int w = 0; w < (r / n_queues == 1 ? 1 : grid); ++w)
+            if (mine[w] > 7u || mine[w] != (((uint32_t)base[q] + (uint32_t)w) & 7u)) {
+                *why = "workgroup " + std::to_string(w) + " of a dispatch of queue " + std::to_string(q) + " ran on XCD " +
+                       std::to_string(mine[w]) + ", not on XCD (" + std::to_string(base[q]) + " + " + std::to_string(w) + ") mod 8";
                 return false;
             }
     }
@@ -623,29 +627,19 @@ int slhip_queues_open(const sl_env_batch *env, int n_slices, const int32_t *boun
     c->B = env->B;
     memcpy(c->bounds, bounds, sizeof(int32_t) * (n_slices + 1));
     if (flags & SL_QUEUES_RELEASE_FREE) {
-        int grid = 1;
+        int grid = 8;
         for (int i = 0; i < n_slices; ++i) grid = std::max(grid, bounds[i + 1] - bounds[i]);    // (>= workgroups of a slice)
         grid = std::min(grid, 4096);
         std::string why;
-        hipError_t err = hipSuccess;
-        if (!placement_is_stable(n_slices, grid, &why)) {
+        if (!probe_placement(n_slices, grid, c->base, &why)) {
             c->downgraded = why;
+        } else if (hipHostMalloc((void **)&c->flag, 64, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            c->flag = nullptr;
+            c->downgraded = "no host memory for the placement flag";
         } else {
-            // (one word per env of the batch: a workgroup uses the word of its first env)
-            err = hipMalloc((void **)&c->seen, sizeof(uint32_t) * (size_t)(env->B + 1));
-            if (err == hipSuccess) err = hipMemset(c->seen, 0, sizeof(uint32_t) * (size_t)(env->B + 1));
-            if (err == hipSuccess) err = hipHostMalloc((void **)&c->flag, 64, hipHostMallocDefault);
-            if (err == hipSuccess) err = hipDeviceSynchronize();
-            if (err != hipSuccess) {
-                (void)hipGetLastError();
-                if (c->seen) (void)hipFree(c->seen);
-                if (c->flag) (void)hipHostFree(c->flag);
-                c->seen = c->flag = nullptr;
-                c->downgraded = "no memory for the placement record";
-            } else {
-                *c->flag = 0;
-                c->release_free = true;
-            }
+            *c->flag = 0;
+            c->release_free = true;
         }
     }
     *handle = c;
@@ -663,9 +657,9 @@ int slhip_queues_selftest(void *handle, int what, int arg) {
     StepQueues *c = (StepQueues *)handle;
     if (!c) return fail(SL_E_ARG, "null pointer");
     if (what == SL_QUEUES_SELFTEST_PLANT) {
-        // the record of env 0's workgroup starts out with two XCDs in it: the next step must raise the flag
-        if (!c->release_free) return fail(SL_E_UNSUPPORTED, "no placement record in this mode");
-        if (hipMemset(c->seen, 3, 1) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return hip_fail(hipGetLastError(), "selftest");
+        // slice 0 is told to expect its workgroups one XCD further on than they run: the next step must raise the flag
+        if (!c->release_free) return fail(SL_E_UNSUPPORTED, "no placement check in this mode");
+        c->base[0] = (c->base[0] + 1) & 7;
         return SL_OK;
     }
     if (what == SL_QUEUES_SELFTEST_SWAP) {
@@ -695,9 +689,9 @@ int slhip_queues_steps(void *handle, const sl_env_batch *env, const int32_t *act
     if ((rc = jump_table(&jump))) return rc;
     // one prepared launch per slice; per step only the action and output pointers are patched into its argument block
     sl::PreparedStep ps[8];
-    // (SL_AQL_NO_RECORD=1, A/B timing only: release-free steps WITHOUT their placement check)
-    static const bool no_record = getenv("SL_AQL_NO_RECORD") != nullptr;
-    uint32_t *const seen = no_record ? nullptr : c->seen;
+    // (SL_AQL_NO_CHECK=1, A/B timing only: release-free steps WITHOUT their placement check)
+    static const bool no_check = getenv("SL_AQL_NO_CHECK") != nullptr;
+    uint32_t *const flag = no_check ? nullptr : c->flag;
     for (int i = 0; i < c->n_slices; ++i) {
         const int lo = c->bounds[i], hi = c->bounds[i + 1];
         ps[i].grid = 0;
@@ -705,8 +699,8 @@ int slhip_queues_steps(void *handle, const sl_env_batch *env, const int32_t *act
         const hipError_t err = sl::launch_env_rollout_rowlane(*env, lo, hi - lo, actions, 1, env->B, nullptr, nullptr, jump,
                                                               nullptr, &ps[i]);
         if (err != hipSuccess) return hip_fail(err, "AQL dispatch (prepare)");
-        memcpy(ps[i].args + ps[i].off_seen, &seen, sizeof(void *));
-        memcpy(ps[i].args + ps[i].off_flag, &c->flag, sizeof(void *));
+        memcpy(ps[i].args + ps[i].off_base, &c->base[i], sizeof(int));
+        memcpy(ps[i].args + ps[i].off_flag, &flag, sizeof(void *));
         // (compared with the per-step fields blanked: they are patched into every dispatch anyway)
         const void *none = nullptr;
         memcpy(ps[i].args + ps[i].off_actions, &none, sizeof(void *));
@@ -742,7 +736,7 @@ int slhip_queues_steps(void *handle, const sl_env_batch *env, const int32_t *act
             memcpy(p.args + p.off_actions, &a_t, sizeof(void *));
             memcpy(p.args + p.off_out, &o_t, sizeof(void *));
             const int queue = c->swap ? (int)((i + c->steps) % c->n_slices) : i;
-            const sl::AqlLaunch a{queue, head != 0 && t == 0, c->release_free, c->seen, c->flag};
+            const sl::AqlLaunch a{queue, head != 0 && t == 0, c->release_free};
             sl::AqlPatch patch{c->serial * 8u + (uint32_t)i, c->version[i], 2, {p.off_actions, p.off_out}};
 #ifdef SL_TRACE
             if (g_trace_base && g_trace_next < g_trace_slots) {
@@ -809,10 +803,9 @@ int slhip_queues_close(void *handle) {
     long long ticket = -1;
     hipError_t err = sl::aql_marker(c->n_slices, c->pending, &ticket);
     if (err == hipSuccess) err = sl::aql_wait(ticket);
-    // (a fence that failed or timed out leaves step kernels in flight that still write the record and the flag:
-    //  those few kilobytes are leaked rather than freed under them)
+    // (a fence that failed or timed out leaves step kernels in flight that may still write the flag: it is leaked
+    //  rather than freed under them)
     if (err == hipSuccess && !sl::aql_poisoned()) {
-        if (c->seen) (void)hipFree(c->seen);
         if (c->flag) (void)hipHostFree(c->flag);
     }
     delete c;

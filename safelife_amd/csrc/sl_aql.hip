@@ -552,9 +552,9 @@ hipError_t aql_dispatch(const AqlLaunch &a, hipFunction_t f, unsigned grid, unsi
     const Hsa &h = hsa();
     std::lock_guard<std::mutex> lock(d->mu);
     // release-free (opt-in): the step goes without a release fence, so what it wrote stays in the L2 of the XCD its
-    // workgroups ran on, which is where the next step's workgroups of the same index read it -- valid as long as a
-    // workgroup index keeps its XCD, which every step verifies itself against the record of the steps before it
-    // (a.xcd_seen / a.xcd_flag).  Otherwise agent scope on both sides, as a HIP stream.
+    // workgroups ran on, which is where the next step's workgroups of the same index read it -- valid as long as
+    // workgroup i of this queue keeps its XCD, which every step verifies itself (sl_rowlane.hip: xcd_base / xcd_flag).
+    // Otherwise agent scope on both sides, as a HIP stream.
     const int release = a.release_free ? HSA_FENCE_SCOPE_NONE : d->step_release;
     const uint16_t hd = header(HSA_PACKET_TYPE_KERNEL_DISPATCH, true, a.head ? HSA_FENCE_SCOPE_SYSTEM : d->step_acquire, release);
     return emit(*d, h, a.queue, f, grid, threads, lds, args, arg_bytes, hd, hsa_signal_t{0}, true, patch);

@@ -60,10 +60,8 @@ hipError_t launch_se_distributions(const sl_env_batch &env, const sl_episode_que
 struct AqlLaunch {
     int queue;              // index of the queue (one per slice)
     bool head;              // first step after work of HIP streams: system-scope acquire
-    bool release_free;      // opt-in: no release fence behind this step (valid while a workgroup index keeps its XCD)
-    u32 *xcd_seen;          // release-free stepping: the placement record, one word per env of the BATCH (a workgroup
-                            // uses the word of its first env): the XCDs the workgroup that steps these envs has run on
-    u32 *xcd_flag;          // ... and the host-visible word a step raises when its workgroup finds another XCD there
+    bool release_free;      // opt-in: no release fence behind this step (valid while workgroup i of the slice's queue keeps
+                            // its XCD: the kernel checks itself against the placement found when the queues were opened)
 };
 // A single-step launch of the fused kernel that is not issued but handed back: kernel handle, geometry and the packed
 // argument block with the offsets of the fields that change from step to step -- what the queues dispatch, any number
@@ -72,7 +70,7 @@ struct PreparedStep {
     hipFunction_t f;
     unsigned grid, threads, lds;
     size_t arg_bytes;
-    size_t off_actions, off_out, off_seen, off_flag, off_trace;
+    size_t off_actions, off_out, off_base, off_flag, off_trace;
     alignas(16) unsigned char args[1024];
 };
 // prepared (optional, T == 1 only): fill it instead of launching

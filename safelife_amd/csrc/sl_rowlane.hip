@@ -2143,10 +2143,10 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     sl_env_batch env, int hot_E, int tstride, int T_arg, sl_step_out *__restrict__ out_rec,
     float *__restrict__ reward_t, uint8_t *__restrict__ done_t, double *__restrict__ shaped_t,
     const Jump *__restrict__ jump,
-    // queue stepping without a release fence between steps (sl_aql.hip, opt-in): the placement record -- word e of the
-    // batch collects the XCDs that workgroups whose first env is e have run on -- and the host-visible word a workgroup
-    // raises when it finds an XCD other than its own there; both null on every other launch
-    u32 *__restrict__ xcd_seen, u32 *__restrict__ xcd_flag) {
+    // queue stepping without a release fence between steps (sl_aql.hip, opt-in): workgroup i of this launch must run on
+    // XCD (xcd_base + i) mod 8 -- where the launches before it left this slice's state -- and raises the host-visible
+    // word xcd_flag if it finds itself anywhere else; xcd_flag is null on every other launch
+    int xcd_base, u32 *__restrict__ xcd_flag) {
     using Gm = Geom<H, W>;
     constexpr int WS = Gm::WS, HW = Gm::HW;
     const int T = ONE ? 1 : T_arg;
@@ -2228,7 +2228,6 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     int pre_i[4] = {0, 0, 0, 0}, pre_y1 = 0, pre_x1 = 0;   // the move of step 0, on cells taken from global memory
     u32 pre_c[4] = {0u, 0u, 0u, 0u};
     bool pre_write = false;
-    u32 xcd_old = 0, xcd_bit = 0;
     if (lwave) {
         ly = hot_scalars[el].agent_row;
         lx = hot_scalars[el].agent_col;
@@ -2247,14 +2246,13 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
             pre_c[3] = src[gi[3]];
         }
     } else {
-        // Release-free queue stepping: the state this workgroup is about to load was left in the L2 of the XCD its
-        // predecessor (same first env, previous step) ran on.  One returning atomic -- in flight under the bulk loads,
-        // looked at behind the load barrier -- ORs this workgroup's XCD into the record and brings back where the
-        // predecessors ran.
-        if (xcd_seen && wave == 1) {
-            xcd_bit = 1u << (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u);        // XCC_ID
-            if (lane == 0) xcd_old = __hip_atomic_fetch_or(xcd_seen + e0b, xcd_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        // Release-free queue stepping: the state this workgroup is about to load was left in the L2 of the XCD that
+        // workgroup i of this slice's queue always runs on.  Scalar code, no memory access unless it fails (a returning
+        // atomic on a per-workgroup record, looked at behind the load barrier, cost 0.25 us per step: the record sits
+        // behind the fabric while the state it guards sits in the L2).
+        if (xcd_flag && wave == 1 && (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u) != (((u32)xcd_base + blockIdx.x) & 7u) &&
+            lane == 0)
+            __hip_atomic_store(xcd_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         // everything bulky goes through the LDS DMA, issued by the waves that are not the leader
         constexpr int DW = LEADX ? WAVES : WAVES - 1;
         const int dw = LEADX ? wave : wave - 1;
@@ -2292,9 +2290,6 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     if (lwave) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else __syncthreads();
     SL_STAMP(2);
-    // (a predecessor ran on another XCD: what the loads above brought may be stale -- say so where the host looks at
-    //  every sync; the word only ever goes from 0 to 1)
-    if (xcd_old & ~xcd_bit) __hip_atomic_store(xcd_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 
     RowWords<H, W> b;
     Elig elig;
@@ -2919,7 +2914,8 @@ struct RolloutArgs {
     uint8_t *done_t;
     double *shaped_t;
     const Jump *jump;
-    u32 *xcd_seen, *xcd_flag;
+    int xcd_base;
+    u32 *xcd_flag;
 };
 static_assert(sizeof(RolloutArgs) <= sizeof(PreparedStep::args), "argument block of a prepared step");
 
@@ -2931,7 +2927,7 @@ hipError_t pick_rollout_t(const sl_env_batch &env, int T, void **kernel, hipFunc
     const int variant = (env.n_tables == 1 ? 1 : 0) | (env.spawner_free ? 2 : 0) | (env.wrap.flags ? 4 : (lean ? 8 : 0));
     typedef void (*kernel_t)(const u16 *, const u16 *, const sl_pcg64 *, sl_env_scalars *, const int8_t *,
                              const int32_t *, int, int, sl_env_batch, int, int, int, sl_step_out *, float *,
-                             uint8_t *, double *, const Jump *, u32 *, u32 *);
+                             uint8_t *, double *, const Jump *, int, u32 *);
 #define SL_VARIANTS(ONE)                                                                                               \
     k_env_rollout_rowlane<H, W, false, true, false, false, ONE>, k_env_rollout_rowlane<H, W, true, true, false, false, ONE>,   \
     k_env_rollout_rowlane<H, W, false, false, false, false, ONE>, k_env_rollout_rowlane<H, W, true, false, false, false, ONE>, \
@@ -2985,7 +2981,7 @@ hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, c
     if (err != hipSuccess) return err;
     const unsigned grid = (unsigned)((e_count + Gm::NB - 1) / Gm::NB);
     RolloutArgs args = {env.board, env.goals, env.rng, env.scalars, env.score_lut, actions, e_first, e_first + e_count, env,
-                        env.E, tstride, T, env.out, reward_t, done_t, env.wrap.shaped_reward_t, jump, nullptr, nullptr};
+                        env.E, tstride, T, env.out, reward_t, done_t, env.wrap.shaped_reward_t, jump, 0, nullptr};
     if (prepared) {
         // not launched: the argument block and the launch geometry, for the library's own queues (sl_aql.hip) to
         // dispatch any number of times with the per-step fields patched in
@@ -2998,7 +2994,7 @@ hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, c
         memcpy(prepared->args, &args, sizeof(args));
         prepared->off_actions = offsetof(RolloutArgs, actions);
         prepared->off_out = offsetof(RolloutArgs, out);
-        prepared->off_seen = offsetof(RolloutArgs, xcd_seen);
+        prepared->off_base = offsetof(RolloutArgs, xcd_base);
         prepared->off_flag = offsetof(RolloutArgs, xcd_flag);
         prepared->off_trace = offsetof(RolloutArgs, reward_t);
         return hipSuccess;
@@ -3010,7 +3006,7 @@ hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, c
     }
     void *params[] = {&args.board, &args.goals, &args.rng, &args.scalars, &args.lut, &args.actions, &args.first, &args.end,
                       &args.env, &args.E, &args.tstride, &args.T, &args.out, &args.reward_t, &args.done_t, &args.shaped_t,
-                      &args.jump, &args.xcd_seen, &args.xcd_flag};
+                      &args.jump, &args.xcd_base, &args.xcd_flag};
     return hipLaunchKernel(kernel, dim3(grid), dim3(threads), params, (size_t)lds, stream);
 }
 

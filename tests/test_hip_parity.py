@@ -988,9 +988,10 @@ def test_queue_steps_write_one_record_set_per_step():
 
 
 def test_queue_stepping_refuses_a_planted_placement_record():
-    """Release-free queue stepping (opt-in) rests on a workgroup index always running on the same XCD; every step ORs
-    its XCD into the record of its envs and raises a flag when it finds another one there.  With a record that starts
-    out with two XCDs in one word (self-test hook) the next sync must refuse, and keep refusing."""
+    """Release-free queue stepping (opt-in) rests on workgroup i of a slice's queue always running on the same XCD;
+    every workgroup of every step compares where it runs with where the probe at open found that index and raises a
+    flag when it differs.  Told to expect slice 0 one XCD further on (self-test hook) the next sync must refuse, and
+    keep refusing."""
     import torch
     from safelife_amd import _hip
     from safelife_amd.vector_env import SafeLifeVectorEnv

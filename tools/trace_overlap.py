@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
-"""Timeline of consecutive two-slice steps from the kernels' own clocks (needs a -DSL_TRACE build, tools/build_trace.sh):
+"""Timeline of consecutive sliced steps from the kernels' own clocks (needs a -DSL_TRACE build, tools/build_trace.sh):
 
-    SAFELIFE_HIP_LIB=tools/lib_trace.so python tools/trace_overlap.py [steps]
+    SAFELIFE_HIP_LIB=tools/lib_trace.so python tools/trace_overlap.py [steps] [--queues N] [--fences none|agent]
+
+Default: two slices on two HIP streams (slhip_env_step_slices).  --queues N: N slices dispatched from the library's AQL
+queues (slhip_queues_steps, all steps enqueued by one call), with a stream's fences (agent) or release-free (none).
 
 Every wave stamps s_memrealtime (100 MHz) at its start and when its stores are acknowledged; every launch of
 slhip_env_step_slices writes its stamps to its own buffer.  The counters of the eight XCDs are offset against each
@@ -17,17 +20,28 @@ from safelife_amd import _hip
 from safelife_amd.levels import _device_counts
 from safelife_amd.vector_env import SafeLifeVectorEnv
 
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 6
-B, SL = 8192, 2
+import argparse
+ap = argparse.ArgumentParser()
+ap.add_argument("steps", nargs="?", type=int, default=6)
+ap.add_argument("--queues", type=int, default=0)
+ap.add_argument("--fences", default="agent")
+args = ap.parse_args()
+N = args.steps
+B, SL = 8192, (args.queues or 2)
 pool = bench.load_pool("prune_still_25", _device_counts)
 env = SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25), output_channels=bench.TRAIN_CHANNELS,
-                        auto_reset=True, with_obs=False, slices=SL)
+                        auto_reset=True, with_obs=False, slices=2 if args.queues else SL)
 env.reset()
+if args.queues:
+    env.queues_open(args.queues, release_free=(args.fences == "none"))
+    print("AQL queues: %d, release-free: %s" % (env.queue_slices, env.queue_release_free))
 acts = torch.randint(0, 9, (64 + N, B), device=env.device, dtype=torch.int32)
 ptrs = [acts[t].data_ptr() for t in range(64 + N)]      # (addresses: the loop below is all the host does per step)
-step = env.step_async
+step = env.step_queues if args.queues else env.step_async
 for t in range(64):
     step(ptrs[t])
+if args.queues:
+    env.queues_sync()
 torch.cuda.synchronize()
 lib = _hip.lib()
 waves = (B // SL // 8) * 4
@@ -36,8 +50,12 @@ lib.slhip_trace_set.argtypes = [C.c_void_p, C.c_longlong, C.c_int]
 assert lib.slhip_trace_set(trace.data_ptr(), waves * 16 * 8, N * SL) == 0
 import gc
 gc.disable()
-for t in range(64, 64 + N):
-    step(ptrs[t])
+if args.queues:
+    env.step_queues_many(acts[64:64 + N], assume_ordered=True)
+    env.queues_sync()
+else:
+    for t in range(64, 64 + N):
+        step(ptrs[t])
 torch.cuda.synchronize()
 tr = trace.cpu().numpy()
 xcc = (tr[:, :, 11] & 0xF).astype(int)
@@ -50,8 +68,9 @@ for x in range(8):
     t0 = start[0][m[0]].min() if m[0].any() else start[m].min()
     rows.append([(start[i][m[i]].min() - t0, start[i][m[i]].max() - t0, end[i][m[i]].max() - t0) for i in range(N * SL)])
 med = np.median(np.array(rows), axis=0)
-print("two-slice steps of %d envs, per launch: first wave start / last wave start / last store acknowledged, ns since the "
-      "first wave of the first launch (median over the XCDs)" % B)
+print("%d-slice steps of %d envs (%s), per launch: first wave start / last wave start / last store acknowledged, ns since "
+      "the first wave of the first launch (median over the XCDs)"
+      % (SL, B, ("AQL queues, fences: " + ("none" if env.queue_release_free else "agent")) if args.queues else "HIP streams"))
 prev_end = {}
 for i in range(N * SL):
     s, step = i % SL, i // SL
