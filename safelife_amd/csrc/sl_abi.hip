@@ -749,9 +749,12 @@ int slhip_queues_steps(void *handle, const sl_env_batch *env, const int32_t *act
             if (err != hipSuccess) return hip_fail(err, "AQL dispatch");
         }
         ++c->steps;
-        // the first step goes out at once (the device starts while the rest is being written), the others in
-        // batches of eight steps: one flush of the argument ring (sfence + read-back, ~1 us) per batch
-        if (t == 0 || (t & 7) == 0 || c->swap) sl::aql_flush();
+        // A flush of the argument ring (sfence + read-back) and the doorbells cost ~1.5 us; a step's four dispatches
+        // ~1-3 us of host time, and the device needs the next step ~6 us after the last.  So the first steps go out one
+        // by one (the device starts at once and is never left waiting while a batch is being written: with eight steps
+        // per flush from the start the kernels' own clocks showed it idle for 7 us behind step 0), later ones -- the
+        // host is ahead by then -- in twos and fours.
+        if (t < 4 || (t < 16 && (t & 1)) || (t & 3) == 3 || c->swap) sl::aql_flush();
     }
     return SL_OK;
 }

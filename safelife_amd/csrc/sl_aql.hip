@@ -127,6 +127,8 @@ struct Queue {
     hsa_signal_t fence{0};
     unsigned char *karg = nullptr;
     uint64_t karg_next = 0;
+    uint64_t read_seen = 0;         // the queue's read index when it was last looked at (it lives in memory the device
+                                    // writes: every look is a cache miss, so it is only looked at when it matters)
     struct Slot {
         uint64_t packet = 0;        // index of the packet that used the slot last
         bool used = false;
@@ -393,9 +395,13 @@ uint16_t header(uint16_t type, bool barrier, int acquire, int release) {
 }
 
 // the next packet slot of the queue (waits while the ring is full)
-void *claim(const Hsa &h, hsa_queue_t *q, uint64_t *index) {
+void *claim(const Hsa &h, Queue &qq, uint64_t *index) {
+    hsa_queue_t *q = qq.q;
     const uint64_t idx = h.hsa_queue_add_write_index_relaxed(q, 1);
-    while (idx - h.hsa_queue_load_read_index_scacquire(q) >= q->size) _mm_pause();
+    while (idx - qq.read_seen >= q->size) {
+        qq.read_seen = h.hsa_queue_load_read_index_scacquire(q);
+        if (idx - qq.read_seen >= q->size) _mm_pause();
+    }
     *index = idx;
     return (unsigned char *)q->base_address + (idx & (q->size - 1)) * 64;
 }
@@ -479,11 +485,11 @@ hipError_t emit(Device &d, const Hsa &h, int queue, hipFunction_t f, unsigned gr
     const unsigned si = (unsigned)(q.karg_next++ % KARG_SLOTS);
     Queue::Slot &sl = q.slots[si];
     unsigned char *slot = q.karg + si * KARG_SLOT;
-    if (sl.used && h.hsa_queue_load_read_index_scacquire(q.q) < sl.packet + 2) {
+    if (sl.used && q.read_seen < sl.packet + 2 && (q.read_seen = h.hsa_queue_load_read_index_scacquire(q.q)) < sl.packet + 2) {
         // the slot's last dispatch may still be reading it: hand over what is pending (it may be that very packet) and
         // wait until the packet BEHIND it has been taken off the ring
         publish(d, h);
-        while (h.hsa_queue_load_read_index_scacquire(q.q) < sl.packet + 2) _mm_pause();
+        while ((q.read_seen = h.hsa_queue_load_read_index_scacquire(q.q)) < sl.packet + 2) _mm_pause();
     }
     const size_t total = (k->kernarg + 63) & ~(size_t)63;
     if (patch && patch->owner && sl.owner == patch->owner && sl.version == patch->version) {
@@ -498,7 +504,7 @@ hipError_t emit(Device &d, const Hsa &h, int queue, hipFunction_t f, unsigned gr
         sl.version = patch ? patch->version : 0;
     }
     uint64_t idx;
-    hsa_kernel_dispatch_packet_t *p = (hsa_kernel_dispatch_packet_t *)claim(h, q.q, &idx);
+    hsa_kernel_dispatch_packet_t *p = (hsa_kernel_dispatch_packet_t *)claim(h, q, &idx);
     sl.packet = idx;
     sl.used = true;
     p->workgroup_size_x = (uint16_t)threads;
@@ -535,7 +541,7 @@ hipError_t emit(Device &d, const Hsa &h, int queue, hipFunction_t f, unsigned gr
 void barrier(Device &d, const Hsa &h, int queue, const hsa_signal_t *deps, int n_deps, int release, hsa_signal_t completion) {
     Queue &q = d.queues[queue];
     uint64_t idx;
-    hsa_barrier_and_packet_t *p = (hsa_barrier_and_packet_t *)claim(h, q.q, &idx);
+    hsa_barrier_and_packet_t *p = (hsa_barrier_and_packet_t *)claim(h, q, &idx);
     memset((unsigned char *)p + 4, 0, 60);
     for (int i = 0; i < n_deps && i < 5; ++i) p->dep_signal[i] = deps[i];
     p->completion_signal = completion;
@@ -569,7 +575,7 @@ void aql_warm(int queue, hipFunction_t f, const void *args, size_t arg_bytes, co
     if (!k || arg_bytes > k->kernarg || k->kernarg > KARG_SLOT) return;
     Queue &q = d->queues[queue];
     const size_t total = (k->kernarg + 63) & ~(size_t)63;
-    const uint64_t read = h.hsa_queue_load_read_index_scacquire(q.q);
+    const uint64_t read = q.read_seen = h.hsa_queue_load_read_index_scacquire(q.q);
     for (size_t si = 0; si < KARG_SLOTS; ++si) {
         Queue::Slot &sl = q.slots[si];
         if (sl.used && read < sl.packet + 2) continue;          // still (possibly) being read: rewritten when its turn comes

@@ -166,7 +166,8 @@ struct Geom {
     //  to the few hundred bytes the observation epilogue parks its per-board parameters in)
     static constexpr int GSH_BYTES = WAVES_PER_SIMD < 4 ? 512 : WAVES * 64 * WS * 4;
     static constexpr int OFF_LUT = OFF_GSH + GSH_BYTES;             // 4 KiB compact score table
-    static constexpr int LDS_BYTES = OFF_LUT + 4096;
+    static constexpr int OFF_MOVE = OFF_LUT + 4096;                 // NB x 16 bytes: the agents' moves, leader -> rows
+    static constexpr int LDS_BYTES = OFF_MOVE + NB * 16;
     // training wrappers (WRAP variants only): per-board sl_wrap_state, the movement table, and -- when the
     // goal words occupy OFF_GSH -- the baseline rows of the side-effect count
     static constexpr int OFF_WST = LDS_BYTES;
@@ -2190,7 +2191,11 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     // (and the LEAN single-step instantiation of the spawner variant where it fits: 114 -> 125 VGPRs at 25x25, C4's
     //  share 9.6 -> 9.25 us per two-slice step on top of the even deal of the draws; the non-LEAN one and 26x26 tip
     //  into 8 bytes of scratch with it and keep the words in LDS)
-    constexpr bool GSH_REG = !SPAWN || Gm::WAVES_PER_SIMD < 4 || (ONE && LEAN && W <= 25);
+#ifndef SL_SPAWN_GSH_REG
+#define SL_SPAWN_GSH_REG 1      /* A/B knob: the LEAN single-step spawner variant keeps the goal words in registers (1) or
+                                   takes the move box (0) -- both together tip it into scratch */
+#endif
+    constexpr bool GSH_REG = !SPAWN || Gm::WAVES_PER_SIMD < 4 || (SL_SPAWN_GSH_REG && ONE && LEAN && W <= 25);
     u32 gsh_reg[GSH_REG ? WS : 1];
     u32 *gsh_lane = GSH_REG ? gsh_reg : (u32 *)(smem + Gm::OFF_GSH) + (wave * 64 + lane) * WS;
     const int8_t *lds_lut = (const int8_t *)(smem + Gm::OFF_LUT);
@@ -2246,13 +2251,6 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
             pre_c[3] = src[gi[3]];
         }
     } else {
-        // Release-free queue stepping: the state this workgroup is about to load was left in the L2 of the XCD that
-        // workgroup i of this slice's queue always runs on.  Scalar code, no memory access unless it fails (a returning
-        // atomic on a per-workgroup record, looked at behind the load barrier, cost 0.25 us per step: the record sits
-        // behind the fabric while the state it guards sits in the L2).
-        if (xcd_flag && wave == 1 && (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u) != (((u32)xcd_base + blockIdx.x) & 7u) &&
-            lane == 0)
-            __hip_atomic_store(xcd_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         // everything bulky goes through the LDS DMA, issued by the waves that are not the leader
         constexpr int DW = LEADX ? WAVES : WAVES - 1;
         const int dw = LEADX ? wave : wave - 1;
@@ -2270,6 +2268,15 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
                                                      min(env.wrap.move_table_len & ~1, Gm::MVT_N) * 8, lane, dw);
         }
     }
+#ifndef SL_MOVE_BOX
+#define SL_MOVE_BOX 1           /* A/B knob: 0 = the round-3 form of the move (leader writes the image, a barrier of its own) */
+#endif
+    constexpr bool MOVE_BOX = SL_MOVE_BOX && ONE && !(SPAWN && GSH_REG && Gm::WAVES_PER_SIMD == 4);
+    // (Round 4, measured and dropped: every lane fetching its OWN goal row from global memory at the start -- thirteen
+    //  2-byte aligned dwords, permuted into the split layout behind the load barrier -- instead of the pass over the
+    //  LDS image, the "goal rows" phase of the trace.  Same-box A/B, K = 400: 6.46 us per step without it, 6.60-6.65
+    //  with it through the queues, 8.03 against 8.72 through stream slices: the extra vector-memory instructions in
+    //  front of the DMA cost more than the LDS pass they replace.)
     // Every kernel argument the rest of the kernel needs that did not arrive preloaded: fetched in ONE batch
     // here, in the shadow of the bulk loads.
     {
@@ -2277,19 +2284,42 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
         const void *p0 = out_rec, *p1 = env.pool_board, *p2 = env.pool_goals, *p3 = env.pool_exit_locs;
         const void *p4 = env.pool_rng, *p5 = env.pool_scalars, *p6 = env.exit_locs;
         asm volatile("" ::"s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(T), "s"(p0), "s"(p1), "s"(p2), "s"(p3),
-                     "s"(p4), "s"(p5), "s"(p6), "s"(reward_t), "s"(done_t));
+                     "s"(p4), "s"(p5), "s"(p6), "s"(reward_t), "s"(done_t), "s"(xcd_base), "s"(xcd_flag));
     }
     typedef __attribute__((address_space(3))) int *lds_int;       // (a generic volatile pointer would go through FLAT)
     lds_int dirty_flag = (lds_int)(smem + Gm::OFF_GOALS);              // in the region's leading pad
     if (tid == 0) *dirty_flag = 0;
     const bool has_queue = !LEAN && env.finished.capacity > 0;
     const bool hand_over = env.auto_reset || has_queue;           // (uniform) leaders may ask the rows for something
+    // Round 4, single-step launches: the leaders decide the move HERE, in front of the load barrier (their four cells
+    // came from global memory, two dependent round trips that run under the bulk loads), and leave what is to be
+    // written -- (image index, cell) x 4 -- in LDS.  The board's own wave puts it into the image right behind the
+    // barrier, in front of its row reads (LDS operations of one wave stay in order), so no workgroup barrier stands
+    // between the loads and the CA any more, and the leaders' serial section is off the rows' path.
+    typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t *const move_box = (u32x4_t *)(smem + Gm::OFF_MOVE);
+    if (MOVE_BOX && lwave) {
+        u32x4_t mv = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
+        if (lead && ly >= 0) pre_write = act_rule(pre_c, action, ly, lx, pre_y1, pre_x1);
+        if (pre_write)
+            mv = u32x4_t{(u32)pre_i[0] | (pre_c[0] << 16), (u32)pre_i[1] | (pre_c[1] << 16), (u32)pre_i[2] | (pre_c[2] << 16),
+                         (u32)pre_i[3] | (pre_c[3] << 16)};
+        if (lead) move_box[lq] = mv;
+    }
     SL_STAMP(1);
     // the load barrier: the DMA waves wait for their loads, the leader wave only for its LDS stores (it moved none
     // of the spans, and what it has in flight is its own business)
     if (lwave) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else __syncthreads();
     SL_STAMP(2);
+    // Release-free queue stepping: the state this workgroup has just loaded was left in the L2 of the XCD that
+    // workgroup i of this slice's queue always runs on.  Scalar code, no memory access unless it fails, and behind the
+    // bulk loads: the two arguments arrive with the batch above (a returning atomic on a per-workgroup record, looked
+    // at here, cost 0.25 us per step -- the record sits behind the fabric while the state it guards sits in the L2; and
+    // the same comparison in FRONT of the loads cost a scalar-cache round trip before the first DMA instruction).
+    if (xcd_flag && wave == 1 && (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u) != (((u32)xcd_base + blockIdx.x) & 7u) &&
+        lane == 0)
+        __hip_atomic_store(xcd_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 
     RowWords<H, W> b;
     Elig elig;
@@ -2298,6 +2328,16 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
 #pragma unroll
     for (int k = 0; k < WS; ++k) asm volatile("" : "=v"(b[k]));
     if (rwave) {
+    if (MOVE_BOX && rlead) {
+        // the move the board's leader decided: into the image, by the board's own wave, ahead of its row reads
+        // (a loop that is not unrolled: one live register instead of four in the variants that sit at the limit)
+        const u32 *mv = (const u32 *)(move_box + gb);
+#pragma nounroll
+        for (int k = 0; k < 4; ++k) {
+            const u32 w = mv[k];
+            if ((w & 0xFFFFu) != 0xFFFFu) board16[w & 0xFFFFu] = (u16)(w >> 16);
+        }
+    }
     if (live) {
         read_row<H, W>(goals, gb, r, b);
 #pragma unroll
@@ -2448,21 +2488,23 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
                 __builtin_amdgcn_global_load_lds((glds_src_t)(src + k), (glds_dst_t)(base_rows + k * 256), 4, 0, 0);
         }
         // safelife_env.py:151
-        if (lwave) {
-            if (t == 0) {
-                if (lead && ly >= 0) pre_write = act_rule(pre_c, action, ly, lx, pre_y1, pre_x1);
-                if (pre_write) {
-                    lboard16[pre_i[0]] = (u16)pre_c[0];
-                    lboard16[pre_i[1]] = (u16)pre_c[1];
-                    lboard16[pre_i[2]] = (u16)pre_c[2];
-                    lboard16[pre_i[3]] = (u16)pre_c[3];
+        if (!MOVE_BOX) {
+            if (lwave) {
+                if (t == 0) {
+                    if (lead && ly >= 0) pre_write = act_rule(pre_c, action, ly, lx, pre_y1, pre_x1);
+                    if (pre_write) {
+                        lboard16[pre_i[0]] = (u16)pre_c[0];
+                        lboard16[pre_i[1]] = (u16)pre_c[1];
+                        lboard16[pre_i[2]] = (u16)pre_c[2];
+                        lboard16[pre_i[3]] = (u16)pre_c[3];
+                    }
+                } else if (lead && ly >= 0) {
+                    action = actions[(size_t)t * B + el];
+                    act_gather<H, W>(lboard16, ly, lx, action);
                 }
-            } else if (lead && ly >= 0) {
-                action = actions[(size_t)t * B + el];
-                act_gather<H, W>(lboard16, ly, lx, action);
             }
-        }
-        wg_sync();                                 // the move is in the image
+            wg_sync();                             // the move is in the image
+        }                                          // (single-step launches: it went in behind the load barrier)
         SL_STAMP(4);
         // safelife_env.py:152 : board first, then goals unless they are static (safelife_game.py:746-761)
         if (rwave) {
