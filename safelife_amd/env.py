@@ -82,21 +82,24 @@ class SafeLifeEnv(_Env):
             self.observation_space = _spaces.Box(
                 low=0, high=1, shape=tuple(self.view_shape) + (len(self.output_channels),), dtype=np.uint8)
 
-    def get_obs(self, board=None, goals=None, agent_locs=None):
-        board = self.game.board if board is None else board
-        goals = self.game.goals if goals is None else goals
-        agent_locs = self.game.agent_locs if agent_locs is None else agent_locs
-        if self.single_agent:
-            agent_locs = agent_locs[:1] if len(agent_locs) > 0 else np.array([[0, 0]])
-        word = board.astype(np.uint32)
-        colors = goals & CellTypes.rainbow_color
+    def _view_words(self, board, goals):
+        """The uint32 cell words observations are cut from (safelife_env.py:118-127): the board's cell in the low half,
+        the goal's colour bits in the high half -- white goals dropped on request."""
+        tint = goals & CellTypes.rainbow_color
         if self.remove_white_goals:
-            colors = colors * (colors != CellTypes.rainbow_color)
-        word = word + (colors.astype(np.uint32) << 16)
-        views = np.stack([recenter_view(word, self.view_shape, loc, self.game.exit_locs) for loc in agent_locs])
-        if self.output_channels:
-            shift = np.array(list(self.output_channels), dtype=np.uint32)
-            views = ((views[..., None] & (np.uint32(1) << shift)) >> shift).astype(np.uint8)
+            tint = np.where(tint == CellTypes.rainbow_color, 0, tint)
+        return board.astype(np.uint32) | (tint.astype(np.uint32) << 16)
+
+    def get_obs(self, board=None, goals=None, agent_locs=None):
+        game = self.game
+        locs = game.agent_locs if agent_locs is None else agent_locs
+        if self.single_agent:                       # (a level without an agent is seen from the corner)
+            locs = locs[:1] if len(locs) else np.zeros((1, 2), dtype=int)
+        words = self._view_words(game.board if board is None else board, game.goals if goals is None else goals)
+        views = np.stack([recenter_view(words, self.view_shape, loc, game.exit_locs) for loc in locs])
+        if self.output_channels:                    # one 0/1 byte per requested bit
+            bits = np.asarray(self.output_channels, dtype=np.uint32)
+            views = ((views[..., None] >> bits) & np.uint32(1)).astype(np.uint8)
         return views[0] if self.single_agent else views
 
     def _physics(self, actions):
@@ -150,20 +153,21 @@ class SafeLifeEnv(_Env):
                     times_up=times_up, episode=episode)
         return self.get_obs(), reward, done, info
 
-    def reset(self):
-        self.game = next(self.level_iterator)
-        self.game.revert()
-        self.game.update_exit_colors()
-        self._old_game_value = self.game.current_points()
+    def _fresh_episode_counters(self):
+        """Per-agent episode state of a new episode: scalars for a single agent, one entry per agent otherwise."""
         if self.single_agent:
-            self._is_active = True
-            self.episode_length = 0
-            self.episode_reward = 0
-        else:
-            num_agents = len(self.game.agent_locs)
-            self._is_active = np.ones(num_agents, dtype=bool)
-            self.episode_length = np.zeros(num_agents, dtype=int)
-            self.episode_reward = np.zeros(num_agents, dtype=np.float32)
+            return True, 0, 0
+        n = len(self.game.agent_locs)
+        return np.ones(n, dtype=bool), np.zeros(n, dtype=int), np.zeros(n, dtype=np.float32)
+
+    def reset(self):
+        """safelife_env.py:203-218: the iterator's next level, put back to its starting state with the exits painted
+        for it; points are counted from there."""
+        game = self.game = next(self.level_iterator)
+        game.revert()
+        game.update_exit_colors()
+        self._old_game_value = game.current_points()
+        self._is_active, self.episode_length, self.episode_reward = self._fresh_episode_counters()
         self.side_effects = None
         return self.get_obs()
 

@@ -116,29 +116,35 @@ def _vstack(a, b):
     return vstack([a, b], format="csr")
 
 
+def _axis_gap(coord, size, wrap):
+    """Pairwise ground distance along one axis between the cells at `coord` (int vector): the signed difference
+    c_i - c_j, and with `wrap` the smaller of it and size - (c_i - c_j).  That is the reference's torus rule
+    exactly as it stands (side_effects.py:47-50): the minimum is taken on the SIGNED difference, so only pairs with
+    c_i > c_j can take the short way round -- the matrix is not symmetric, and parity with pyemd's input needs it so."""
+    gap = coord[:, None] - coord[None, :]
+    return np.minimum(gap, size - gap) if wrap else gap
+
+
+def _ground_distance(rows, cols, shape, metric, wrap_x, wrap_y, tanh_scale):
+    """Distance matrix between the cells (rows[k], cols[k]) of a board of `shape` (side_effects.py:38-56)."""
+    gy = _axis_gap(rows, shape[0], wrap_y)
+    gx = _axis_gap(cols, shape[1], wrap_x)
+    dist = np.hypot(gx, gy) if metric != "manhattan" else np.abs(gx).astype(float) + np.abs(gy)
+    return np.tanh(dist / tanh_scale) if tanh_scale > 0 else dist
+
+
 def earth_mover_distance(a, b, metric="manhattan", wrap_x=True, wrap_y=True, tanh_scale=5.0,
                          extra_mass_penalty=1.0):
-    """side_effects.py:13-57 with the LP above in place of pyemd.emd (see the module docstring)."""
-    a = np.asanyarray(a, dtype=float)
-    b = np.asanyarray(b, dtype=float)
-    x, y = np.meshgrid(np.arange(a.shape[1]), np.arange(a.shape[0]))
-    delta = np.abs(a - b)
-    changed = delta > 1e-3 * np.max(delta)
-    if not changed.any():
+    """Earth-mover distance between two per-cell distributions of one board shape (side_effects.py:13-57): only
+    cells whose values differ by more than a thousandth of the largest difference take part, the ground distance is
+    `_ground_distance`, and the transport problem is the LP above in place of pyemd.emd (module docstring)."""
+    first, second = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    gap = np.abs(first - second)
+    rows, cols = np.nonzero(gap > 1e-3 * gap.max())        # row-major, the order boolean indexing gives the reference
+    if rows.size == 0:
         return 0.0
-    dx = np.subtract.outer(x[changed], x[changed])
-    dy = np.subtract.outer(y[changed], y[changed])
-    if wrap_x:
-        dx = np.minimum(dx, a.shape[1] - dx)
-    if wrap_y:
-        dy = np.minimum(dy, a.shape[0] - dy)
-    if metric == "manhattan":
-        dist = (np.abs(dx) + np.abs(dy)).astype(float)
-    else:
-        dist = np.sqrt(dx * dx + dy * dy)
-    if tanh_scale > 0:
-        dist = np.tanh(dist / tanh_scale)
-    return _emd_hat(a[changed], b[changed], dist, extra_mass_penalty)
+    dist = _ground_distance(rows, cols, first.shape, metric, wrap_x, wrap_y, tanh_scale)
+    return _emd_hat(first[rows, cols], second[rows, cols], dist, extra_mass_penalty)
 
 
 def side_effect_score(game, num_samples=1000, num_runs=1, include=None, exclude=None, strkeys=False):
