@@ -567,6 +567,87 @@ def main():
         extra["obs_policy_layout_u8_25x25x15_us_per_step"] = e0.elapsed_time(e1) / n * 1e3
         del env2
 
+        # f4 closed loop (training/base_algo.py:152-244, ppo.py:61-73, models.py:80-109): observation (policy layout,
+        # uint8, written by the step kernel) -> policy -> one categorical draw per env on the device -> step, nothing on
+        # the host.  Serial (VectorRunner: one stream, one launch per step) and pipelined (PipelinedRunner: two groups
+        # of 4096 envs, each group's policy / draw / step on the group's own stream, the groups overlapping), with a
+        # trivial policy (uniform probabilities, no arithmetic: what is left is the plumbing) and with a network of
+        # the reference's SafeLifePolicyNetwork shape (stock torch convolutions, float32, random weights: NOT part of
+        # this build's kernels).  Wall clock, device idle before and after.
+        from safelife_amd.runner import VectorRunner, PipelinedRunner
+
+        class TrivialPolicy(object):
+            def __init__(self):
+                self.cache = {}
+
+            def __call__(self, obs):
+                n = obs.shape[0]
+                if n not in self.cache:
+                    self.cache[n] = (torch.zeros(n, device=dev), torch.full((n, 9), 1.0 / 9.0, device=dev))
+                return self.cache[n]
+
+        class RefShapedPolicy(torch.nn.Module):
+            def __init__(self, c):
+                super().__init__()
+                nn = torch.nn
+                self.cnn = nn.Sequential(nn.Conv2d(c, 32, 5, 2), nn.ReLU(), nn.Conv2d(32, 64, 3, 2), nn.ReLU(),
+                                         nn.Conv2d(64, 64, 3, 1), nn.ReLU())
+                self.dense = nn.Sequential(nn.Linear(64 * 3 * 3, 512), nn.ReLU())
+                self.logits, self.value = nn.Linear(512, 9), nn.Linear(512, 1)
+
+            def forward(self, obs):
+                x = self.dense(self.cnn(obs).flatten(1))
+                return self.value(x)[..., 0], torch.softmax(self.logits(x), dim=-1)
+
+        def wall(fn, n, warm=5):
+            for _ in range(warm):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e6
+
+        def loop_env(slices):
+            e = SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25), output_channels=TRAIN_CHANNELS,
+                                  auto_reset=True, level_stride=1, with_obs=False, policy_layout="uint8", slices=slices)
+            return e
+        cnn = RefShapedPolicy(len(TRAIN_CHANNELS)).to(dev).eval()
+        cl = {}
+        for pname, pol, n in (("trivial", TrivialPolicy(), 200), ("refshaped_cnn", cnn, 20)):
+            r1 = VectorRunner(loop_env(1), pol, copy_obs=False)
+            cl["serial_%s_us_per_step" % pname] = wall(r1.take_one_step, n)
+            r2 = PipelinedRunner(loop_env(2), pol)
+            r2.start()
+            cl["pipelined_%s_us_per_step" % pname] = wall(lambda: r2.run(1), n)
+            r2.finish()
+            del r1, r2
+        # the parts, each by itself: the two-group step with the policy-layout observation, the draw, the forward pass
+        e2 = loop_env(2)
+        e2.reset()
+        e2.fence()
+        fixed = torch.randint(0, 9, (B,), device=dev, dtype=torch.int32)
+        torch.cuda.synchronize()
+
+        def both_groups():
+            e2.step_slice(0, fixed)
+            e2.step_slice(1, fixed)
+        cl["parts_step_two_groups_us"] = wall(both_groups, 200)
+        e2.join()
+        uni = torch.full((B, 9), 1.0 / 9.0, device=dev)
+        acts_buf = torch.zeros(B, dtype=torch.int32, device=dev)
+        cl["parts_draw_us"] = wall(lambda: acts_buf.copy_(torch.multinomial(uni, 1).view(-1)), 200)
+        obs_f = e2.policy_tensor
+        with torch.no_grad():
+            cl["parts_refshaped_cnn_forward_us"] = wall(lambda: cnn(obs_f.to(torch.float32)), 20)
+        cl["note"] = ("8192 envs, 25x25x15 uint8 observation in the policy layout written by the step kernel; serial = "
+                      "VectorRunner (one stream), pipelined = PipelinedRunner (two groups of 4096 envs on two streams); the "
+                      "network has the reference's SafeLifePolicyNetwork shape (conv 5x5/2-32, 3x3/2-64, 3x3-64, dense 512), "
+                      "stock torch float32 kernels, random weights")
+        extra["closed_loop"] = cl
+        del e2, cnn
+
         def time_steps(env3, n_envs, n=200):
             acts = torch.randint(0, 9, (n + 20, n_envs), generator=gen, device=dev, dtype=torch.int32)
             env3.reset()

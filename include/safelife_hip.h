@@ -316,6 +316,13 @@ int slhip_streams_order(void *const *before, int n_before, void *const *after, i
 int slhip_env_step_slices(const sl_env_batch *env, int n_slices, const int32_t *bounds, const int32_t *actions,
                           void *const *streams);
 
+/* One step for the envs [first, first + count) only, one launch on `stream` (actions: int32 [B], indexed by the env's
+ * index in the batch; `first` a multiple of 64 keeps the row kernels' alignment).  What a pipelined driver uses: the
+ * policy of one group of envs runs while another group steps (training/base_algo.py:208-238 walks its envs one by one);
+ * with a group's policy, action draw and step all on the group's own stream nothing needs a fence
+ * (safelife_amd/runner.py: PipelinedRunner). */
+int slhip_env_step_range(const sl_env_batch *env, int first, int count, const int32_t *actions, void *stream);
+
 /* Sliced stepping WITHOUT HIP's launch path: slhip_env_step_slices hides one slice's kernel boundary under the other
  * slices' kernels, but a launch through a HIP stream costs the host 2.4-3 us, so one stepping thread feeds two slices per
  * ~8 us step and no more.  These entry points issue the SAME kernel from HSA queues of the library's own, one per slice

@@ -20,7 +20,7 @@ SL_E_SHAPE, SL_E_ARG, SL_E_HIP, SL_E_UNSUPPORTED = -1, -2, -3, -4
 EXPORTS = (
     "slhip_abi_version", "slhip_last_error", "slhip_device_count",
     "slhip_advance_board", "slhip_advance_board_each", "slhip_life_occupancy", "slhip_alive_counts", "slhip_execute_actions",
-    "slhip_env_prepare", "slhip_env_reset", "slhip_env_step", "slhip_env_step_slices", "slhip_env_rollout",
+    "slhip_env_prepare", "slhip_env_reset", "slhip_env_step", "slhip_env_step_slices", "slhip_env_step_range", "slhip_env_rollout",
     "slhip_streams_concurrent", "slhip_streams_order",
     "slhip_env_obs",
     "slhip_obs_to_policy", "slhip_side_effects",
@@ -139,6 +139,8 @@ def lib():
         L.slhip_env_reset.argtypes = [C.POINTER(EnvBatch), _p, _p]
         L.slhip_env_step.argtypes = [C.POINTER(EnvBatch), _p, _p]
         L.slhip_env_step_slices.argtypes = [C.POINTER(EnvBatch), C.c_int, _p, _p, _p]
+        if hasattr(L, "slhip_env_step_range"):
+            L.slhip_env_step_range.argtypes = [C.POINTER(EnvBatch), C.c_int, C.c_int, _p, _p]
         L.slhip_streams_concurrent.argtypes = [_p, _p, C.POINTER(C.c_int)]
         L.slhip_streams_order.argtypes = [_p, C.c_int, _p, C.c_int]
         L.slhip_env_rollout.argtypes = [C.POINTER(EnvBatch), _p, C.c_int, _p, _p, _p]

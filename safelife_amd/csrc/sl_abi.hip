@@ -434,6 +434,15 @@ int slhip_env_step(const sl_env_batch *env, const int32_t *actions, void *stream
     return slhip_env_rollout(env, actions, 1, nullptr, nullptr, stream);
 }
 
+int slhip_env_step_range(const sl_env_batch *env, int first, int count, const int32_t *actions, void *stream) {
+    int rc = check_env(env);
+    if (rc) return rc;
+    if (!actions) return fail(SL_E_ARG, "null pointer");
+    if (first < 0 || count < 0 || first + count > env->B) return fail(SL_E_ARG, "env range outside the batch");
+    if (count == 0) return SL_OK;
+    return rollout_range(env, first, count, actions, 1, env->B, nullptr, nullptr, stream);
+}
+
 int slhip_streams_order(void *const *before, int n_before, void *const *after, int n_after) {
     if (n_before < 0 || n_after < 0 || (n_before && !before) || (n_after && !after)) return fail(SL_E_ARG, "bad stream lists");
     // ordering events: a ring of timing-less events, created on first use (an event may be re-recorded once the

@@ -91,3 +91,59 @@ class VectorRunner(object):
         """n steps; yields each StepResult (a generator, so that a learner can consume them as they come)."""
         for _ in range(n):
             yield self.take_one_step()
+
+
+class PipelinedRunner(object):
+    """The same loop with the envs in GROUPS (the env's slices), each on a stream of its own: a group's observation ->
+    policy -> action draw -> step all run on that stream, in that order, so nothing inside a group needs a fence, and the
+    groups overlap -- one group's step kernel runs while another group's policy does (the reference's trainers walk their
+    envs one after the other, training/base_algo.py:208-238; here the walk is over groups and the device does two things
+    at once).  The draw writes the group's part of ONE int32 action tensor, which is what the step kernel reads.
+
+    Parameters: as ``VectorRunner``; `env` built with ``slices >= 2``.  ``policy(obs [n,C,W,H]) -> (values, probs)``.
+    ``on_step(group, lo, hi)`` (optional) is called, with the group's stream current, after each group step: the
+    group's ``env.reward[lo:hi]`` / ``env.done[lo:hi]`` / ``env.policy_tensor[lo:hi]`` are valid on that stream there.
+    """
+
+    def __init__(self, env, policy, generator=None, on_step=None):
+        import torch
+        self.torch = torch
+        if env.policy_tensor is None or not env.auto_reset or env.slices < 2:
+            raise ValueError("PipelinedRunner needs SafeLifeVectorEnv(policy_layout=..., auto_reset=True, slices>=2)")
+        self.env, self.policy, self.generator, self.on_step = env, policy, generator, on_step
+        self.actions = torch.zeros(env.num_envs, dtype=torch.int32, device=env.device)
+        self.num_steps = 0
+        self._started = False
+
+    def start(self):
+        if not self._started:
+            self.env.reset()
+            self.env.fence()                    # the groups' streams wait for the reset once
+            self._started = True
+
+    def step_group(self, g):
+        torch, env = self.torch, self.env
+        lo, hi = env.slice_bounds[g], env.slice_bounds[g + 1]
+        if hi <= lo:
+            return
+        with torch.cuda.stream(env.slice_stream(g)):
+            obs = env.policy_tensor[lo:hi]
+            with torch.no_grad():
+                values, probs = self.policy(obs if obs.dtype == torch.float32 else obs.to(torch.float32))
+            drawn = torch.multinomial(probs, 1, generator=self.generator)
+            self.actions[lo:hi].copy_(drawn.view(-1))           # int64 -> int32, straight into the step's buffer
+            env.step_slice(g, self.actions)
+            if self.on_step is not None:
+                self.on_step(g, lo, hi)
+
+    def run(self, n_steps):
+        """n_steps steps of every env."""
+        self.start()
+        for _ in range(n_steps):
+            for g in range(self.env.slices):
+                self.step_group(g)
+            self.num_steps += 1
+
+    def finish(self):
+        """The caller's current stream waits for every group."""
+        self.env.join()

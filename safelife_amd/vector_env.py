@@ -592,6 +592,28 @@ class SafeLifeVectorEnv(object):
         if rc:
             _hip.check(rc)
 
+    def step_slice(self, i, actions):
+        """One step of slice i only (envs ``slice_bounds[i] .. slice_bounds[i+1]``), one launch on the slice's own
+        stream (``slice_stream(i)``); `actions`: the int32 device tensor [num_envs] of the whole batch (or its address) --
+        only the slice's entries are read.  No fence: whoever writes the slice's actions and reads its outputs does so
+        on the same stream (runner.PipelinedRunner), or orders itself against it."""
+        if not 0 <= i < self.slices or self.slices < 2:
+            raise ValueError("no such slice (construct the env with slices >= 2)")
+        ptr = actions if isinstance(actions, int) else actions.data_ptr()
+        if self._queues_pending:
+            self._settle()
+        if self._caller_ahead:
+            self.fence()
+        lo, hi = self.slice_bounds[i], self.slice_bounds[i + 1]
+        rc = self._lib.slhip_env_step_range(self._sref, lo, hi - lo, ptr, self._stream_ptrs[i])
+        self._async_pending = True
+        if rc:
+            _hip.check(rc)
+
+    def slice_stream(self, i):
+        """The torch stream slice i is stepped on."""
+        return self._slice_streams[i]
+
     def rollout(self, actions, reward_out=None, done_out=None):
         """T steps in one launch.  actions: int [T,B].  Returns (reward[T,B], done[T,B])."""
         torch = self.torch

@@ -1340,6 +1340,58 @@ def test_side_effect_keys_overflow_is_reported_and_survived():
         assert np.array_equal(got_in[int(k)], want_in[k]) and np.array_equal(got_act[int(k)], want_act[k])
 
 
+def test_pipelined_runner_vs_oracle():
+    """PipelinedRunner: the envs in two groups, each group's observation -> policy -> draw -> step on the group's own
+    stream (slhip_env_step_range), the groups overlapping.  A scripted policy that DEPENDS on the observation it is
+    handed (so a step that ran ahead of its policy, or a policy ahead of its observation, would show) against the
+    oracle stepped with the same rule on the host: rewards and dones of every step, then the full state."""
+    import torch
+    from safelife_amd.runner import PipelinedRunner
+    B, T = 448, 40
+    chans = (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 25, 26, 27)
+    pool, _ = util.pool_from_fixture("append_spawn_25", _device_counts, min_performance_fraction=0.05)
+    common = dict(first_level=np.arange(B) % len(pool), auto_reset=True, level_stride=3, time_limit=15, view_shape=(9, 9),
+                  output_channels=chans)
+    dev = util.DeviceBackend(pool, B, slices=2, policy_layout="uint8", **common)
+    cpu = util.OracleBackend(pool, B, **common)
+    env = dev.env
+    counters = {}
+
+    def rule(total, t):                     # the action: a hash of the observation's bit count and the step number
+        return (total * 7 + t * 3) % 9
+
+    def scripted(obs):                      # obs: this group's [n, C, W, H] float32
+        key = obs.shape[0]                  # (the two groups have different sizes: 256 and 192 envs)
+        t = counters.get(key, 0)
+        counters[key] = t + 1
+        total = obs.sum(dim=(1, 2, 3)).to(torch.int64)
+        probs = torch.zeros((obs.shape[0], 9), device=obs.device)
+        probs[torch.arange(obs.shape[0], device=obs.device), rule(total, t)] = 1.0
+        return torch.zeros(obs.shape[0], device=obs.device), probs
+    seen = []
+
+    def on_step(g, lo, hi):
+        seen.append((g, env.reward[lo:hi].clone(), env.done[lo:hi].clone()))
+    runner = PipelinedRunner(env, scripted, on_step=on_step)
+    assert env.slice_bounds == (0, 256, B)
+    obs = cpu.reset()                       # (h, w, c) uint8
+    runner.run(T)
+    runner.finish()
+    torch.cuda.synchronize()
+    k = 0
+    for t in range(T):
+        a = rule(obs.reshape(B, -1).sum(axis=1).astype(np.int64), t).astype(np.int32)
+        obs, r, d = cpu.step(a)
+        for g, (lo, hi) in enumerate(((0, 256), (256, B))):
+            gg, rw, dn = seen[k]
+            k += 1
+            assert gg == g
+            assert np.array_equal(rw.cpu().numpy(), r[lo:hi]) and np.array_equal(dn.cpu().numpy().astype(bool), d[lo:hi].astype(bool)), (t, g)
+    for name in ENV_STATE:
+        assert np.array_equal(dev.get(name), cpu.get(name)), name
+    assert cpu.get("episode_idx").min() >= 1
+
+
 @pytest.mark.parametrize("name", ["v10_append-spawn", "v10_prune-still_open", "v10_navigation", "append_still_1_chan19"])
 def test_vector_runner_replays_reference_trace(name):
     """VectorRunner (obs -> policy -> device-side action draw -> fused step -> reset bookkeeping, the batched

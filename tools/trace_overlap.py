@@ -80,3 +80,15 @@ for i in range(N * SL):
     prev_end[s] = med[i][2]
 per_step = (med[-1][2] - med[SL - 1][2]) / (N - 1)
 print("steady state: %.2f us per step (end of the last launch of a step to the end of the last launch of the next)" % (per_step / 1e3))
+
+# per-wave phases of the launches above (steady state: the first two steps left out), time spent in each
+names = ["loads issued", "loads landed (barrier)", "goal rows", "move in the image", "CA", "score + barrier", "leaders",
+         "end barrier", "stores issued", "stores acknowledged"]
+st = tr[2 * SL:, :, :11].astype(np.float64) * 10.0
+ph = np.diff(st, axis=2)
+print("phases, ns per wave (mean / p50 / p90 over the waves of %d launches): " % (st.shape[0]))
+for i, n in enumerate(names):
+    v = ph[:, :, i].reshape(-1)
+    print("  %-24s %6.0f %6.0f %6.0f" % (n, v.mean(), np.percentile(v, 50), np.percentile(v, 90)))
+life = (st[:, :, 10] - st[:, :, 0]).reshape(-1)
+print("  %-24s %6.0f %6.0f %6.0f" % ("wave lifetime", life.mean(), np.percentile(life, 50), np.percentile(life, 90)))
