@@ -596,7 +596,7 @@ def main():
                 self.logits, self.value = nn.Linear(512, 9), nn.Linear(512, 1)
 
             def forward(self, obs):
-                x = self.dense(self.cnn(obs).flatten(1))
+                x = self.dense(self.cnn(obs.to(torch.float32)).flatten(1))
                 return self.value(x)[..., 0], torch.softmax(self.logits(x), dim=-1)
 
         def wall(fn, n, warm=5):
@@ -616,7 +616,7 @@ def main():
         cnn = RefShapedPolicy(len(TRAIN_CHANNELS)).to(dev).eval()
         cl = {}
         for pname, pol, n in (("trivial", TrivialPolicy(), 200), ("refshaped_cnn", cnn, 20)):
-            r1 = VectorRunner(loop_env(1), pol, copy_obs=False)
+            r1 = VectorRunner(loop_env(1), pol, copy_obs=False, cast_obs=False)
             cl["serial_%s_us_per_step" % pname] = wall(r1.take_one_step, n)
             r2 = PipelinedRunner(loop_env(2), pol)
             r2.start()
@@ -637,10 +637,12 @@ def main():
         e2.join()
         uni = torch.full((B, 9), 1.0 / 9.0, device=dev)
         acts_buf = torch.zeros(B, dtype=torch.int32, device=dev)
-        cl["parts_draw_us"] = wall(lambda: acts_buf.copy_(torch.multinomial(uni, 1).view(-1)), 200)
+        cl["parts_draw_torch_multinomial_us"] = wall(lambda: acts_buf.copy_(torch.multinomial(uni, 1).view(-1)), 200)
+        st_ptr = _hip.current_stream_ptr()
+        cl["parts_draw_us"] = wall(lambda: _hip.lib().slhip_sample_actions(uni.data_ptr(), B, 9, 1, 2, acts_buf.data_ptr(), st_ptr), 200)
         obs_f = e2.policy_tensor
         with torch.no_grad():
-            cl["parts_refshaped_cnn_forward_us"] = wall(lambda: cnn(obs_f.to(torch.float32)), 20)
+            cl["parts_refshaped_cnn_forward_us"] = wall(lambda: cnn(obs_f), 20)
         cl["note"] = ("8192 envs, 25x25x15 uint8 observation in the policy layout written by the step kernel; serial = "
                       "VectorRunner (one stream), pipelined = PipelinedRunner (two groups of 4096 envs on two streams); the "
                       "network has the reference's SafeLifePolicyNetwork shape (conv 5x5/2-32, 3x3/2-64, 3x3-64, dense 512), "

@@ -462,6 +462,14 @@ int slhip_env_obs(const sl_env_batch *env, void *stream);
 int slhip_obs_to_policy(const uint32_t *view, int B, int vh, int vw, const int32_t *channels, int C,
                         void *out, int dtype, void *stream);
 
+/* One categorical draw per env from policy probabilities, on the device, written as the int32 action the step kernels
+ * read (training/ppo.py:66-69 draws on the host with numpy; there is no random stream to be compatible with).
+ * probs: float32 [B, n_actions] (rows sum to 1); the draw of env e in call `counter` of a run seeded `seed` is a
+ * function of (seed, counter, e) alone -- splitmix64, 24-bit uniform, inverse CDF -- so runs are reproducible and
+ * shards may use their global env indices through `seed`. */
+int slhip_sample_actions(const float *probs, int B, int n_actions, unsigned long long seed, unsigned long long counter,
+                         int32_t *actions, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

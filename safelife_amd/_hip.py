@@ -23,7 +23,7 @@ EXPORTS = (
     "slhip_env_prepare", "slhip_env_reset", "slhip_env_step", "slhip_env_step_slices", "slhip_env_step_range", "slhip_env_rollout",
     "slhip_streams_concurrent", "slhip_streams_order",
     "slhip_env_obs",
-    "slhip_obs_to_policy", "slhip_side_effects",
+    "slhip_obs_to_policy", "slhip_sample_actions", "slhip_side_effects",
     "slhip_gather_unique_id", "slhip_gather_init", "slhip_gather_window", "slhip_gather_destroy",
     "slhip_gather_window_async", "slhip_gather_done", "slhip_gather_wait_streams",
     "slhip_gather_window_queued",
@@ -158,6 +158,8 @@ def lib():
             L.slhip_queues_selftest.argtypes = [C.c_void_p, C.c_int, C.c_int]
             L.slhip_gather_window_queued.argtypes = [_p, _p, _p, C.c_size_t, C.c_void_p, _p, C.POINTER(C.c_longlong)]
         L.slhip_side_effects.argtypes = [C.POINTER(EnvBatch), C.POINTER(EpisodeQueue), C.c_int, C.c_int] + [_p] * 9
+        if hasattr(L, "slhip_sample_actions"):
+            L.slhip_sample_actions.argtypes = [_p, C.c_int, C.c_int, C.c_ulonglong, C.c_ulonglong, _p, _p]
         L.slhip_obs_to_policy.argtypes = [_p, C.c_int, C.c_int, C.c_int, _p, C.c_int, _p, C.c_int, _p]
         L.slhip_gather_unique_id.argtypes = [_p]
         L.slhip_gather_init.argtypes = [_p, C.c_int, C.c_int, C.POINTER(_p)]

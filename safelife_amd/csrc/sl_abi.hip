@@ -1075,6 +1075,15 @@ int slhip_env_obs(const sl_env_batch *env, void *stream) {
     return err == hipSuccess ? SL_OK : hip_fail(err, "env_obs launch");
 }
 
+int slhip_sample_actions(const float *probs, int B, int n_actions, unsigned long long seed, unsigned long long counter,
+                         int32_t *actions, void *stream) {
+    if (B < 0 || n_actions < 1 || n_actions > 64) return fail(SL_E_ARG, "bad sizes");
+    if (!probs || !actions) return fail(SL_E_ARG, "null pointer");
+    if (B == 0) return SL_OK;
+    hipError_t err = sl::launch_sample_actions(probs, B, n_actions, seed, counter, actions, (hipStream_t)stream);
+    return err == hipSuccess ? SL_OK : hip_fail(err, "sample_actions launch");
+}
+
 int slhip_obs_to_policy(const uint32_t *view, int B, int vh, int vw, const int32_t *channels, int C, void *out,
                         int dtype, void *stream) {
     if (B < 0 || vh < 1 || vw < 1) return fail(SL_E_ARG, "bad view shape");

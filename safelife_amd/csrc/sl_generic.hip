@@ -579,6 +579,37 @@ __global__ __launch_bounds__(256) void k_obs_to_policy(const u32 *__restrict__ v
 
 // ------------------------------------------------------------------------------ launchers
 
+// One categorical draw per env from the policy's probabilities (training/ppo.py:66-69 draws on the host with numpy):
+// u = a 24-bit uniform from splitmix64(seed, counter, env), the action = the first k with u < p_0 + ... + p_k (the last
+// action takes what rounding leaves).  One thread per env; the result goes straight into the int32 buffer the step reads.
+__global__ __launch_bounds__(256) void k_sample_actions(const float *__restrict__ probs, int B, int A, unsigned long long seed,
+                                                        unsigned long long counter, int32_t *__restrict__ actions) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= B) return;
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (counter * 0x100000001B3ull + (unsigned long long)e + 1ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const float u = (float)(unsigned)(z >> 40) * (1.0f / 16777216.0f);
+    const float *p = probs + (size_t)e * A;
+    float cum = 0.0f;
+    int a = A - 1;
+    for (int k = 0; k < A - 1; ++k) {
+        cum += p[k];
+        if (u < cum) {
+            a = k;
+            break;
+        }
+    }
+    actions[e] = a;
+}
+
+hipError_t launch_sample_actions(const float *probs, int B, int A, unsigned long long seed, unsigned long long counter,
+                                 int32_t *actions, hipStream_t stream) {
+    hipLaunchKernelGGL(k_sample_actions, dim3((B + 255) / 256), dim3(256), 0, stream, probs, B, A, seed, counter, actions);
+    return hipGetLastError();
+}
+
 hipError_t launch_obs_to_policy(const u32 *view, int B, int vh, int vw, const sl_channel_list &ch, int C, void *out,
                                 int dtype, hipStream_t stream) {
     const long long total = (long long)B * C * vw * vh;

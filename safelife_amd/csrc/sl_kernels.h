@@ -27,6 +27,8 @@ hipError_t launch_env_obs_generic(const sl_env_batch &env, hipStream_t stream);
 struct sl_channel_list {
     int32_t c[SL_MAX_CHANNELS];
 };
+hipError_t launch_sample_actions(const float *probs, int B, int A, unsigned long long seed, unsigned long long counter,
+                                 int32_t *actions, hipStream_t stream);
 hipError_t launch_obs_to_policy(const u32 *view, int B, int vh, int vw, const sl_channel_list &ch, int C, void *out,
                                 int dtype, hipStream_t stream);
 

@@ -32,16 +32,17 @@ class VectorRunner(object):
     generator : torch.Generator  for the action draws (device generator); None = torch's default
     copy_obs : bool              ``obs`` / ``next_obs`` of a result are views of the env's tensor, which the next
                                  step overwrites; True returns an own copy of ``obs`` (what a replay buffer needs)
+    cast_obs : bool              True: the policy gets float32 (training/ppo.py:64); False: the env's tensor as it is
     """
 
-    def __init__(self, env, policy, generator=None, copy_obs=True):
+    def __init__(self, env, policy, generator=None, copy_obs=True, cast_obs=True):
         import torch
         self.torch = torch
         if env.policy_tensor is None:
             raise ValueError("VectorRunner needs SafeLifeVectorEnv(policy_layout=...)")
         if not env.auto_reset:
             raise ValueError("VectorRunner needs auto_reset=True (finished envs reload inside the step kernel)")
-        self.env, self.policy, self.generator, self.copy_obs = env, policy, generator, copy_obs
+        self.env, self.policy, self.generator, self.copy_obs, self.cast_obs = env, policy, generator, copy_obs, cast_obs
         B = env.num_envs
         self.env_ids = torch.arange(B, device=env.device, dtype=torch.int64)
         self.num_resets = torch.zeros(B, device=env.device, dtype=torch.int64)       # env.num_resets of the reference
@@ -79,7 +80,8 @@ class VectorRunner(object):
         the fused step."""
         torch = self.torch
         obs, agent_ids = self.obs_for_envs()
-        model_in = obs if obs.dtype == torch.float32 else obs.to(torch.float32)
+        # (training/ppo.py:64 hands the network float32; cast_obs=False leaves a uint8 policy tensor as it is)
+        model_in = obs if (obs.dtype == torch.float32 or not self.cast_obs) else obs.to(torch.float32)
         with torch.no_grad():
             values, policies = self.policy(model_in)
         actions = torch.multinomial(policies, 1, generator=self.generator).squeeze(1)
@@ -98,22 +100,37 @@ class PipelinedRunner(object):
     policy -> action draw -> step all run on that stream, in that order, so nothing inside a group needs a fence, and the
     groups overlap -- one group's step kernel runs while another group's policy does (the reference's trainers walk their
     envs one after the other, training/base_algo.py:208-238; here the walk is over groups and the device does two things
-    at once).  The draw writes the group's part of ONE int32 action tensor, which is what the step kernel reads.
+    at once).  The draw is the library's own kernel (``slhip_sample_actions``: one thread per env, straight into the
+    group's part of the ONE int32 action tensor the step kernel reads); ``sampler="torch"`` uses ``torch.multinomial``
+    and a copy instead (20 times the device time at 8192 envs).
 
-    Parameters: as ``VectorRunner``; `env` built with ``slices >= 2``.  ``policy(obs [n,C,W,H]) -> (values, probs)``.
+    Parameters: `env` built with ``policy_layout=...``, ``auto_reset=True``, ``slices >= 2``.
+    ``policy(obs [n,C,W,H]) -> (values, probs float32 [n,9])`` gets the env's policy tensor AS IT IS (uint8 or
+    float32: a network casts its own input, a cheap policy need not pay for a float copy of the observation).
     ``on_step(group, lo, hi)`` (optional) is called, with the group's stream current, after each group step: the
     group's ``env.reward[lo:hi]`` / ``env.done[lo:hi]`` / ``env.policy_tensor[lo:hi]`` are valid on that stream there.
     """
 
-    def __init__(self, env, policy, generator=None, on_step=None):
+    def __init__(self, env, policy, seed=0, on_step=None, sampler="device", generator=None):
         import torch
-        self.torch = torch
+        from . import _hip
+        self.torch, self._hip = torch, _hip
         if env.policy_tensor is None or not env.auto_reset or env.slices < 2:
             raise ValueError("PipelinedRunner needs SafeLifeVectorEnv(policy_layout=..., auto_reset=True, slices>=2)")
-        self.env, self.policy, self.generator, self.on_step = env, policy, generator, on_step
+        if sampler not in ("device", "torch"):
+            raise ValueError("sampler must be 'device' or 'torch'")
+        self.env, self.policy, self.on_step, self.sampler, self.generator = env, policy, on_step, sampler, generator
+        self.seed = int(seed) & (2 ** 64 - 1)
         self.actions = torch.zeros(env.num_envs, dtype=torch.int32, device=env.device)
         self.num_steps = 0
         self._started = False
+        self._lib = _hip.lib()
+        self._groups = []
+        for g in range(env.slices):
+            lo, hi = env.slice_bounds[g], env.slice_bounds[g + 1]
+            st = env.slice_stream(g)
+            self._groups.append((g, lo, hi, st, torch.cuda.stream(st), env.policy_tensor[lo:hi],
+                                 self.actions.data_ptr() + 4 * lo, st.cuda_stream))
 
     def start(self):
         if not self._started:
@@ -123,15 +140,23 @@ class PipelinedRunner(object):
 
     def step_group(self, g):
         torch, env = self.torch, self.env
-        lo, hi = env.slice_bounds[g], env.slice_bounds[g + 1]
+        g, lo, hi, st, ctx, obs, act_ptr, st_ptr = self._groups[g]
         if hi <= lo:
             return
-        with torch.cuda.stream(env.slice_stream(g)):
-            obs = env.policy_tensor[lo:hi]
+        with ctx:
             with torch.no_grad():
-                values, probs = self.policy(obs if obs.dtype == torch.float32 else obs.to(torch.float32))
-            drawn = torch.multinomial(probs, 1, generator=self.generator)
-            self.actions[lo:hi].copy_(drawn.view(-1))           # int64 -> int32, straight into the step's buffer
+                values, probs = self.policy(obs)
+            if self.sampler == "device":
+                if probs.dtype != torch.float32 or not probs.is_contiguous():
+                    probs = probs.to(torch.float32).contiguous()
+                # (seed offset by the group's first env: every env of the batch has its own draw per step)
+                rc = self._lib.slhip_sample_actions(probs.data_ptr(), hi - lo, probs.shape[1], (self.seed + lo) & (2 ** 64 - 1),
+                                                    self.num_steps, act_ptr, st_ptr)
+                if rc:
+                    self._hip.check(rc)
+            else:
+                drawn = torch.multinomial(probs, 1, generator=self.generator)
+                self.actions[lo:hi].copy_(drawn.view(-1))       # int64 -> int32, into the step's buffer
             env.step_slice(g, self.actions)
             if self.on_step is not None:
                 self.on_step(g, lo, hi)

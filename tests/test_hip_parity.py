@@ -1340,6 +1340,35 @@ def test_side_effect_keys_overflow_is_reported_and_survived():
         assert np.array_equal(got_in[int(k)], want_in[k]) and np.array_equal(got_act[int(k)], want_act[k])
 
 
+def test_sample_actions_kernel():
+    """slhip_sample_actions: one-hot rows give that action; a fixed distribution is hit within sampling error; a call
+    is a function of (seed, counter) -- the same arguments give the same draws, another counter gives others."""
+    import torch
+    from safelife_amd import _hip
+    lib = _hip.lib()
+    B = 65536
+    dev = torch.device("cuda")
+    st = _hip.current_stream_ptr()
+    onehot = torch.zeros((B, 9), device=dev)
+    want = torch.arange(B, device=dev) % 9
+    onehot[torch.arange(B, device=dev), want] = 1.0
+    out = torch.full((B,), -1, dtype=torch.int32, device=dev)
+    _hip.check(lib.slhip_sample_actions(onehot.data_ptr(), B, 9, 5, 0, out.data_ptr(), st))
+    assert torch.equal(out.to(torch.int64), want)
+    p = torch.tensor([0.05, 0.3, 0.0, 0.15, 0.1, 0.1, 0.2, 0.02, 0.08], device=dev)
+    probs = p.repeat(B, 1).contiguous()
+    a1 = torch.empty(B, dtype=torch.int32, device=dev)
+    a2 = torch.empty_like(a1)
+    a3 = torch.empty_like(a1)
+    _hip.check(lib.slhip_sample_actions(probs.data_ptr(), B, 9, 5, 7, a1.data_ptr(), st))
+    _hip.check(lib.slhip_sample_actions(probs.data_ptr(), B, 9, 5, 7, a2.data_ptr(), st))
+    _hip.check(lib.slhip_sample_actions(probs.data_ptr(), B, 9, 5, 8, a3.data_ptr(), st))
+    assert torch.equal(a1, a2) and not torch.equal(a1, a3)
+    freq = torch.bincount(a1.to(torch.int64), minlength=9).double() / B
+    assert float((freq - p.double()).abs().max()) < 0.01 and int((a1 == 2).sum()) == 0
+    assert int(a1.min()) >= 0 and int(a1.max()) <= 8
+
+
 def test_pipelined_runner_vs_oracle():
     """PipelinedRunner: the envs in two groups, each group's observation -> policy -> draw -> step on the group's own
     stream (slhip_env_step_range), the groups overlapping.  A scripted policy that DEPENDS on the observation it is
@@ -1360,11 +1389,11 @@ def test_pipelined_runner_vs_oracle():
     def rule(total, t):                     # the action: a hash of the observation's bit count and the step number
         return (total * 7 + t * 3) % 9
 
-    def scripted(obs):                      # obs: this group's [n, C, W, H] float32
+    def scripted(obs):                      # obs: this group's [n, C, W, H] uint8 (the env's policy tensor as it is)
         key = obs.shape[0]                  # (the two groups have different sizes: 256 and 192 envs)
         t = counters.get(key, 0)
         counters[key] = t + 1
-        total = obs.sum(dim=(1, 2, 3)).to(torch.int64)
+        total = obs.to(torch.int64).sum(dim=(1, 2, 3))
         probs = torch.zeros((obs.shape[0], 9), device=obs.device)
         probs[torch.arange(obs.shape[0], device=obs.device), rule(total, t)] = 1.0
         return torch.zeros(obs.shape[0], device=obs.device), probs
