@@ -2272,6 +2272,10 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
 #define SL_MOVE_BOX 1           /* A/B knob: 0 = the round-3 form of the move (leader writes the image, a barrier of its own) */
 #endif
     constexpr bool MOVE_BOX = SL_MOVE_BOX && ONE && !(SPAWN && GSH_REG && Gm::WAVES_PER_SIMD == 4);
+    // (Round 4, measured and dropped -- as round 3's variant of it was: every wave sending its OWN boards to global
+    //  memory right behind its CA pass, under the score phase and the leaders' work, the leaders storing the agent's
+    //  and the exits' cells themselves behind the end barrier.  Same-box A/B, K = 400: 6.47-6.52 us per step without,
+    //  6.70-6.75 with it through release-free queues; 7.61 / 8.09 with agent fences; 8.34 / 8.79 through streams.)
     // (Round 4, measured and dropped: every lane fetching its OWN goal row from global memory at the start -- thirteen
     //  2-byte aligned dwords, permuted into the split layout behind the load barrier -- instead of the pass over the
     //  LDS image, the "goal rows" phase of the trace.  Same-box A/B, K = 400: 6.46 us per step without it, 6.60-6.65
@@ -2330,12 +2334,13 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     if (rwave) {
     if (MOVE_BOX && rlead) {
         // the move the board's leader decided: into the image, by the board's own wave, ahead of its row reads
-        // (a loop that is not unrolled: one live register instead of four in the variants that sit at the limit)
-        const u32 *mv = (const u32 *)(move_box + gb);
-#pragma nounroll
-        for (int k = 0; k < 4; ++k) {
-            const u32 w = mv[k];
-            if ((w & 0xFFFFu) != 0xFFFFu) board16[w & 0xFFFFu] = (u16)(w >> 16);
+        // (one 16-byte read: four dependent read -> write round trips in a loop cost 0.3 us on the step's chain)
+        const u32x4_t mv = move_box[gb];
+        if ((mv.x & 0xFFFFu) != 0xFFFFu) {
+            board16[mv.x & 0xFFFFu] = (u16)(mv.x >> 16);
+            board16[mv.y & 0xFFFFu] = (u16)(mv.y >> 16);
+            board16[mv.z & 0xFFFFu] = (u16)(mv.z >> 16);
+            board16[mv.w & 0xFFFFu] = (u16)(mv.w >> 16);
         }
     }
     if (live) {
