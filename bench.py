@@ -920,10 +920,11 @@ def main():
                          "host_enqueue_ms_per_step": (t_enqueued - t_start) / K * 1e3,
                          "measured_ceiling": ceiling,
                          "note": "frac = bytes_per_env_step x envs / ms_per_step / peak.  frac_device uses launch_ms, the "
-                                 "HIP-event time of ONE step = launches_per_step concurrent launches; rocprofv3 serialises "
-                                 "the two streams (profiles/round3_*_slices2_kernel_trace.txt: per-launch durations), "
-                                 "profiles/round3_*_overlap.txt shows the overlap from the kernels' own clocks, and "
-                                 "--slices 1 is the one-launch step whose duration events and trace agree on"},
+                                 "HIP-event time of ONE step through the stream slices; rocprofv3 serialises the queues' "
+                                 "dispatches (profiles/round4_d_queues4_*_kernel_trace.txt: per-launch durations), "
+                                 "profiles/round4_b_overlap_queues4_*.txt shows the four queues' overlap from the kernels' "
+                                 "own clocks; traffic is null for release-free stepping (per-dispatch counters cannot "
+                                 "attribute it: profiles/round4_c_tcc_*.txt, DESIGN 4.1d)"},
         }
         if world > 1 or gather.collective:
             out["gather_every"] = every_used
