@@ -744,13 +744,16 @@ def main():
         if envw.last_queues_us:
             extra["training_wrappers_queues_us_per_step"] = envw.last_queues_us
         del envw
-        # ... with SimpleSideEffectPenalty's "inaction" baseline (env_wrappers.py:179-180): one more launch per slice
-        # and step, a CA step of every env's baseline board
-        us = time_steps(SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25), output_channels=TRAIN_CHANNELS,
-                                          auto_reset=True, with_obs=False, slices=args.slices,
-                                          wrappers=dict(movement_bonus=0.1, exit_bonus=0.5, penalty_coef=0.3,
-                                                        baseline="inaction", inaction_seed=11)), B)
-        extra["training_wrappers_inaction_baseline_us_per_step"] = us
+        # ... with SimpleSideEffectPenalty's "inaction" baseline (env_wrappers.py:179-180): a CA step of every env's
+        # baseline board per step, a third pass of the step kernel's CA loop
+        envi = SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25), output_channels=TRAIN_CHANNELS,
+                                 auto_reset=True, with_obs=False, slices=args.slices,
+                                 wrappers=dict(movement_bonus=0.1, exit_bonus=0.5, penalty_coef=0.3,
+                                               baseline="inaction", inaction_seed=11))
+        extra["training_wrappers_inaction_baseline_us_per_step"] = time_steps(envi, B)
+        if envi.last_queues_us:
+            extra["training_wrappers_inaction_baseline_queues_us_per_step"] = envi.last_queues_us
+        del envi
         # per-GPU shares of the sharded configs of BASELINE.json (C4: append-spawn 25x25, C5: navigation 64x64)
         for tag, pname, n_envs in (("c4_append_spawn_25", "append_spawn_25", 8192), ("c5_navigation_64", "navigation_64", 4096)):
             if not os.path.exists(os.path.join(REPO, "tests", "golden", "pool_%s.npz" % pname)):

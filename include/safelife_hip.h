@@ -151,9 +151,10 @@ typedef struct sl_level_scalars {
  * "inaction": the reference advances the baseline board outside any game method, so its spawners draw from the
  * process-wide generator (safelife/random.py:13).  With many envs that is one generator per env, inaction_rng[e];
  * an env whose generator starts in the state the process-wide one had reproduces the reference run exactly
- * (tests/golden/trace_wrap_inaction_*).  Every slhip_env_step / slhip_env_step_slices call first advances the
- * baselines (a launch of its own on the same stream; an env whose num_steps is 0 takes its current board as the
- * baseline first, which is what the wrapper's reset() does); slhip_env_rollout with T > 1 refuses the flag. */
+ * (tests/golden/trace_wrap_inaction_*).  The baselines are advanced inside the step kernels (row-kernel shapes: a
+ * third pass of the kernel's CA loop, every step of a T-step launch, through streams and queues alike; other shapes: a
+ * launch of its own in front of each step, T = 1 only); an env whose num_steps is 0 takes its current board as the
+ * baseline first, which is what the wrapper's reset() does. */
 #define SL_WRAP_MOVEMENT 1
 #define SL_WRAP_AS_PENALTY 2            /* MovementBonusWrapper.as_penalty */
 #define SL_WRAP_EXIT_BONUS 4
@@ -186,8 +187,7 @@ typedef struct sl_wrappers {
                                      filled by slhip_env_prepare() (needed with SL_WRAP_SIDE_EFFECT) */
     uint16_t *inaction_board;     /* SL_WRAP_INACTION: [B,H,W] the baseline boards (state; 16-byte aligned) */
     sl_pcg64 *inaction_rng;       /* SL_WRAP_INACTION: [B] the baselines' generators (state) */
-    uint32_t *inaction_rows;      /* SL_WRAP_INACTION: workspace [B, H, (W+1)/2], the baselines as the row kernels
-                                     read them (player bits cleared, register layout) */
+    uint32_t *inaction_rows;      /* (unused since ABI 9: the row kernels lay the advanced baselines out in LDS) */
 } sl_wrappers;
 
 /* Finished episodes, queued on the device by the step kernels for the side-effect pass (safelife_env.py:183-192
@@ -329,7 +329,7 @@ int slhip_env_step_range(const sl_env_batch *env, int first, int count, const in
  * (csrc/sl_aql.hip): a dispatch is a 64-byte packet and a doorbell, and the packets and argument blocks of MANY steps
  * are written by one call.  Ordering is a stream's: every dispatch waits for its queue's previous one (barrier bit) with
  * agent-scope acquire / release fences -- independent of where workgroups run.
- *   open   : slices as in slhip_env_step_slices (1 to 8); row-kernel shapes only, no "inaction" wrapper
+ *   open   : slices as in slhip_env_step_slices (1 to 8); row-kernel shapes only
  *            (SL_E_UNSUPPORTED otherwise, or when the HSA runtime offers no queue -- callers then keep to streams).
  *   steps  : n_steps consecutive steps of every env, all enqueued by this call (the queue rings give back-pressure: the
  *            call blocks while they are full).  Step t takes its actions from actions + t * action_stride (int32

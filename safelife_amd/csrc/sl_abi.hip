@@ -383,8 +383,8 @@ static bool use_rowlane(const sl_env_batch *env, int e_first) {
                                  (((uintptr_t)env->wrap.state | (uintptr_t)env->wrap.move_table) & 15)))
         why = "wrapper workspace missing or unaligned";
     else if ((env->wrap.flags & SL_WRAP_INACTION) &&
-             (!env->wrap.inaction_rows || (((uintptr_t)env->wrap.inaction_board | (uintptr_t)env->wrap.inaction_rng) & 15)))
-        why = "inaction-baseline workspace missing or unaligned";
+             ((((uintptr_t)env->wrap.inaction_board | (uintptr_t)env->wrap.inaction_rng) & 15) || (slice_bytes & 15)))
+        why = "inaction-baseline state unaligned";
     if (!why) return true;
     static std::atomic<bool> warned{false};
     if (!warned.exchange(true))
@@ -401,15 +401,14 @@ static int rollout_range(const sl_env_batch *env, int e_first, int e_count, cons
     if ((rc = jump_table(&jump))) return rc;
     hipError_t err;
     const bool inaction = (env->wrap.flags & SL_WRAP_INACTION) != 0;
-    if (inaction && T > 1) return fail(SL_E_UNSUPPORTED, "the inaction baseline advances between steps: T must be 1");
     if (use_rowlane(env, e_first)) {
-        // (env_wrappers.py:179-180 advances the baseline after the env's step; the two do not touch each other's
-        //  state, and the step reads the result, so it goes first)
-        if (inaction && (err = sl::launch_inaction_rowlane(*env, e_first, e_count, jump, (hipStream_t)stream)) != hipSuccess)
-            return hip_fail(err, "inaction baseline launch");
+        // (the "inaction" baseline of SimpleSideEffectPenalty is part of the WRAP variants of the row kernel: a third
+        //  pass of its CA loop, every step of a T-step launch)
         err = sl::launch_env_rollout_rowlane(*env, e_first, e_count, actions, T, tstride, reward_t, done_t, jump,
                                              (hipStream_t)stream);
     } else {
+        if (inaction && T > 1)
+            return fail(SL_E_UNSUPPORTED, "the inaction baseline advances between steps: T must be 1 on the generic kernels");
         if (T > 1 && e_count != env->B) return fail(SL_E_UNSUPPORTED, "T-step launches of a slice need the row kernels");
         const sl_env_batch s = env_slice(*env, e_first, e_count);
         if (inaction && (err = sl::launch_inaction_generic(s, jump, (hipStream_t)stream)) != hipSuccess)
@@ -689,8 +688,6 @@ int slhip_queues_steps(void *handle, const sl_env_batch *env, const int32_t *act
     if (!c || !env || !actions) return fail(SL_E_ARG, "null pointer");
     if (n_steps < 0) return fail(SL_E_ARG, "n_steps < 0");
     if (env->H != c->H || env->W != c->W || env->B != c->B) return fail(SL_E_ARG, "the queues were opened for another batch");
-    if (env->wrap.flags & SL_WRAP_INACTION)
-        return fail(SL_E_UNSUPPORTED, "the inaction baseline is a launch of its own: HIP streams only");
     if (n_steps == 0) return SL_OK;
     sl::aql_timeline_mark("slhip_queues_steps entered");
     const sl::Jump *jump;

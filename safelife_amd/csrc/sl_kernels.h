@@ -110,7 +110,4 @@ void aql_timeline_mark(const char *what);           // SL_AQL_TIMELINE=1 (debugg
 void aql_timeline_dump();                           // ... and the timeline since the last dump, on stderr
 bool aql_poisoned();                                // a wait timed out: work may still be in flight
 
-// the same for envs [e_first, e_first + e_count) on the row kernels (also writes wrap.inaction_rows)
-hipError_t launch_inaction_rowlane(const sl_env_batch &env, int e_first, int e_count, const Jump *jump, hipStream_t stream);
-
 }  // namespace sl

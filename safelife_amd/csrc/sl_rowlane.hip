@@ -176,6 +176,9 @@ struct Geom {
     static constexpr int OFF_BASE = OFF_MVT + MVT_N * 8;
     static constexpr int LDS_WRAP_GSHREG = OFF_BASE;                           // baseline rows reuse OFF_GSH
     static constexpr int LDS_WRAP_GSHLDS = OFF_BASE + WAVES * 64 * WS * 4;
+    // "inaction" baseline of SimpleSideEffectPenalty (WRAP variants, when the flag is set): a third board image and
+    // the baselines' generators, behind whichever wrapper layout the variant uses
+    static constexpr int INACTION_BYTES = REGION + NB * 32;
     static constexpr int LDS_ADVANCE = OFF_RNG + NB * 32;  // advance_board needs no score state
     // LDS image of a board: row-major cells, except that for 128-byte rows (W = 64) the 16-byte chunks of
     // row y are XOR-swizzled with (y >> 1) & 7.  Unswizzled, all 64 row lanes would hit the same two banks
@@ -1137,67 +1140,6 @@ __global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_ad
     if (live) write_row<H, W>(board, gb, r, b);
     __syncthreads();
     store_span<H, W>(out + (size_t)e0b * Gm::HW, board, nbb, tid);
-    if (lane < 4 * Gm::G && wave * Gm::G + (lane >> 2) < nbb)
-        ((u64 *)(rng + e0b + wave * Gm::G))[lane] = rng_lds[lane];
-}
-
-// SimpleSideEffectPenalty's "inaction" baseline (env_wrappers.py:179-180) for envs [e_first, e_first + e_count): each
-// env's baseline board one CA step on, with the baseline's own generator, written back as a board (the state) and as
-// rows in the register layout with the player bits cleared (what the fused step's wrapper epilogue compares with).
-// An env that has not stepped since its reset (num_steps == 0) starts from its current board -- the wrapper's reset()
-// copies it (:168-172) -- read row by row from global memory by the lanes concerned.
-template <int H, int W>
-__global__ __launch_bounds__(64 * WAVES, (Geom<H, W>::WAVES_PER_SIMD)) void k_inaction_rowlane(
-    const u16 *__restrict__ env_board, u16 *__restrict__ base_board, const sl_env_scalars *__restrict__ scalars,
-    sl_pcg64 *rng, u32 *__restrict__ rows_out, int e_first, int e_count, const Jump *__restrict__ jump) {
-    using Gm = Geom<H, W>;
-    constexpr int WS = Gm::WS;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l0 = blockIdx.x * Gm::NB;                     // first board of the workgroup, within the range
-    if (l0 >= e_count) return;
-    const int nbb = min(Gm::NB, e_count - l0);
-    const int e0b = e_first + l0;
-    const LaneMap<H, W> lm(lane);
-    const int g = lm.g, r = lm.r, up = lm.up, dn = lm.dn;
-    const int gb = wave * Gm::G + g;
-    const bool rowl = lane < Gm::NL && gb < nbb;
-    const bool live = rowl && lm.real;
-    const unsigned e = e0b + (rowl ? gb : 0);
-    unsigned char *board = smem + Gm::OFF_BOARD;
-    u64 *rng_lds = (u64 *)(smem + Gm::OFF_RNG) + 4 * Gm::G * wave;
-
-    load_span<H, W>(base_board + (size_t)e0b * Gm::HW, board, nbb, lane, wave);
-    if (lane < 4 * Gm::G && wave * Gm::G + (lane >> 2) < nbb)
-        rng_lds[lane] = ((const u64 *)(rng + e0b + wave * Gm::G))[lane];
-    const bool fresh = rowl && scalars[e].num_steps == 0;
-    const double p = live ? (double)scalars[e].spawn_prob : 0.0;
-    __syncthreads();
-    const Consts cst = make_consts();
-    const pl::PConsts pcst = pl::make_pconsts();
-    RowWords<H, W> b;
-#pragma unroll
-    for (int k = 0; k < WS; ++k) b[k] = 0;
-    if (rowl) read_row<H, W>(board, gb, r, b);
-    if (fresh) {
-        const u16 *row = env_board + ((size_t)e * H + r) * W;
-#pragma unroll
-        for (int k = 0; k < WS; ++k) {
-            const u32 lo = row[k];
-            const u32 hi = (Gm::ODD && k == WS - 1) ? 0u : row[k + WS];
-            b[k] = lo | (hi << 16);
-        }
-    }
-    ca_step<H, W, true, false>(b, live, true, up, dn, cst, pcst, rng_lds, live ? g : 0, p, jump);
-    if (live) {
-        write_row<H, W>(board, gb, r, b);
-        u32 *out = rows_out + ((size_t)e * H + r) * WS;
-#pragma unroll
-        for (int k = 0; k < WS; ++k)
-            out[k] = b[k] & ~(PLAYER | (PLAYER << 16)) & ((Gm::ODD && k == WS - 1) ? 0xFFFFu : 0xFFFFFFFFu);
-    }
-    __syncthreads();
-    store_span<H, W>(base_board + (size_t)e0b * Gm::HW, board, nbb, tid);
     if (lane < 4 * Gm::G && wave * Gm::G + (lane >> 2) < nbb)
         ((u64 *)(rng + e0b + wave * Gm::G))[lane] = rng_lds[lane];
 }
@@ -2202,6 +2144,12 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     // wrappers: this wave's baseline rows, word k of lane l at [k * 64 + l] (the layout the b32 DMA writes)
     constexpr bool BASE_IN_GSH = GSH_REG && Gm::GSH_BYTES >= WAVES * 64 * WS * 4;
     unsigned char *base_rows = smem + (BASE_IN_GSH ? Gm::OFF_GSH : Gm::OFF_BASE) + wave * 64 * WS * 4;
+    // SimpleSideEffectPenalty's "inaction" baseline (env_wrappers.py:179-180), folded into this kernel in round 4: the
+    // baseline boards of the workgroup's envs in a third LDS image, advanced by one more pass of the CA loop below
+    const bool inaction = WRAP && (env.wrap.flags & SL_WRAP_INACTION) != 0;
+    constexpr int OFF_INB = BASE_IN_GSH ? Gm::LDS_WRAP_GSHREG : Gm::LDS_WRAP_GSHLDS;
+    unsigned char *inb = smem + OFF_INB;
+    u64 *irng_lds = (u64 *)(smem + OFF_INB + Gm::REGION) + 4 * Gm::G * wave;
     sl_wrap_state *wst = (sl_wrap_state *)(smem + Gm::OFF_WST);
     const double *mvt = (const double *)(smem + Gm::OFF_MVT);
     const int8_t *__restrict__ lut = env.score_lut + 4096;        // wide form of table t at + t * SCORE_LUT_BYTES
@@ -2266,6 +2214,11 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
             if (env.wrap.flags & SL_WRAP_MOVEMENT)
                 dma_to_lds<Gm::MVT_N * 8, false, DW>((const unsigned char *)env.wrap.move_table, smem + Gm::OFF_MVT,
                                                      min(env.wrap.move_table_len & ~1, Gm::MVT_N) * 8, lane, dw);
+            if (inaction) {
+                load_span<H, W, DW>(env.wrap.inaction_board + (size_t)e0b * HW, inb, nbb, lane, dw);
+                dma_to_lds<Gm::NB * 32, false, DW>((const unsigned char *)(env.wrap.inaction_rng + e0b),
+                                                   smem + OFF_INB + Gm::REGION, nbb * 32, lane, dw);
+            }
         }
     }
 #ifndef SL_MOVE_BOX
@@ -2332,17 +2285,6 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
 #pragma unroll
     for (int k = 0; k < WS; ++k) asm volatile("" : "=v"(b[k]));
     if (rwave) {
-    if (MOVE_BOX && rlead) {
-        // the move the board's leader decided: into the image, by the board's own wave, ahead of its row reads
-        // (one 16-byte read: four dependent read -> write round trips in a loop cost 0.3 us on the step's chain)
-        const u32x4_t mv = move_box[gb];
-        if ((mv.x & 0xFFFFu) != 0xFFFFu) {
-            board16[mv.x & 0xFFFFu] = (u16)(mv.x >> 16);
-            board16[mv.y & 0xFFFFu] = (u16)(mv.y >> 16);
-            board16[mv.z & 0xFFFFu] = (u16)(mv.z >> 16);
-            board16[mv.w & 0xFFFFu] = (u16)(mv.w >> 16);
-        }
-    }
     if (live) {
         read_row<H, W>(goals, gb, r, b);
 #pragma unroll
@@ -2483,14 +2425,36 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
             if (hand_over) hand_over_block();            // step also the barrier in front of the stores
         }
         if (t >= T) break;
-        if (WRAP && (env.wrap.flags & SL_WRAP_SIDE_EFFECT)) {
+        if (WRAP && (env.wrap.flags & SL_WRAP_SIDE_EFFECT) && !inaction) {
             // baseline row (level, r) of every lane -> LDS, asynchronously; read after the CA pass
-            // ("inaction": the env's own baseline, advanced by k_inaction_rowlane just before this launch)
-            const u32 *src = (env.wrap.flags & SL_WRAP_INACTION) ? env.wrap.inaction_rows + ((size_t)e * H + r) * WS
-                                                                 : env.wrap.pool_baseline + ((size_t)level * H + r) * WS;
+            // ("inaction": the env's own baseline instead, advanced and laid out by this kernel's third CA pass)
+            const u32 *src = env.wrap.pool_baseline + ((size_t)level * H + r) * WS;
 #pragma unroll
             for (int k = 0; k < WS; ++k)
                 __builtin_amdgcn_global_load_lds((glds_src_t)(src + k), (glds_dst_t)(base_rows + k * 256), 4, 0, 0);
+        }
+        if (WRAP && inaction) {
+            // An env in the first step of an episode (num_steps == 0) takes its board as it stands now -- after the
+            // reset, before this step's action -- as its baseline: what the wrapper's reset() copies.
+            const bool fresh = rowl && ((const sl_env_scalars *)(smem + Gm::OFF_REC))[gb].num_steps == 0;
+            if (rwave && __ballot(fresh)) {
+                if (fresh && live) {
+                    read_row<H, W>(board, gb, r, b);
+                    write_row<H, W>(inb, gb, r, b);
+                }
+            }
+            if (!MOVE_BOX) wg_sync();           // (the leaders write the move into the image: behind the rows' reads)
+        }
+        if (MOVE_BOX && rwave && rlead) {
+            // the move the board's leader decided: into the image, by the board's own wave, ahead of its row reads
+            // (one 16-byte read: four dependent read -> write round trips in a loop cost 0.3 us on the step's chain)
+            const u32x4_t mv = move_box[gb];
+            if ((mv.x & 0xFFFFu) != 0xFFFFu) {
+                board16[mv.x & 0xFFFFu] = (u16)(mv.x >> 16);
+                board16[mv.y & 0xFFFFu] = (u16)(mv.y >> 16);
+                board16[mv.z & 0xFFFFu] = (u16)(mv.z >> 16);
+                board16[mv.w & 0xFFFFu] = (u16)(mv.w >> 16);
+            }
         }
         // safelife_env.py:151
         if (!MOVE_BOX) {
@@ -2514,18 +2478,23 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
         // safelife_env.py:152 : board first, then goals unless they are static (safelife_game.py:746-761)
         if (rwave) {
         const bool dyn = rowl && gstatic != 1;
-        const int passes = __ballot(dyn) ? 2 : 1;
+        const int goal_pass = __ballot(dyn) ? 1 : -1;
+        // (WRAP, "inaction": one more pass, over the baseline boards with the baselines' own generators)
+        const int base_pass = (WRAP && inaction) ? (goal_pass > 0 ? 2 : 1) : -1;
+        const int passes = 1 + (goal_pass > 0 ? 1 : 0) + (base_pass > 0 ? 1 : 0);
         bool board_dirty = !SPARSE_STORE;
 #pragma nounroll
         for (int pass = 0; pass < passes; ++pass) {
-            const bool has = rowl && (pass == 0 || dyn);     // row to advance (halo copies included)
+            const bool base = WRAP && pass == base_pass;
+            const bool has = rowl && (pass == 0 || base || dyn);     // row to advance (halo copies included)
             const bool mine = has && lm.real;
-            unsigned char *img = pass == 0 ? board : goals;
+            unsigned char *img = pass == 0 ? board : (base ? inb : goals);
+            u64 *const pass_rng = base ? irng_lds : rng_lds;
             if (has) read_row<H, W>(img, gb, r, b);
             bool changed = true;                             // (wave-uniform) some cell of the wave's rows changed
             if constexpr (use_planes<H, W>()) {
                 u32 row_changed = 0;
-                changed = ca_step<H, W, SPAWN, false>(b, mine, mine, up, dn, cst, pcst, rng_lds, live ? g : 0, p, jump,
+                changed = ca_step<H, W, SPAWN, false>(b, mine, mine, up, dn, cst, pcst, pass_rng, live ? g : 0, p, jump,
                                                       &row_changed);
                 if (SPARSE_STORE && pass == 0) {             // which of the wave's boards changed
                     const unsigned long long rows = __ballot(mine && row_changed != 0);
@@ -2545,10 +2514,18 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
 #pragma unroll
                     for (int k = 0; k < WS; ++k) old[k] = 0;
                     if (mine) read_row<H, W>(img, gb, r, old);
-                    resolve_draws<H, W>(old, b, elig, rng_lds, live ? g : 0, p, jump);
+                    resolve_draws<H, W>(old, b, elig, pass_rng, live ? g : 0, p, jump);
                 }
             }
-            if (pass == 1) {
+            if (base && mine) {
+                // the advanced baseline row as the side-effect count reads it: player bits cleared, word k of lane l
+                // at [k * 64 + l] (the layout the starting-state baseline's DMA writes)
+#pragma unroll
+                for (int k = 0; k < WS; ++k)
+                    ((u32 *)base_rows)[k * 64 + lane] =
+                        b[k] & ~(PLAYER | (PLAYER << 16)) & ((Gm::ODD && k == WS - 1) ? 0xFFFFu : 0xFFFFFFFFu);
+            }
+            if (pass == goal_pass) {
                 u32 diff = 0;
                 if (mine) {
                     RowWords<H, W> old;
@@ -2572,7 +2549,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
             }
             if (mine && changed) write_row<H, W>(img, gb, r, b);
         }
-        if (passes == 2) {               // board rows back into registers for scoring
+        if (passes > 1) {                // board rows back into registers for scoring
             wave_sync();
             if (live) read_row<H, W>(board, gb, r, b);
         }
@@ -2766,6 +2743,12 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     if (WRAP)       // (10-row boards: 24 per workgroup, more state words than threads)
         for (int i = tid2; i < nbb * (int)(sizeof(sl_wrap_state) / 4); i += 64 * WAVES)
             ((u32 *)(env.wrap.state + e0b))[i] = ((const u32 *)wst)[i];
+    if (WRAP && inaction && T > 0) {
+        if (rwave) store_span<H, W>(env.wrap.inaction_board + (size_t)e0b * HW, inb, nbb, tid2);
+        if (lane2 < 4 * Gm::G && wave2 * Gm::G + (lane2 >> 2) < nbb)
+            ((u64 *)(env.wrap.inaction_rng + e0b + wave2 * Gm::G))[lane2] =
+                ((const u64 *)(smem + OFF_INB + Gm::REGION) + 4 * Gm::G * wave2)[lane2];
+    }
 
     SL_STAMP(9);
 #ifdef SL_TRACE
@@ -2895,18 +2878,6 @@ hipError_t launch_advance_t(const u16 *in, u16 *out, int B, const float *spawn_p
 }
 
 template <int H, int W>
-hipError_t launch_inaction_t(const sl_env_batch &env, int e_first, int e_count, const Jump *jump, hipStream_t stream) {
-    using Gm = Geom<H, W>;
-    auto fn = k_inaction_rowlane<H, W>;
-    hipError_t err = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, Gm::LDS_ADVANCE);
-    if (err != hipSuccess) return err;
-    hipLaunchKernelGGL(fn, dim3((e_count + Gm::NB - 1) / Gm::NB), dim3(64 * WAVES), Gm::LDS_ADVANCE, stream,
-                       (const u16 *)env.board, env.wrap.inaction_board, (const sl_env_scalars *)env.scalars,
-                       env.wrap.inaction_rng, env.wrap.inaction_rows, e_first, e_count, jump);
-    return hipGetLastError();
-}
-
-template <int H, int W>
 hipError_t launch_occupancy_t(const u16 *in, int32_t *counts, size_t counts_stride, int B, const int32_t *n_valid,
                                      int valid_period, const int32_t *pre_steps, const float *spawn_prob, int n_steps,
                                      sl_pcg64 *rng, const Jump *jump, hipStream_t stream) {
@@ -2988,7 +2959,9 @@ hipError_t pick_rollout_t(const sl_env_batch &env, int T, void **kernel, hipFunc
     *threads_out = 64 * (WAVES + ((variant & 8) && Gm::LEADX_OK ? 1 : 0));     // LEAN: a fifth, leader wave
     const kernel_t fn = table[slot];
     const bool spawn = !(variant & 2), base_in_gsh = !spawn && Gm::WAVES_PER_SIMD == 4;
-    const int lds = !(variant & 4) ? Gm::LDS_BYTES : (base_in_gsh ? Gm::LDS_WRAP_GSHREG : Gm::LDS_WRAP_GSHLDS);
+    const int lds_wrap = base_in_gsh ? Gm::LDS_WRAP_GSHREG : Gm::LDS_WRAP_GSHLDS;
+    const int lds = !(variant & 4) ? Gm::LDS_BYTES : lds_wrap + ((env.wrap.flags & SL_WRAP_INACTION) ? Gm::INACTION_BYTES : 0);
+    const int lds_limit = !(variant & 4) ? Gm::LDS_BYTES : lds_wrap + Gm::INACTION_BYTES;     // (set once per variant)
     // per (device, variant), once: raise the dynamic LDS limit and look up the module-level handle of the kernel
     struct Entry {
         std::atomic<hipFunction_t> fn{nullptr};
@@ -3001,7 +2974,7 @@ hipError_t pick_rollout_t(const sl_env_batch &env, int T, void **kernel, hipFunc
     if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     Entry &ce = cache[slot][dev];
     if (!ce.ready.load(std::memory_order_acquire)) {
-        err = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        err = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_limit);
         if (err != hipSuccess) return err;
         hipFunction_t f = nullptr;
         if (hipGetFuncBySymbol(&f, (const void *)fn) != hipSuccess) f = nullptr;
@@ -3073,7 +3046,6 @@ hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, c
     PREFIX template hipError_t rl::launch_occupancy_t<h, w>(const u16 *, int32_t *, size_t, int, const int32_t *, int,    \
                                                             const int32_t *, const float *, int, sl_pcg64 *, const Jump *, \
                                                             hipStream_t);                                                  \
-    PREFIX template hipError_t rl::launch_inaction_t<h, w>(const sl_env_batch &, int, int, const Jump *, hipStream_t);     \
     PREFIX template hipError_t rl::launch_rollout_t<h, w>(const sl_env_batch &, int, int, const int32_t *, int, int,      \
                                                           float *, uint8_t *, const Jump *, hipStream_t, PreparedStep *);
 #ifdef SL_ROWLANE_PART
@@ -3144,13 +3116,6 @@ hipFunction_t rowlane_probe_function() {
         return nullptr;
     }
     return f;
-}
-
-hipError_t launch_inaction_rowlane(const sl_env_batch &env, int e_first, int e_count, const Jump *jump, hipStream_t stream) {
-#define X(h, w) if (env.H == h && env.W == w) return rl::launch_inaction_t<h, w>(env, e_first, e_count, jump, stream);
-    SL_ROWLANE_SHAPES(X)
-#undef X
-    return hipErrorInvalidValue;
 }
 
 hipError_t launch_env_rollout_rowlane(const sl_env_batch &env, int e_first, int e_count, const int32_t *actions,

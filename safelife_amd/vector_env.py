@@ -338,8 +338,8 @@ class SafeLifeVectorEnv(object):
         w.pool_baseline = t["pool_baseline"].data_ptr()
         self.shaped_reward = t["shaped_reward"]
         if w.flags & _hip.WRAP_INACTION:
-            # env_wrappers.py:179-180: the baseline board advances once per step (a launch of its own in front of
-            # every step; slhip_env_rollout with T > 1 refuses the flag).  One generator per env.
+            # env_wrappers.py:179-180: the baseline board advances once per step (inside the step kernel: a third pass
+            # of its CA loop).  One generator per env.
             words = cfg.get("inaction_rng")
             if words is None:
                 seq = cfg.get("inaction_seed")
@@ -351,10 +351,9 @@ class SafeLifeVectorEnv(object):
             words = np.ascontiguousarray(words, dtype=np.uint64).reshape(B, 4)
             t["inaction_rng"] = torch.from_numpy(words.view(np.int64).copy()).to(dev)
             t["inaction_board"] = torch.zeros((B, H, W), dtype=torch.int16, device=dev)
-            t["inaction_rows"] = torch.zeros((B, H, (W + 1) // 2), dtype=torch.int32, device=dev)
             w.inaction_board = t["inaction_board"].data_ptr()
             w.inaction_rng = t["inaction_rng"].data_ptr()
-            w.inaction_rows = t["inaction_rows"].data_ptr()
+            w.inaction_rows = None
 
     # ------------------------------------------------------------------ gym-like surface
 

@@ -327,8 +327,31 @@ def test_env_batch_inaction_baseline_vs_oracle(pool_name, B, T, extra, kw):
             assert np.array_equal(dev.get("inaction_board")[keep], cpu.get("inaction_board")[keep]), t
     assert n_done > B // 2
     assert np.array_equal(dev.get("board"), cpu.get("board"))
-    with pytest.raises(Exception):      # the baseline advances between steps: no T-step launches
-        dev.env.rollout(rng.integers(0, 9, (3, B)).astype(np.int32))
+    # the baseline advances inside the step kernel: T-step launches and the library's queues carry it too
+    import torch
+    T2 = 14
+    a = rng.integers(0, 9, (T2, B)).astype(np.int32)
+    dev.env.rollout(a)
+    want = []
+    for t in range(T2):
+        cpu.step(a[t])
+        want.append(cpu.get("shaped_reward"))
+    assert np.array_equal(dev.env.shaped_reward_t.cpu().numpy(), np.stack(want))
+    assert np.array_equal(dev.get("inaction_rng"), cpu.get("inaction_rng"))
+    a = rng.integers(0, 9, (T2, B)).astype(np.int32)
+    d_a = torch.from_numpy(a).to(dev.env.device)
+    try:
+        dev.env.queues_open(2)
+    except Exception as e:              # no HSA queue on this box
+        print("queues unavailable:", e)
+    else:
+        dev.env.step_queues_many(d_a)
+        for t in range(T2):
+            cpu.step(a[t])
+        assert np.array_equal(dev.get("shaped_reward"), cpu.get("shaped_reward"))
+        assert np.array_equal(dev.get("inaction_rng"), cpu.get("inaction_rng"))
+        assert np.array_equal(dev.get("board"), cpu.get("board"))
+        dev.env.queues_close()
 
 
 def test_generic_kernels_with_wrappers():
