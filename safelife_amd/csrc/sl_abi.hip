@@ -356,11 +356,22 @@ int slhip_env_prepare(const sl_env_batch *env, void *stream) {
     return err == hipSuccess ? SL_OK : hip_fail(err, "env_prepare launch");
 }
 
+static bool use_rowlane(const sl_env_batch *env, int e_first);
 int slhip_env_reset(const sl_env_batch *env, const uint8_t *mask, void *stream) {
     int rc = check_env(env);
     if (rc) return rc;
     if (env->B == 0) return SL_OK;
-    hipError_t err = sl::launch_env_reset_generic(*env, mask, (hipStream_t)stream);
+    hipError_t err;
+    if (use_rowlane(env, 0)) {
+        // the fused row kernel in its reset mode: the block that serves the in-kernel auto-reset, for the masked envs
+        // (eight boards per workgroup; the size-generic kernel below takes a workgroup per board: 31 us for 8192 envs)
+        const sl::Jump *jump;
+        if ((rc = jump_table(&jump))) return rc;
+        err = sl::launch_env_rollout_rowlane(*env, 0, env->B, (const int32_t *)env->scalars, -1, env->B, nullptr, nullptr, jump,
+                                             (hipStream_t)stream, nullptr, mask);
+    } else {
+        err = sl::launch_env_reset_generic(*env, mask, (hipStream_t)stream);
+    }
     return err == hipSuccess ? SL_OK : hip_fail(err, "env_reset launch");
 }
 

@@ -76,9 +76,12 @@ struct PreparedStep {
     alignas(16) unsigned char args[1024];
 };
 // prepared (optional, T == 1 only): fill it instead of launching
+// T == -1: SafeLifeEnv.reset() of the envs with reset_mask[e] != 0 (device uint8 [B] indexed by the env's index in the
+// batch; null: all) instead of steps; `actions` is then only a readable dummy
 hipError_t launch_env_rollout_rowlane(const sl_env_batch &env, int e_first, int e_count, const int32_t *actions,
                                       int T, int tstride, float *reward_t, uint8_t *done_t, const Jump *jump,
-                                      hipStream_t stream, PreparedStep *prepared = nullptr);
+                                      hipStream_t stream, PreparedStep *prepared = nullptr,
+                                      const uint8_t *reset_mask = nullptr);
 
 // sl_aql.hip : user-mode queues of the library's own next to HIP's streams
 const char *aql_open(int n_queues);                 // null when usable, else why not

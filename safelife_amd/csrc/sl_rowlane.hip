@@ -2089,7 +2089,9 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     // queue stepping without a release fence between steps (sl_aql.hip, opt-in): workgroup i of this launch must run on
     // XCD (xcd_base + i) mod 8 -- where the launches before it left this slice's state -- and raises the host-visible
     // word xcd_flag if it finds itself anywhere else; xcd_flag is null on every other launch
-    int xcd_base, u32 *__restrict__ xcd_flag) {
+    int xcd_base, u32 *__restrict__ xcd_flag,
+    // T_arg == -1: SafeLifeEnv.reset() for the envs with reset_mask[e] != 0 (null: all of them) instead of steps
+    const uint8_t *__restrict__ reset_mask) {
     using Gm = Geom<H, W>;
     constexpr int WS = Gm::WS, HW = Gm::HW;
     const int T = ONE ? 1 : T_arg;
@@ -2709,7 +2711,29 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
         }
     }
 
-    if (T <= 0) wg_sync();
+    if (T < 0) {
+        // slhip_env_reset on the row kernels (safelife_env.py:203-218): the leaders ask for what the auto-reset asks for
+        // at the end of an episode -- an env that holds a level moves on to its next one and counts an episode, one that
+        // has never been loaded takes level_idx as it stands -- and the block that serves the auto-reset does the rest
+        if (lwave) {
+            if (lane == 0) box[0].any = 0;
+            if (lead) {
+                int next = -1;
+                if (!reset_mask || reset_mask[el]) {
+                    const bool was = lrec->loaded != 0;
+                    next = was ? (lrec->level_idx + env.level_stride) % env.L : lrec->level_idx;
+                    if (!was) lrec->episode_idx -= 1;       // (the block below counts one)
+                    atomicOr(&box[0].any, 1);
+                }
+                box[lq].reset_level = next;
+                box[lq].qslot = -1;
+            }
+        }
+        wg_sync();
+        hand_over_block();
+    } else if (T == 0) {
+        wg_sync();
+    }
     SL_STAMP(7);
     // write-back of the records: the leaders complete their LDS copies, the leader wave stores them
     if (lwave) {
@@ -2717,7 +2741,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
             lrec->agent_row = ly;
             lrec->agent_col = lx;
             lrec->goals_static = box[lq].gstat;
-            lrec->loaded = 1;
+            if (T >= 0) lrec->loaded = 1;           // (a reset launch marks the envs it loads, above)
         }
         wave_sync();
         int lane3 = lane;
@@ -2934,6 +2958,7 @@ struct RolloutArgs {
     const Jump *jump;
     int xcd_base;
     u32 *xcd_flag;
+    const uint8_t *reset_mask;
 };
 static_assert(sizeof(RolloutArgs) <= sizeof(PreparedStep::args), "argument block of a prepared step");
 
@@ -2945,7 +2970,7 @@ hipError_t pick_rollout_t(const sl_env_batch &env, int T, void **kernel, hipFunc
     const int variant = (env.n_tables == 1 ? 1 : 0) | (env.spawner_free ? 2 : 0) | (env.wrap.flags ? 4 : (lean ? 8 : 0));
     typedef void (*kernel_t)(const u16 *, const u16 *, const sl_pcg64 *, sl_env_scalars *, const int8_t *,
                              const int32_t *, int, int, sl_env_batch, int, int, int, sl_step_out *, float *,
-                             uint8_t *, double *, const Jump *, int, u32 *);
+                             uint8_t *, double *, const Jump *, int, u32 *, const uint8_t *);
 #define SL_VARIANTS(ONE)                                                                                               \
     k_env_rollout_rowlane<H, W, false, true, false, false, ONE>, k_env_rollout_rowlane<H, W, true, true, false, false, ONE>,   \
     k_env_rollout_rowlane<H, W, false, false, false, false, ONE>, k_env_rollout_rowlane<H, W, true, false, false, false, ONE>, \
@@ -2991,7 +3016,7 @@ hipError_t pick_rollout_t(const sl_env_batch &env, int T, void **kernel, hipFunc
 template <int H, int W>
 hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, const int32_t *actions, int T,
                                    int tstride, float *reward_t, uint8_t *done_t, const Jump *jump,
-                                   hipStream_t stream, PreparedStep *prepared) {
+                                   hipStream_t stream, PreparedStep *prepared, const uint8_t *reset_mask) {
     using Gm = Geom<H, W>;
     void *kernel = nullptr;
     hipFunction_t f = nullptr;
@@ -3001,7 +3026,7 @@ hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, c
     if (err != hipSuccess) return err;
     const unsigned grid = (unsigned)((e_count + Gm::NB - 1) / Gm::NB);
     RolloutArgs args = {env.board, env.goals, env.rng, env.scalars, env.score_lut, actions, e_first, e_first + e_count, env,
-                        env.E, tstride, T, env.out, reward_t, done_t, env.wrap.shaped_reward_t, jump, 0, nullptr};
+                        env.E, tstride, T, env.out, reward_t, done_t, env.wrap.shaped_reward_t, jump, 0, nullptr, reset_mask};
     if (prepared) {
         // not launched: the argument block and the launch geometry, for the library's own queues (sl_aql.hip) to
         // dispatch any number of times with the per-step fields patched in
@@ -3026,7 +3051,7 @@ hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, c
     }
     void *params[] = {&args.board, &args.goals, &args.rng, &args.scalars, &args.lut, &args.actions, &args.first, &args.end,
                       &args.env, &args.E, &args.tstride, &args.T, &args.out, &args.reward_t, &args.done_t, &args.shaped_t,
-                      &args.jump, &args.xcd_base, &args.xcd_flag};
+                      &args.jump, &args.xcd_base, &args.xcd_flag, &args.reset_mask};
     return hipLaunchKernel(kernel, dim3(grid), dim3(threads), params, (size_t)lds, stream);
 }
 
@@ -3047,7 +3072,8 @@ hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, c
                                                             const int32_t *, const float *, int, sl_pcg64 *, const Jump *, \
                                                             hipStream_t);                                                  \
     PREFIX template hipError_t rl::launch_rollout_t<h, w>(const sl_env_batch &, int, int, const int32_t *, int, int,      \
-                                                          float *, uint8_t *, const Jump *, hipStream_t, PreparedStep *);
+                                                          float *, uint8_t *, const Jump *, hipStream_t, PreparedStep *,     \
+                                                          const uint8_t *);
 #ifdef SL_ROWLANE_PART
 #define X(h, w) SL_ROWLANE_LAUNCHERS(, h, w)
 #if SL_ROWLANE_PART == 1
@@ -3120,8 +3146,8 @@ hipFunction_t rowlane_probe_function() {
 
 hipError_t launch_env_rollout_rowlane(const sl_env_batch &env, int e_first, int e_count, const int32_t *actions,
                                       int T, int tstride, float *reward_t, uint8_t *done_t, const Jump *jump,
-                                      hipStream_t stream, PreparedStep *prepared) {
-#define X(h, w) if (env.H == h && env.W == w) return rl::launch_rollout_t<h, w>(env, e_first, e_count, actions, T, tstride, reward_t, done_t, jump, stream, prepared);
+                                      hipStream_t stream, PreparedStep *prepared, const uint8_t *reset_mask) {
+#define X(h, w) if (env.H == h && env.W == w) return rl::launch_rollout_t<h, w>(env, e_first, e_count, actions, T, tstride, reward_t, done_t, jump, stream, prepared, reset_mask);
     SL_ROWLANE_SHAPES(X)
 #undef X
     return hipErrorInvalidValue;
