@@ -770,8 +770,8 @@ int slhip_queues_steps(void *handle, const sl_env_batch *env, const int32_t *act
         // ~1-3 us of host time, and the device needs the next step ~6 us after the last.  So the first steps go out one
         // by one (the device starts at once and is never left waiting while a batch is being written: with eight steps
         // per flush from the start the kernels' own clocks showed it idle for 7 us behind step 0), later ones -- the
-        // host is ahead by then -- in twos and fours.
-        if (t < 4 || (t < 16 && (t & 1)) || (t & 3) == 3 || c->swap) sl::aql_flush();
+        // host is ahead by then -- in fours.
+        if (t < 3 || (t & 3) == 3 || c->swap) sl::aql_flush();
     }
     return SL_OK;
 }
