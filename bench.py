@@ -326,8 +326,11 @@ def main():
     shift = (every - (P + W + K) % every) % every
     # ... two steps ahead of the end: the exchange itself (RCCL's send / receive kernel and its hand-shake, ~25 us on
     # the device) then runs under the last steps.
+    # (queue stepping: the stepping thread has long finished enqueuing by then, the library's worker has RCCL's group
+    #  waiting on its stream behind a gate, and the window closes five steps ahead of the end so that the exchange
+    #  itself runs under the last steps)
     if K >= 8 and every >= 8:
-        shift = (shift + 2) % every
+        shift = (shift + (5 if n_queues > 0 else 2)) % every
     dbg = os.environ.get("SL_BENCH_DEBUG") == "1"
     import gc
 
@@ -945,6 +948,12 @@ def main():
                 return oracle.alive_counts_batch(b, g)
             out["cpu_baseline"] = cpu_baseline(load_pool(args.pool, cpu_counts), B, args.cpu_steps, 7)
             out["cpu_baseline"]["parity_check"] = parity
+        # (RCCL writes a version banner through C stdio, which would otherwise come out at exit, BEHIND this line)
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()
