@@ -247,10 +247,6 @@ struct GatherComm {
     static constexpr int RING = 8;
     hipEvent_t order_ev[8] = {};             // writer stream -> gather stream
     hipEvent_t done_ev[RING] = {};           // recorded behind ticket t's group: slot t % RING
-    // windows written from the AQL queues: the RCCL group goes onto its stream at once, behind a wait for this word
-    // (hipStreamWaitValue32 on signal memory), which the worker sets when the window's marker has passed -- RCCL's
-    // ~30 us of host-side launch work then run while the window's steps are still running, not after them
-    uint32_t *gate = nullptr;
 };
 }  // namespace
 
@@ -897,12 +893,7 @@ static void gather_worker(GatherComm *g) {
         int rc = SL_OK;
         // a window written from the AQL queues: their marker (system-scope release behind the window's last step) is
         // waited for HERE, on this thread -- the stepping thread keeps dispatching the next window's steps meanwhile
-        const bool gated = rq.marker >= 0 && g->gate &&
-                           hipStreamWaitValue32(rq.stream, g->gate, (uint32_t)(rq.ticket + 1), hipStreamWaitValueGte, 0xFFFFFFFFu) == hipSuccess;
-        if (rq.marker >= 0 && !gated) {
-            (void)hipGetLastError();
-            if (sl::aql_wait(rq.marker) != hipSuccess) rc = SL_E_HIP;
-        }
+        if (rq.marker >= 0 && sl::aql_wait(rq.marker) != hipSuccess) rc = SL_E_HIP;
         for (int i = 0; i < rq.n_writers && rc == SL_OK; ++i) {     // the exchange's stream waits for the window's writers
             if (rq.writers[i] == rq.stream) continue;
             hipError_t err = hipEventRecord(g->order_ev[i], rq.writers[i]);
@@ -917,16 +908,6 @@ static void gather_worker(GatherComm *g) {
             g->issued.store(rq.ticket + 1, std::memory_order_release);
         }
         g->cv_done.notify_all();
-        if (gated) {
-            // the group is enqueued behind the gate: open it when the window is complete and visible (or at once if
-            // the wait fails: the stream must not hang; the error is reported)
-            const bool ok = sl::aql_wait(rq.marker) == hipSuccess;
-            __atomic_store_n(g->gate, (uint32_t)(rq.ticket + 1), __ATOMIC_RELEASE);
-            if (!ok) {
-                std::lock_guard<std::mutex> lock(g->m);
-                if (g->error == 0) g->error = SL_E_HIP;
-            }
-        }
     }
 }
 
@@ -959,16 +940,6 @@ static int gather_submit(void *comm, const void *send, void *recv, size_t bytes,
         for (int i = 0; i < 8 && err == hipSuccess; ++i) err = hipEventCreateWithFlags(&g->order_ev[i], hipEventDisableTiming);
         for (int i = 0; i < GatherComm::RING && err == hipSuccess; ++i) err = hipEventCreateWithFlags(&g->done_ev[i], hipEventDisableTiming);
         if (err != hipSuccess) return hip_fail(err, "gather events");
-        int can_wait = 0;
-        if (hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, g->device) == hipSuccess && can_wait &&
-            !getenv("SL_GATHER_NO_GATE")) {
-            void *p = nullptr;
-            if (hipExtMallocWithFlags(&p, 8, hipMallocSignalMemory) == hipSuccess) {
-                g->gate = (uint32_t *)p;
-                *g->gate = 0;
-            }
-        }
-        (void)hipGetLastError();
         g->worker = std::thread(gather_worker, g);
     }
     if (g->submitted - g->issued.load(std::memory_order_acquire) >= GatherComm::RING)
@@ -1042,7 +1013,6 @@ int slhip_gather_destroy(void *comm) {
             if (e) (void)hipEventDestroy(e);
         for (auto &e : g->done_ev)
             if (e) (void)hipEventDestroy(e);
-        if (g->gate) (void)hipFree(g->gate);
     }
     const Rccl &r = rccl();
     const int rc = r.ok ? r.CommDestroy(g->comm) : 0;
