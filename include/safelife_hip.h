@@ -368,6 +368,10 @@ int slhip_env_step_range(const sl_env_batch *env, int first, int count, const in
 #define SL_QUEUES_SELFTEST_PLANT 1
 #define SL_QUEUES_SELFTEST_SWAP 2
 int slhip_queues_open(const sl_env_batch *env, int n_slices, const int32_t *bounds, int flags, void **handle);
+/* Which of the first n_queues queues share a hardware pipe with HIP `stream` (bit q of *mask)?  Kernels of such a stream
+ * -- the gather's RCCL group, a policy network -- and the slice of that queue take turns instead of overlapping; see
+ * slhip_queues_open_on. */
+int slhip_queues_stream_shares(int n_queues, void *stream, int *mask);
 int slhip_queues_mode(void *handle, const char **why_not);
 int slhip_queues_steps(void *handle, const sl_env_batch *env, const int32_t *actions, long long action_stride,
                        long long out_stride, int n_steps, int head);

@@ -623,6 +623,52 @@ bool probe_placement(int n_queues, int grid, int *base, std::string *why) {
 }
 }  // namespace
 
+// Which of the library's queues does a HIP stream share a hardware pipe with?  MI355X has four compute pipes; the queues
+// of a process -- HIP's own hardware queues behind its streams, and these -- are spread over them, and two queues of one
+// pipe take turns: a kernel of the stream (RCCL's exchange, ~40 us per window; a policy network's) holds up the slice
+// whose queue sits on its pipe while the other slices run on (the kernels' own clocks show one queue's next launch 40 us
+// late behind every exchange, profiles/round4_g_*), and it also moves that queue's workgroups to other XCDs.  Measured
+// here, per queue: a 200 us one-wavefront kernel on the stream, then -- once it runs -- a one-workgroup dispatch on the
+// queue; a dispatch that comes back only when the long kernel ends shares its pipe.
+int slhip_queues_stream_shares(int n_queues, void *stream, int *mask) {
+    if (!mask || n_queues < 1 || n_queues > 8) return fail(SL_E_ARG, "bad arguments (1 to 8 queues)");
+    *mask = 0;
+    if (const char *why = sl::aql_open(n_queues)) return fail(SL_E_UNSUPPORTED, std::string("AQL queues unavailable: ") + why);
+    hipFunction_t f = nullptr;
+    if (hipGetFuncBySymbol(&f, (const void *)sl::k_xcd_probe) != hipSuccess || sl::aql_probe(f)) {
+        (void)hipGetLastError();
+        return fail(SL_E_UNSUPPORTED, "the probe kernel was not found");
+    }
+    uint32_t *out = nullptr;
+    hipError_t err = hipMalloc((void **)&out, 64);
+    if (err != hipSuccess) return hip_fail(err, "hipMalloc");
+    const hipStream_t st = (hipStream_t)stream;
+    const long long ticks = 20000;                  // 200 us of the 100 MHz counter
+    struct {
+        uint32_t *out;
+    } args = {out};
+    for (int q = 0; q < n_queues && err == hipSuccess; ++q) {
+        double best = 1e30;
+        for (int rep = 0; rep < 2 && err == hipSuccess; ++rep) {     // (the first pass also warms the kernels up)
+            err = hipStreamSynchronize(st);
+            if (err == hipSuccess) err = sl::aql_fence(n_queues);
+            if (err == hipSuccess) err = sl::launch_idle(ticks, st);
+            const auto t0 = std::chrono::steady_clock::now();
+            while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < 40.0) {}
+            const auto t1 = std::chrono::steady_clock::now();
+            if (err == hipSuccess) err = sl::aql_dispatch(sl::AqlLaunch{q, false, false}, f, 1, 256, 0, &args, sizeof(args));
+            if (err == hipSuccess) err = sl::aql_fence(n_queues);
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
+            if (us < best) best = us;
+        }
+        if (best > 80.0) *mask |= 1 << q;           // (alone: a few microseconds; behind the long kernel: >= 150)
+    }
+    if (err == hipSuccess) err = hipStreamSynchronize(st);
+    (void)hipFree(out);
+    if (err != hipSuccess) return hip_fail(err, "queues_stream_shares");
+    return SL_OK;
+}
+
 int slhip_queues_open(const sl_env_batch *env, int n_slices, const int32_t *bounds, int flags, void **handle) {
     int rc = check_env(env);
     if (rc) return rc;

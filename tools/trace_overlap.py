@@ -21,10 +21,14 @@ from safelife_amd.levels import _device_counts
 from safelife_amd.vector_env import SafeLifeVectorEnv
 
 import argparse
+if "--gather-every" in sys.argv:
+    os.environ["SAFELIFE_FORCE_GATHER"] = "1"
 ap = argparse.ArgumentParser()
 ap.add_argument("steps", nargs="?", type=int, default=6)
 ap.add_argument("--queues", type=int, default=0)
 ap.add_argument("--fences", default="agent")
+ap.add_argument("--gather-every", type=int, default=0,
+                help="queue mode: hand a window of this many steps to the RCCL exchange (one rank, to itself) inside the trace")
 args = ap.parse_args()
 N = args.steps
 B, SL = 8192, (args.queues or 2)
@@ -50,7 +54,17 @@ lib.slhip_trace_set.argtypes = [C.c_void_p, C.c_longlong, C.c_int]
 assert lib.slhip_trace_set(trace.data_ptr(), waves * 16 * 8, N * SL) == 0
 import gc
 gc.disable()
-if args.queues:
+if args.queues and args.gather_every:
+    from safelife_amd.sharding import RewardGather
+    gather = RewardGather(env, every=args.gather_every, world=1, rank=0)
+    gather.queued = True
+    gather.prime()
+    torch.cuda.synchronize()
+    gather.run_queued(0, N, acts[64].data_ptr(), B, shift=0, assume_ordered=True)
+    gather.flush()
+    env.queues_sync()
+    print("windows of %d steps handed to the exchange: %d" % (args.gather_every, gather.windows))
+elif args.queues:
     env.step_queues_many(acts[64:64 + N], assume_ordered=True)
     env.queues_sync()
 else:
