@@ -330,9 +330,11 @@ def main():
     #  waiting on its stream behind a gate, and the window closes five steps ahead of the end so that the exchange
     #  itself runs under the last steps)
     if K >= 8 and every >= 8:
-        shift = (shift + (5 if n_queues > 0 else 2)) % every
+        shift = (shift + int(os.environ.get("SAFELIFE_BENCH_WINDOW_AHEAD", "5" if n_queues > 0 else "2"))) % every
     dbg = os.environ.get("SL_BENCH_DEBUG") == "1"
     import gc
+
+    queue_ids = [None]
 
     def attempt(fences):
         """Reset, P checkpointed steps, W warm-up steps, the K timed steps.  Returns the measurements, or None when
@@ -342,7 +344,19 @@ def main():
         env.reset()
         if n_queues > 0:
             try:
-                env.queues_open(n_queues, release_free=(fences == "none"))
+                # N > 1 (or the forced one-rank exchange): the step queue that RCCL's kernel would hold up is left
+                # out -- three slices on the three queues the exchange does not touch (probed once, collectively)
+                if os.environ.get("SAFELIFE_BENCH_QUEUE_IDS"):        # (experiments: slices on exactly these queues)
+                    queue_ids[0] = [int(x) for x in os.environ["SAFELIFE_BENCH_QUEUE_IDS"].split(",")]
+                if gather.collective and n_queues == 4 and queue_ids[0] is None:
+                    try:
+                        free = gather.free_queues(4)
+                    except _hip.SafeLifeHipError as e:
+                        print("bench: gather_stream_shares failed (%s)" % e, file=sys.stderr)
+                        free = [0, 1, 2, 3]
+                    queue_ids[0] = free[:3] if 3 <= len(free) < 4 else [0, 1, 2, 3]
+                ids = queue_ids[0] if ((gather.collective and n_queues == 4) or os.environ.get("SAFELIFE_BENCH_QUEUE_IDS")) else None
+                env.queues_open(len(ids) if ids else n_queues, release_free=(fences == "none"), queue_ids=ids)
                 res["use_queues"], res["queues_why"] = True, None
                 res["fences"] = "none" if env.queue_release_free else "agent"
                 if fences == "none" and not env.queue_release_free:
@@ -902,6 +916,10 @@ def main():
                                                                    else ("%d slice(s) per GPU, one launch and one stream each"
                                                                          % env.slices)),
                        "stepping": "aql-queues" if use_queues else "hip-streams",
+                       "queue_ids": (getattr(env, "queue_ids", None) if use_queues else None),
+                       "queue_ids_note": ("the step queue RCCL's exchange kernel would hold up is left out (probed: "
+                                          "slhip_gather_stream_shares)" if (use_queues and gather.collective and
+                                                                            len(getattr(env, "queue_ids", [])) == 3) else None),
                        "queue_fences": ({"none": "none: bench opted in to release-free stepping (SL_QUEUES_RELEASE_FREE) -- "
                                                  "agent-scope acquire, NO release between the steps of a queue; placement "
                                                  "probed at open and verified by every step",

@@ -368,9 +368,12 @@ int slhip_env_step_range(const sl_env_batch *env, int first, int count, const in
 #define SL_QUEUES_SELFTEST_PLANT 1
 #define SL_QUEUES_SELFTEST_SWAP 2
 int slhip_queues_open(const sl_env_batch *env, int n_slices, const int32_t *bounds, int flags, void **handle);
-/* Which of the first n_queues queues share a hardware pipe with HIP `stream` (bit q of *mask)?  Kernels of such a stream
- * -- the gather's RCCL group, a policy network -- and the slice of that queue take turns instead of overlapping; see
- * slhip_queues_open_on. */
+/* The same with slice i on queue queue_ids[i] (distinct, 0 to 7; NULL: slice i on queue i) -- for callers that leave
+ * out a queue another kernel of theirs would hold up (slhip_gather_stream_shares). */
+int slhip_queues_open_on(const sl_env_batch *env, int n_slices, const int32_t *bounds, const int32_t *queue_ids, int flags,
+                         void **handle);
+/* Which of the queues 0 .. n_queues - 1 does a long one-wavefront kernel on HIP `stream` hold up (bit q of *mask)?
+ * (On MI355X: none -- a kernel that fits next to the steps runs beside them whatever its queue.) */
 int slhip_queues_stream_shares(int n_queues, void *stream, int *mask);
 int slhip_queues_mode(void *handle, const char **why_not);
 int slhip_queues_steps(void *handle, const sl_env_batch *env, const int32_t *actions, long long action_stride,
@@ -433,6 +436,13 @@ int slhip_gather_unique_id(void *id_out);
 int slhip_gather_init(const void *id, int world, int rank, void **comm);
 int slhip_gather_window(void *comm, const void *send, void *recv, size_t bytes, void *stream);
 int slhip_gather_destroy(void *comm);
+
+/* Which of the library's step queues 0 .. n_queues - 1 (slhip_queues_*) does the exchange hold up when it runs on
+ * `stream` (bit q of *mask)?  RCCL's kernel is dispatched from one of HIP's hardware queues; the step queue that takes
+ * turns with it stands still for the length of the exchange (~40 us per window next to a running step loop) while the
+ * others step on.  Measured with a real 8 MiB exchange per queue -- COLLECTIVE: every rank calls it, with the same
+ * n_queues.  A caller that steps through queues then opens them with slhip_queues_open_on, leaving the marked queue out. */
+int slhip_gather_stream_shares(void *comm, int n_queues, void *stream, int *mask);
 
 /* The same hand-off off the caller's thread: the request is queued and a worker thread of the library issues the
  * stream ordering (the exchange's `stream` waits for what is enqueued on the window's `writers`, HOST array of up to 8

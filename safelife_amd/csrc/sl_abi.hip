@@ -553,6 +553,8 @@ __global__ void k_xcd_probe(u32 *__restrict__ out) {
 namespace {
 struct StepQueues {
     int n_slices = 0;
+    int qmap[8] = {0, 1, 2, 3, 4, 5, 6, 7};     // slice i is dispatched on the library's queue qmap[i] (slhip_queues_open_on)
+    int n_phys = 0;                             // queues 0 .. n_phys - 1 exist
     int32_t bounds[9] = {};
     int H = 0, W = 0, B = 0;
     // SL_QUEUES_RELEASE_FREE (opt-in): no release fence between the steps of a queue; the placement this rests on is
@@ -670,16 +672,30 @@ int slhip_queues_stream_shares(int n_queues, void *stream, int *mask) {
 }
 
 int slhip_queues_open(const sl_env_batch *env, int n_slices, const int32_t *bounds, int flags, void **handle) {
+    return slhip_queues_open_on(env, n_slices, bounds, nullptr, flags, handle);
+}
+
+int slhip_queues_open_on(const sl_env_batch *env, int n_slices, const int32_t *bounds, const int32_t *queue_ids, int flags,
+                         void **handle) {
     int rc = check_env(env);
     if (rc) return rc;
     if (!handle || !bounds || n_slices < 1 || n_slices > 8) return fail(SL_E_ARG, "bad queue arguments (1 to 8 slices)");
+    int n_phys = n_slices;
+    if (queue_ids) {
+        unsigned seen = 0;
+        for (int i = 0; i < n_slices; ++i) {
+            if (queue_ids[i] < 0 || queue_ids[i] > 7 || (seen >> queue_ids[i] & 1u)) return fail(SL_E_ARG, "queue ids: distinct, 0 to 7");
+            seen |= 1u << queue_ids[i];
+            n_phys = std::max(n_phys, queue_ids[i] + 1);
+        }
+    }
     if (flags & ~SL_QUEUES_RELEASE_FREE) return fail(SL_E_ARG, "unknown queue flags");
     if (bounds[0] != 0 || bounds[n_slices] != env->B) return fail(SL_E_ARG, "slice bounds must run from 0 to B");
     for (int i = 0; i < n_slices; ++i) {
         if (bounds[i + 1] < bounds[i]) return fail(SL_E_ARG, "slice bounds must not decrease");
         if (!use_rowlane(env, bounds[i])) return fail(SL_E_UNSUPPORTED, "queue stepping needs the row kernels");
     }
-    if (const char *why = sl::aql_open(n_slices)) return fail(SL_E_UNSUPPORTED, std::string("AQL queues unavailable: ") + why);
+    if (const char *why = sl::aql_open(n_phys)) return fail(SL_E_UNSUPPORTED, std::string("AQL queues unavailable: ") + why);
     if (sl::aql_poisoned()) return fail(SL_E_HIP, "AQL queues: an earlier wait timed out on this device");
     if (const char *why = sl::aql_probe(sl::rowlane_probe_function()))
         return fail(SL_E_UNSUPPORTED, std::string("AQL queues unavailable: ") + why);
@@ -687,6 +703,9 @@ int slhip_queues_open(const sl_env_batch *env, int n_slices, const int32_t *boun
     static std::atomic<uint32_t> serials{0};
     c->serial = ++serials;
     c->n_slices = n_slices;
+    c->n_phys = n_phys;
+    if (queue_ids)
+        for (int i = 0; i < n_slices; ++i) c->qmap[i] = queue_ids[i];
     c->H = env->H;
     c->W = env->W;
     c->B = env->B;
@@ -696,7 +715,8 @@ int slhip_queues_open(const sl_env_batch *env, int n_slices, const int32_t *boun
         for (int i = 0; i < n_slices; ++i) grid = std::max(grid, bounds[i + 1] - bounds[i]);    // (>= workgroups of a slice)
         grid = std::min(grid, 4096);
         std::string why;
-        if (!probe_placement(n_slices, grid, c->base, &why)) {
+        int phys_base[8] = {};
+        if (!probe_placement(n_phys, grid, phys_base, &why)) {
             c->downgraded = why;
         } else if (hipHostMalloc((void **)&c->flag, 64, hipHostMallocDefault) != hipSuccess) {
             (void)hipGetLastError();
@@ -705,6 +725,7 @@ int slhip_queues_open(const sl_env_batch *env, int n_slices, const int32_t *boun
         } else {
             *c->flag = 0;
             c->release_free = true;
+            for (int i = 0; i < n_slices; ++i) c->base[i] = phys_base[c->qmap[i]];
         }
     }
     *handle = c;
@@ -776,7 +797,7 @@ int slhip_queues_steps(void *handle, const sl_env_batch *env, const int32_t *act
             // a new batch (or a changed one): its block goes into every idle slot of the slice's argument ring now,
             // once (~40 us per slice), instead of ~0.6 us per dispatch for the ring's first lap
             if (!c->swap)
-                sl::aql_warm(i, ps[i].f, ps[i].args, ps[i].arg_bytes,
+                sl::aql_warm(c->qmap[i], ps[i].f, ps[i].args, ps[i].arg_bytes,
                              sl::AqlPatch{c->serial * 8u + (uint32_t)i, c->version[i], 0, {}});
 #endif
         }
@@ -790,7 +811,7 @@ int slhip_queues_steps(void *handle, const sl_env_batch *env, const int32_t *act
         const int32_t *a_t = actions + (long long)t * action_stride;
         sl_step_out *o_t = env->out + (long long)t * out_stride;
         if (c->swap) {
-            const hipError_t err = sl::aql_drain(c->n_slices);
+            const hipError_t err = sl::aql_drain(c->n_phys);
             if (err != hipSuccess) return hip_fail(err, "AQL drain (self-test)");
         }
         for (int i = 0; i < c->n_slices; ++i) {
@@ -798,7 +819,7 @@ int slhip_queues_steps(void *handle, const sl_env_batch *env, const int32_t *act
             if (!p.grid) continue;
             memcpy(p.args + p.off_actions, &a_t, sizeof(void *));
             memcpy(p.args + p.off_out, &o_t, sizeof(void *));
-            const int queue = c->swap ? (int)((i + c->steps) % c->n_slices) : i;
+            const int queue = c->qmap[c->swap ? (int)((i + c->steps) % c->n_slices) : i];
             const sl::AqlLaunch a{queue, head != 0 && t == 0, c->release_free};
             sl::AqlPatch patch{c->serial * 8u + (uint32_t)i, c->version[i], 2, {p.off_actions, p.off_out}};
 #ifdef SL_TRACE
@@ -837,7 +858,7 @@ static int queues_flag(StepQueues *c) {
 int slhip_queues_marker(void *handle, long long *ticket) {
     StepQueues *c = (StepQueues *)handle;
     if (!c || !ticket) return fail(SL_E_ARG, "null pointer");
-    const hipError_t err = sl::aql_marker(c->n_slices, c->pending, ticket);
+    const hipError_t err = sl::aql_marker(c->n_phys, c->pending, ticket);
     if (err != hipSuccess) return hip_fail(err, "AQL marker");
     return SL_OK;
 }
@@ -854,7 +875,7 @@ int slhip_queues_sync(void *handle) {
     StepQueues *c = (StepQueues *)handle;
     if (!c) return fail(SL_E_ARG, "null pointer");
     long long ticket = -1;
-    hipError_t err = sl::aql_marker(c->n_slices, c->pending, &ticket);
+    hipError_t err = sl::aql_marker(c->n_phys, c->pending, &ticket);
     if (err == hipSuccess) err = sl::aql_wait(ticket);
     if (err != hipSuccess) return hip_fail(err, "AQL fence");
     c->pending = false;
@@ -867,7 +888,7 @@ int slhip_queues_close(void *handle) {
     StepQueues *c = (StepQueues *)handle;
     if (!c) return SL_OK;
     long long ticket = -1;
-    hipError_t err = sl::aql_marker(c->n_slices, c->pending, &ticket);
+    hipError_t err = sl::aql_marker(c->n_phys, c->pending, &ticket);
     if (err == hipSuccess) err = sl::aql_wait(ticket);
     // (a fence that failed or timed out leaves step kernels in flight that may still write the flag: it is leaked
     //  rather than freed under them)
@@ -922,6 +943,68 @@ static int gather_issue(GatherComm *g, const void *send, void *recv, size_t byte
     const int rc_end = r.GroupEnd();
     if (rc) return rccl_fail(r, rc, "ncclSend / ncclRecv");
     if (rc_end) return rccl_fail(r, rc_end, "ncclGroupEnd");
+    return SL_OK;
+}
+
+// Which of the library's queues 0 .. n_queues - 1 does the EXCHANGE hold up when it runs on `stream`?  Measured with the
+// real thing: an 8 MiB window through RCCL on the stream (every rank must make this call: the exchange is collective),
+// and, as soon as the group has been issued, a one-workgroup dispatch on the queue -- alone it is back within a few
+// microseconds; on a queue that takes turns with the stream's hardware queue only when RCCL's kernel has ended.
+int slhip_gather_stream_shares(void *comm, int n_queues, void *stream, int *mask) {
+    GatherComm *g = (GatherComm *)comm;
+    if (!g || !mask || n_queues < 1 || n_queues > 8) return fail(SL_E_ARG, "bad arguments (1 to 8 queues)");
+    *mask = 0;
+    if (const char *why = sl::aql_open(n_queues)) return fail(SL_E_UNSUPPORTED, std::string("AQL queues unavailable: ") + why);
+    hipFunction_t f = nullptr;
+    if (hipGetFuncBySymbol(&f, (const void *)sl::k_xcd_probe) != hipSuccess || sl::aql_probe(f)) {
+        (void)hipGetLastError();
+        return fail(SL_E_UNSUPPORTED, "the probe kernel was not found");
+    }
+    const size_t bytes = 8u << 20;
+    char *send = nullptr, *recv = nullptr;
+    uint32_t *out = nullptr;
+    hipError_t err = hipMalloc((void **)&send, bytes);
+    if (err == hipSuccess && g->rank == 0) err = hipMalloc((void **)&recv, bytes * (size_t)g->world);
+    if (err == hipSuccess) err = hipMalloc((void **)&out, 64);
+    const hipStream_t st = (hipStream_t)stream;
+    struct {
+        uint32_t *out;
+    } args = {out};
+    int rc = SL_OK;
+    auto tiny = [&](int q, double *us) {            // one workgroup on queue q, host time until it is back
+        const auto t0 = std::chrono::steady_clock::now();
+        hipError_t e = sl::aql_dispatch(sl::AqlLaunch{q, false, false}, f, 1, 256, 0, &args, sizeof(args));
+        if (e == hipSuccess) e = sl::aql_fence(n_queues);
+        *us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        return e;
+    };
+    double alone[8], behind[8];
+    for (int q = 0; q < n_queues && err == hipSuccess && rc == SL_OK; ++q) {
+        alone[q] = behind[q] = 1e30;
+        for (int rep = 0; rep < 3 && err == hipSuccess && rc == SL_OK; ++rep) {
+            double us = 0;
+            err = hipStreamSynchronize(st);
+            if (err == hipSuccess) err = sl::aql_fence(n_queues);
+            if (err == hipSuccess) err = tiny(q, &us);
+            alone[q] = std::min(alone[q], us);
+            if (err != hipSuccess) break;
+            rc = gather_issue(g, send, recv, bytes, st);
+            if (rc == SL_OK) err = tiny(q, &us);
+            if (rep > 0) behind[q] = std::min(behind[q], us);      // (the first exchange of a stream sets things up)
+        }
+        // (measured: 9 us alone and 9-10 us behind the exchange on a queue it does not touch; 15 and 22 us on the one
+        //  that shares a pipe with the stream's hardware queue)
+        if (err == hipSuccess && rc == SL_OK && behind[q] > alone[q] + 3.0) *mask |= 1 << q;
+    }
+    if (err == hipSuccess) err = hipStreamSynchronize(st);
+    if (getenv("SL_GATHER_DEBUG"))
+        for (int q = 0; q < n_queues; ++q)
+            fprintf(stderr, "gather_stream_shares: queue %d alone %.1f us, behind the exchange %.1f us\n", q, alone[q], behind[q]);
+    (void)hipFree(send);
+    if (recv) (void)hipFree(recv);
+    (void)hipFree(out);
+    if (rc != SL_OK) return rc;
+    if (err != hipSuccess) return hip_fail(err, "gather_stream_shares");
     return SL_OK;
 }
 

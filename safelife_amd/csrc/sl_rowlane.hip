@@ -2070,6 +2070,32 @@ static_assert(sizeof(BoardBox) == 32, "mailbox stride");
 template <int H, int W, bool LEAN>
 constexpr bool leadx() { return LEAN && Geom<H, W>::LEADX_OK; }
 
+#ifndef SL_SPAWN_GSH_REG
+#define SL_SPAWN_GSH_REG 1      /* A/B knob: the LEAN single-step spawner variant keeps the goal words in registers (1) or
+                                   takes the move box (0) -- both together tip it into scratch */
+#endif
+// the goal colours of a lane's row live in registers (else in the OFF_GSH region of LDS)
+template <int H, int W>
+constexpr bool gsh_in_registers(bool spawn, bool lean, bool one) {
+    return !spawn || Geom<H, W>::WAVES_PER_SIMD < 4 || (SL_SPAWN_GSH_REG && one && lean && W <= 25);
+}
+#ifndef SL_LEAN_LDS
+#define SL_LEAN_LDS 1           /* A/B knob: 0 = every variant asks for the full LDS layout (rounds 1-3) */
+#endif
+// LEAN variants whose goal words live in registers use nothing of the OFF_GSH region (no observation parks its
+// parameters there, no wrapper its baseline rows): the score table and the move box move down into it and the
+// workgroup asks for 13 KB less (25x25: 37.7 -> 24.4 KB).  The four workgroups a CU holds of the four-queue step then
+// leave 62 instead of 9 KB of its LDS free -- room for the workgroups of OTHER kernels: RCCL's exchange kernel (40
+// workgroups of 19.5 KB) otherwise waits tens of microseconds for a CU on which two step workgroups happen to retire
+// together, and while it waits the hardware pipe it is being dispatched from serves nobody else -- the slice whose
+// queue shares that pipe stands still (profiles/round4_g_*).
+template <int H, int W>
+constexpr bool lean_lds(bool spawn, bool lean, bool one) {
+    return SL_LEAN_LDS && lean && gsh_in_registers<H, W>(spawn, lean, one);
+}
+template <int H, int W>
+constexpr int lean_lds_bytes() { return Geom<H, W>::OFF_GSH + 4096 + Geom<H, W>::NB * 16; }
+
 template <int H, int W, bool LDS_LUT, bool SPAWN, bool WRAP, bool LEAN, bool ONE>
 __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
                              (leadx<H, W, LEAN>() ? 5 : Geom<H, W>::WAVES_PER_SIMD)) void k_env_rollout_rowlane(
@@ -2135,14 +2161,12 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     // (and the LEAN single-step instantiation of the spawner variant where it fits: 114 -> 125 VGPRs at 25x25, C4's
     //  share 9.6 -> 9.25 us per two-slice step on top of the even deal of the draws; the non-LEAN one and 26x26 tip
     //  into 8 bytes of scratch with it and keep the words in LDS)
-#ifndef SL_SPAWN_GSH_REG
-#define SL_SPAWN_GSH_REG 1      /* A/B knob: the LEAN single-step spawner variant keeps the goal words in registers (1) or
-                                   takes the move box (0) -- both together tip it into scratch */
-#endif
-    constexpr bool GSH_REG = !SPAWN || Gm::WAVES_PER_SIMD < 4 || (SL_SPAWN_GSH_REG && ONE && LEAN && W <= 25);
+    constexpr bool GSH_REG = gsh_in_registers<H, W>(SPAWN, LEAN, ONE);
+    constexpr bool SHRINK = lean_lds<H, W>(SPAWN, LEAN, ONE);
+    constexpr int OFF_LUT_V = SHRINK ? Gm::OFF_GSH : Gm::OFF_LUT, OFF_MOVE_V = SHRINK ? Gm::OFF_GSH + 4096 : Gm::OFF_MOVE;
     u32 gsh_reg[GSH_REG ? WS : 1];
     u32 *gsh_lane = GSH_REG ? gsh_reg : (u32 *)(smem + Gm::OFF_GSH) + (wave * 64 + lane) * WS;
-    const int8_t *lds_lut = (const int8_t *)(smem + Gm::OFF_LUT);
+    const int8_t *lds_lut = (const int8_t *)(smem + OFF_LUT_V);
     // wrappers: this wave's baseline rows, word k of lane l at [k * 64 + l] (the layout the b32 DMA writes)
     constexpr bool BASE_IN_GSH = GSH_REG && Gm::GSH_BYTES >= WAVES * 64 * WS * 4;
     unsigned char *base_rows = smem + (BASE_IN_GSH ? Gm::OFF_GSH : Gm::OFF_BASE) + wave * 64 * WS * 4;
@@ -2206,7 +2230,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
         const int dw = LEADX ? wave : wave - 1;
         dma_to_lds<Gm::NB * 32, false, DW>((const unsigned char *)(k_rng + e0b), smem + Gm::OFF_RNG, nbb * 32, lane, dw);
         dma_to_lds<Gm::NB * 64, false, DW>((const unsigned char *)(hot_scalars + e0b), smem + Gm::OFF_REC, nbb * 64, lane, dw);
-        if (LDS_LUT) dma_to_lds<4096, false, DW>((const unsigned char *)k_lut, smem + Gm::OFF_LUT, 4096, lane, dw);
+        if (LDS_LUT) dma_to_lds<4096, false, DW>((const unsigned char *)k_lut, smem + OFF_LUT_V, 4096, lane, dw);
         load_span<H, W, DW>(k_board + (size_t)e0b * HW, board, nbb, lane, dw);
         load_span<H, W, DW>(k_goals + (size_t)e0b * HW, goals, nbb, lane, dw);
         if (WRAP) {
@@ -2256,7 +2280,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     // barrier, in front of its row reads (LDS operations of one wave stay in order), so no workgroup barrier stands
     // between the loads and the CA any more, and the leaders' serial section is off the rows' path.
     typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
-    u32x4_t *const move_box = (u32x4_t *)(smem + Gm::OFF_MOVE);
+    u32x4_t *const move_box = (u32x4_t *)(smem + OFF_MOVE_V);
     if (MOVE_BOX && lwave) {
         u32x4_t mv = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
         if (lead && ly >= 0) pre_write = act_rule(pre_c, action, ly, lx, pre_y1, pre_x1);
@@ -2985,7 +3009,8 @@ hipError_t pick_rollout_t(const sl_env_batch &env, int T, void **kernel, hipFunc
     const kernel_t fn = table[slot];
     const bool spawn = !(variant & 2), base_in_gsh = !spawn && Gm::WAVES_PER_SIMD == 4;
     const int lds_wrap = base_in_gsh ? Gm::LDS_WRAP_GSHREG : Gm::LDS_WRAP_GSHLDS;
-    const int lds = !(variant & 4) ? Gm::LDS_BYTES : lds_wrap + ((env.wrap.flags & SL_WRAP_INACTION) ? Gm::INACTION_BYTES : 0);
+    const int lds_plain = lean_lds<H, W>(spawn, (variant & 8) != 0, T == 1) ? lean_lds_bytes<H, W>() : Gm::LDS_BYTES;
+    const int lds = !(variant & 4) ? lds_plain : lds_wrap + ((env.wrap.flags & SL_WRAP_INACTION) ? Gm::INACTION_BYTES : 0);
     const int lds_limit = !(variant & 4) ? Gm::LDS_BYTES : lds_wrap + Gm::INACTION_BYTES;     // (set once per variant)
     // per (device, variant), once: raise the dynamic LDS limit and look up the module-level handle of the kernel
     struct Entry {

@@ -25,6 +25,7 @@ Two transports:
 """
 import ctypes as C
 import os
+import sys
 import time
 
 import numpy as np
@@ -35,6 +36,9 @@ def shard_bounds(total_envs, world, rank):
     base, rem = divmod(int(total_envs), int(world))
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+_DEBUG = os.environ.get("SL_GATHER_DEBUG") == "1"
 
 
 class RewardGather(object):
@@ -114,6 +118,21 @@ class RewardGather(object):
         self._stream = torch.cuda.Stream(device=self.env.device)       # the exchange's own stream
         self._gptr = (C.c_void_p * 1)(self._stream.cuda_stream)
         self._ticket = [-1, -1]                                         # the window each buffer was last handed off as
+
+    def free_queues(self, n_queues=4):
+        """The library's step queues 0 .. n_queues - 1 that the exchange does NOT hold up (rccl transport; COLLECTIVE:
+        every rank calls it).  RCCL's kernel comes from one of HIP's hardware queues, and the step queue that takes turns
+        with it stands still for the length of every exchange while the others step on; a driver that steps through
+        queues leaves that one out: ``env.queues_open(queue_ids=gather.free_queues()[:3])``.  Returns all of them where
+        nothing is to be exchanged."""
+        ids = list(range(int(n_queues)))
+        if not (self.collective and self.backend == "rccl"):
+            return ids
+        from . import _hip
+        mask = C.c_int(0)
+        _hip.check(self._lib.slhip_gather_stream_shares(self._comm, int(n_queues), self._gptr[0], C.byref(mask)))
+        self.shared_queues = mask.value
+        return [q for q in ids if not (mask.value >> q) & 1]
 
     def _order(self, before, after):
         """Streams of `after` wait for what is enqueued on the streams of `before` (events, no host wait)."""
@@ -260,13 +279,18 @@ class RewardGather(object):
                 self.work[which], self.busy[which] = None, False
                 self.exposed_s += time.perf_counter() - w0
             env.set_step_outputs(self._slot_ptr[which][slot])
+            d0 = time.perf_counter()
             env.step_queues_many(action_ptr + 4 * action_stride * (t - t0), seg, action_stride, out_stride=B,
                                  assume_ordered=assume_ordered)
+            d1 = time.perf_counter()
             if slot + seg == self.every:
                 self.last = which
                 w0 = time.perf_counter()
                 self.work[which] = self._issue(which)
                 self.exposed_s += time.perf_counter() - w0
+            if _DEBUG:
+                print("run_queued: %d steps enqueued in %.1f us, hand-over %.1f us" % (seg, (d1 - d0) * 1e6,
+                      (time.perf_counter() - d1) * 1e6), file=sys.stderr)
             t += seg
 
     def flush(self):

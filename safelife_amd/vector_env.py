@@ -444,9 +444,12 @@ class SafeLifeVectorEnv(object):
     # ---- sliced stepping on the library's own AQL queues (csrc/sl_aql.hip, slhip_queues_*): what step_async() does
     # ---- with stream slices, without HIP's per-launch host cost -- three to six slices per step become affordable
 
-    def queues_open(self, slices=None, release_free=None):
+    def queues_open(self, slices=None, release_free=None, queue_ids=None):
         """Open one AQL queue per slice (default: SAFELIFE_QUEUE_SLICES or 4).  Raises SafeLifeHipError when the
         batch or the runtime does not support it -- callers keep to step_async() then.
+
+        ``queue_ids``: which of the library's queues the slices go onto (default: slice i on queue i) -- a driver whose
+        own kernels would hold one of them up leaves that one out (``sharding.RewardGather.free_queues``).
 
         ``release_free`` (default: True only if SAFELIFE_QUEUE_FENCES=none): OPT-IN to steps without a release fence
         (include/safelife_hip.h, SL_QUEUES_RELEASE_FREE) -- ~0.9 us faster per C3 step, valid only while a workgroup
@@ -456,15 +459,20 @@ class SafeLifeVectorEnv(object):
         if self._queues is not None:
             return
         B = self.num_envs
-        n = int(slices if slices is not None else os.environ.get("SAFELIFE_QUEUE_SLICES", "4"))
+        n = int(slices if slices is not None else (len(queue_ids) if queue_ids is not None else
+                                                   os.environ.get("SAFELIFE_QUEUE_SLICES", "4")))
         n = max(1, min(n, 8, (B + 63) // 64))
+        if queue_ids is not None and len(queue_ids) < n:
+            raise ValueError("queue_ids: one queue per slice")
         per = -(-(-(-B // n)) // 64) * 64
         bounds = [min(B, i * per) for i in range(n)] + [B]
         if release_free is None:
             release_free = os.environ.get("SAFELIFE_QUEUE_FENCES", "agent") == "none"
         handle = C.c_void_p()
-        _hip.check(self._lib.slhip_queues_open(self._sref, n, (C.c_int32 * (n + 1))(*bounds),
-                                               _hip.QUEUES_RELEASE_FREE if release_free else 0, C.byref(handle)))
+        ids = (C.c_int32 * n)(*[int(q) for q in queue_ids[:n]]) if queue_ids is not None else None
+        _hip.check(self._lib.slhip_queues_open_on(self._sref, n, (C.c_int32 * (n + 1))(*bounds), ids,
+                                                  _hip.QUEUES_RELEASE_FREE if release_free else 0, C.byref(handle)))
+        self.queue_ids = list(queue_ids[:n]) if queue_ids is not None else list(range(n))
         why = C.c_char_p()
         mode = self._lib.slhip_queues_mode(handle, C.byref(why))
         self._queues, self.queue_slices = handle, n
