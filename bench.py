@@ -324,13 +324,16 @@ def main():
     # rollouts exchanges once per rollout), so the hand-off falls where the host is ahead of the device instead of
     # in the middle of the launches
     shift = (every - (P + W + K) % every) % every
-    # ... two steps ahead of the end: the exchange itself (RCCL's send / receive kernel and its hand-shake, ~25 us on
-    # the device) then runs under the last steps.
-    # (queue stepping: the stepping thread has long finished enqueuing by then, the library's worker has RCCL's group
-    #  waiting on its stream behind a gate, and the window closes five steps ahead of the end so that the exchange
-    #  itself runs under the last steps)
+    # ... some steps ahead of the end, so that the exchange runs under the last steps: two for stream slices (RCCL's
+    # send / receive kernel and its hand-shake take ~25 us on the device); ten (at most half a window) for queue
+    # stepping, where the chain behind the window's last step is longer -- the marker's system-scope release, the
+    # worker's RCCL group, its kernel next to a full chip, the completion event: ~70-100 us, and the closing
+    # synchronize of a stream that has just run something costs another ~40 (round 4: 11-13 us per step with the
+    # window closing five steps before the end of a 20-step region, 9.0-9.2 with ten)
+    window_ahead = 0
     if K >= 8 and every >= 8:
-        shift = (shift + int(os.environ.get("SAFELIFE_BENCH_WINDOW_AHEAD", "5" if n_queues > 0 else "2"))) % every
+        window_ahead = int(os.environ.get("SAFELIFE_BENCH_WINDOW_AHEAD", str(min(10, every // 2)) if n_queues > 0 else "2"))
+        shift = (shift + window_ahead) % every
     dbg = os.environ.get("SL_BENCH_DEBUG") == "1"
     import gc
 
@@ -916,6 +919,7 @@ def main():
                                                                    else ("%d slice(s) per GPU, one launch and one stream each"
                                                                          % env.slices)),
                        "stepping": "aql-queues" if use_queues else "hip-streams",
+                       "gather_window_closes_steps_before_end": (window_ahead if gather.collective else None),
                        "queue_ids": (getattr(env, "queue_ids", None) if use_queues else None),
                        "queue_ids_note": ("the step queue RCCL's exchange kernel would hold up is left out (probed: "
                                           "slhip_gather_stream_shares)" if (use_queues and gather.collective and
