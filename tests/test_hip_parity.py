@@ -912,10 +912,10 @@ def test_sliced_stepping_soak(pool_name, B):
                 assert np.array_equal(env.numpy(name), ref), (trial, n, name)
 
 
-def _queues_or_skip(env, slices=None, release_free=False):
+def _queues_or_skip(env, slices=None, release_free=False, queue_ids=None):
     from safelife_amd._hip import SafeLifeHipError
     try:
-        env.queues_open(slices, release_free=release_free)
+        env.queues_open(slices, release_free=release_free, queue_ids=queue_ids)
     except SafeLifeHipError as e:           # no HSA queue to be had (not an MI355X box as the driver's): say why
         pytest.skip("AQL queues unavailable: %s" % e)
     if release_free and not env.queue_release_free:
@@ -928,6 +928,8 @@ def _queues_or_skip(env, slices=None, release_free=False):
     ("append_spawn_25", 1500, 4, dict(time_limit=20, view_shape=(25, 25), output_channels=tuple(range(15)))),
     ("navigation_64", 300, 2, dict(time_limit=15, view_shape=(15, 15), with_obs=False)),
     ("prune_still_25", 333, 3, dict(time_limit=9, view_shape=(5, 7), wrappers=TRAINING_WRAPPERS)),
+    # slices on chosen queues (slhip_queues_open_on): what a driver does that leaves out the queue its exchange holds up
+    ("prune_still_25", 900, (3, 0, 2), dict(time_limit=14, view_shape=(9, 9), with_obs=False)),
 ])
 def test_queue_stepping_vs_oracle(pool_name, B, queue_slices, kw, release_free):
     """slhip_queues_*: the slices of a step dispatched from the library's own AQL queues instead of HIP streams (same
@@ -942,7 +944,11 @@ def test_queue_stepping_vs_oracle(pool_name, B, queue_slices, kw, release_free):
     dev = util.DeviceBackend(pool, B, **common)
     cpu = util.OracleBackend(pool, B, **common)
     env = dev.env
-    _queues_or_skip(env, queue_slices, release_free)
+    if isinstance(queue_slices, tuple):
+        _queues_or_skip(env, None, release_free, queue_ids=list(queue_slices))
+        assert env.queue_ids == list(queue_slices) and env.queue_slices == len(queue_slices)
+    else:
+        _queues_or_skip(env, queue_slices, release_free)
     assert env.queue_release_free == release_free
     dev.env.reset()
     cpu.env.reset()
@@ -1010,6 +1016,24 @@ def test_queue_steps_write_one_record_set_per_step():
         assert np.array_equal(rec[t, :, 1].astype(np.uint32) & 0xFF, cpu.get("done").astype(np.uint32)), t
 
 
+def test_queues_stream_shares_probe():
+    """slhip_queues_stream_shares: a long one-wavefront kernel on a HIP stream against a one-workgroup dispatch on each of
+    the library's queues -- returns a mask over the queues asked about (on MI355X such a kernel holds none of them up:
+    it is RCCL's exchange kernel that does, which slhip_gather_stream_shares measures; tests/rccl_gather_check.py)."""
+    import ctypes as C
+    import torch
+    from safelife_amd import _hip
+    lib = _hip.lib()
+    mask = C.c_int(-1)
+    rc = lib.slhip_queues_stream_shares(4, C.c_void_p(torch.cuda.Stream().cuda_stream), C.byref(mask))
+    if rc == _hip.SL_E_UNSUPPORTED:
+        pytest.skip("AQL queues unavailable: %s" % lib.slhip_last_error().decode())
+    assert rc == 0, lib.slhip_last_error()
+    assert 0 <= mask.value < 16
+    assert lib.slhip_queues_stream_shares(0, None, C.byref(mask)) != 0            # argument errors are errors
+
+
+@pytest.mark.gpu
 def test_queue_stepping_refuses_a_planted_placement_record():
     """Release-free queue stepping (opt-in) rests on workgroup i of a slice's queue always running on the same XCD;
     every workgroup of every step compares where it runs with where the probe at open found that index and raises a
