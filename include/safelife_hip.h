@@ -454,6 +454,9 @@ int slhip_gather_stream_shares(void *comm, int n_queues, void *stream, int *mask
  * enqueued the group).  At most 8 windows may be outstanding. */
 int slhip_gather_window_async(void *comm, const void *send, void *recv, size_t bytes, void *const *writers, int n_writers,
                               void *stream, long long *ticket);
+/* A window will be handed over within the next few milliseconds: the worker thread, if it sleeps, wakes up now and polls
+ * for the request (a wake-up at the hand-over itself costs tens of microseconds, milliseconds on a busy host). */
+int slhip_gather_poke(void *comm);
 int slhip_gather_done(void *comm, long long ticket, int block, int *done);
 int slhip_gather_wait_streams(void *comm, long long ticket, void *const *streams, int n_streams);
 /* A window that was written from the library's AQL queues (slhip_queues_steps): the call puts a marker behind the steps

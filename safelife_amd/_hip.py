@@ -27,7 +27,7 @@ EXPORTS = (
     "slhip_gather_unique_id", "slhip_gather_init", "slhip_gather_window", "slhip_gather_destroy",
     "slhip_gather_window_async", "slhip_gather_done", "slhip_gather_wait_streams",
     "slhip_gather_window_queued",
-    "slhip_queues_open", "slhip_queues_open_on", "slhip_queues_stream_shares", "slhip_gather_stream_shares", "slhip_queues_mode", "slhip_queues_steps", "slhip_queues_step", "slhip_queues_marker",
+    "slhip_queues_open", "slhip_queues_open_on", "slhip_queues_stream_shares", "slhip_gather_stream_shares", "slhip_gather_poke", "slhip_queues_mode", "slhip_queues_steps", "slhip_queues_step", "slhip_queues_marker",
     "slhip_queues_wait", "slhip_queues_sync", "slhip_queues_close", "slhip_queues_selftest",
 )
 QUEUES_RELEASE_FREE = 1
@@ -152,6 +152,7 @@ def lib():
                 L.slhip_queues_open_on.argtypes = [C.POINTER(EnvBatch), C.c_int, _p, _p, C.c_int, C.POINTER(C.c_void_p)]
                 L.slhip_queues_stream_shares.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_int)]
                 L.slhip_gather_stream_shares.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+                L.slhip_gather_poke.argtypes = [C.c_void_p]
             L.slhip_queues_sync.argtypes = [C.c_void_p]
             L.slhip_queues_close.argtypes = [C.c_void_p]
         if hasattr(L, "slhip_queues_steps"):

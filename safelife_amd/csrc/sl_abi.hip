@@ -243,6 +243,7 @@ struct GatherComm {
     bool stop = false;
     long long submitted = 0;                 // tickets handed out
     std::atomic<long long> pushed{0};        // == submitted, readable without the lock (the worker polls it)
+    bool poked = false;                      // slhip_gather_poke: a window is about to close -- wake up and poll
     std::atomic<long long> issued{0};        // tickets whose RCCL group has been enqueued (and done event recorded)
     int error = 0;
     static constexpr int RING = 8;
@@ -1035,16 +1036,23 @@ static void gather_worker(GatherComm *g) {
             // A worker that has just handed a window over polls for the next one for a while before it goes to sleep:
             // a wake-up through the condition variable costs tens of microseconds on a quiet host and milliseconds on
             // a busy one, and a window of a running step loop follows the last within a few hundred microseconds.
+            // (slhip_gather_poke: the stepping thread says a window is coming -- the sleeping worker wakes up NOW and polls)
             const long long seen = g->issued.load(std::memory_order_relaxed);
-            const auto t0 = std::chrono::steady_clock::now();
-            while (g->pushed.load(std::memory_order_acquire) <= seen &&
-                   std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < 3000.0)
-                __builtin_ia32_pause();
-            std::unique_lock<std::mutex> lock(g->m);
-            g->cv.wait(lock, [g] { return g->stop || !g->queue.empty(); });
-            if (g->queue.empty()) return;
-            rq = g->queue.front();
-            g->queue.pop_front();
+            for (;;) {
+                const auto t0 = std::chrono::steady_clock::now();
+                while (g->pushed.load(std::memory_order_acquire) <= seen &&
+                       std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < 3000.0)
+                    __builtin_ia32_pause();
+                std::unique_lock<std::mutex> lock(g->m);
+                g->cv.wait(lock, [g] { return g->stop || !g->queue.empty() || g->poked; });
+                g->poked = false;
+                if (!g->queue.empty()) {
+                    rq = g->queue.front();
+                    g->queue.pop_front();
+                    break;
+                }
+                if (g->stop) return;
+            }
         }
         int rc = SL_OK;
         // a window written from the AQL queues: their marker (system-scope release behind the window's last step) is
@@ -1108,6 +1116,18 @@ static int gather_submit(void *comm, const void *send, void *recv, size_t bytes,
     *ticket = rq.ticket;
     g->queue.push_back(rq);
     g->pushed.store(g->submitted, std::memory_order_release);
+    g->cv.notify_one();
+    return SL_OK;
+}
+
+int slhip_gather_poke(void *comm) {
+    GatherComm *g = (GatherComm *)comm;
+    if (!g) return fail(SL_E_ARG, "null pointer");
+    if (!g->worker.joinable()) return SL_OK;            // (no asynchronous window yet: nobody to wake)
+    {
+        std::lock_guard<std::mutex> lock(g->m);
+        g->poked = true;
+    }
     g->cv.notify_one();
     return SL_OK;
 }

@@ -268,6 +268,8 @@ class RewardGather(object):
         if not self.collective:             # one rank: the records stay in the env's own tensor
             env.step_queues_many(action_ptr, n, action_stride, assume_ordered=assume_ordered)
             return
+        if self.backend == "rccl":
+            self._lib.slhip_gather_poke(self._comm)         # the worker wakes up now, not when the window closes
         t = t0
         while t < t0 + n:
             tt = t + shift
