@@ -196,13 +196,19 @@ SL_PL_DEV V pdn(const VCtx<VERT> &vc, V v) {
 template <int W>
 struct PG {
     static constexpr int WS = (W + 1) / 2, WH = W - WS;
-    static constexpr int NW = W == 64 ? 2 : 1;                      // words per plane
+    // Even rows of 30 to 60 cells (round 4; single steps only -- ca_planes): TWO words per plane, one per HALF of the
+    // split layout, each laid out like a half of the one-word form -- bit 0 the cell beyond its left end, bits 1..WS
+    // its cells, bit WS + 1 the cell beyond its right end -- so the neighbours are plain shifts again and the two
+    // words never exchange a bit; the WS + 2 entries (seam, the row's words, seam) fill two transposition groups.
+    static constexpr bool SPLIT = W > 28 && W < 64 && (W & 1) == 0 && WS + 2 <= 32;
+    static constexpr int NW = (W == 64 || SPLIT) ? 2 : 1;          // words per plane
     static constexpr int NG = NW;                                   // 16-entry transposition groups
-    static constexpr int NE = NW == 1 ? WS + 2 : 16;                // entries per group
+    static constexpr int NE = (NW == 1 && !SPLIT) ? WS + 2 : 16;    // entries per group (SPLIT: WS + 2 - 16 in the second)
     static constexpr bool ODD = (W & 1) != 0;
-    static_assert((NW == 1 && WS + 2 <= 16 && W >= 4) || W == 64, "bit-plane step: rows of 4 to 28 cells, or 64");
+    static_assert((NW == 1 && WS + 2 <= 16 && W >= 4) || W == 64 || SPLIT, "bit-plane step: rows of 4 to 28 cells, even rows of 30 to 60, or 64");
     // the planes' bits that are cells of the row (the rest: seam copies and padding)
-    static constexpr uint32_t REAL = NW == 2 ? 0xFFFFFFFFu : (((1u << WS) - 1u) << 1) | (((1u << WH) - 1u) << 17);
+    static constexpr uint32_t REAL = SPLIT ? ((1u << WS) - 1u) << 1
+                                           : NW == 2 ? 0xFFFFFFFFu : (((1u << WS) - 1u) << 1) | (((1u << WH) - 1u) << 17);
 };
 
 struct PConsts {        // masks kept in VGPRs for the whole kernel
@@ -286,9 +292,32 @@ SL_PL_DEV Pl<1> qleft(const Pl<1> &a) { return Pl<1>{{padd(a.w[0], a.w[0])}}; }
 SL_PL_DEV Pl<1> qright(const Pl<1> &a) { return Pl<1>{{pshr(a.w[0], 1)}}; }
 SL_PL_DEV Pl<2> qleft(const Pl<2> &a) { return Pl<2>{{palign(a.w[0], a.w[1], 31), palign(a.w[1], a.w[0], 31)}}; }
 SL_PL_DEV Pl<2> qright(const Pl<2> &a) { return Pl<2>{{palign(a.w[1], a.w[0], 1), palign(a.w[0], a.w[1], 1)}}; }
+// (SPLIT, PG<W>::SPLIT: every word carries its own seam bits -- plain shifts, whatever the number of words)
+template <bool SPLIT, int NW>
+SL_PL_DEV Pl<NW> qleft_m(const Pl<NW> &a) {
+    if constexpr (SPLIT) {
+        Pl<NW> r;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) r.w[i] = padd(a.w[i], a.w[i]);
+        return r;
+    } else {
+        return qleft(a);
+    }
+}
+template <bool SPLIT, int NW>
+SL_PL_DEV Pl<NW> qright_m(const Pl<NW> &a) {
+    if constexpr (SPLIT) {
+        Pl<NW> r;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) r.w[i] = pshr(a.w[i], 1);
+        return r;
+    } else {
+        return qright(a);
+    }
+}
 // OR / majority / parity of a plane with its two horizontal neighbours
-template <int NW>
-SL_PL_DEV Pl<NW> row_or(const Pl<NW> &a) { return QB_OR3(qleft(a), a, qright(a)); }
+template <int NW, bool SPLIT = false>
+SL_PL_DEV Pl<NW> row_or(const Pl<NW> &a) { return QB_OR3((qleft_m<SPLIT, NW>(a)), a, (qright_m<SPLIT, NW>(a))); }
 
 // Column triple of a plane: values from the rows above (u) and below (d).
 template <int VERT, int NW>
@@ -302,10 +331,10 @@ struct Col {
         }
     }
 };
-template <int VERT, int NW>
+template <int VERT, int NW, bool SPLIT = false>
 SL_PL_DEV Pl<NW> box_or(const VCtx<VERT> &vc, const Pl<NW> &x) {        // OR over the 3 x 3 block
     const Col<VERT, NW> c(vc, x);
-    return row_or(QB_OR3(c.u, x, c.d));
+    return row_or<NW, SPLIT>(QB_OR3(c.u, x, c.d));
 }
 
 // ---- words <-> planes ------------------------------------------------------------------------------------------------
@@ -387,12 +416,12 @@ template <int NW>
 struct Verdict {
     Pl<NW> dies, born, dead_free, is3, fS;
 };
-template <int VERT, int NW, bool SPAWN>
+template <int VERT, int NW, bool SPAWN, bool SPLIT = false>
 SL_PL_DEV Verdict<NW> decide(const VCtx<VERT> &vc, const Pl<NW> &A, const Pl<NW> &Z, const Pl<NW> &P, const Pl<NW> &I,
                              const Pl<NW> &S, const Pl<NW> &realm) {
     const Col<VERT, NW> cA(vc, A);
     const Pl<NW> s0 = QB_XOR3(cA.u, A, cA.d), s1 = QB_MAJ(cA.u, A, cA.d);         // alive cells in the column: s0 + 2 s1
-    const Pl<NW> s0l = qleft(s0), s0r = qright(s0), s1l = qleft(s1), s1r = qright(s1);
+    const Pl<NW> s0l = qleft_m<SPLIT, NW>(s0), s0r = qright_m<SPLIT, NW>(s0), s1l = qleft_m<SPLIT, NW>(s1), s1r = qright_m<SPLIT, NW>(s1);
     const Pl<NW> ones = QB_XOR3(s0l, s0, s0r), c1 = QB_MAJ(s0l, s0, s0r);         // count = ones + 2 (c1 + t) + 4 c2
     const Pl<NW> t = QB_XOR3(s1l, s1, s1r), c2 = QB_MAJ(s1l, s1, s1r);
     const Pl<NW> u = c1 ^ t;                                                      // bit 1 of the count
@@ -401,22 +430,22 @@ SL_PL_DEV Verdict<NW> decide(const VCtx<VERT> &vc, const Pl<NW> &A, const Pl<NW>
     Verdict<NW> v;
     v.is3 = SL_QB3(TA & TB & ~TC, ones, u, hi3);
     const Pl<NW> is4 = SL_QB3(~TA & ~TB & TC, ones, u, b2x);
-    const Pl<NW> fP = box_or<VERT, NW>(vc, P), fI = box_or<VERT, NW>(vc, I);
+    const Pl<NW> fP = box_or<VERT, NW, SPLIT>(vc, P), fI = box_or<VERT, NW, SPLIT>(vc, I);
     const Pl<NW> keep_a = SL_QB3(TA | TB | TC, Z, fP, v.is3) | is4;               // an alive cell stays
     v.dead_free = SL_QB3(TA & ~TB & ~TC, realm, A, Z | fI);                       // dead, neither frozen nor inhibited
     v.dies = SL_QB3(TA & TB & ~TC, realm, A, keep_a);
     v.born = v.dead_free & v.is3;
-    v.fS = SPAWN ? box_or<VERT, NW>(vc, S) : A;
+    v.fS = SPAWN ? box_or<VERT, NW, SPLIT>(vc, S) : A;
     return v;
 }
 
 // What a new cell inherits (advance_board.c:16-21,28-29): a flag an ALIVE neighbour carries, seen in at least two of
 // the nine cells.
-template <int VERT, int NW>
+template <int VERT, int NW, bool SPLIT = false>
 SL_PL_DEV Pl<NW> seen_twice(const VCtx<VERT> &vc, const Pl<NW> &q) {
     const Col<VERT, NW> cq(vc, q);
     const Pl<NW> once = QB_OR3(cq.u, q, cq.d), twice = QB_MAJ(cq.u, q, cq.d);
-    return row_or(twice) | QB_MAJ(qleft(once), once, qright(once));              // a column has two | two columns have one
+    return row_or<NW, SPLIT>(twice) | QB_MAJ((qleft_m<SPLIT, NW>(once)), once, (qright_m<SPLIT, NW>(once)));   // a column has two | two columns have one
 }
 
 // ---- the step ---------------------------------------------------------------------------------------
@@ -433,19 +462,28 @@ SL_PL_DEV bool ca_planes(V (&b)[(W + 1) / 2], const VCtx<VERT> &vc, const V &rea
                          V *row_changed = nullptr) {
     using G = PG<W>;
     constexpr int WS = G::WS, NE = G::NE, NW = G::NW;
+    constexpr bool SPLIT = G::SPLIT;
+    constexpr int NE1 = SPLIT ? WS + 2 - 16 : NE;       // entries of the second group
     // -- entries of the transposition groups
     V e_first = b[0], e_wrap = b[0], e_last = b[0];
-    if (NW == 1) {          // seam words around the row's words
+    if (NW == 1 || SPLIT) { // seam words around the row's words
         e_first = G::ODD ? pperm(b[WS - 1], b[WS - 2], 0x05040302u)              // (cell W-1, cell WS-1)
                          : pperm(b[WS - 1], b[WS - 1], 0x01000302u);
         e_wrap = G::ODD ? pperm(b[0], b[WS - 1], 0x05040100u) : b[WS - 1];       // odd: (cell WS-1, cell 0)
         e_last = pperm(b[0], b[0], 0x01000302u);                                 // (cell WS, cell 0)
     }
-    auto ent0 = [&](int i) -> V {
-        if (NW == 2) return b[i];
-        return i == 0 ? e_first : i < WS ? b[i - 1 < 0 ? 0 : i - 1] : i == WS ? e_wrap : e_last;
+    auto seamed = [&](int i) -> V {     // entry i of the seamed row: seam, words 0 .. WS-1, seam
+        return i == 0 ? e_first : i < WS ? b[i - 1 < 0 ? 0 : i - 1] : i == WS ? e_wrap : i == WS + 1 ? e_last : pconst(0);
     };
-    auto ent1 = [&](int i) -> V { return b[NW == 2 ? 16 + i : 0]; };
+    auto ent0 = [&](int i) -> V {
+        if (SPLIT) return seamed(i);
+        if (NW == 2) return b[i];
+        return seamed(i);
+    };
+    auto ent1 = [&](int i) -> V {
+        if (SPLIT) return seamed(16 + i);
+        return b[NW == 2 ? 16 + i : 0];
+    };
     // the planes of a group's two halves -> the row's plane words: one word as it is; two words: (cells 0-15 |
     // 32-47) and (16-31 | 48-63) re-paired into cells 0-31 and 32-63
     auto pair_up = [&](const V &t0, const V &t1) {
@@ -465,11 +503,11 @@ SL_PL_DEV bool ca_planes(V (&b)[(W + 1) / 2], const VCtx<VERT> &vc, const V &rea
     Grp g0, g1;
     V a0, z0, p0, i0, s0, a1, z1, p1, i1, s1;
     group_fast<NE, SPAWN>(ent0, c, g0, a0, z0, p0, i0, s0);
-    if (NW == 2) group_fast<NE, SPAWN>(ent1, c, g1, a1, z1, p1, i1, s1);
+    if (NW == 2) group_fast<NE1, SPAWN>(ent1, c, g1, a1, z1, p1, i1, s1);
     else a1 = a0, z1 = z0, p1 = p0, i1 = i0, s1 = s0;
     const Pl<NW> A = pair_up(a0, a1), Z = pair_up(z0, z1), P = pair_up(p0, p1), I = pair_up(i0, i1);
     const Pl<NW> S = SPAWN ? pair_up(s0, s1) : A;
-    const Verdict<NW> v = decide<VERT, NW, SPAWN>(vc, A, Z, P, I, S, realm);
+    const Verdict<NW> v = decide<VERT, NW, SPAWN, SPLIT>(vc, A, Z, P, I, S, realm);
     Pl<NW> spawned = qzero<NW>();
     if (SPAWN) {
         const Pl<NW> elig = SL_QB3(TA & ~TB & TC, v.dead_free, v.is3, v.fS);
@@ -493,20 +531,20 @@ SL_PL_DEV bool ca_planes(V (&b)[(W + 1) / 2], const VCtx<VERT> &vc, const V &rea
         // destructible 3 from the low bytes; exit 8 and the colours 9-11 from the high bytes
         V d0, x0, c00, c10, c20, d1, x1, c01, c11, c21;
         group_slow<NE>(ent0, c, g0, d0, x0, c00, c10, c20);
-        if (NW == 2) group_slow<NE>(ent1, c, g1, d1, x1, c01, c11, c21);
+        if (NW == 2) group_slow<NE1>(ent1, c, g1, d1, x1, c01, c11, c21);
         else d1 = d0, x1 = x0, c01 = c00, c11 = c10, c21 = c20;
         const Pl<NW> D = pair_up(d0, d1), X = pair_up(x0, x1);
         const Pl<NW> C[3] = {pair_up(c00, c01), pair_up(c10, c11), pair_up(c20, c21)};
         // flags an ALIVE cell hands on: exit|destructible, colours
-        const Pl<NW> twD = seen_twice<VERT, NW>(vc, SL_QB3((TA | TB) & TC, X, D, A));
+        const Pl<NW> twD = seen_twice<VERT, NW, SPLIT>(vc, SL_QB3((TA | TB) & TC, X, D, A));
         Pl<NW> nvD = v.born & twD;
         Pl<NW> nvC[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const Pl<NW> tw = seen_twice<VERT, NW>(vc, C[j] & A);
+            const Pl<NW> tw = seen_twice<VERT, NW, SPLIT>(vc, C[j] & A);
             if (SPAWN) {
                 // colours of SPAWNING cells go straight in (advance_board.c:19)
-                const Pl<NW> f = box_or<VERT, NW>(vc, S & C[j]);
+                const Pl<NW> f = box_or<VERT, NW, SPLIT>(vc, S & C[j]);
                 nvC[j] = SL_QB3(TA & (TB | TC), fresh, tw, f);
             } else {
                 nvC[j] = fresh & tw;
@@ -533,6 +571,12 @@ SL_PL_DEV bool ca_planes(V (&b)[(W + 1) / 2], const VCtx<VERT> &vc, const V &rea
             if (NW == 1) {
 #pragma unroll
                 for (int k = 0; k < WS; ++k) nm[k] = group_entry(lo, hi, k + 1);       // word k = entry k + 1
+            } else if (SPLIT) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {                                          // entry 16 grp + k = word 16 grp + k - 1
+                    const int word = 16 * grp + k - 1;
+                    if (word >= 0 && word < WS) nm[word] = group_entry(lo, hi, k);
+                }
             } else {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) nm[(16 * grp + k) % WS] = group_entry(lo, hi, k);
@@ -547,8 +591,8 @@ SL_PL_DEV bool ca_planes(V (&b)[(W + 1) / 2], const VCtx<VERT> &vc, const V &rea
     }
 #pragma unroll
     for (int k = 0; k < WS; ++k) {
-        const V src = NW == 1 ? gsrc[0] : gsrc[k / 16];
-        const int sh = NW == 1 ? k + 1 : k % 16;
+        const V src = NW == 1 ? gsrc[0] : SPLIT ? gsrc[(k + 1) / 16] : gsrc[k / 16];
+        const int sh = NW == 1 ? k + 1 : SPLIT ? (k + 1) % 16 : k % 16;
         const V m = pmul24(pshr(src, sh) & c.one2, 0xFFFFu);
         b[k] = SL_PB3((TA & ~TB) | TC, b[k], m, nm[k]);
     }

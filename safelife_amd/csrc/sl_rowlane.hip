@@ -30,6 +30,7 @@
 #include <atomic>
 #include <cstddef>
 #include <cstring>
+#include <type_traits>
 
 #include "sl_kernels.h"
 #include "sl_planes.h"
@@ -185,13 +186,32 @@ struct Geom {
     // (row pitch = half the bank sweep: measured 95 % of the LDS cycles were bank conflicts); swizzled,
     // "chunk j of every row" spreads over all 64 banks.  The HBM<->LDS DMA applies the permutation on the
     // global side (an LDS slot is fixed per lane, the global address is free), so HBM keeps the plain layout.
-    static constexpr bool SWZ = W == 64;
+    // Round 4: the same for EVERY row that is a whole number of 16-byte chunks (W a multiple of 8) -- the rows are then
+    // read and written as aligned 16-byte chunks instead of cell by cell (the 16-bit accesses of the other shapes are
+    // conflict-free only where the row pitch is an odd number of dwords, 25 and 26 cells: at 32 cells the 64 row lanes
+    // hit two banks, at 48 four, at 40 eight), and where the chunk count CH = W / 8 is even the chunks of a row are
+    // XOR-permuted with a key that runs through its low bits over sixteen rows: 64 cells (y >> 1) & 7, 32 cells
+    // (y >> 2) & 3, 16 and 48 cells (y >> 3) & 1; an odd chunk count (8, 24, 40 cells) sweeps the banks by itself.
+    // (The key has a period of sixteen rows and the DMA works on rows of the whole span: H must be a multiple of 16
+    //  wherever there is a key.)
+#ifndef SL_SWZ_ALL
+#define SL_SWZ_ALL 1            /* A/B knob: 0 = only 64-cell rows are chunked and swizzled (rounds 1-3) */
+#endif
+    static constexpr int CH = W / 8;
+    static constexpr bool SWZ = W == 64 || (SL_SWZ_ALL && W % 8 == 0 && (W == 8 || W == 24 || W == 40 || H % 16 == 0));
+    static constexpr int KM = !SWZ ? 0 : W == 64 ? 7 : W == 32 ? 3 : (W == 16 || W == 48) ? 1 : 0;
+    static constexpr int KS = W == 64 ? 1 : W == 32 ? 2 : 3;
+    static_assert(KM == 0 || H % 16 == 0, "swizzled images: the key's period is sixteen rows");
+    static __device__ __forceinline__ int key(int y) { return KM ? (y >> KS) & KM : 0; }
+    static __device__ __forceinline__ int swz_chunk(int s) {           // LDS slot (16-byte chunk of the span) -> global chunk
+        return KM ? s ^ key(s / CH) : s;
+    }
     static __device__ __forceinline__ int cell(int y, int x) {          // (row, col) -> cell index in the image
         // (24-bit multiply: a quarter of the issue cycles of v_mul_lo_u32, and the operands are tiny)
-        return SWZ ? __mul24(y, W) + ((((x >> 3) ^ (y >> 1)) & 7) << 3) + (x & 7) : __mul24(y, W) + x;
+        return KM ? __mul24(y, W) + (((x >> 3) ^ key(y)) << 3) + (x & 7) : __mul24(y, W) + x;
     }
     static __device__ __forceinline__ int flat(int i) {                 // row-major index -> cell index
-        return SWZ ? cell(i / W, i % W) : i;
+        return KM ? cell(i / W, i % W) : i;
     }
     // validity of the halves of word k as a 0x0001-per-half mask
     static constexpr u32 vm1(int k) { return (ODD && k == WS - 1) ? 0x00000001u : 0x00010001u; }
@@ -210,7 +230,7 @@ __device__ __forceinline__ void read_row(const unsigned char *region, int gb, in
     if (Gm::SWZ) {      // eight aligned 16-byte reads (chunk j sits at j ^ key), then one v_perm per word
         typedef const __attribute__((address_space(3))) u32x4 *lds_c128;
         lds_c128 row = (lds_c128)(region + Gm::PAD) + (gb * Gm::HW + r * W) / 8;
-        const int key = (r >> 1) & 7;
+        const int key = Gm::key(r);
         u32 d[W / 2];
 #pragma unroll
         for (int j = 0; j < W / 8; ++j) {
@@ -242,7 +262,7 @@ __device__ __forceinline__ void write_row(unsigned char *region, int gb, int r, 
     using Gm = Geom<H, W>;
     if (Gm::SWZ) {
         u32x4 *row = (u32x4 *)(region + Gm::PAD) + (gb * Gm::HW + r * W) / 8;
-        const int key = (r >> 1) & 7;
+        const int key = Gm::key(r);
 #pragma unroll
         for (int j = 0; j < W / 8; ++j) {       // dword q = (cell 2q, cell 2q+1)
             u32 q[4];
@@ -590,12 +610,17 @@ __device__ pl::Pl<NW> resolve_draws_planes(const pl::Pl<NW> &elig, u64 *rng_lds,
             const int log2c = need <= 1 ? 0 : 32 - __clz(need - 1);            // c = 2^log2c >= total / 64
             const int first = lane << log2c;
             const int n_here = min(max(total - first, 0), 1 << log2c);
+            // (the threshold is the BOARD's: a lane that holds none of its rows -- halo copies, idle lanes of boards
+            //  of fewer than 64 rows -- makes draws too and may carry no probability of its own)
+            const u32 bthr_hi = __builtin_amdgcn_readlane((u32)(thr >> 32), LaneMap<H, W>::first_lane(0) + 1);
+            const u32 bthr_lo = __builtin_amdgcn_readlane((u32)thr, LaneMap<H, W>::first_lane(0) + 1);
+            const u64 bthr = ((u64)bthr_hi << 32) | bthr_lo;
             u32 bits = 0;
             if (n_here > 0) {
                 U128 cur = pcg_jump(jump, first, st, inc);
                 for (int i = 0; i < n_here; ++i) {
                     cur = pcg_step(cur, inc);
-                    bits |= (pcg_output_u53(cur) < thr ? 1u : 0u) << i;         // advance_board.c:115
+                    bits |= (pcg_output_u53(cur) < bthr ? 1u : 0u) << i;        // advance_board.c:115
                 }
                 if (first + n_here == total) {      // the lane that made the board's last draw holds its new state
                     rng_lds[4 * g + 0] = cur.hi;
@@ -730,7 +755,14 @@ __device__ pl::Pl<NW> resolve_draws_planes(const pl::Pl<NW> &elig, u64 *rng_lds,
 // whether any cell of the wave changed -- the word form does not know and says yes.  `take`: the lane takes the
 // new row even if it is not `mine` (the halo copies of the word form compute their own rows).
 template <int H, int W>
-constexpr bool use_planes() { return (W + 1) / 2 + 2 <= 16 || W == 64; }
+constexpr bool use_planes_multi() { return (W + 1) / 2 + 2 <= 16 || W == 64; }     // rows kept in plane form across steps
+template <int H, int W>
+constexpr bool use_planes() {       // single steps: also even rows of 30 to 60 cells (two words per plane, one per half)
+#ifndef SL_SPLIT_PLANES
+#define SL_SPLIT_PLANES 1       /* A/B knob: 0 = rows of 30 to 48 cells keep the word form of the CA (rounds 1-3) */
+#endif
+    return use_planes_multi<H, W>() || (SL_SPLIT_PLANES && W > 28 && W < 64 && (W & 1) == 0);
+}
 
 template <int H, int W, bool SPAWN, bool COLFIRST>
 __device__ __forceinline__ bool ca_step(RowWords<H, W> &b, bool mine, bool take, int up, int dn, const Consts &c,
@@ -851,7 +883,7 @@ template <int H, int W>
 __device__ __forceinline__ void act_cells(int ly, int lx, int action, int (&img)[4], int (&gix)[4], int &y1, int &x1) {
     using Gm = Geom<H, W>;
     const int dir = (action - 1) & 3;
-    if (Gm::SWZ) {
+    if (Gm::KM) {
         const int dy = (dir & 1) ? 0 : dir - 1, dx = (dir & 1) ? 2 - dir : 0;
         y1 = wrap1(ly + dy, H);
         x1 = wrap1(lx + dx, W);
@@ -1001,13 +1033,16 @@ typedef __attribute__((address_space(3))) void *glds_dst_t;
 // `bytes` of global memory -> LDS with the asynchronous global_load_lds DMA (16 bytes per lane,
 // 1 KiB per wave instruction, no VGPR staging, no ds_write).  Chunk c of 1 KiB is moved by wave
 // c % WAVES.  Completion: the vmcnt(0) the compiler places in front of the next __syncthreads().
-// SWZ: LDS slot s (16-byte chunk) receives global chunk swz_chunk(s) -- the board-image swizzle of Geom.
-__device__ __forceinline__ int swz_chunk(int s) { return s ^ ((s >> 4) & 7); }     // 8 chunks per row; key (row>>1)&7
+// Perm: LDS slot s (16-byte chunk) receives global chunk Perm::swz_chunk(s) -- the board-image swizzle of Geom.
+struct NoPerm {
+    static __device__ __forceinline__ int swz_chunk(int s) { return s; }
+};
 
 // NW: number of waves that share the move (wave = 0..NW-1 among them).
-template <int MAX_BYTES, bool SWZ = false, int NW = WAVES>
+template <int MAX_BYTES, bool SWZ = false, int NW = WAVES, class Perm = NoPerm>
 __device__ __forceinline__ void dma_to_lds(const unsigned char *__restrict__ src, unsigned char *dst, int bytes,
                                            int lane, int wave) {
+    static_assert(!SWZ || !std::is_same<Perm, NoPerm>::value, "a swizzled move names its geometry");
     const int nv = bytes >> 4;
     constexpr int NCH = (MAX_BYTES + 1023) / 1024;
 #pragma unroll
@@ -1015,7 +1050,7 @@ __device__ __forceinline__ void dma_to_lds(const unsigned char *__restrict__ src
         const int c = wave + NW * j;
         const int s = c * 64 + lane;
         if (s < nv)
-            __builtin_amdgcn_global_load_lds((glds_src_t)(src + (SWZ ? swz_chunk(s) : s) * 16),
+            __builtin_amdgcn_global_load_lds((glds_src_t)(src + (SWZ ? Perm::swz_chunk(s) : s) * 16),
                                              (glds_dst_t)(dst + c * 1024), 16, 0, SL_LOAD_AUX);
     }
 }
@@ -1024,7 +1059,7 @@ template <int H, int W, int NW = WAVES>
 __device__ __forceinline__ void load_span(const u16 *__restrict__ src, unsigned char *region, int nbb, int lane, int wave) {
     using Gm = Geom<H, W>;
     const int bytes = nbb * Gm::HW * 2;
-    dma_to_lds<Gm::SPAN, Gm::SWZ, NW>((const unsigned char *)src, region + Gm::PAD, bytes, lane, wave);
+    dma_to_lds<Gm::SPAN, Gm::KM != 0, NW, Gm>((const unsigned char *)src, region + Gm::PAD, bytes, lane, wave);
     const int nv = bytes >> 4, rem = (bytes & 15) >> 1;          // leftover cells: tail workgroup only
     if (wave == 0 && lane < rem) ((u16 *)(region + Gm::PAD))[nv * 8 + lane] = src[nv * 8 + lane];
 }
@@ -1052,7 +1087,7 @@ __device__ __forceinline__ void store_span(u16 *__restrict__ dst, const unsigned
 #pragma unroll
     for (int i = 0; i < NVI; ++i) {
         const int slot = tid + 64 * WAVES * i;
-        if (slot < nv) store16(d + (Gm::SWZ ? swz_chunk(slot) : slot), s[slot]);
+        if (slot < nv) store16(d + Gm::swz_chunk(slot), s[slot]);
     }
     const int rem = (bytes & 15) >> 1;
     if (tid < rem) dst[nv * 8 + tid] = ((const u16 *)s)[nv * 8 + tid];
@@ -1064,7 +1099,7 @@ template <int H, int W, class Box>
 __device__ __forceinline__ void store_span_dirty(u16 *__restrict__ dst, const unsigned char *region, int nbb, int tid,
                                                  const Box *box) {
     using Gm = Geom<H, W>;
-    static_assert(!Gm::SWZ, "row-major images only");
+    static_assert(Gm::KM == 0, "row-major images only");
     const int bytes = nbb * Gm::HW * 2;
     const int nv = bytes >> 4;
     u32x4 *d = (u32x4 *)dst;
@@ -1188,7 +1223,7 @@ __global__ __launch_bounds__(64) void k_advance_small(const u16 *__restrict__ in
     const Consts cst = make_consts();
     const pl::PConsts pcst = pl::make_pconsts();
     wave_sync();
-    constexpr bool PLANES = use_planes<H, W>();
+    constexpr bool PLANES = use_planes_multi<H, W>();
     if constexpr (PLANES) {
         constexpr int NW = pl::PG<W>::NW;
         if (wave_n > 1) {               // many steps: one transposition at either end
@@ -1378,7 +1413,7 @@ __global__ __launch_bounds__(64) void k_occupancy_rowlane(const u16 *__restrict_
     // rows of up to 28 cells, or 64: the row stays in bit-plane form for all the steps (sl_planes.h) -- one
     // transposition at the start, the CA on whole rows, and the counting visits only the cells that ARE alive
     // (a handful per row) instead of every cell position
-    constexpr bool PLANES = use_planes<H, W>();
+    constexpr bool PLANES = use_planes_multi<H, W>();
     constexpr int NW = pl::PG<PLANES ? W : 8>::NW;
     pl::PState<NW> st;
     const pl::VCtx<Gm::VERT> vctx = {lm.up, lm.dn, 4 * partner};

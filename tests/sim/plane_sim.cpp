@@ -127,14 +127,19 @@ static void run(int VERT, int H, int B, int steps, bool persistent, std::vector<
                 }
             }
         };
-        if (persistent) {           // the rows stay in plane form for all the steps
-            load_rows();
-            PState<NW> st;
-            planes_load<W>(b, cst, st);
-            for (int s = 0; s < steps; ++s) planes_step<W, 0, SPAWN>(st, vc, realm, draw);
-            planes_store<W>(b, cst, st);
-            store_rows();
-        } else {
+        bool kept = false;
+        if constexpr (!PG<W>::SPLIT) {      // (the split two-word layout of rows of 30 to 60 cells is single-step only)
+            if (persistent) {       // the rows stay in plane form for all the steps
+                load_rows();
+                PState<NW> st;
+                planes_load<W>(b, cst, st);
+                for (int s = 0; s < steps; ++s) planes_step<W, 0, SPAWN>(st, vc, realm, draw);
+                planes_store<W>(b, cst, st);
+                store_rows();
+                kept = true;
+            }
+        }
+        if (!kept) {
             for (int s = 0; s < steps; ++s) {
                 load_rows();
                 ca_planes<W, 0, SPAWN>(b, vc, realm, cst, draw);
@@ -170,7 +175,7 @@ int main(int argc, char **argv) {
     fclose(f);
     bool ok = false;
 #define SL_W(w) if (W == w) ok = run_w<w>(H, B, steps, spawn, boards, prob, rng);
-    SL_W(4) SL_W(5) SL_W(8) SL_W(10) SL_W(12) SL_W(15) SL_W(16) SL_W(20) SL_W(24) SL_W(25) SL_W(26) SL_W(27) SL_W(28) SL_W(64)
+    SL_W(4) SL_W(5) SL_W(8) SL_W(10) SL_W(12) SL_W(15) SL_W(16) SL_W(20) SL_W(24) SL_W(25) SL_W(26) SL_W(27) SL_W(28) SL_W(30) SL_W(32) SL_W(40) SL_W(48) SL_W(64)
 #undef SL_W
     if (!ok) return 3;
     f = fopen(argv[2], "wb");

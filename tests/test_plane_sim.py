@@ -40,7 +40,9 @@ def _run(sim, tmp_path, boards, prob, words, steps, spawn, keep_planes=False):
 
 # (H, W): square shapes of the row kernels, plus shapes that force each vertical lane layout and both row parities
 SHAPES = [(25, 25), (26, 26), (8, 8), (10, 10), (12, 12), (15, 15), (16, 16), (20, 20), (24, 24),
-          (10, 25), (25, 10), (9, 27), (64, 28), (40, 5), (30, 4), (64, 64), (20, 64)]
+          (10, 25), (25, 10), (9, 27), (64, 28), (40, 5), (30, 4), (64, 64), (20, 64),
+          # even rows of 30 to 48 cells: two plane words, one per half of the split layout (round 4)
+          (30, 30), (32, 32), (40, 40), (48, 48), (12, 40), (64, 30)]
 
 
 @pytest.mark.parametrize("H,W", SHAPES)
