@@ -757,11 +757,12 @@ __device__ pl::Pl<NW> resolve_draws_planes(const pl::Pl<NW> &elig, u64 *rng_lds,
 template <int H, int W>
 constexpr bool use_planes_multi() { return (W + 1) / 2 + 2 <= 16 || W == 64; }     // rows kept in plane form across steps
 template <int H, int W>
-constexpr bool use_planes() {       // single steps: also even rows of 30 to 60 cells (two words per plane, one per half)
+constexpr bool use_planes() {       // single steps: also even rows of 32 to 60 cells (two words per plane, one per half;
+                                    // at 30 cells the word form is the faster one: 8.8 against 9.3-9.8 us per step)
 #ifndef SL_SPLIT_PLANES
 #define SL_SPLIT_PLANES 1       /* A/B knob: 0 = rows of 30 to 48 cells keep the word form of the CA (rounds 1-3) */
 #endif
-    return use_planes_multi<H, W>() || (SL_SPLIT_PLANES && W > 28 && W < 64 && (W & 1) == 0);
+    return use_planes_multi<H, W>() || (SL_SPLIT_PLANES && W >= 32 && W < 64 && (W & 1) == 0);
 }
 
 template <int H, int W, bool SPAWN, bool COLFIRST>
