@@ -202,6 +202,14 @@ struct Geom {
     static constexpr int KM = !SWZ ? 0 : W == 64 ? 7 : W == 32 ? 3 : (W == 16 || W == 48) ? 1 : 0;
     static constexpr int KS = W == 64 ? 1 : W == 32 ? 2 : 3;
     static_assert(KM == 0 || H % 16 == 0, "swizzled images: the key's period is sixteen rows");
+    // Even rows that are not whole chunks (10, 12, 20, 26, 30 cells): every row of the image still starts on a dword
+    // (the image starts 16-byte aligned, a board and a row are an even number of cells), so the rows are read and
+    // written as W / 2 aligned dwords -- half the LDS instructions of the cell-by-cell form for the same number of
+    // vector instructions (one v_perm per word of the split layout either way).
+#ifndef SL_ROW_DWORDS
+#define SL_ROW_DWORDS 1         /* A/B knob: 0 = such rows cell by cell (rounds 1-3) */
+#endif
+    static constexpr bool DW = SL_ROW_DWORDS && !SWZ && (W & 1) == 0;
     static __device__ __forceinline__ int key(int y) { return KM ? (y >> KS) & KM : 0; }
     static __device__ __forceinline__ int swz_chunk(int s) {           // LDS slot (16-byte chunk of the span) -> global chunk
         return KM ? s ^ key(s / CH) : s;
@@ -245,6 +253,19 @@ __device__ __forceinline__ void read_row(const unsigned char *region, int gb, in
             b[k] = __builtin_amdgcn_perm(d[(k + Gm::WS) >> 1], d[k >> 1], (k & 1) ? 0x07060302u : 0x05040100u);
         return;
     }
+    if (Gm::DW) {       // even rows: every row starts on a dword -- W / 2 aligned dword reads, one v_perm per word
+        typedef const __attribute__((address_space(3), aligned(4))) u32 *lds_c32;
+        lds_c32 row = (lds_c32)(region + Gm::PAD) + (gb * Gm::HW + r * W) / 2;
+        u32 d[W / 2];
+#pragma unroll
+        for (int j = 0; j < W / 2; ++j) d[j] = row[j];
+#pragma unroll
+        for (int k = 0; k < Gm::WS; ++k) {      // cell c sits in dword c >> 1, half c & 1
+            const u32 sel = ((k & 1) ? 0x0302u : 0x0100u) | ((((k + Gm::WS) & 1) ? 0x0706u : 0x0504u) << 16);
+            b[k] = __builtin_amdgcn_perm(d[(k + Gm::WS) >> 1], d[k >> 1], sel);
+        }
+        return;
+    }
     typedef const volatile __attribute__((address_space(3))) u16 *lds_cv16;
     lds_cv16 c = (lds_cv16)(region + Gm::PAD) + gb * Gm::HW + r * W;
     u32 lo[Gm::WS], hi[Gm::WS];
@@ -274,6 +295,18 @@ __device__ __forceinline__ void write_row(unsigned char *region, int gb, int r, 
             }
             u32x4 v = {q[0], q[1], q[2], q[3]};
             row[j ^ key] = v;
+        }
+        return;
+    }
+    if (Gm::DW) {
+        typedef __attribute__((address_space(3), aligned(4))) u32 *lds_32;
+        lds_32 row = (lds_32)(region + Gm::PAD) + (gb * Gm::HW + r * W) / 2;
+#pragma unroll
+        for (int j = 0; j < W / 2; ++j) {       // dword j = (cell 2j, cell 2j + 1); cell c = low half of word c, or high of c - WS
+            const int c0 = 2 * j, c1 = 2 * j + 1;
+            const int w0 = c0 < Gm::WS ? c0 : c0 - Gm::WS, w1 = c1 < Gm::WS ? c1 : c1 - Gm::WS;
+            const u32 sel = (c0 < Gm::WS ? 0x0100u : 0x0302u) | ((c1 < Gm::WS ? 0x0504u : 0x0706u) << 16);
+            row[j] = __builtin_amdgcn_perm(n[w1], n[w0], sel);
         }
         return;
     }
