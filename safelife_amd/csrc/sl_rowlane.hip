@@ -210,6 +210,12 @@ struct Geom {
 #define SL_ROW_DWORDS 1         /* A/B knob: 0 = such rows cell by cell (rounds 1-3) */
 #endif
     static constexpr bool DW = SL_ROW_DWORDS && !SWZ && (W & 1) == 0;
+    // Odd rows, READS only (a row's first or last cell shares its dword with a neighbouring row, which another lane
+    // writes): the WS + 1 aligned dwords that cover the row, shifted into place per lane.
+#ifndef SL_ROW_ODD_DWORDS
+#define SL_ROW_ODD_DWORDS 1     /* A/B knob: 0 = odd rows are read cell by cell (rounds 1-3) */
+#endif
+    static constexpr bool ODW = SL_ROW_ODD_DWORDS && !SWZ && (W & 1) == 1;
     static __device__ __forceinline__ int key(int y) { return KM ? (y >> KS) & KM : 0; }
     static __device__ __forceinline__ int swz_chunk(int s) {           // LDS slot (16-byte chunk of the span) -> global chunk
         return KM ? s ^ key(s / CH) : s;
@@ -263,6 +269,24 @@ __device__ __forceinline__ void read_row(const unsigned char *region, int gb, in
         for (int k = 0; k < Gm::WS; ++k) {      // cell c sits in dword c >> 1, half c & 1
             const u32 sel = ((k & 1) ? 0x0302u : 0x0100u) | ((((k + Gm::WS) & 1) ? 0x0706u : 0x0504u) << 16);
             b[k] = __builtin_amdgcn_perm(d[(k + Gm::WS) >> 1], d[k >> 1], sel);
+        }
+        return;
+    }
+    if (Gm::ODW) {      // odd rows (25, 15 cells): a row starts on a dword only every other row -- the aligned dwords
+                        // around it (one more than the row has), moved down by the row's odd half with v_alignbit
+        typedef const __attribute__((address_space(3), aligned(4))) u32 *lds_c32;
+        const int first = gb * Gm::HW + r * W;                   // the row's first cell
+        lds_c32 row = (lds_c32)(region + Gm::PAD) + (first >> 1);
+        const u32 sh = (u32)(first & 1) << 4;
+        u32 d[Gm::WS + 1], x[Gm::WS];
+#pragma unroll
+        for (int j = 0; j < Gm::WS + 1; ++j) d[j] = row[j];
+#pragma unroll
+        for (int j = 0; j < Gm::WS; ++j) x[j] = __builtin_amdgcn_alignbit(d[j + 1], d[j], sh);      // (cell 2j, cell 2j + 1)
+#pragma unroll
+        for (int k = 0; k < Gm::WS; ++k) {
+            const u32 sel = ((k & 1) ? 0x0302u : 0x0100u) | ((((k + Gm::WS) & 1) ? 0x0706u : 0x0504u) << 16);
+            b[k] = k == Gm::WS - 1 ? (x[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu : __builtin_amdgcn_perm(x[(k + Gm::WS) >> 1], x[k >> 1], sel);
         }
         return;
     }
