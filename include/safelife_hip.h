@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SL_ABI_VERSION 9
+#define SL_ABI_VERSION 10       /* 10: slhip_queues_open_on, slhip_queues_stream_shares, slhip_gather_stream_shares, slhip_gather_poke */
 #define SL_MAX_CELLS 16384        /* H*W limit of one board */
 #define SL_MAX_CHANNELS 32
 
