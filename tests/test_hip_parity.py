@@ -930,6 +930,8 @@ def _queues_or_skip(env, slices=None, release_free=False, queue_ids=None):
     ("prune_still_25", 333, 3, dict(time_limit=9, view_shape=(5, 7), wrappers=TRAINING_WRAPPERS)),
     # slices on chosen queues (slhip_queues_open_on): what a driver does that leaves out the queue its exchange holds up
     ("prune_still_25", 900, (3, 0, 2), dict(time_limit=14, view_shape=(9, 9), with_obs=False)),
+    # the headline batch itself: all 8192 envs of C3 on four queues against the oracle, every step of the runs
+    ("prune_still_25", 8192, 4, dict(time_limit=40, view_shape=(25, 25), with_obs=False)),
 ])
 def test_queue_stepping_vs_oracle(pool_name, B, queue_slices, kw, release_free):
     """slhip_queues_*: the slices of a step dispatched from the library's own AQL queues instead of HIP streams (same
