@@ -150,7 +150,10 @@ struct Geom {
     // -- measured and switched off: the wave's lifetime drops (4.7 -> 4.57 us at 4096 envs) but the two-slice step does
     //    not move (8.26 us) and the one-launch step loses (9.6 -> 10.9 us: twenty waves per CU spread unevenly over
     //    the SIMDs)
-    static constexpr bool LEADX_OK = false;
+#ifndef SL_LEADX
+#define SL_LEADX 0              /* A/B knob: 1 = the LEAN variants of the 25 / 26-cell shapes get a fifth, row-less leader wave */
+#endif
+    static constexpr bool LEADX_OK = SL_LEADX && (W == 25 || W == 26);
     static constexpr int NL = G * GL;                      // lanes in use
     static constexpr int NB = WAVES * G;                   // boards per workgroup
     static_assert((NB * HW) % 8 == 0, "workgroup span must be a multiple of 16 bytes");
