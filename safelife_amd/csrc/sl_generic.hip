@@ -1,4 +1,4 @@
-// sl_generic.hip -- size-generic gfx950 kernels: one 256-thread workgroup per board, the board
+// sl_generic.hip -- size-generic gfx950 kernels: one workgroup (64 to 256 threads) per board, the board
 // staged in LDS, one cell per lane per pass.  Correct for every 3 <= H, W with H*W <= SL_MAX_CELLS;
 // this is the path for board shapes the row-per-lane kernels (sl_rowlane.hip) do not cover, and
 // the implementation of the non-fused primitives (alive_counts, execute_actions, life_occupancy).
@@ -16,8 +16,13 @@
 
 namespace sl {
 
-constexpr int GB = 256;          // threads per workgroup
-constexpr int GW = GB / 64;      // waves per workgroup
+constexpr int GB_MAX = 256;      // threads per workgroup, at most
+constexpr int GW = GB_MAX / 64;  // waves per workgroup, at most
+// Threads per workgroup (= per board): one wavefront for boards of up to 256 cells, two up to 1024, else four -- a
+// 13x13 board left more than half of a 256-thread workgroup's lanes idle and paid four waves' barriers for every
+// phase (round 4: 185 -> see profiles/round4_i_board_shapes.txt).  Device code reads the size it was launched with.
+#define GB ((int)blockDim.x)
+static inline unsigned generic_threads(int HW) { return HW <= 256 ? 64u : HW <= 1024 ? 128u : 256u; }
 
 __device__ __forceinline__ int row_of(int i, int W, float inv_w) {
     int y = (int)(((float)i + 0.5f) * inv_w);
@@ -73,6 +78,7 @@ __device__ void ca_step_block(const u16 *cur, u16 *rows, u16 *nxt, int H, int W,
         int woff = 0, tot = 0;
 #pragma unroll
         for (int w = 0; w < GW; ++w) {
+            if (w * 64 >= GB) break;
             int t = wave_tot[w];
             woff += (w < wave) ? t : 0;
             tot += t;
@@ -116,7 +122,7 @@ size_t generic_lds_bytes(int HW, int nbuf) { return 128 + (size_t)nbuf * ((HW + 
 
 // ------------------------------------------------------------------ advance_board / occupancy
 
-__global__ __launch_bounds__(GB) void k_advance_generic(const u16 *__restrict__ in, u16 *__restrict__ out,
+__global__ __launch_bounds__(GB_MAX) void k_advance_generic(const u16 *__restrict__ in, u16 *__restrict__ out,
                                                         int H, int W, const float *__restrict__ spawn_prob,
                                                         int n_steps, sl_pcg64 *rng,
                                                         const Jump *__restrict__ jump,
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(GB) void k_advance_generic(const u16 *__restrict__ 
 // SimpleSideEffectPenalty's "inaction" baseline (env_wrappers.py:179-180): every env's baseline board one CA step on,
 // with the baseline's own generator.  An env that has not stepped since its reset (num_steps == 0) starts from its
 // current board: the wrapper's reset() copies it (:168-172).
-__global__ __launch_bounds__(GB) void k_inaction_generic(sl_env_batch env, const Jump *__restrict__ jump) {
+__global__ __launch_bounds__(GB_MAX) void k_inaction_generic(sl_env_batch env, const Jump *__restrict__ jump) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int H = env.H, W = env.W, HW = H * W, b = blockIdx.x, tid = threadIdx.x;
     GenericLds l = carve(smem, HW, 3);
@@ -176,12 +182,12 @@ __global__ __launch_bounds__(GB) void k_inaction_generic(sl_env_batch env, const
 
 // ------------------------------------------------------------------------------ alive_counts
 
-__global__ __launch_bounds__(GB) void k_alive_counts(const u16 *__restrict__ board,
+__global__ __launch_bounds__(GB_MAX) void k_alive_counts(const u16 *__restrict__ board,
                                                      const u16 *__restrict__ goals, int HW,
                                                      int64_t *__restrict__ out) {
     __shared__ int hist[72];
     const int b = blockIdx.x, tid = threadIdx.x;
-    if (tid < 72) hist[tid] = 0;
+    for (int i = tid; i < 72; i += GB) hist[i] = 0;
     __syncthreads();
     const u16 *bd = board + (size_t)b * HW, *gl = goals + (size_t)b * HW;
     for (int i = tid; i < HW; i += GB) {
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(GB) void k_alive_counts(const u16 *__restrict__ boa
         if (bin >= 0) atomicAdd(&hist[bin], 1);
     }
     __syncthreads();
-    if (tid < 72) out[(size_t)b * 72 + tid] = hist[tid];
+    for (int i = tid; i < 72; i += GB) out[(size_t)b * 72 + i] = hist[i];
 }
 
 // --------------------------------------------------------------------------- execute_actions
@@ -223,7 +229,7 @@ __device__ int block_sum(int v, int *wave_tot) {
     __syncthreads();
     int s = 0;
 #pragma unroll
-    for (int w = 0; w < GW; ++w) s += wave_tot[w];
+    for (int w = 0; w < GW && w * 64 < GB; ++w) s += wave_tot[w];
     return s;
 }
 
@@ -356,7 +362,7 @@ __device__ void reset_block(const sl_env_batch &env, int e, u16 *brd, int *ivar,
 
 // ------------------------------------------------------------------------- env step / reset
 
-__global__ __launch_bounds__(GB) void k_env_rollout_generic(sl_env_batch env,
+__global__ __launch_bounds__(GB_MAX) void k_env_rollout_generic(sl_env_batch env,
                                                             const int32_t *__restrict__ actions, int T,
                                                             float *__restrict__ reward_t,
                                                             uint8_t *__restrict__ done_t,
@@ -529,7 +535,7 @@ __global__ __launch_bounds__(GB) void k_env_rollout_generic(sl_env_batch env,
     write_obs(env, e, cur, ggoals, ivar[0], ivar[1], exits);
 }
 
-__global__ __launch_bounds__(GB) void k_env_reset_generic(sl_env_batch env,
+__global__ __launch_bounds__(GB_MAX) void k_env_reset_generic(sl_env_batch env,
                                                           const uint8_t *__restrict__ mask) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int HW = env.H * env.W, e = blockIdx.x, tid = threadIdx.x;
@@ -550,7 +556,7 @@ __global__ __launch_bounds__(GB) void k_env_reset_generic(sl_env_batch env,
               env.exit_locs + (size_t)e * env.E);
 }
 
-__global__ __launch_bounds__(GB) void k_env_obs_generic(sl_env_batch env) {
+__global__ __launch_bounds__(GB_MAX) void k_env_obs_generic(sl_env_batch env) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int HW = env.H * env.W, e = blockIdx.x, tid = threadIdx.x;
     GenericLds l = carve(smem, HW, 1);
@@ -632,14 +638,14 @@ hipError_t launch_advance_generic(const u16 *in, u16 *out, int B, int H, int W, 
     size_t lds = generic_lds_bytes(H * W, 3);
     hipError_t err = set_lds((const void *)k_advance_generic, lds);
     if (err != hipSuccess) return err;
-    hipLaunchKernelGGL(k_advance_generic, dim3(B), dim3(GB), lds, stream, in, out, H, W, spawn_prob,
+    hipLaunchKernelGGL(k_advance_generic, dim3(B), dim3(generic_threads(H * W)), lds, stream, in, out, H, W, spawn_prob,
                        n_steps, rng, jump, occupancy, n_each);
     return hipGetLastError();
 }
 
 hipError_t launch_alive_counts(const u16 *board, const u16 *goals, int B, int HW, int64_t *out,
                                hipStream_t stream) {
-    hipLaunchKernelGGL(k_alive_counts, dim3(B), dim3(GB), 0, stream, board, goals, HW, out);
+    hipLaunchKernelGGL(k_alive_counts, dim3(B), dim3(generic_threads(HW)), 0, stream, board, goals, HW, out);
     return hipGetLastError();
 }
 
@@ -656,7 +662,7 @@ hipError_t launch_env_rollout_generic(const sl_env_batch &env, const int32_t *ac
     size_t lds = generic_lds_bytes(env.H * env.W, 4);
     hipError_t err = set_lds((const void *)k_env_rollout_generic, lds);
     if (err != hipSuccess) return err;
-    hipLaunchKernelGGL(k_env_rollout_generic, dim3(env.B), dim3(GB), lds, stream, env, actions, T,
+    hipLaunchKernelGGL(k_env_rollout_generic, dim3(env.B), dim3(generic_threads(env.H * env.W)), lds, stream, env, actions, T,
                        reward_t, done_t, jump);
     return hipGetLastError();
 }
@@ -665,7 +671,7 @@ hipError_t launch_inaction_generic(const sl_env_batch &env, const Jump *jump, hi
     size_t lds = generic_lds_bytes(env.H * env.W, 3);
     hipError_t err = set_lds((const void *)k_inaction_generic, lds);
     if (err != hipSuccess) return err;
-    hipLaunchKernelGGL(k_inaction_generic, dim3(env.B), dim3(GB), lds, stream, env, jump);
+    hipLaunchKernelGGL(k_inaction_generic, dim3(env.B), dim3(generic_threads(env.H * env.W)), lds, stream, env, jump);
     return hipGetLastError();
 }
 
@@ -673,7 +679,7 @@ hipError_t launch_env_reset_generic(const sl_env_batch &env, const uint8_t *mask
     size_t lds = generic_lds_bytes(env.H * env.W, 1);
     hipError_t err = set_lds((const void *)k_env_reset_generic, lds);
     if (err != hipSuccess) return err;
-    hipLaunchKernelGGL(k_env_reset_generic, dim3(env.B), dim3(GB), lds, stream, env, mask);
+    hipLaunchKernelGGL(k_env_reset_generic, dim3(env.B), dim3(generic_threads(env.H * env.W)), lds, stream, env, mask);
     return hipGetLastError();
 }
 
@@ -681,7 +687,7 @@ hipError_t launch_env_obs_generic(const sl_env_batch &env, hipStream_t stream) {
     size_t lds = generic_lds_bytes(env.H * env.W, 1);
     hipError_t err = set_lds((const void *)k_env_obs_generic, lds);
     if (err != hipSuccess) return err;
-    hipLaunchKernelGGL(k_env_obs_generic, dim3(env.B), dim3(GB), lds, stream, env);
+    hipLaunchKernelGGL(k_env_obs_generic, dim3(env.B), dim3(generic_threads(env.H * env.W)), lds, stream, env);
     return hipGetLastError();
 }
 
