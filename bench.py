@@ -775,7 +775,9 @@ def main():
             extra["training_wrappers_inaction_baseline_queues_us_per_step"] = envi.last_queues_us
         del envi
         # per-GPU shares of the sharded configs of BASELINE.json (C4: append-spawn 25x25, C5: navigation 64x64)
-        for tag, pname, n_envs in (("c4_append_spawn_25", "append_spawn_25", 8192), ("c5_navigation_64", "navigation_64", 4096)):
+        # (and the shape the reference's own random-level YAMLs use, levels/random/*.yaml: board_shape [26, 26])
+        for tag, pname, n_envs in (("c4_append_spawn_25", "append_spawn_25", 8192), ("c5_navigation_64", "navigation_64", 4096),
+                                   ("append_still_26x26", "append_still_26", 8192)):
             if not os.path.exists(os.path.join(REPO, "tests", "golden", "pool_%s.npz" % pname)):
                 continue
             p2 = load_pool(pname, _device_counts)
