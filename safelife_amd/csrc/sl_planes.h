@@ -615,17 +615,26 @@ template <int W>
 SL_PL_DEV void planes_load(const V (&b)[(W + 1) / 2], const PConsts &c, PState<PG<W>::NW> &st) {
     using G = PG<W>;
     constexpr int WS = G::WS, NE = G::NE, NW = G::NW;
+    constexpr bool SPLIT = G::SPLIT;
+    constexpr int NE1 = SPLIT ? WS + 2 - 16 : NE;
     V e_first = b[0], e_wrap = b[0], e_last = b[0];
-    if (NW == 1) {
+    if (NW == 1 || SPLIT) {
         e_first = G::ODD ? pperm(b[WS - 1], b[WS - 2], 0x05040302u) : pperm(b[WS - 1], b[WS - 1], 0x01000302u);
         e_wrap = G::ODD ? pperm(b[0], b[WS - 1], 0x05040100u) : b[WS - 1];
         e_last = pperm(b[0], b[0], 0x01000302u);
     }
-    auto ent0 = [&](int i) -> V {
-        if (NW == 2) return b[i];
-        return i == 0 ? e_first : i < WS ? b[i - 1 < 0 ? 0 : i - 1] : i == WS ? e_wrap : e_last;
+    auto seamed = [&](int i) -> V {
+        return i == 0 ? e_first : i < WS ? b[i - 1 < 0 ? 0 : i - 1] : i == WS ? e_wrap : i == WS + 1 ? e_last : pconst(0);
     };
-    auto ent1 = [&](int i) -> V { return b[NW == 2 ? 16 + i : 0]; };
+    auto ent0 = [&](int i) -> V {
+        if (SPLIT) return seamed(i);
+        if (NW == 2) return b[i];
+        return seamed(i);
+    };
+    auto ent1 = [&](int i) -> V {
+        if (SPLIT) return seamed(16 + i);
+        return b[NW == 2 ? 16 + i : 0];
+    };
     V t[2][11];
 #pragma unroll
     for (int g = 0; g < G::NG; ++g) {
@@ -634,8 +643,8 @@ SL_PL_DEV void planes_load(const V (&b)[(W + 1) / 2], const PConsts &c, PState<P
             group_fast<NE, true>(ent0, c, gr, t[g][0], t[g][3], t[g][4], t[g][5], t[g][6]);
             group_slow<NE>(ent0, c, gr, t[g][2], t[g][7], t[g][8], t[g][9], t[g][10]);
         } else {
-            group_fast<NE, true>(ent1, c, gr, t[g][0], t[g][3], t[g][4], t[g][5], t[g][6]);
-            group_slow<NE>(ent1, c, gr, t[g][2], t[g][7], t[g][8], t[g][9], t[g][10]);
+            group_fast<NE1, true>(ent1, c, gr, t[g][0], t[g][3], t[g][4], t[g][5], t[g][6]);
+            group_slow<NE1>(ent1, c, gr, t[g][2], t[g][7], t[g][8], t[g][9], t[g][10]);
         }
         t[g][1] = bf_hi(bf_lo(gr.x[0], gr.x[2], 2, c.m2), bf_lo(gr.x[1], gr.x[3], 2, c.m2), 1, c.m1);     // agent: bit 1
     }
@@ -656,7 +665,14 @@ SL_PL_DEV void planes_load(const V (&b)[(W + 1) / 2], const PConsts &c, PState<P
 template <int W>
 SL_PL_DEV Pl<PG<W>::NW> with_seams(const Pl<PG<W>::NW> &m) {
     using G = PG<W>;
-    if constexpr (G::NW == 2) {
+    if constexpr (G::SPLIT) {       // every word has its own seams: bit 0 and bit WS + 1 copy cells of the other word
+        constexpr int WS = G::WS;
+        const V a = m.w[0], b = m.w[1];
+        Pl<G::NW> out;
+        out.w[0] = (a & pconst(G::REAL)) | (pshr(b, WS) & pconst(1u)) | (pshl(b, WS) & pconst(1u << (WS + 1)));   // cell W-1, cell WS
+        out.w[1] = (b & pconst(G::REAL)) | (pshr(a, WS) & pconst(1u)) | (pshl(a, WS) & pconst(1u << (WS + 1)));   // cell WS-1, cell 0
+        return out;
+    } else if constexpr (G::NW == 2) {
         return m;
     } else {
         constexpr int WS = G::WS, WH = G::WH;
@@ -676,10 +692,11 @@ SL_PL_DEV Pl<PG<W>::NW> with_seams(const Pl<PG<W>::NW> &m) {
 template <int W, int VERT, bool SPAWN, class Draw>
 SL_PL_DEV bool planes_step(PState<PG<W>::NW> &st, const VCtx<VERT> &vc, const V &realm_word, Draw &&draw) {
     constexpr int NW = PG<W>::NW;
+    constexpr bool SPLIT = PG<W>::SPLIT;
     Pl<NW> realm;
 #pragma unroll
     for (int i = 0; i < NW; ++i) realm.w[i] = realm_word;
-    const Verdict<NW> v = decide<VERT, NW, SPAWN>(vc, st.A, st.Z, st.P, st.I, st.S, realm);
+    const Verdict<NW> v = decide<VERT, NW, SPAWN, SPLIT>(vc, st.A, st.Z, st.P, st.I, st.S, realm);
     Pl<NW> spawned = qzero<NW>();
     if (SPAWN) {
         const Pl<NW> elig = SL_QB3(TA & ~TB & TC, v.dead_free, v.is3, v.fS);
@@ -691,11 +708,11 @@ SL_PL_DEV bool planes_step(PState<PG<W>::NW> &st, const VCtx<VERT> &vc, const V 
     const bool births = qany(fresh);
     Pl<NW> nvD = qzero<NW>(), nvC[3] = {qzero<NW>(), qzero<NW>(), qzero<NW>()};
     if (births) {
-        nvD = v.born & seen_twice<VERT, NW>(vc, SL_QB3((TA | TB) & TC, st.X, st.D, st.A));
+        nvD = v.born & seen_twice<VERT, NW, SPLIT>(vc, SL_QB3((TA | TB) & TC, st.X, st.D, st.A));
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const Pl<NW> tw = seen_twice<VERT, NW>(vc, st.C[j] & st.A);
-            if (SPAWN) nvC[j] = SL_QB3(TA & (TB | TC), fresh, tw, (box_or<VERT, NW>(vc, st.S & st.C[j])));
+            const Pl<NW> tw = seen_twice<VERT, NW, SPLIT>(vc, st.C[j] & st.A);
+            if (SPAWN) nvC[j] = SL_QB3(TA & (TB | TC), fresh, tw, (box_or<VERT, NW, SPLIT>(vc, st.S & st.C[j])));
             else nvC[j] = fresh & tw;
         }
         if (SPAWN) nvD = nvD | spawned;
@@ -758,6 +775,14 @@ SL_PL_DEV void planes_store(V (&b)[(W + 1) / 2], const PConsts &c, const PState<
         group_back(f, d, cc, c, lo, hi);
 #pragma unroll
         for (int k = 0; k < (NW == 1 ? WS : 16); ++k) {
+            if (G::SPLIT) {         // entry 16 grp + k = word 16 grp + k - 1
+                const int word = 16 * grp + k - 1;
+                if (word >= 0 && word < WS) {
+                    const V m = pmul24(pshr(gsrc[grp], k) & c.one2, 0xFFFFu);
+                    b[word] = SL_PB3((TA & ~TB) | TC, b[word], m, group_entry(lo, hi, k));
+                }
+                continue;
+            }
             const int word = NW == 1 ? k : 16 * grp + k;
             const V nmw = group_entry(lo, hi, NW == 1 ? k + 1 : k);
             const V m = pmul24(pshr(gsrc[grp], NW == 1 ? k + 1 : k) & c.one2, 0xFFFFu);

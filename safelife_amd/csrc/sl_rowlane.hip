@@ -815,7 +815,12 @@ __device__ pl::Pl<NW> resolve_draws_planes(const pl::Pl<NW> &elig, u64 *rng_lds,
 // whether any cell of the wave changed -- the word form does not know and says yes.  `take`: the lane takes the
 // new row even if it is not `mine` (the halo copies of the word form compute their own rows).
 template <int H, int W>
-constexpr bool use_planes_multi() { return (W + 1) / 2 + 2 <= 16 || W == 64; }     // rows kept in plane form across steps
+#ifndef SL_SPLIT_PLANES_MULTI
+#define SL_SPLIT_PLANES_MULTI 1 /* A/B knob: 0 = advance_board (n > 1) and life_occupancy keep rows of 32..48 cells in word form */
+#endif
+constexpr bool use_planes_multi() {                     // rows kept in plane form across steps
+    return (W + 1) / 2 + 2 <= 16 || W == 64 || (SL_SPLIT_PLANES_MULTI && W >= 32 && W < 64 && (W & 1) == 0);
+}
 template <int H, int W>
 constexpr bool use_planes() {       // single steps: also even rows of 32 to 60 cells (two words per plane, one per half;
                                     // at 30 cells the word form is the faster one: 8.8 against 9.3-9.8 us per step)
@@ -1505,7 +1510,9 @@ __global__ __launch_bounds__(64) void k_occupancy_rowlane(const u16 *__restrict_
                     u32 val = 0;
 #pragma unroll
                     for (int k = 0; k < MINI_BITS; ++k) val |= ((mini[sl][k][i] >> pos) & 1u) << k;
-                    const int x = NW == 2 ? 32 * i + pos : (pos < 16 ? pos - 1 : pos - 17 + WS);     // the cell's column
+                    // the cell's column (split two-word planes: word i holds cells i WS .. from bit 1 on)
+                    const int x = pl::PG<PLANES ? W : 8>::SPLIT ? i * WS + pos - 1
+                                                                  : NW == 2 ? 32 * i + pos : (pos < 16 ? pos - 1 : pos - 17 + WS);
                     __hip_atomic_fetch_add(cnt + x * Oc::CELL_DWORDS + sl / Oc::PER_DWORD,
                                            val << (Oc::CB * (sl % Oc::PER_DWORD)), __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WAVEFRONT);

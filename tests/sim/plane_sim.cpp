@@ -128,16 +128,14 @@ static void run(int VERT, int H, int B, int steps, bool persistent, std::vector<
             }
         };
         bool kept = false;
-        if constexpr (!PG<W>::SPLIT) {      // (the split two-word layout of rows of 30 to 60 cells is single-step only)
-            if (persistent) {       // the rows stay in plane form for all the steps
-                load_rows();
-                PState<NW> st;
-                planes_load<W>(b, cst, st);
-                for (int s = 0; s < steps; ++s) planes_step<W, 0, SPAWN>(st, vc, realm, draw);
-                planes_store<W>(b, cst, st);
-                store_rows();
-                kept = true;
-            }
+        if (persistent) {           // the rows stay in plane form for all the steps
+            load_rows();
+            PState<NW> st;
+            planes_load<W>(b, cst, st);
+            for (int s = 0; s < steps; ++s) planes_step<W, 0, SPAWN>(st, vc, realm, draw);
+            planes_store<W>(b, cst, st);
+            store_rows();
+            kept = true;
         }
         if (!kept) {
             for (int s = 0; s < steps; ++s) {

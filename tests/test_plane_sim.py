@@ -82,7 +82,8 @@ def test_plane_step_known_patterns(sim, tmp_path):
     assert np.array_equal(got, exp)
 
 
-@pytest.mark.parametrize("H,W", [(25, 25), (26, 26), (10, 10), (25, 10), (9, 27), (40, 5), (64, 64), (20, 64)])
+@pytest.mark.parametrize("H,W", [(25, 25), (26, 26), (10, 10), (25, 10), (9, 27), (40, 5), (64, 64), (20, 64),
+                                 (32, 32), (40, 40), (48, 48), (30, 30), (12, 40)])
 def test_planes_kept_across_steps_match_oracle(sim, tmp_path, H, W):
     """The multi-step form (life_occupancy's thousand steps): one transposition in, the row stays in plane form --
     seam bits and the V_SHIFT halo lanes follow through the masks each step applies -- and one merge out."""

@@ -11,7 +11,8 @@ from safelife_amd import speedups as sp
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-SHAPES = [(25, 25), (26, 26), (64, 64), (15, 15), (20, 20), (10, 10), (3, 3), (5, 40), (33, 7), (9, 9), (100, 100)]
+SHAPES = [(25, 25), (26, 26), (64, 64), (15, 15), (20, 20), (10, 10), (3, 3), (5, 40), (33, 7), (9, 9), (100, 100),
+          (8, 8), (12, 12), (16, 16), (24, 24), (30, 30), (32, 32), (40, 40), (48, 48)]
 t_end, n = time.time() + budget, 0
 while time.time() < t_end:
     H, W = SHAPES[rng.integers(0, len(SHAPES))]
