@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SL_ABI_VERSION 10       /* 10: slhip_queues_open_on, slhip_queues_stream_shares, slhip_gather_stream_shares, slhip_gather_poke */
+#define SL_ABI_VERSION 11       /* 11: sl_env_batch.goal_cache, slhip_goal_cache_bytes; 10: slhip_queues_open_on, slhip_queues_stream_shares, slhip_gather_stream_shares, slhip_gather_poke */
 #define SL_MAX_CELLS 16384        /* H*W limit of one board */
 #define SL_MAX_CHANNELS 32
 
@@ -268,6 +268,13 @@ typedef struct sl_env_batch {
     /* workspace */
     int8_t *score_lut;           /* [n_tables,4096+65536] per-cell score tables derived from points_table by
                                     slhip_env_prepare(); NULL => the size-generic kernels are used */
+    uint32_t *goal_cache;        /* optional workspace of slhip_goal_cache_bytes() bytes, 16-byte aligned, ZEROED by the
+                                    caller: the fused step kernels keep the goal colours of boards whose goals are
+                                    static (safelife_game.py:753-760) in the form their lanes use, and a launch whose
+                                    boards all have them there moves no goal array at all.  The kernels maintain it
+                                    across steps, resets and slices; whoever writes `goals`, `scalars.goals_static` or
+                                    `scalars.level_idx` from OUTSIDE the library zeroes it again.  Only batches without
+                                    observation, wrappers and finished-episode queue use it.  NULL = none */
     sl_wrappers wrap;            /* training wrappers; wrap.flags == 0 => none */
     sl_episode_queue finished;   /* episodes that ended, for the side-effect pass; finished.capacity == 0 => none */
 } sl_env_batch;
@@ -277,6 +284,11 @@ typedef struct sl_env_batch {
  * Synchronises the stream.  Returns SL_E_UNSUPPORTED when a table entry does not fit int8; the
  * caller then passes score_lut = NULL and every shape runs on the size-generic kernels. */
 int slhip_env_prepare(const sl_env_batch *env, void *stream);
+
+/* Bytes of env->goal_cache for this batch (0: the board shape has no row kernels -- leave goal_cache NULL).
+ * *boards_per_block (optional): the cache is one block of bytes / ceil(B / boards_per_block) bytes per group of that many
+ * consecutive envs; a block's first 32-bit word is its flag (1: the group steps on cached goal words). */
+size_t slhip_goal_cache_bytes(const sl_env_batch *env, int *boards_per_block);
 
 /* SafeLifeEnv.reset() for the envs with mask[e] != 0 (mask NULL = all): an env that has never been loaded
  * takes pool level level_idx[e]; any other moves on to (level_idx[e] + level_stride) % L and counts an

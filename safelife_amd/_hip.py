@@ -20,7 +20,7 @@ SL_E_SHAPE, SL_E_ARG, SL_E_HIP, SL_E_UNSUPPORTED = -1, -2, -3, -4
 EXPORTS = (
     "slhip_abi_version", "slhip_last_error", "slhip_device_count",
     "slhip_advance_board", "slhip_advance_board_each", "slhip_life_occupancy", "slhip_alive_counts", "slhip_execute_actions",
-    "slhip_env_prepare", "slhip_env_reset", "slhip_env_step", "slhip_env_step_slices", "slhip_env_step_range", "slhip_env_rollout",
+    "slhip_env_prepare", "slhip_goal_cache_bytes", "slhip_env_reset", "slhip_env_step", "slhip_env_step_slices", "slhip_env_step_range", "slhip_env_rollout",
     "slhip_streams_concurrent", "slhip_streams_order",
     "slhip_env_obs",
     "slhip_obs_to_policy", "slhip_sample_actions", "slhip_side_effects",
@@ -53,7 +53,7 @@ ENV_SCALARS_HEAD = ("B", "H", "W", "E", "time_limit", "exit_points", "n_tables",
 ENV_STATE_PTRS = ("board", "goals", "exit_locs", "rng", "scalars", "points_table")
 ENV_POOL_PTRS = ("pool_board", "pool_goals", "pool_exit_locs", "pool_rng", "pool_scalars")
 ENV_OUT_PTRS = ("out", "obs", "score_lut")
-SL_ABI_VERSION = 10
+SL_ABI_VERSION = 11
 
 #: int32 column of each field inside `struct sl_env_scalars` (64 bytes = 16 columns)
 SCALAR_COLS = {"agent_row": 0, "agent_col": 1, "num_steps": 2, "old_value": 3, "required_points": 4,
@@ -105,7 +105,7 @@ class EnvBatch(C.Structure):
         + [("L", C.c_int32), ("level_stride", C.c_int32)]
         + [(n, _p) for n in ENV_POOL_PTRS]
         + [("out", _p), ("obs", _p), ("policy_obs", _p), ("policy_dtype", C.c_int32), ("reserved1", C.c_int32),
-           ("score_lut", _p)]
+           ("score_lut", _p), ("goal_cache", _p)]
         + [("wrap", Wrappers), ("finished", EpisodeQueue)]
     )
 
@@ -136,6 +136,9 @@ def lib():
         L.slhip_execute_actions.argtypes = [_p, C.c_int, C.c_int, C.c_int, _p, _p, C.c_int, C.c_int,
                                             C.c_int, _p]
         L.slhip_env_prepare.argtypes = [C.POINTER(EnvBatch), _p]
+        if hasattr(L, "slhip_goal_cache_bytes"):
+            L.slhip_goal_cache_bytes.argtypes = [C.POINTER(EnvBatch), C.POINTER(C.c_int)]
+            L.slhip_goal_cache_bytes.restype = C.c_size_t
         L.slhip_env_reset.argtypes = [C.POINTER(EnvBatch), _p, _p]
         L.slhip_env_step.argtypes = [C.POINTER(EnvBatch), _p, _p]
         L.slhip_env_step_slices.argtypes = [C.POINTER(EnvBatch), C.c_int, _p, _p, _p]

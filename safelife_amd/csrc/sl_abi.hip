@@ -229,6 +229,8 @@ struct GatherRequest {
     long long ticket;
     long long marker;       // >= 0: the window was written from the library's AQL queues; the worker waits for this
                             // marker of theirs (slhip_queues_marker) instead of ordering streams
+    const volatile uint32_t *placement;     // release-free queues: their placement word -- a window whose steps ran on the
+                                            // wrong XCD is not handed to RCCL (null: stream's fences, nothing to check)
 };
 struct GatherComm {
     void *comm;
@@ -358,6 +360,20 @@ int slhip_env_prepare(const sl_env_batch *env, void *stream) {
     return err == hipSuccess ? SL_OK : hip_fail(err, "env_prepare launch");
 }
 
+size_t slhip_goal_cache_bytes(const sl_env_batch *env, int *boards_per_block) {
+    if (boards_per_block) *boards_per_block = 0;
+    if (!env || env->B <= 0 || force_generic()) return 0;
+    return sl::rowlane_goal_cache_bytes(env->H, env->W, env->B, boards_per_block);
+}
+
+// A launch of the size-generic kernels on a batch that carries a goal-word cache: they load levels without keeping its
+// flags, so every flag goes down first (the row kernels' launcher does the same for its own odd launches).
+static hipError_t drop_goal_cache(const sl_env_batch *env, hipStream_t st) {
+    if (!env->goal_cache) return hipSuccess;
+    const size_t bytes = sl::rowlane_goal_cache_bytes(env->H, env->W, env->B);
+    return bytes ? hipMemsetAsync(env->goal_cache, 0, bytes, st) : hipSuccess;
+}
+
 static bool use_rowlane(const sl_env_batch *env, int e_first);
 int slhip_env_reset(const sl_env_batch *env, const uint8_t *mask, void *stream) {
     int rc = check_env(env);
@@ -372,7 +388,8 @@ int slhip_env_reset(const sl_env_batch *env, const uint8_t *mask, void *stream) 
         err = sl::launch_env_rollout_rowlane(*env, 0, env->B, (const int32_t *)env->scalars, -1, env->B, nullptr, nullptr, jump,
                                              (hipStream_t)stream, nullptr, mask);
     } else {
-        err = sl::launch_env_reset_generic(*env, mask, (hipStream_t)stream);
+        err = drop_goal_cache(env, (hipStream_t)stream);
+        if (err == hipSuccess) err = sl::launch_env_reset_generic(*env, mask, (hipStream_t)stream);
     }
     return err == hipSuccess ? SL_OK : hip_fail(err, "env_reset launch");
 }
@@ -424,6 +441,7 @@ static int rollout_range(const sl_env_batch *env, int e_first, int e_count, cons
             return fail(SL_E_UNSUPPORTED, "the inaction baseline advances between steps: T must be 1 on the generic kernels");
         if (T > 1 && e_count != env->B) return fail(SL_E_UNSUPPORTED, "T-step launches of a slice need the row kernels");
         const sl_env_batch s = env_slice(*env, e_first, e_count);
+        if ((err = drop_goal_cache(env, (hipStream_t)stream)) != hipSuccess) return hip_fail(err, "goal cache");
         if (inaction && (err = sl::launch_inaction_generic(s, jump, (hipStream_t)stream)) != hipSuccess)
             return hip_fail(err, "inaction baseline launch");
         err = sl::launch_env_rollout_generic(s, actions + e_first, T, reward_t ? reward_t + e_first : nullptr,
@@ -974,57 +992,79 @@ int slhip_gather_stream_shares(void *comm, int n_queues, void *stream, int *mask
     GatherComm *g = (GatherComm *)comm;
     if (!g || !mask || n_queues < 1 || n_queues > 8) return fail(SL_E_ARG, "bad arguments (1 to 8 queues)");
     *mask = 0;
-    if (const char *why = sl::aql_open(n_queues)) return fail(SL_E_UNSUPPORTED, std::string("AQL queues unavailable: ") + why);
+    // COLLECTIVE: every rank issues the same 5 * n_queues exchanges whatever happens to it locally -- a rank whose queues
+    // or probe kernel are unavailable still takes part (its peers would otherwise block inside RCCL's group for ever)
+    // and reports its error afterwards.  Only a rank that cannot even allocate the exchange's buffers leaves early.
+    std::string local_why;
+    if (const char *why = sl::aql_open(n_queues)) local_why = std::string("AQL queues unavailable: ") + why;
     hipFunction_t f = nullptr;
-    if (hipGetFuncBySymbol(&f, (const void *)sl::k_xcd_probe) != hipSuccess || sl::aql_probe(f)) {
+    if (local_why.empty() && (hipGetFuncBySymbol(&f, (const void *)sl::k_xcd_probe) != hipSuccess || sl::aql_probe(f))) {
         (void)hipGetLastError();
-        return fail(SL_E_UNSUPPORTED, "the probe kernel was not found");
+        local_why = "the probe kernel was not found";
     }
     const size_t bytes = 8u << 20;
     char *send = nullptr, *recv = nullptr;
     uint32_t *out = nullptr;
     hipError_t err = hipMalloc((void **)&send, bytes);
     if (err == hipSuccess && g->rank == 0) err = hipMalloc((void **)&recv, bytes * (size_t)g->world);
-    if (err == hipSuccess) err = hipMalloc((void **)&out, 64);
+    if (err != hipSuccess) {
+        if (send) (void)hipFree(send);
+        return hip_fail(err, "gather_stream_shares (exchange buffers)");
+    }
+    if (local_why.empty() && hipMalloc((void **)&out, 64) != hipSuccess) {
+        (void)hipGetLastError();
+        local_why = "no memory for the probe's output";
+    }
     const hipStream_t st = (hipStream_t)stream;
     struct {
         uint32_t *out;
     } args = {out};
     int rc = SL_OK;
+    hipError_t probe_err = hipSuccess;              // local: the one-workgroup dispatches
     auto tiny = [&](int q, double *us) {            // one workgroup on queue q, host time until it is back
+        *us = 0;
+        if (!local_why.empty() || probe_err != hipSuccess) return;
         const auto t0 = std::chrono::steady_clock::now();
         hipError_t e = sl::aql_dispatch(sl::AqlLaunch{q, false, false}, f, 1, 256, 0, &args, sizeof(args));
         if (e == hipSuccess) e = sl::aql_fence(n_queues);
         *us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-        return e;
+        probe_err = e;
     };
+    constexpr int REPS = 5;
     double alone[8], behind[8];
-    for (int q = 0; q < n_queues && err == hipSuccess && rc == SL_OK; ++q) {
+    for (int q = 0; q < n_queues; ++q) {
         alone[q] = behind[q] = 1e30;
-        for (int rep = 0; rep < 3 && err == hipSuccess && rc == SL_OK; ++rep) {
+        for (int rep = 0; rep < REPS; ++rep) {
             double us = 0;
-            err = hipStreamSynchronize(st);
-            if (err == hipSuccess) err = sl::aql_fence(n_queues);
-            if (err == hipSuccess) err = tiny(q, &us);
+            (void)hipStreamSynchronize(st);
+            if (local_why.empty() && probe_err == hipSuccess) probe_err = sl::aql_fence(n_queues);
+            tiny(q, &us);
             alone[q] = std::min(alone[q], us);
-            if (err != hipSuccess) break;
-            rc = gather_issue(g, send, recv, bytes, st);
-            if (rc == SL_OK) err = tiny(q, &us);
+            if (rc == SL_OK) rc = gather_issue(g, send, recv, bytes, st);      // (an RCCL error is every rank's error)
+            tiny(q, &us);
             if (rep > 0) behind[q] = std::min(behind[q], us);      // (the first exchange of a stream sets things up)
         }
         // (measured: 9 us alone and 9-10 us behind the exchange on a queue it does not touch; 15 and 22 us on the one
-        //  that shares a pipe with the stream's hardware queue)
-        if (err == hipSuccess && rc == SL_OK && behind[q] > alone[q] + 3.0) *mask |= 1 << q;
+        //  that shares a pipe with the stream's hardware queue.  Minima over the repetitions: host noise only ever adds.)
+        if (local_why.empty() && probe_err == hipSuccess && rc == SL_OK && behind[q] > alone[q] + 3.0) *mask |= 1 << q;
     }
-    if (err == hipSuccess) err = hipStreamSynchronize(st);
+    err = hipStreamSynchronize(st);
     if (getenv("SL_GATHER_DEBUG"))
         for (int q = 0; q < n_queues; ++q)
             fprintf(stderr, "gather_stream_shares: queue %d alone %.1f us, behind the exchange %.1f us\n", q, alone[q], behind[q]);
     (void)hipFree(send);
     if (recv) (void)hipFree(recv);
-    (void)hipFree(out);
+    if (out) (void)hipFree(out);
     if (rc != SL_OK) return rc;
     if (err != hipSuccess) return hip_fail(err, "gather_stream_shares");
+    if (!local_why.empty()) {
+        *mask = 0;
+        return fail(SL_E_UNSUPPORTED, local_why);
+    }
+    if (probe_err != hipSuccess) {
+        *mask = 0;
+        return hip_fail(probe_err, "gather_stream_shares (probe dispatch)");
+    }
     return SL_OK;
 }
 
@@ -1058,6 +1098,9 @@ static void gather_worker(GatherComm *g) {
         // a window written from the AQL queues: their marker (system-scope release behind the window's last step) is
         // waited for HERE, on this thread -- the stepping thread keeps dispatching the next window's steps meanwhile
         if (rq.marker >= 0 && sl::aql_wait(rq.marker) != hipSuccess) rc = SL_E_HIP;
+        // (release-free stepping: the same verdict slhip_queues_wait would give -- records of envs that may have read
+        //  stale state never reach rank 0; the ticket fails and every later call on the communicator says so)
+        if (rc == SL_OK && rq.placement && *rq.placement) rc = SL_E_HIP;
         for (int i = 0; i < rq.n_writers && rc == SL_OK; ++i) {     // the exchange's stream waits for the window's writers
             if (rq.writers[i] == rq.stream) continue;
             hipError_t err = hipEventRecord(g->order_ev[i], rq.writers[i]);
@@ -1076,7 +1119,7 @@ static void gather_worker(GatherComm *g) {
 }
 
 static int gather_submit(void *comm, const void *send, void *recv, size_t bytes, void *const *writers, int n_writers,
-                         void *stream, long long marker, long long *ticket);
+                         void *stream, long long marker, long long *ticket, const volatile uint32_t *placement = nullptr);
 int slhip_gather_window_async(void *comm, const void *send, void *recv, size_t bytes, void *const *writers, int n_writers,
                               void *stream, long long *ticket) {
     return gather_submit(comm, send, recv, bytes, writers, n_writers, stream, -1, ticket);
@@ -1089,11 +1132,12 @@ int slhip_gather_window_queued(void *comm, const void *send, void *recv, size_t 
     if (!queues) return fail(SL_E_ARG, "null pointer");
     const int rc = slhip_queues_marker(queues, &marker);
     if (rc) return rc;
-    return gather_submit(comm, send, recv, bytes, nullptr, 0, stream, marker, ticket);
+    const StepQueues *c = (const StepQueues *)queues;
+    return gather_submit(comm, send, recv, bytes, nullptr, 0, stream, marker, ticket, c->release_free ? c->flag : nullptr);
 }
 
 static int gather_submit(void *comm, const void *send, void *recv, size_t bytes, void *const *writers, int n_writers,
-                         void *stream, long long marker, long long *ticket) {
+                         void *stream, long long marker, long long *ticket, const volatile uint32_t *placement) {
     GatherComm *g = (GatherComm *)comm;
     if (!g || !send || (g->rank == 0 && !recv) || n_writers < 0 || n_writers > 8 || (n_writers && !writers) || !ticket)
         return fail(SL_E_ARG, "bad gather arguments");
@@ -1112,6 +1156,7 @@ static int gather_submit(void *comm, const void *send, void *recv, size_t bytes,
     rq.send = send, rq.recv = recv, rq.bytes = bytes, rq.n_writers = n_writers, rq.stream = (hipStream_t)stream;
     for (int i = 0; i < n_writers; ++i) rq.writers[i] = (hipStream_t)writers[i];
     rq.marker = marker;
+    rq.placement = placement;
     rq.ticket = g->submitted++;
     *ticket = rq.ticket;
     g->queue.push_back(rq);

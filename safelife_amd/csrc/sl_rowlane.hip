@@ -2173,6 +2173,38 @@ static_assert(sizeof(BoardBox) == 32, "mailbox stride");
 template <int H, int W, bool LEAN>
 constexpr bool leadx() { return LEAN && Geom<H, W>::LEADX_OK; }
 
+// ---- the goal-word cache (round 5) ----------------------------------------------------------------------------------
+// Goals are static in nearly every level (safelife_game.py:753-760 finds that out once per episode), yet every launch
+// moved the workgroup's goal span into LDS, had every lane read its goal row back out of the image (14 LDS reads),
+// re-assemble the split-halves words (26 permutes) and shift the colours into the score index (26 more) -- ~0.35 us of a
+// 6.2 us step by the timing-only builds of round 4.  The LEAN kernels now KEEP those words: a workgroup whose boards all
+// have static goals writes each lane's WS pre-shifted goal words (goal_shift) to a per-workgroup block of `goal_cache`, in
+// the order the lanes read them back (16 bytes per lane and 1 KiB per wave instruction, then single dwords), and raises
+// the workgroup's flag word; a launch that finds the flag raised moves no goal span at all and loads the words straight
+// into registers, under the board's DMA.  A board that resets (or whose goals evolve) lowers the flag in the same
+// launch, and the next launch takes the LDS route again and decides anew.  Same bytes per env-step as the goal span
+// (WS dwords per row lane instead of W cells), no LDS traffic, no vector instructions.
+//
+// Layout: one block per workgroup of the BATCH (env index / NB: launches start at multiples of NB -- the launcher passes
+// no cache otherwise), whatever slice, queue or stream steps it: a 256-byte header whose first dword is the flag, then
+// WAVES x WS x 64 dwords.  Zeroing the whole cache lowers every flag.
+template <int H, int W>
+struct GoalCache {
+    using Gm = Geom<H, W>;
+    static constexpr int X4 = Gm::WS / 4, TAIL = Gm::WS % 4;       // 16-byte loads per lane, then single dwords
+    static constexpr int WAVE_DWORDS = Gm::WS * 64;
+    static constexpr int HEAD_DWORDS = 64;
+    static constexpr int BLOCK_DWORDS = HEAD_DWORDS + WAVES * WAVE_DWORDS;
+    static __host__ __device__ constexpr size_t bytes(int B) { return 4 * (size_t)((B + Gm::NB - 1) / Gm::NB) * BLOCK_DWORDS; }
+    // the lane's words of wave `wave` of block `blk`: words 4c..4c+3 at x4(c), word 4 X4 + j at tail(j)
+    static __device__ __forceinline__ u32x4 *x4(u32 *blk, int wave, int lane, int c) {
+        return (u32x4 *)(blk + HEAD_DWORDS + wave * WAVE_DWORDS + c * 256 + lane * 4);
+    }
+    static __device__ __forceinline__ u32 *tail(u32 *blk, int wave, int lane, int j) {
+        return blk + HEAD_DWORDS + wave * WAVE_DWORDS + X4 * 256 + j * 64 + lane;
+    }
+};
+
 #ifndef SL_SPAWN_GSH_REG
 #define SL_SPAWN_GSH_REG 1      /* A/B knob: the LEAN single-step spawner variant keeps the goal words in registers (1) or
                                    takes the move box (0) -- both together tip it into scratch */
@@ -2205,8 +2237,12 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     // the eight arguments the prologue needs before anything else come first: with
     // -amdgpu-kernarg-preload-count=8 they arrive in SGPRs with the wave instead of behind an s_load
     const u16 *__restrict__ hot_board, const u16 *__restrict__ hot_goals, const sl_pcg64 *__restrict__ hot_rng,
-    sl_env_scalars *__restrict__ hot_scalars, const int8_t *__restrict__ hot_lut,
+    sl_env_scalars *__restrict__ hot_scalars,
+    // the goal-word cache of the batch (GoalCache above), or null: its flag word is the kernel's first fetch
+    u32 *__restrict__ hot_gcache,
     const int32_t *__restrict__ actions, int hot_first, int hot_end,
+    // (the preload ends here -- 14 SGPRs next to the kernarg pointer; the score table's DMA is the last to be issued)
+    const int8_t *__restrict__ hot_lut,
     // The batch constants travel by value.  (Measured alternative: the struct resident in device memory behind
     // a pointer -- ~100 bytes of arguments instead of ~700 -- is SLOWER, 12.1 vs 11.5 us per C3 step and 16.6 vs
     // 13.8 in the first steps after a reset: loads through a global pointer are not invariant for the compiler,
@@ -2269,6 +2305,23 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     constexpr int OFF_LUT_V = SHRINK ? Gm::OFF_GSH : Gm::OFF_LUT, OFF_MOVE_V = SHRINK ? Gm::OFF_GSH + 4096 : Gm::OFF_MOVE;
     u32 gsh_reg[GSH_REG ? WS : 1];
     u32 *gsh_lane = GSH_REG ? gsh_reg : (u32 *)(smem + Gm::OFF_GSH) + (wave * 64 + lane) * WS;
+    // the goal-word cache (GoalCache above): LEAN kernels whose goal words live in registers
+    constexpr bool GCACHE = LEAN && GSH_REG && !LEADX;
+    using Gc = GoalCache<H, W>;
+    u32 *const gc_block = GCACHE && hot_gcache ? hot_gcache + (size_t)((unsigned)hot_first / Gm::NB + blockIdx.x) * Gc::BLOCK_DWORDS
+                                               : nullptr;
+    u32 *const gc_flag = gc_block;
+    // (wave-uniform) this launch runs without the goal span: every board of the workgroup has static goals and its words
+    // are in the cache.  Step launches only: a reset launch rewrites goals, an observation launch reads the image.
+    // The flag is FETCHED here, first thing, and LOOKED AT where the goal span would be issued (gc_look below) -- behind
+    // the record loads and the board's DMA instructions, so that its round trip runs under them.
+    u32 gc_word = 0;
+    if (GCACHE && gc_flag && T > 0) gc_word = *(const u32 *)gc_flag;
+    bool goals_free = false;
+    auto gc_look = [&]() {
+        asm volatile("" : "+s"(gc_word));
+        goals_free = GCACHE && gc_word == 1u;
+    };
     const int8_t *lds_lut = (const int8_t *)(smem + OFF_LUT_V);
     // wrappers: this wave's baseline rows, word k of lane l at [k * 64 + l] (the layout the b32 DMA writes)
     constexpr bool BASE_IN_GSH = GSH_REG && Gm::GSH_BYTES >= WAVES * 64 * WS * 4;
@@ -2291,8 +2344,8 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     // s_load next to its first use: dependent scalar-cache round trips in a row).
     const u16 *k_board = hot_board, *k_goals = hot_goals;
     const sl_pcg64 *k_rng = hot_rng;
-    const int8_t *k_lut = hot_lut;
-    asm volatile("" ::"s"(k_board), "s"(k_goals), "s"(k_rng), "s"(k_lut));
+    const int8_t *k_lut = hot_lut;                      // (not preloaded: its DMA goes last, behind the look at the flag)
+    asm volatile("" ::"s"(k_board), "s"(k_goals), "s"(k_rng));
     // what the rows need of their board's record (every lane loads, unconditionally: a load inside a branch is
     // waited for at the end of that branch, in front of the DMA issue)
     const sl_env_scalars *const sc = hot_scalars + e;
@@ -2327,15 +2380,17 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
             pre_c[2] = src[gi[2]];
             pre_c[3] = src[gi[3]];
         }
+        gc_look();
     } else {
         // everything bulky goes through the LDS DMA, issued by the waves that are not the leader
         constexpr int DW = LEADX ? WAVES : WAVES - 1;
         const int dw = LEADX ? wave : wave - 1;
         dma_to_lds<Gm::NB * 32, false, DW>((const unsigned char *)(k_rng + e0b), smem + Gm::OFF_RNG, nbb * 32, lane, dw);
         dma_to_lds<Gm::NB * 64, false, DW>((const unsigned char *)(hot_scalars + e0b), smem + Gm::OFF_REC, nbb * 64, lane, dw);
-        if (LDS_LUT) dma_to_lds<4096, false, DW>((const unsigned char *)k_lut, smem + OFF_LUT_V, 4096, lane, dw);
         load_span<H, W, DW>(k_board + (size_t)e0b * HW, board, nbb, lane, dw);
-        load_span<H, W, DW>(k_goals + (size_t)e0b * HW, goals, nbb, lane, dw);
+        gc_look();
+        if (!goals_free) load_span<H, W, DW>(k_goals + (size_t)e0b * HW, goals, nbb, lane, dw);
+        if (LDS_LUT) dma_to_lds<4096, false, DW>((const unsigned char *)k_lut, smem + OFF_LUT_V, 4096, lane, dw);
         if (WRAP) {
             dma_to_lds<Gm::NB * (int)sizeof(sl_wrap_state), false, DW>((const unsigned char *)(env.wrap.state + e0b),
                                                                        smem + Gm::OFF_WST,
@@ -2349,6 +2404,19 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
                                                    smem + OFF_INB + Gm::REGION, nbb * 32, lane, dw);
             }
         }
+    }
+    if (GCACHE && goals_free && live) {
+        // the lane's goal words, as an earlier launch left them (GoalCache): straight into the registers the score reads
+#pragma unroll
+        for (int c = 0; c < Gc::X4; ++c) {
+            const u32x4 v = *Gc::x4(gc_block, wave, lane, c);
+            gsh_reg[4 * c + 0] = v.x;
+            gsh_reg[4 * c + 1] = v.y;
+            gsh_reg[4 * c + 2] = v.z;
+            gsh_reg[4 * c + 3] = v.w;
+        }
+#pragma unroll
+        for (int j = 0; j < Gc::TAIL; ++j) gsh_reg[4 * Gc::X4 + j] = *Gc::tail(gc_block, wave, lane, j);
     }
 #ifndef SL_MOVE_BOX
 #define SL_MOVE_BOX 1           /* A/B knob: 0 = the round-3 form of the move (leader writes the image, a barrier of its own) */
@@ -2413,8 +2481,9 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     //  "defined, value irrelevant" costs no instruction, thirteen zeroing moves would)
 #pragma unroll
     for (int k = 0; k < WS; ++k) asm volatile("" : "=v"(b[k]));
+    if (GCACHE && goals_free) gstatic = 1;           // (what the flag vouches for; the goal image does not exist in this launch)
     if (rwave) {
-    if (live) {
+    if (live && !goals_free) {
         read_row<H, W>(goals, gb, r, b);
 #pragma unroll
         for (int k = 0; k < WS; ++k) gsh_lane[k] = goal_shift(b[k]);
@@ -2440,8 +2509,11 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     // What the leaders ask of the rows at the end of a step -- queue the finished episode's board, load the next
     // level -- is carried out behind the NEXT workgroup barrier: the one at the top of the following step, or the
     // one in front of the final stores.
+    bool any_reset = false;             // (wave-uniform) some board of the workgroup loaded a level in this launch
+    bool goal_row_dirty = false;        // the lane's goal row in the image differs from global memory
     auto hand_over_block = [&]() {
         const int any = box[0].any;
+        if (any & 1) any_reset = true;
         if (!LEAN && (any & 2)) {
             // the step that ended an episode queued it for the side-effect pass (include/safelife_hip.h): the board
             // as the agent left it, from the LDS image, before any reset reloads the slot
@@ -2490,6 +2562,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
             for (int k = r2; k < E; k += H)
                 env.exit_locs[(size_t)e * E + k] = env.pool_exit_locs[(size_t)level * E + k];
             *dirty_flag = 1;                             // (any wave that changes its goals raises the flag)
+            goal_row_dirty = true;
             if (r2 == 0) box[gb].dirty = 1;              // (and the whole board is new)
         }
         wave_sync();
@@ -2674,6 +2747,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
 #pragma unroll
                     for (int k = 0; k < WS; ++k) gsh_lane[k] = goal_shift(b[k]);
                     *dirty_flag = 1;
+                    goal_row_dirty = true;
                 }
             }
             if (mine && changed) write_row<H, W>(img, gb, r, b);
@@ -2887,7 +2961,43 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     if (rwave) {
         if constexpr (SPARSE_STORE) store_span_dirty<H, W>(env.board + (size_t)e0b * HW, board, nbb, tid2, box);
         else store_span<H, W>(env.board + (size_t)e0b * HW, board, nbb, tid2);
-        if (dirty) store_span<H, W>(env.goals + (size_t)e0b * HW, goals, nbb, tid2);
+        if (dirty && !goals_free) store_span<H, W>(env.goals + (size_t)e0b * HW, goals, nbb, tid2);
+        if (GCACHE && dirty && goals_free && live && goal_row_dirty) {
+            // a launch without the goal span: only the rows this launch wrote exist in the image -- each goes to global
+            // memory by itself (rare: a board that reset)
+            int r3 = r;
+            asm volatile("" : "+v"(r3));
+            const u16 *src = (const u16 *)(goals + Gm::PAD) + gb * HW;
+            u16 *gdst = env.goals + (size_t)e * HW + r3 * W;
+#pragma unroll 1
+            for (int x = 0; x < W; ++x) gdst[x] = src[Gm::cell(r3, x)];
+        }
+    }
+    if (GCACHE && gc_flag && T != 0) {
+        // GoalCache: a launch that had the goal span keeps the lanes' words if every board of the workgroup ends it with
+        // static goals (the words in the registers are current: a reset and an evolving goal both rewrite them); a
+        // launch that ran on cached words lowers the flag if one of its boards took a new level.
+        bool all_static = !any_reset;
+        if (!goals_free) {
+            all_static = true;
+#pragma unroll
+            for (int q = 0; q < Gm::NB; ++q)
+                if (q < nbb && box[q].gstat != 1) all_static = false;
+            if (all_static && rwave && live && (nbb == Gm::NB || e0b + nbb >= env.B)) {
+#pragma unroll
+                for (int c = 0; c < Gc::X4; ++c)
+                    *Gc::x4(gc_block, wave2, lane2, c) = u32x4{gsh_lane[4 * c], gsh_lane[4 * c + 1], gsh_lane[4 * c + 2], gsh_lane[4 * c + 3]};
+#pragma unroll
+                for (int j = 0; j < Gc::TAIL; ++j) *Gc::tail(gc_block, wave2, lane2, j) = gsh_lane[4 * Gc::X4 + j];
+            }
+        }
+        // (a workgroup at the ragged end of a SLICE holds fewer boards than the block has words for: it may use and
+        //  lower the flag, never raise it)
+        const bool gc_full = nbb == Gm::NB || e0b + nbb >= env.B;
+        if (tid2 == 0) {
+            if (!all_static) *gc_flag = 0u;
+            else if (!goals_free && gc_full) *gc_flag = 1u;
+        }
     }
     if (lane2 < 4 * Gm::G && wave2 * Gm::G + (lane2 >> 2) < nbb)
         ((u64 *)(env.rng + e0b + wave2 * Gm::G))[lane2] = ((const u64 *)(smem + Gm::OFF_RNG) + 4 * Gm::G * wave2)[lane2];
@@ -3073,9 +3183,10 @@ struct RolloutArgs {
     const u16 *board, *goals;
     const sl_pcg64 *rng;
     sl_env_scalars *scalars;
-    const int8_t *lut;
+    u32 *gcache;
     const int32_t *actions;
     int first, end;
+    const int8_t *lut;
     sl_env_batch env;
     int E, tstride, T;
     sl_step_out *out;
@@ -3091,12 +3202,13 @@ static_assert(sizeof(RolloutArgs) <= sizeof(PreparedStep::args), "argument block
 
 // variant selection, LDS size and the module-level handle of the kernel that steps `env` (T steps per launch)
 template <int H, int W>
-hipError_t pick_rollout_t(const sl_env_batch &env, int T, void **kernel, hipFunction_t *f_out, unsigned *threads_out, int *lds_out) {
+hipError_t pick_rollout_t(const sl_env_batch &env, int T, void **kernel, hipFunction_t *f_out, unsigned *threads_out, int *lds_out,
+                          bool *gcache_ok) {
     using Gm = Geom<H, W>;
     const bool lean = !env.wrap.flags && !env.obs && !env.policy_obs && env.finished.capacity == 0;
     const int variant = (env.n_tables == 1 ? 1 : 0) | (env.spawner_free ? 2 : 0) | (env.wrap.flags ? 4 : (lean ? 8 : 0));
-    typedef void (*kernel_t)(const u16 *, const u16 *, const sl_pcg64 *, sl_env_scalars *, const int8_t *,
-                             const int32_t *, int, int, sl_env_batch, int, int, int, sl_step_out *, float *,
+    typedef void (*kernel_t)(const u16 *, const u16 *, const sl_pcg64 *, sl_env_scalars *, u32 *,
+                             const int32_t *, int, int, const int8_t *, sl_env_batch, int, int, int, sl_step_out *, float *,
                              uint8_t *, double *, const Jump *, int, u32 *, const uint8_t *);
 #define SL_VARIANTS(ONE)                                                                                               \
     k_env_rollout_rowlane<H, W, false, true, false, false, ONE>, k_env_rollout_rowlane<H, W, true, true, false, false, ONE>,   \
@@ -3111,6 +3223,8 @@ hipError_t pick_rollout_t(const sl_env_batch &env, int T, void **kernel, hipFunc
     *threads_out = 64 * (WAVES + ((variant & 8) && Gm::LEADX_OK ? 1 : 0));     // LEAN: a fifth, leader wave
     const kernel_t fn = table[slot];
     const bool spawn = !(variant & 2), base_in_gsh = !spawn && Gm::WAVES_PER_SIMD == 4;
+    // (the kernel's GCACHE: LEAN instantiations whose goal words live in registers)
+    *gcache_ok = (variant & 8) && gsh_in_registers<H, W>(spawn, true, T == 1) && !Gm::LEADX_OK;
     const int lds_wrap = base_in_gsh ? Gm::LDS_WRAP_GSHREG : Gm::LDS_WRAP_GSHLDS;
     const int lds_plain = lean_lds<H, W>(spawn, (variant & 8) != 0, T == 1) ? lean_lds_bytes<H, W>() : Gm::LDS_BYTES;
     const int lds = !(variant & 4) ? lds_plain : lds_wrap + ((env.wrap.flags & SL_WRAP_INACTION) ? Gm::INACTION_BYTES : 0);
@@ -3150,10 +3264,24 @@ hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, c
     hipFunction_t f = nullptr;
     unsigned threads = 0;
     int lds = 0;
-    hipError_t err = pick_rollout_t<H, W>(env, T, &kernel, &f, &threads, &lds);
+    bool gcache_ok = false;
+    hipError_t err = pick_rollout_t<H, W>(env, T, &kernel, &f, &threads, &lds, &gcache_ok);
     if (err != hipSuccess) return err;
     const unsigned grid = (unsigned)((e_count + Gm::NB - 1) / Gm::NB);
-    RolloutArgs args = {env.board, env.goals, env.rng, env.scalars, env.score_lut, actions, e_first, e_first + e_count, env,
+    // the goal-word cache (GoalCache): handed to launches whose workgroups coincide with its blocks.  Any other launch of
+    // a batch that has one may load levels without lowering the flags -- it lowers them all first.
+    u32 *gcache = nullptr;
+    if (env.goal_cache) {
+        if (gcache_ok && e_first % Gm::NB == 0) {
+            gcache = env.goal_cache;
+        } else if (T != 0 && !prepared) {
+            err = hipMemsetAsync(env.goal_cache, 0, GoalCache<H, W>::bytes(env.B), stream);
+            if (err != hipSuccess) return err;
+        } else if (T != 0 && gcache_ok) {
+            return hipErrorNotSupported;        // (a prepared launch off the blocks' grid: the queues' slices never are)
+        }
+    }
+    RolloutArgs args = {env.board, env.goals, env.rng, env.scalars, gcache, actions, e_first, e_first + e_count, env.score_lut, env,
                         env.E, tstride, T, env.out, reward_t, done_t, env.wrap.shaped_reward_t, jump, 0, nullptr, reset_mask};
     if (prepared) {
         // not launched: the argument block and the launch geometry, for the library's own queues (sl_aql.hip) to
@@ -3177,8 +3305,8 @@ hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, c
         void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
         return hipModuleLaunchKernel(f, grid, 1, 1, threads, 1, 1, (unsigned)lds, stream, nullptr, extra);
     }
-    void *params[] = {&args.board, &args.goals, &args.rng, &args.scalars, &args.lut, &args.actions, &args.first, &args.end,
-                      &args.env, &args.E, &args.tstride, &args.T, &args.out, &args.reward_t, &args.done_t, &args.shaped_t,
+    void *params[] = {&args.board, &args.goals, &args.rng, &args.scalars, &args.gcache, &args.actions, &args.first, &args.end,
+                      &args.lut, &args.env, &args.E, &args.tstride, &args.T, &args.out, &args.reward_t, &args.done_t, &args.shaped_t,
                       &args.jump, &args.xcd_base, &args.xcd_flag, &args.reset_mask};
     return hipLaunchKernel(kernel, dim3(grid), dim3(threads), params, (size_t)lds, stream);
 }
@@ -3188,9 +3316,15 @@ hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, c
 // The shapes are compiled in three translation units (this file, and sl_rowlane_b.hip / sl_rowlane_c.hip, which
 // include it with SL_ROWLANE_PART defined): the launcher templates of a part's shapes are explicitly instantiated
 // there -- their kernels with them -- and only declared here.
+#ifdef SL_DEV_SHAPES            /* development builds: the shapes of BASELINE.json only (a quarter of the compile time) */
+#define SL_ROWLANE_SHAPES_A(X) X(25, 25) X(64, 64)
+#define SL_ROWLANE_SHAPES_B(X)
+#define SL_ROWLANE_SHAPES_C(X)
+#else
 #define SL_ROWLANE_SHAPES_A(X) X(25, 25) X(26, 26) X(64, 64) X(24, 24)
 #define SL_ROWLANE_SHAPES_B(X) X(15, 15) X(20, 20) X(10, 10) X(8, 8) X(12, 12) X(16, 16)
 #define SL_ROWLANE_SHAPES_C(X) X(30, 30) X(32, 32) X(40, 40) X(48, 48)
+#endif
 #define SL_ROWLANE_SHAPES(X) SL_ROWLANE_SHAPES_A(X) SL_ROWLANE_SHAPES_B(X) SL_ROWLANE_SHAPES_C(X)
 
 #define SL_ROWLANE_LAUNCHERS(PREFIX, h, w)                                                                                 \
@@ -3206,9 +3340,9 @@ hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, c
 #define X(h, w) SL_ROWLANE_LAUNCHERS(, h, w)
 #if SL_ROWLANE_PART == 1
 SL_ROWLANE_SHAPES_B(X)
-#else
+#elif SL_ROWLANE_PART == 2
 SL_ROWLANE_SHAPES_C(X)
-#endif
+#endif      /* any other part number: no shape at all -- tools/isa_one.sh instantiates single kernels behind it */
 #undef X
 #else
 #define X(h, w) SL_ROWLANE_LAUNCHERS(extern, h, w)
@@ -3223,6 +3357,18 @@ int rowlane_policy_room(int H, int W) {
         return ((rl::Geom<h, w>::GSH_BYTES + 4096 - ((rl::Geom<h, w>::NB * rl::OBS_PAR_INTS * 4 + 15) & ~15)) / 4 - 1) * 16 / 17;
     SL_ROWLANE_SHAPES(X)
 #undef X
+    return 0;
+}
+
+size_t rowlane_goal_cache_bytes(int H, int W, int B, int *boards_per_block) {
+#define X(h, w)                                                         \
+    if (H == h && W == w) {                                             \
+        if (boards_per_block) *boards_per_block = rl::Geom<h, w>::NB;   \
+        return rl::GoalCache<h, w>::bytes(B);                           \
+    }
+    SL_ROWLANE_SHAPES(X)
+#undef X
+    if (boards_per_block) *boards_per_block = 0;
     return 0;
 }
 

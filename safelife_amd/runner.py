@@ -123,6 +123,7 @@ class PipelinedRunner(object):
         self.seed = int(seed) & (2 ** 64 - 1)
         self.actions = torch.zeros(env.num_envs, dtype=torch.int32, device=env.device)
         self.num_steps = 0
+        self._group_steps = [0] * env.slices        # steps taken per group: the draw counter of the group's next step
         self._started = False
         self._lib = _hip.lib()
         self._groups = []
@@ -143,6 +144,15 @@ class PipelinedRunner(object):
         g, lo, hi, st, ctx, obs, act_ptr, st_ptr = self._groups[g]
         if hi <= lo:
             return
+        # Work the caller put on ITS stream since the last fence (env.reset(mask), step(), a snapshot ...) is fenced HERE,
+        # while the caller's stream is still the current one: inside the group's stream context env.fence() would take
+        # the group's own stream for the caller's and order the slices against the wrong one.
+        if env._queues_pending:
+            env._settle()
+        if env._caller_ahead:
+            env.fence()
+        draw = self._group_steps[g]
+        self._group_steps[g] = draw + 1
         with ctx:
             with torch.no_grad():
                 values, probs = self.policy(obs)
@@ -151,7 +161,7 @@ class PipelinedRunner(object):
                     probs = probs.to(torch.float32).contiguous()
                 # (seed offset by the group's first env: every env of the batch has its own draw per step)
                 rc = self._lib.slhip_sample_actions(probs.data_ptr(), hi - lo, probs.shape[1], (self.seed + lo) & (2 ** 64 - 1),
-                                                    self.num_steps, act_ptr, st_ptr)
+                                                    draw, act_ptr, st_ptr)
                 if rc:
                     self._hip.check(rc)
             else:
@@ -167,7 +177,7 @@ class PipelinedRunner(object):
         for _ in range(n_steps):
             for g in range(self.env.slices):
                 self.step_group(g)
-            self.num_steps += 1
+            self.num_steps = min(self._group_steps)
 
     def finish(self):
         """The caller's current stream waits for every group."""

@@ -202,7 +202,9 @@ class RewardGather(object):
         """`streams` wait (stream-level) for the exchange of buffer `which`."""
         if self.backend == "rccl":
             # (a window later the exchange has long finished: one query instead of a stream wait per writer)
-            if self.busy[which] and self.queued:
+            # queued windows, or nobody to make wait: block on the ticket (a buffer whose exchange may still be in
+            # flight is never handed back unfenced)
+            if self.busy[which] and (self.queued or not streams):
                 done = C.c_int(0)
                 from . import _hip
                 _hip.check(self._lib.slhip_gather_done(self._comm, self._ticket[which], 1, C.byref(done)))
@@ -265,6 +267,13 @@ class RewardGather(object):
         exchange right behind the call that completes it.  `action_ptr`: device address of step t0's actions, steps
         `action_stride` int32 elements apart.  ``assume_ordered``: as ``SafeLifeVectorEnv.step_queues``."""
         env, B = self.env, self.B
+        # The windows of this call are written from the library's AQL queues: the exchange must be ordered against THEM
+        # (a marker behind the window's last step, waited for by the library's worker), not against HIP streams that
+        # never wrote the window -- so this entry point switches the gather to its queued mode itself instead of
+        # trusting the caller to have set the attribute.
+        if getattr(env, "_queues", None) is None:
+            raise RuntimeError("run_queued: the env has no open step queues (env.queues_open() first)")
+        self.queued = True
         if not self.collective:             # one rank: the records stay in the env's own tensor
             env.step_queues_many(action_ptr, n, action_stride, assume_ordered=assume_ordered)
             return

@@ -289,6 +289,35 @@ class SafeLifeVectorEnv(object):
             s.score_lut = None          # points outside int8: every shape runs the size-generic kernels
         else:
             _hip.check(rc)
+        # The goal-word cache (include/safelife_hip.h, sl_env_batch.goal_cache): plain batches -- no observation, no
+        # wrappers, no finished-episode queue -- whose boards have static goals step without moving the goal array.
+        # SAFELIFE_GOAL_CACHE=0 leaves it out (A/B runs).
+        self.goal_cache_group = 0           # envs per block of the cache (one block per workgroup of the batch), 0 = none
+        plain = not (wrappers or side_effects or self.obs is not None or self.policy_tensor is not None)
+        if plain and s.score_lut and os.environ.get("SAFELIFE_GOAL_CACHE", "1") != "0":
+            group = C.c_int(0)
+            total = int(self._lib.slhip_goal_cache_bytes(self._sref, C.byref(group)))
+            if total > 0:
+                t["goal_cache"] = torch.zeros(total // 4, dtype=torch.int32, device=dev)
+                s.goal_cache = t["goal_cache"].data_ptr()
+                self.goal_cache_group = int(group.value)
+
+    def goal_cache_flags(self):
+        """Per group of ``goal_cache_group`` consecutive envs: 1 where the group currently steps on cached goal words
+        (host copy; None without a cache)."""
+        if not self.goal_cache_group:
+            return None
+        self._settle()
+        n = -(-self.num_envs // self.goal_cache_group)
+        return self.t["goal_cache"].view(n, -1)[:, 0].cpu().numpy()
+
+    def goal_cache_invalidate(self):
+        """Call after writing ``goals``, or the ``goals_static`` / ``level_idx`` columns of the scalars, from outside the
+        library (the kernels keep the cache themselves across steps, resets and slices)."""
+        if self.goal_cache_group:
+            self._settle()
+            self.t["goal_cache"].zero_()
+            self._caller_ahead = True
 
     def _setup_wrappers(self, cfg):
         torch, t, s, dev = self.torch, self.t, self.struct, self.device

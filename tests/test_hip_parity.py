@@ -1550,6 +1550,95 @@ def test_get_obs_leaves_state_alone(pool_name, B, kw):
     assert np.array_equal(dev.get("obs"), want) and np.array_equal(dev.get("reward"), r2)
 
 
+@pytest.mark.parametrize("pool_name,B,kw", [
+    ("prune_still_25", 8192 + 3, dict(time_limit=12)),          # C3's kernel, a ragged last workgroup
+    ("append_spawn_25", 1027, dict(time_limit=9)),               # C4's kernel (spawner draws)
+    ("navigation_64", 258, dict(time_limit=7)),                  # C5's kernel (one board per wavefront, four per workgroup)
+    ("append_still_26", 515, dict(time_limit=10)),
+])
+def test_goal_word_cache_vs_oracle(pool_name, B, kw):
+    """The goal-word cache of the plain step kernels (sl_env_batch.goal_cache): single steps, masked resets, T-step
+    launches, slices and queue steps in one run, every step's reward / done and the full state against the oracle --
+    and the cache must actually be in use: a raised flag implies static goals on every board of its workgroup, and
+    some flags are raised."""
+    import torch
+    from safelife_amd import _hip
+    pool, _ = util.pool_from_fixture(pool_name, _device_counts)
+    common = dict(auto_reset=True, level_stride=3, view_shape=(15, 15), with_obs=False, **kw)
+    first = (np.arange(B) * 5) % len(pool)
+    dev = util.DeviceBackend(pool, B, first_level=first, slices=2, **common)
+    cpu = util.OracleBackend(pool, B, first_level=first, **common)
+    env = dev.env
+    assert env.goal_cache_group > 0 and env.struct.goal_cache
+    env.reset()
+    cpu.env.reset()
+    rng = np.random.default_rng(21)
+
+    def check(tag):
+        for name in ("board", "goals", "rng", "agent_loc", "episode_idx", "level_idx", "num_steps", "goals_static"):
+            assert np.array_equal(dev.get(name), cpu.get(name)), (tag, name)
+
+    def flags():
+        torch.cuda.synchronize()
+        return env.goal_cache_flags()
+
+    def both(a):
+        env.step(a)
+        cpu.env.step(a)
+        assert np.array_equal(dev.get("reward"), cpu.get("reward")) and np.array_equal(dev.get("done"), cpu.get("done"))
+
+    for t in range(10):                                         # single steps on the caller's stream
+        both(rng.integers(0, 9, B).astype(np.int32))
+    check("steps")
+    f = flags()
+    assert f.max() == 1 and f.sum() >= 1, "no workgroup runs on cached goal words"
+    mask = (np.arange(B) % 3 == 0).astype(np.uint8)            # masked reset: every third env takes its next level now
+    env.reset(mask)
+    cpu.env.reset(mask)
+    check("masked reset")
+    for t in range(6):                                          # the slices, each on its own stream
+        a = torch.from_numpy(rng.integers(0, 9, B).astype(np.int32)).to(env.device)
+        env.step_async(a)
+        env.join()
+        cpu.env.step(a.cpu().numpy())
+        assert np.array_equal(dev.get("reward"), cpu.get("reward")), ("slices", t)
+    check("slices")
+    T = 7                                                       # one T-step launch (levels load in its middle)
+    a = rng.integers(0, 9, (T, B)).astype(np.int32)
+    r_t, d_t = env.rollout(a)
+    want = []
+    for k in range(T):
+        cpu.env.step(a[k])
+        want.append(cpu.get("reward"))
+    assert np.array_equal(r_t.cpu().numpy(), np.stack(want))
+    check("rollout")
+    for t in range(3):
+        both(rng.integers(0, 9, B).astype(np.int32))
+    try:                                                        # queue steps, where the runtime offers queues
+        env.queues_open(4)
+    except _hip.SafeLifeHipError:
+        pass
+    else:
+        acts = torch.from_numpy(rng.integers(0, 9, (15, B)).astype(np.int32)).to(env.device)
+        env.step_queues_many(acts)
+        env.queues_sync()
+        for k in range(15):
+            cpu.env.step(acts[k].cpu().numpy())
+        assert np.array_equal(dev.get("reward"), cpu.get("reward")) and np.array_equal(dev.get("done"), cpu.get("done"))
+        check("queues")
+        env.queues_close()
+    for t in range(8):
+        both(rng.integers(0, 9, B).astype(np.int32))
+    check("end")
+    assert cpu.get("episode_idx").min() >= 1
+    f = flags()
+    nb = env.goal_cache_group
+    static = cpu.get("goals_static") == 1
+    for w in np.nonzero(f)[0]:
+        assert static[w * nb:(w + 1) * nb].all(), w
+    assert f.sum() > 0
+
+
 def test_sharded_equals_unsharded():
     """env e behaves the same whichever rank owns it -- two half-size envs with
     env_offset 0 / B/2 (what ranks 0 and 1 of a 2-GPU run hold) against one env of size B."""
