@@ -268,7 +268,7 @@ def main():
                          "repeated with 'agent', on every rank).  config.queue_fences says which mode produced the line")
     ap.add_argument("--stream-leg", type=int, default=1,
                     help="queue stepping only: 1 = also run K steps of the same kernel through the stream slices under HIP "
-                         "events (roofline.launch_ms); 0 = leave it out (profiling runs: only the queues' launches in the trace)")
+                         "events (roofline.stream_leg_*); 0 = leave it out (profiling runs: only the queues' launches in the trace)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-steps", type=int, default=1001)
     ap.add_argument("--rollout", type=int, default=32,
@@ -339,9 +339,11 @@ def main():
 
     queue_ids = [None]
 
-    def attempt(fences):
+    def attempt(fences, gather=gather, P=P, shift=shift):
         """Reset, P checkpointed steps, W warm-up steps, the K timed steps.  Returns the measurements, or None when
-        release-free queue stepping was refused by its placement check on ANY rank (the caller repeats with 'agent')."""
+        release-free queue stepping was refused by its placement check on ANY rank (the caller repeats with 'agent').
+        (`gather`, `P`, `shift`: the extras below repeat the region with another exchange and without checkpoints.)"""
+        every = gather.every
         res = {"use_queues": False, "queues_why": "switched off", "fences": None}
         env.queues_close()
         env.reset()
@@ -513,7 +515,7 @@ def main():
     stream_wall_ms = None
     if use_queues and args.stream_leg:
         # the timed steps ran on the library's queues, not on a HIP stream.  The same kernel through the stream
-        # slices, K steps under HIP events, gives the per-launch device figure (roofline.launch_ms) next to the
+        # slices, K steps under HIP events, gives the per-launch device figure (roofline.stream_leg_launch_ms) next to the
         # queues' wall clock.
         torch.cuda.synchronize()
         for t in range(P, P + W):
@@ -531,6 +533,44 @@ def main():
         kernel_ms = evs[0][0].elapsed_time(evs[0][1]) / K
 
     extra = {}
+    if use_queues and args.extras and world == 1 and not gather.collective:
+        # What the driver's one-GPU line does not show (outside the timed region; same K, same warm-up, no checkpoints):
+        # (a) the library's DEFAULT fences -- what SafeLifeVectorEnv.queues_open() gives a user;
+        # (b) the step as every N > 1 run takes it: the RCCL exchange on (one rank, to itself), three slices on the three
+        #     queues the exchange does not hold up, one window closing inside the region.
+        try:
+            if res["fences"] != "agent":
+                r2 = attempt("agent", P=0)
+                if r2 is not None:
+                    extra["queue_fences_agent_us_per_step"] = r2["elapsed"] / K * 1e6
+            else:
+                extra["queue_fences_agent_us_per_step"] = elapsed / K * 1e6
+            env.queues_close()
+            g2 = RewardGather(env, every=gather_window(args.gather_every, K), world=1, rank=0, force=True)
+            g2.prime()
+            shift2 = (g2.every - (W + K) % g2.every) % g2.every
+            if K >= 8 and g2.every >= 8:
+                shift2 = (shift2 + min(10, g2.every // 2)) % g2.every
+            queue_ids[0] = None
+            r3 = attempt(res["fences"], gather=g2, P=0, shift=shift2)
+            if r3 is None:
+                r3 = attempt("agent", gather=g2, P=0, shift=shift2)
+            if r3 is not None:
+                extra["forced_gather_us_per_step"] = r3["elapsed"] / K * 1e6
+                extra["forced_gather_queue_ids"] = list(getattr(env, "queue_ids", []))
+                extra["forced_gather_windows_in_region"] = r3["gather_windows"]
+                extra["forced_gather_fences"] = r3["fences"]
+                extra["forced_gather_note"] = ("the same %d-step region with the RCCL exchange forced on for one rank "
+                                               "(send / receive to itself), windows of %d steps, the step queue the "
+                                               "exchange's kernel shares a hardware pipe with left out: what --gpus N > 1 "
+                                               "runs per rank" % (K, g2.every))
+            env.queues_close()
+            g2.flush()
+            g2.close()
+            queue_ids[0] = None
+        except _hip.SafeLifeHipError as e:
+            extra["forced_gather_error"] = str(e)
+        env.set_step_outputs(None)
     if args.rollout > 0:
         T = args.rollout
         reps = max(1, K // T)
@@ -814,7 +854,7 @@ def main():
                 # (roll-forward by the episode's length + 2 x 1000-step occupancy + distributions) runs on the
                 # device for whatever the queue holds -- all inside the timed region; the earth-mover distances
                 # (host, pyemd: parity unpinned) are not.
-                n_c5, flush_every, n_meas = n_envs, 512, 1024
+                n_c5, flush_every, n_meas = n_envs, 512, 2048
                 env5 = SafeLifeVectorEnv(p2, n_c5, time_limit=1000, view_shape=(25, 25), output_channels=TRAIN_CHANNELS,
                                          auto_reset=True, with_obs=False, slices=args.slices,
                                          side_effects=dict(capacity=2 * (n_c5 * flush_every // 1000 + 64), num_samples=1000))
@@ -833,8 +873,11 @@ def main():
                 for t in range(20, 20 + n_meas):
                     env5.step_async(acts5[t])
                     if (t - 19) % flush_every == 0:
-                        batches.append(env5.side_effects_flush())
+                        # (round 5) the pass runs on a stream of its own UNDER the steps that follow; the last one of the
+                        # region has nothing to hide under and is waited for in full
+                        batches.append(env5.side_effects_flush(overlap=True))
                 env5.join()
+                env5.side_effects_join()
                 e1.record()
                 torch.cuda.synchronize()
                 ms = e0.elapsed_time(e1)
@@ -843,9 +886,10 @@ def main():
                 extra["c5_with_side_effects_env_steps_per_s_per_gpu"] = n_c5 * n_meas / (ms * 1e-3)
                 extra["c5_with_side_effects_episodes_scored"] = n_eps
                 extra["c5_with_side_effects_note"] = ("%d envs x 64x64 navigation, %d steps, episode-end pass every %d steps "
-                                                      "on the device (%d episodes: roll-forward + 2 x 1000-step "
-                                                      "life_occupancy + distributions); EMD on the host not included"
-                                                      % (n_c5, n_meas, flush_every, n_eps))
+                                                      "on the device, on a side stream under the following steps, the "
+                                                      "region's last pass waited for in full (%d episodes: roll-forward + "
+                                                      "2 x 1000-step life_occupancy + distributions); EMD on the host not "
+                                                      "included" % (n_c5, n_meas, flush_every, n_eps))
                 del env5, batches
 
     if rank == 0:
@@ -885,6 +929,7 @@ def main():
         # events over the same region give the device-side figure next to it
         achieved = bytes_per_step * B / (elapsed / K) / 1e9
         achieved_device = bytes_per_step * B / (kernel_ms * 1e-3) / 1e9
+        stream_key = "stream_leg" if use_queues else "device"
         traffic = None
         try:    # HBM bytes per launch from the committed PMC passes (tools/pmc_run.sh), if they match this run
             with open(os.path.join(REPO, "profiles", "traffic_latest.json")) as f:
@@ -941,20 +986,23 @@ def main():
                          # device time of one step (HIP events on slice 0's stream over the same region): the slice
                          # launches of a step run concurrently, each stream back to back, so a step costs one
                          # stream's launch-to-launch time
-                         "launch_ms": kernel_ms, "launches_per_step": env.queue_slices if use_queues else env.slices,
-                         "launch_ms_note": ("HIP events over %d steps of the SAME kernel issued through the %d stream "
-                                            "slice(s) right after the timed region (wall %.5f ms per step): HIP events "
-                                            "cannot see the library's queues" % (K, env.slices, stream_wall_ms))
-                         if stream_wall_ms is not None else None,
-                         "achieved_device": achieved_device, "frac_device": achieved_device / HBM_PEAK_GBS,
+                         "launches_per_step": env.queue_slices if use_queues else env.slices,
+                         # queue stepping: a SEPARATE leg behind the timed region -- K steps of the same kernel through
+                         # the HIP-stream slices under HIP events (events cannot see the library's queues).  It describes
+                         # another launcher and may well exceed ms_per_step; stream stepping: the events bracket the
+                         # timed region itself.
+                         stream_key + "_launch_ms": kernel_ms,
+                         stream_key + "_note": ("HIP events over %d steps of the SAME kernel issued through the %d stream "
+                                                "slice(s) right after the timed region (wall %.5f ms per step)"
+                                                % (K, env.slices, stream_wall_ms))
+                         if stream_wall_ms is not None else "HIP events over the timed region (slice 0's stream)",
+                         stream_key + "_achieved": achieved_device, stream_key + "_frac": achieved_device / HBM_PEAK_GBS,
                          "host_enqueue_ms_per_step": (t_enqueued - t_start) / K * 1e3,
                          "measured_ceiling": ceiling,
-                         "note": "frac = bytes_per_env_step x envs / ms_per_step / peak.  frac_device uses launch_ms, the "
-                                 "HIP-event time of ONE step through the stream slices; rocprofv3 serialises the queues' "
-                                 "dispatches (profiles/round4_d_queues4_*_kernel_trace.txt: per-launch durations), "
-                                 "profiles/round4_b_overlap_queues4_*.txt shows the four queues' overlap from the kernels' "
-                                 "own clocks; traffic is null for release-free stepping (per-dispatch counters cannot "
-                                 "attribute it: profiles/round4_c_tcc_*.txt, DESIGN 4.1d)"},
+                         "note": "frac = bytes_per_env_step x envs / ms_per_step / peak.  rocprofv3 serialises the queues' "
+                                 "dispatches (its kernel trace gives per-launch durations only); the four queues' overlap "
+                                 "is shown by the kernels' own clocks (tools/trace_overlap.py); traffic is null for "
+                                 "release-free stepping (per-dispatch counters cannot attribute it, DESIGN.md)"},
         }
         if world > 1 or gather.collective:
             out["gather_every"] = every_used

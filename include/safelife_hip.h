@@ -255,6 +255,12 @@ typedef struct sl_env_batch {
     const int32_t *pool_exit_locs;      /* [L,E] */
     const sl_pcg64 *pool_rng;           /* [L] */
     const sl_level_scalars *pool_scalars; /* [L] */
+    const int32_t *pool_next;    /* optional [L]: an env on slot s loads slot pool_next[s] at its next reset instead of
+                                    (s + level_stride) % L.  What a pool that is REFRESHED while the envs step needs
+                                    (safelife_amd.levels.LevelPool.stage / commit: new levels go into spare slots and the
+                                    table is switched between two steps -- the device-resident counterpart of
+                                    level_iterator.py:200-223 handing every reset a fresh level).  Read at launch time:
+                                    the queue launcher patches the pointer into every dispatch.  NULL = the rule above */
     /* per-step outputs */
     sl_step_out *out;            /* [B] */
     uint8_t *obs;                /* [B,vh,vw,C] uint8, or uint32 [B,vh,vw] if n_channels == 0; NULL = skip */
@@ -284,6 +290,10 @@ typedef struct sl_env_batch {
  * Synchronises the stream.  Returns SL_E_UNSUPPORTED when a table entry does not fit int8; the
  * caller then passes score_lut = NULL and every shape runs on the size-generic kernels. */
 int slhip_env_prepare(const sl_env_batch *env, void *stream);
+
+/* Rebuild env->wrap.pool_baseline from the level pool as it stands now, asynchronously on `stream` (what
+ * slhip_env_prepare does once, synchronously): after pool slots have been rewritten. */
+int slhip_pool_baseline(const sl_env_batch *env, void *stream);
 
 /* Bytes of env->goal_cache for this batch (0: the board shape has no row kernels -- leave goal_cache NULL).
  * *boards_per_block (optional): the cache is one block of bytes / ceil(B / boards_per_block) bytes per group of that many

@@ -100,7 +100,7 @@ class EnvBatch(C.Structure):
         ("pool_board", _u16p), ("pool_goals", _u16p), ("pool_agent_loc", _i32p),
         ("pool_exit_locs", _i32p), ("pool_rng", _pcgp), ("pool_spawn_prob", _f32p),
         ("pool_required_reset", _i32p), ("pool_required_step", _i32p),
-        ("pool_initial_points", _i32p), ("pool_table_idx", _i32p),
+        ("pool_initial_points", _i32p), ("pool_table_idx", _i32p), ("pool_next", _i32p),
         ("reward", _f32p), ("done", _u8p), ("success", _u8p), ("times_up", _u8p),
         ("obs", _u8p),
     ]
@@ -367,6 +367,13 @@ class OracleEnv:
             ftype = dict(EnvBatch._fields_)[k]
             setattr(s, k, C.cast(_ptr(a[k]), ftype))
         s.obs = C.cast(_ptr(self.obs), _u8p) if self.obs is not None else None
+        self._pool_next = None
+
+    def set_pool_next(self, table):
+        """Successor table of a refreshed pool (int32 [L], sl_env_batch.pool_next); None = the stride rule.  The pool
+        arrays handed to the constructor are the caller's: it rewrites their slots in place."""
+        self._pool_next = None if table is None else np.ascontiguousarray(table, dtype=np.int32)
+        self.s.pool_next = C.cast(_ptr(self._pool_next), _i32p) if self._pool_next is not None else None
 
     def set_wrappers(self, movement_bonus=None, movement_bonus_power=1e-100, movement_bonus_period=4,
                      as_penalty=True, exit_bonus=None, penalty_coef=None, ignore_reward_cells=False,

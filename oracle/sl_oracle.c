@@ -563,7 +563,8 @@ int slo_env_reset_wrapped(slo_env_batch *env, slo_wrappers *wrap, const uint8_t 
     for (int e = 0; e < env->B; e++) {
         if (mask && !mask[e]) continue;
         if (env->loaded[e]) {      /* SafeLifeEnv.reset() takes next(level_iterator), safelife_env.py:204 */
-            env->level_idx[e] = (env->level_idx[e] + env->level_stride) % env->L;
+            env->level_idx[e] = env->pool_next ? env->pool_next[env->level_idx[e]]
+                                               : (env->level_idx[e] + env->level_stride) % env->L;
             env->episode_idx[e] += 1;
         }
         reset_one(env, e);
@@ -655,7 +656,8 @@ int slo_env_step_wrapped(slo_env_batch *env, slo_wrappers *wrap, const int32_t *
             step_one(env, e, actions[e], scratch);
             if (wrap) wrap_step_one(env, wrap, e);
             if (env->auto_reset && env->done[e]) {
-                env->level_idx[e] = (env->level_idx[e] + env->level_stride) % env->L;
+                env->level_idx[e] = env->pool_next ? env->pool_next[env->level_idx[e]]
+                                                   : (env->level_idx[e] + env->level_stride) % env->L;
                 env->episode_idx[e] += 1;
                 reset_one(env, e);
                 if (wrap) {

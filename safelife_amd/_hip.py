@@ -20,7 +20,7 @@ SL_E_SHAPE, SL_E_ARG, SL_E_HIP, SL_E_UNSUPPORTED = -1, -2, -3, -4
 EXPORTS = (
     "slhip_abi_version", "slhip_last_error", "slhip_device_count",
     "slhip_advance_board", "slhip_advance_board_each", "slhip_life_occupancy", "slhip_alive_counts", "slhip_execute_actions",
-    "slhip_env_prepare", "slhip_goal_cache_bytes", "slhip_env_reset", "slhip_env_step", "slhip_env_step_slices", "slhip_env_step_range", "slhip_env_rollout",
+    "slhip_env_prepare", "slhip_pool_baseline", "slhip_goal_cache_bytes", "slhip_env_reset", "slhip_env_step", "slhip_env_step_slices", "slhip_env_step_range", "slhip_env_rollout",
     "slhip_streams_concurrent", "slhip_streams_order",
     "slhip_env_obs",
     "slhip_obs_to_policy", "slhip_sample_actions", "slhip_side_effects",
@@ -52,6 +52,7 @@ ENV_SCALARS_HEAD = ("B", "H", "W", "E", "time_limit", "exit_points", "n_tables",
                     "remove_white_goals", "view_h", "view_w", "n_channels")
 ENV_STATE_PTRS = ("board", "goals", "exit_locs", "rng", "scalars", "points_table")
 ENV_POOL_PTRS = ("pool_board", "pool_goals", "pool_exit_locs", "pool_rng", "pool_scalars")
+ENV_POOL_TAIL = ("pool_next",)      # (optional: set by SafeLifeVectorEnv for refreshable pools)
 ENV_OUT_PTRS = ("out", "obs", "score_lut")
 SL_ABI_VERSION = 11
 
@@ -103,7 +104,7 @@ class EnvBatch(C.Structure):
         + [("channels", C.c_int32 * SL_MAX_CHANNELS), ("spawner_free", C.c_int32), ("stream_salt", C.c_int32)]
         + [(n, _p) for n in ENV_STATE_PTRS]
         + [("L", C.c_int32), ("level_stride", C.c_int32)]
-        + [(n, _p) for n in ENV_POOL_PTRS]
+        + [(n, _p) for n in ENV_POOL_PTRS + ENV_POOL_TAIL]
         + [("out", _p), ("obs", _p), ("policy_obs", _p), ("policy_dtype", C.c_int32), ("reserved1", C.c_int32),
            ("score_lut", _p), ("goal_cache", _p)]
         + [("wrap", Wrappers), ("finished", EpisodeQueue)]
@@ -136,6 +137,8 @@ def lib():
         L.slhip_execute_actions.argtypes = [_p, C.c_int, C.c_int, C.c_int, _p, _p, C.c_int, C.c_int,
                                             C.c_int, _p]
         L.slhip_env_prepare.argtypes = [C.POINTER(EnvBatch), _p]
+        if hasattr(L, "slhip_pool_baseline"):
+            L.slhip_pool_baseline.argtypes = [C.POINTER(EnvBatch), _p]
         if hasattr(L, "slhip_goal_cache_bytes"):
             L.slhip_goal_cache_bytes.argtypes = [C.POINTER(EnvBatch), C.POINTER(C.c_int)]
             L.slhip_goal_cache_bytes.restype = C.c_size_t

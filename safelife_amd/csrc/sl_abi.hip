@@ -360,6 +360,15 @@ int slhip_env_prepare(const sl_env_batch *env, void *stream) {
     return err == hipSuccess ? SL_OK : hip_fail(err, "env_prepare launch");
 }
 
+int slhip_pool_baseline(const sl_env_batch *env, void *stream) {
+    int rc = check_env(env);
+    if (rc) return rc;
+    if (!(env->wrap.flags & SL_WRAP_SIDE_EFFECT) || !env->wrap.pool_baseline) return SL_OK;
+    if (!sl::rowlane_supports(env->H, env->W)) return SL_OK;       // (the size-generic kernels read the pool itself)
+    hipError_t err = sl::launch_build_baseline(*env, (hipStream_t)stream);
+    return err == hipSuccess ? SL_OK : hip_fail(err, "pool_baseline launch");
+}
+
 size_t slhip_goal_cache_bytes(const sl_env_batch *env, int *boards_per_block) {
     if (boards_per_block) *boards_per_block = 0;
     if (!env || env->B <= 0 || force_generic()) return 0;
@@ -809,6 +818,7 @@ int slhip_queues_steps(void *handle, const sl_env_batch *env, const int32_t *act
     sl_env_batch key;
     memcpy(&key, env, sizeof(key));                 // (bytes, padding included: the caller passes the same buffer)
     key.out = nullptr;
+    key.pool_next = nullptr;                        // (patched into every dispatch as well: a refreshed pool alternates two tables)
     const bool reuse = c->have_prepared && !c->swap && memcmp(&c->prepared_env, &key, sizeof(sl_env_batch)) == 0;
     for (int i = 0; i < c->n_slices && !reuse; ++i) {
         const int lo = c->bounds[i], hi = c->bounds[i + 1];
@@ -823,6 +833,7 @@ int slhip_queues_steps(void *handle, const sl_env_batch *env, const int32_t *act
         const void *none = nullptr;
         memcpy(ps[i].args + ps[i].off_actions, &none, sizeof(void *));
         memcpy(ps[i].args + ps[i].off_out, &none, sizeof(void *));
+        memcpy(ps[i].args + ps[i].off_next, &none, sizeof(void *));
         if (c->last_bytes[i] != ps[i].arg_bytes || memcmp(c->last_args[i], ps[i].args, ps[i].arg_bytes)) {
             memcpy(c->last_args[i], ps[i].args, ps[i].arg_bytes);
             c->last_bytes[i] = ps[i].arg_bytes;
@@ -857,9 +868,10 @@ int slhip_queues_steps(void *handle, const sl_env_batch *env, const int32_t *act
             if (!p.grid) continue;
             memcpy(p.args + p.off_actions, &a_t, sizeof(void *));
             memcpy(p.args + p.off_out, &o_t, sizeof(void *));
+            memcpy(p.args + p.off_next, &env->pool_next, sizeof(void *));
             const int queue = c->qmap[c->swap ? (int)((i + c->steps) % c->n_slices) : i];
             const sl::AqlLaunch a{queue, head != 0 && t == 0, c->release_free};
-            sl::AqlPatch patch{c->serial * 8u + (uint32_t)i, c->version[i], 2, {p.off_actions, p.off_out}};
+            sl::AqlPatch patch{c->serial * 8u + (uint32_t)i, c->version[i], 3, {p.off_actions, p.off_out, p.off_next}};
 #ifdef SL_TRACE
             if (g_trace_base && g_trace_next < g_trace_slots) {
                 float *trace = (float *)(g_trace_base + g_trace_bytes * g_trace_next++);

@@ -515,7 +515,7 @@ __global__ __launch_bounds__(GB_MAX) void k_env_rollout_generic(sl_env_batch env
         nxt = sw;
         if (env.auto_reset && ivar[2]) {
             if (tid == 0) {
-                sc->level_idx = (sc->level_idx + env.level_stride) % env.L;
+                sc->level_idx = env.pool_next ? env.pool_next[sc->level_idx] : (sc->level_idx + env.level_stride) % env.L;
                 sc->episode_idx += 1;
             }
             __syncthreads();
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(GB_MAX) void k_env_reset_generic(sl_env_batch env,
     if (tid == 0) {         // a slot that already holds a level moves on to its next one (safelife_env.py:204)
         sl_env_scalars *sc = env.scalars + e;
         if (sc->loaded) {
-            sc->level_idx = pos_mod(sc->level_idx + env.level_stride, env.L);
+            sc->level_idx = env.pool_next ? env.pool_next[sc->level_idx] : pos_mod(sc->level_idx + env.level_stride, env.L);
             sc->episode_idx += 1;
         }
     }

@@ -74,7 +74,7 @@ struct PreparedStep {
     hipFunction_t f;
     unsigned grid, threads, lds;
     size_t arg_bytes;
-    size_t off_actions, off_out, off_base, off_flag, off_trace;
+    size_t off_actions, off_out, off_base, off_flag, off_trace, off_next;
     alignas(16) unsigned char args[1024];
 };
 // prepared (optional, T == 1 only): fill it instead of launching

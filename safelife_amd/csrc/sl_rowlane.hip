@@ -622,9 +622,30 @@ __device__ void resolve_draws(const RowWords<H, W> &b, RowWords<H, W> &n, const 
 // The same for the bit-plane step (sl_planes.h): `elig` is a plane and so is the result, the cells whose draw
 // succeeded.  One word per plane: bit 1+k = cell k, bit 17+k = cell WS+k -- row-major order = ascending bits of the
 // low half, then of the high half.  Two words (64-cell rows): cell 32 i + k = bit k of word i.
+// Multi-step kernels (life_occupancy: a thousand steps on one board) hand in a JumpCache: with the even deal a lane's
+// first draw of a step is draw (lane << log2c) of the board's stream, and log2c -- the draws per lane, rounded up to a
+// power of two -- hardly ever changes from one step to the next.  So the lane keeps ITS jump (the multiplier A^k and the
+// increment's share C_k * inc, k = lane << log2c) instead of fetching the table entry from global memory and
+// multiplying it out at every step: one 128-bit multiply and one L2 round trip less on the step's critical chain.
+struct JumpCache {
+    int log2c = -1;
+    U128 mult = {0, 0}, plus_inc = {0, 0};
+};
+__device__ __forceinline__ U128 pcg_jump_cached(const Jump *__restrict__ table, int k, int log2c, U128 state, U128 inc,
+                                                JumpCache *jc) {
+    if (!jc) return pcg_jump(table, k, state, inc);
+    if (jc->log2c != log2c) {           // (wave-uniform: log2c is)
+        const Jump j = table[k];
+        jc->mult = U128{j.mult_hi, j.mult_lo};
+        jc->plus_inc = mul128(U128{j.plus_hi, j.plus_lo}, inc);
+        jc->log2c = log2c;
+    }
+    return add128(mul128(jc->mult, state), jc->plus_inc);
+}
+
 template <int H, int W, int NW>
 __device__ pl::Pl<NW> resolve_draws_planes(const pl::Pl<NW> &elig, u64 *rng_lds, int g, double p,
-                                           const Jump *__restrict__ jump) {
+                                           const Jump *__restrict__ jump, JumpCache *jc = nullptr) {
     using Gm = Geom<H, W>;
     int mine = 0;
 #pragma unroll
@@ -677,7 +698,7 @@ __device__ pl::Pl<NW> resolve_draws_planes(const pl::Pl<NW> &elig, u64 *rng_lds,
             const u64 bthr = ((u64)bthr_hi << 32) | bthr_lo;
             u32 bits = 0;
             if (n_here > 0) {
-                U128 cur = pcg_jump(jump, first, st, inc);
+                U128 cur = pcg_jump_cached(jump, first, log2c, st, inc, jc);
                 for (int i = 0; i < n_here; ++i) {
                     cur = pcg_step(cur, inc);
                     bits |= (pcg_output_u53(cur) < bthr ? 1u : 0u) << i;        // advance_board.c:115
@@ -738,7 +759,7 @@ __device__ pl::Pl<NW> resolve_draws_planes(const pl::Pl<NW> &elig, u64 *rng_lds,
             const u64 wthr = wq ? (((u64)th1 << 32) | tl1) : (((u64)th0 << 32) | tl0);
             u32 bits = 0;
             if (n_here > 0) {
-                U128 cur = pcg_jump(jump, first, wst, winc);
+                U128 cur = pcg_jump_cached(jump, first, log2c, wst, winc, jc);
                 for (int i = 0; i < n_here; ++i) {
                     cur = pcg_step(cur, winc);
                     bits |= (pcg_output_u53(cur) < wthr ? 1u : 0u) << i;        // advance_board.c:115
@@ -1353,10 +1374,20 @@ struct OccGeom {
     static constexpr int CELL_DWORDS = SLOTS / PER_DWORD;
     static_assert(CELL_DWORDS >= 1, "at least one dword of counters per cell");
     static constexpr int PITCH = W * CELL_DWORDS + 1;                   // dwords per lane
+    // Round 5, measured and left off (SL_OCC_DIRECT): 64-cell rows WITHOUT counters in LDS -- the register counters
+    // (4-bit, bit-sliced) flushed every 15 counted steps straight into the zeroed int32 output as fire-and-forget global
+    // atomics, one per live cell, so that a wavefront needs 32 bytes of LDS instead of 16.6 KB and the kernel's 127
+    // registers, not its LDS, bound the wavefronts per SIMD (2 -> 4).  Bit exact, and twice as slow: the episode-end pass of
+    // C5 (2137 episodes) 23.3-23.9 ms against 12.5-12.7 -- 64 lanes x 64 addresses per atomic instruction are 64
+    // transactions at the L2, and the pass issues ~1e8 of them (profiles/round5_d_se_pass_variants.txt).
+#ifndef SL_OCC_DIRECT
+#define SL_OCC_DIRECT 0
+#endif
+    static constexpr bool DIRECT = SL_OCC_DIRECT && CB == 8 && use_planes_multi<H, W>();
     static constexpr int OFF_CNT = 0;
-    static constexpr int OFF_RNG = 64 * PITCH * 4;                      // G x 4 u64
+    static constexpr int OFF_RNG = DIRECT ? 0 : 64 * PITCH * 4;         // G x 4 u64
     static constexpr int LDS_BYTES = OFF_RNG + Gm::G * 32;
-    static constexpr int FLUSH_EVERY = CB == 8 ? 255 : 0x7FFFFFFF;
+    static constexpr int FLUSH_EVERY = (CB == 8 && !DIRECT) ? 255 : 0x7FFFFFFF;
 };
 
 // counters of one lane's row -> its slice of the output (add: the output was zeroed), counters cleared.
@@ -1460,7 +1491,8 @@ __global__ __launch_bounds__(64) void k_occupancy_rowlane(const u16 *__restrict_
     u64 *rng_lds = (u64 *)(smem + Oc::OFF_RNG);
     int32_t *dst = counts + (size_t)e * counts_stride + ((size_t)r * W) * 8;    // this lane's row of the output
 
-    for (int i = 0; i < Oc::PITCH; ++i) cnt[i] = 0;
+    if (!Oc::DIRECT)
+        for (int i = 0; i < Oc::PITCH; ++i) cnt[i] = 0;
     if (lane < 4 * nbb) rng_lds[lane] = ((const u64 *)(rng + e0b))[lane];
     const double p = rowl ? (double)spawn_prob[e] : 0.0;
     // V_SHIFT: after a step the halo lanes take the new first / last row from the lanes that own them
@@ -1476,6 +1508,7 @@ __global__ __launch_bounds__(64) void k_occupancy_rowlane(const u16 *__restrict_
     for (int off = 32; off >= 1; off >>= 1) wave_end = max(wave_end, __shfl_xor(wave_end, off));
     wave_sync();
     int since_drain = 0;
+    JumpCache jcache;
     // rows of up to 28 cells, or 64: the row stays in bit-plane form for all the steps (sl_planes.h) -- one
     // transposition at the start, the CA on whole rows, and the counting visits only the cells that ARE alive
     // (a handful per row) instead of every cell position
@@ -1513,9 +1546,13 @@ __global__ __launch_bounds__(64) void k_occupancy_rowlane(const u16 *__restrict_
                     // the cell's column (split two-word planes: word i holds cells i WS .. from bit 1 on)
                     const int x = pl::PG<PLANES ? W : 8>::SPLIT ? i * WS + pos - 1
                                                                   : NW == 2 ? 32 * i + pos : (pos < 16 ? pos - 1 : pos - 17 + WS);
-                    __hip_atomic_fetch_add(cnt + x * Oc::CELL_DWORDS + sl / Oc::PER_DWORD,
-                                           val << (Oc::CB * (sl % Oc::PER_DWORD)), __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    if (Oc::DIRECT)     // straight into the (zeroed) output: counts[y, x, colour of the slot]
+                        __hip_atomic_fetch_add(dst + x * 8 + ((inv >> (3 * sl)) & 7u), (int32_t)val, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                    else
+                        __hip_atomic_fetch_add(cnt + x * Oc::CELL_DWORDS + sl / Oc::PER_DWORD,
+                                               val << (Oc::CB * (sl % Oc::PER_DWORD)), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WAVEFRONT);
                 }
 #pragma unroll
                 for (int k = 0; k < MINI_BITS; ++k) mini[sl][k][i] = 0;
@@ -1529,7 +1566,7 @@ __global__ __launch_bounds__(64) void k_occupancy_rowlane(const u16 *__restrict_
 #ifdef SL_OCC_NODRAW
                 return elig;
 #else
-                return resolve_draws_planes<H, W, NW>(elig, rng_lds, rowl ? g : 0, p, jump);
+                return resolve_draws_planes<H, W, NW>(elig, rng_lds, rowl ? g : 0, p, jump, &jcache);
 #endif
             });
         } else {
@@ -1603,7 +1640,7 @@ __global__ __launch_bounds__(64) void k_occupancy_rowlane(const u16 *__restrict_
     }
     if constexpr (PLANES) flush_mini();
     wave_sync();
-    if (live) {
+    if (live && !Oc::DIRECT) {
         if (Oc::CB == 8) {
             occ_drain<H, W, SLOTS>(cnt, dst, inv);
         } else {            // nothing was drained on the way: plain stores, the output need not be zeroed
@@ -2261,7 +2298,15 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     constexpr int WS = Gm::WS, HW = Gm::HW;
     const int T = ONE ? 1 : T_arg;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifndef SL_SCALAR_WAVE
+#define SL_SCALAR_WAVE 1        /* A/B knob: the wave's index as a scalar (uniform branches and scalar DMA addresses in the prologue) */
+#endif
+#ifndef SL_PRIO_PROLOGUE
+#define SL_PRIO_PROLOGUE 0      /* A/B knob: s_setprio of every wave until its loads have been issued */
+#endif
+    if (SL_PRIO_PROLOGUE) __builtin_amdgcn_s_setprio(SL_PRIO_PROLOGUE);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = SL_SCALAR_WAVE ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
     // envs [hot_first, hot_end) of the batch: one slice (slhip_env_step_slices) or all of it
     const unsigned B = tstride;                        // row pitch of the [T, B] per-step arrays
     const int E = hot_E;
@@ -2275,6 +2320,10 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     const bool rlead = live && r == 0;                 // the row lane that writes the board's mailbox
     constexpr bool LEADX = leadx<H, W, LEAN>();
     const bool lwave = wave == (LEADX ? WAVES : 0);    // the leader wave ...
+#ifndef SL_LEADER_PRIO
+#define SL_LEADER_PRIO 0        /* A/B knob: s_setprio of the leader wave (it holds rows AND leads: the wave its workgroup waits for) */
+#endif
+    if (SL_LEADER_PRIO && __builtin_amdgcn_readfirstlane(tid >> 6) == (LEADX ? WAVES : 0)) __builtin_amdgcn_s_setprio(SL_LEADER_PRIO);
     const bool rwave = !(LEADX && lwave);              // waves that hold rows
     // SL_SPARSE_STORE (measured, off): single-step launches store only the boards the CA changed -- in a level of
     // still lifes 57 % of the boards of a step are untouched apart from the agent's own cells, which the leaders then
@@ -2318,9 +2367,10 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     u32 gc_word = 0;
     if (GCACHE && gc_flag && T > 0) gc_word = *(const u32 *)gc_flag;
     bool goals_free = false;
-    auto gc_look = [&]() {
-        asm volatile("" : "+s"(gc_word));
-        goals_free = GCACHE && gc_word == 1u;
+    auto gc_look = [&]() {      // (through a VGPR: an SGPR constraint here has tripped "illegal VGPR to SGPR copy" in the backend)
+        u32 seen = gc_word;
+        asm volatile("" : "+v"(seen));
+        goals_free = GCACHE && __builtin_amdgcn_readfirstlane(seen) == 1u;
     };
     const int8_t *lds_lut = (const int8_t *)(smem + OFF_LUT_V);
     // wrappers: this wave's baseline rows, word k of lane l at [k * 64 + l] (the layout the b32 DMA writes)
@@ -2436,9 +2486,9 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     {
         const int a0 = env.time_limit, a1 = env.exit_points, a2 = env.auto_reset, a3 = env.L, a4 = env.level_stride;
         const void *p0 = out_rec, *p1 = env.pool_board, *p2 = env.pool_goals, *p3 = env.pool_exit_locs;
-        const void *p4 = env.pool_rng, *p5 = env.pool_scalars, *p6 = env.exit_locs;
+        const void *p4 = env.pool_rng, *p5 = env.pool_scalars, *p6 = env.exit_locs, *p7 = env.pool_next;
         asm volatile("" ::"s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(T), "s"(p0), "s"(p1), "s"(p2), "s"(p3),
-                     "s"(p4), "s"(p5), "s"(p6), "s"(reward_t), "s"(done_t), "s"(xcd_base), "s"(xcd_flag));
+                     "s"(p4), "s"(p5), "s"(p6), "s"(p7), "s"(reward_t), "s"(done_t), "s"(xcd_base), "s"(xcd_flag));
     }
     typedef __attribute__((address_space(3))) int *lds_int;       // (a generic volatile pointer would go through FLAT)
     lds_int dirty_flag = (lds_int)(smem + Gm::OFF_GOALS);              // in the region's leading pad
@@ -2461,6 +2511,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
         if (lead) move_box[lq] = mv;
     }
     SL_STAMP(1);
+    if (SL_PRIO_PROLOGUE) __builtin_amdgcn_s_setprio(0);
     // the load barrier: the DMA waves wait for their loads, the leader wave only for its LDS stores (it moved none
     // of the spans, and what it has in flight is its own business)
     if (lwave) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -2696,6 +2747,11 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
             bool changed = true;                             // (wave-uniform) some cell of the wave's rows changed
             if constexpr (use_planes<H, W>()) {
                 u32 row_changed = 0;
+#ifndef SL_TIMING_SKIP
+#define SL_TIMING_SKIP 0        /* TIMING-ONLY builds (wrong results; tools/exp/timing_only.sh): 1 = no CA, 2 = no row scores, 4 = no leader work */
+#endif
+                if (SL_TIMING_SKIP & 1) changed = false;
+                else
                 changed = ca_step<H, W, SPAWN, false>(b, mine, mine, up, dn, cst, pcst, pass_rng, live ? g : 0, p, jump,
                                                       &row_changed);
                 if (SPARSE_STORE && pass == 0) {             // which of the wave's boards changed
@@ -2758,7 +2814,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
         }
         SL_STAMP(5);
         // safelife_env.py:153-160
-        const int score_rows = group_total<H, W>(
+        const int score_rows = (SL_TIMING_SKIP & 2) ? (int)(b[0] & 1u) : group_total<H, W>(
             live ? row_score<H, W, LDS_LUT>(b, gsh_lane, lut, lut_base, lds_lut, cell_mask, c100) : 0, live ? g : 0);
         if (rlead) {
             box[gb].score = score_rows;
@@ -2788,7 +2844,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
         int w_exits = 0;
         if (lwave) {
             if (lane == 0) box[0].any = 0;
-            if (lead) {
+            if (lead && !(SL_TIMING_SKIP & 4)) {
                 const int score = box[lq].score;
                 const int32_t *exits = pool_exits ? env.pool_exit_locs + (size_t)lrec->level_idx * E
                                                   : env.exit_locs + (size_t)el * E;
@@ -2874,7 +2930,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
                         }
                     }
                     if (env.auto_reset && done) {
-                        next_level = (lrec->level_idx + env.level_stride) % env.L;
+                        next_level = env.pool_next ? env.pool_next[lrec->level_idx] : (lrec->level_idx + env.level_stride) % env.L;
                         any |= 1;
                     }
                     box[lq].qslot = slot;
@@ -2922,7 +2978,8 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
                 int next = -1;
                 if (!reset_mask || reset_mask[el]) {
                     const bool was = lrec->loaded != 0;
-                    next = was ? (lrec->level_idx + env.level_stride) % env.L : lrec->level_idx;
+                    next = !was ? lrec->level_idx
+                                : env.pool_next ? env.pool_next[lrec->level_idx] : (lrec->level_idx + env.level_stride) % env.L;
                     if (!was) lrec->episode_idx -= 1;       // (the block below counts one)
                     atomicOr(&box[0].any, 1);
                 }
@@ -3298,6 +3355,7 @@ hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, c
         prepared->off_base = offsetof(RolloutArgs, xcd_base);
         prepared->off_flag = offsetof(RolloutArgs, xcd_flag);
         prepared->off_trace = offsetof(RolloutArgs, reward_t);
+        prepared->off_next = offsetof(RolloutArgs, env) + offsetof(sl_env_batch, pool_next);
         return hipSuccess;
     }
     if (f) {
@@ -3321,9 +3379,15 @@ hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, c
 #define SL_ROWLANE_SHAPES_B(X)
 #define SL_ROWLANE_SHAPES_C(X)
 #else
+#ifdef SL_DEV_SHAPES            /* development builds: the shapes of BASELINE.json only (a quarter of the compile time) */
+#define SL_ROWLANE_SHAPES_A(X) X(25, 25) X(64, 64)
+#define SL_ROWLANE_SHAPES_B(X)
+#define SL_ROWLANE_SHAPES_C(X)
+#else
 #define SL_ROWLANE_SHAPES_A(X) X(25, 25) X(26, 26) X(64, 64) X(24, 24)
 #define SL_ROWLANE_SHAPES_B(X) X(15, 15) X(20, 20) X(10, 10) X(8, 8) X(12, 12) X(16, 16)
 #define SL_ROWLANE_SHAPES_C(X) X(30, 30) X(32, 32) X(40, 40) X(48, 48)
+#endif
 #endif
 #define SL_ROWLANE_SHAPES(X) SL_ROWLANE_SHAPES_A(X) SL_ROWLANE_SHAPES_B(X) SL_ROWLANE_SHAPES_C(X)
 

@@ -190,7 +190,7 @@ class LevelPool(object):
               "pool_initial_points", "pool_table_idx", "points_table")
 
     def __init__(self, levels, *, min_performance_fraction=1.0, seed=None, counts_fn=None,
-                 exit_slots=None):
+                 exit_slots=None, refreshable=False):
         """
         levels : list of Level (same shape, at most one agent each)
         min_performance_fraction : the MinPerformanceScheduler factor (env_wrappers.py:142-145):
@@ -199,6 +199,14 @@ class LevelPool(object):
         seed : levels without an RNG of their own get children of this SeedSequence, in order
             (as SafeLifeLevelIterator.fill_queue does, level_iterator.py:218).
         counts_fn : (boards[L,H,W], goals[L,H,W]) -> int64 [L,8,9]; defaults to the HIP kernel.
+        refreshable : the pool can take NEW levels while envs are stepping (``replace`` here,
+            ``SafeLifeVectorEnv.pool_stage`` / ``pool_commit`` on the device) -- the device-resident
+            counterpart of the reference's level iterator handing every reset a fresh level
+            (level_iterator.py:200-223, safelife_env.py:203-218).  Every logical level l then has TWO
+            physical slots, l and l + L: a replacement is written into the one that is not current, and
+            the successor table (``next_table``) is switched to it between two steps, so a reset that
+            is loading the old content never sees a half-written slot and envs that are still playing
+            it keep an intact copy until the SAME level is replaced once more.
         """
         if not levels:
             raise ValueError("empty level list")
@@ -209,7 +217,7 @@ class LevelPool(object):
                 raise ValueError("all levels of a pool must share one board shape")
             if len(lv.agent_locs) > 1:
                 raise ValueError("the fused environment is single-agent (use SafeLifeEnv for more)")
-        self.levels = levels
+        self.levels = list(levels)
         self.shape = shape
         H, W = shape
         exits = [lv.exit_locs for lv in levels]
@@ -265,8 +273,23 @@ class LevelPool(object):
             # game.min_performance *= fraction  (float64 product, then the same ceil)
             self.pool_required_step[k] = required_points(np.float64(lv.min_performance) * frac, avail)
 
+        self._frac, self._seq, self._counts_fn = frac, seq, counts_fn
+        self.refreshable = bool(refreshable)
+        self.bank = np.zeros(L, np.int8)              # refreshable: which of its two slots holds level l now
+        if self.refreshable:                          # slots L .. 2L-1: the spare bank (starts as a copy: valid content)
+            for k in self.ARRAYS:
+                if k != "points_table":
+                    setattr(self, k, np.concatenate([getattr(self, k)] * 2, axis=0))
+            self.initial_counts = np.concatenate([self.initial_counts] * 2, axis=0)
+
     def __len__(self):
+        """Levels of the pool (logical: a refreshable pool has twice as many physical slots)."""
         return len(self.levels)
+
+    @property
+    def n_slots(self):
+        """Physical slots = the leading dimension of the ``pool_*`` arrays (``sl_env_batch.L``)."""
+        return self.pool_board.shape[0]
 
     @property
     def exit_slots(self):
@@ -274,6 +297,68 @@ class LevelPool(object):
 
     def arrays(self):
         return {k: getattr(self, k) for k in self.ARRAYS}
+
+    def slot_of(self, level):
+        """Physical slot that holds logical level `level` now."""
+        level = int(level)
+        return level + len(self) * int(self.bank[level])
+
+    def next_table(self, level_stride=1):
+        """int32 [n_slots] for ``sl_env_batch.pool_next``: an env on slot s (either bank of level s % L) loads the
+        CURRENT slot of level (s % L + level_stride) % L at its next reset."""
+        L = len(self)
+        cur = np.arange(L, dtype=np.int64) + L * self.bank.astype(np.int64)
+        succ = cur[(np.arange(self.n_slots) % L + int(level_stride)) % L]
+        return succ.astype(np.int32)
+
+    def replace(self, slots, levels):
+        """New content for the logical levels `slots` (refreshable pools): written into each level's SPARE slot, which
+        becomes its current one.  Returns the physical slots written.  Host arrays only -- the device copy and the
+        switch of the successor table are ``SafeLifeVectorEnv.pool_stage`` / ``pool_commit``.  A new level must fit the
+        pool as built: same shape, no more exits than ``exit_slots``, a points table the pool already has, and no
+        spawner in a pool that was built without any (the kernels were chosen for that)."""
+        if not self.refreshable:
+            raise ValueError("build the pool with refreshable=True")
+        slots = [int(x) for x in slots]
+        levels = list(levels)
+        if len(slots) != len(levels) or len(set(slots)) != len(slots):
+            raise ValueError("one new level per distinct slot")
+        L, E = len(self), self.exit_slots
+        for l, lv in zip(slots, levels):
+            if not 0 <= l < L:
+                raise ValueError("no such level slot: %d" % l)
+            if lv.shape != self.shape or len(lv.agent_locs) > 1 or len(lv.exit_locs) > E:
+                raise ValueError("the new level does not fit the pool (shape, agents or exit slots)")
+            if not self.has_spawner and bool(((lv.board | lv.goals) & CellTypes.spawning).any()):
+                raise ValueError("a level with spawners cannot join a pool that was built spawner-free")
+        phys = [l + L * (1 - int(self.bank[l])) for l in slots]
+        boards = np.stack([lv.board for lv in levels])
+        goals = np.stack([lv.goals for lv in levels])
+        counts = np.asarray((self._counts_fn or _device_counts)(boards, goals), np.int64).reshape(len(levels), 8, 9)
+        for i, (l, p, lv) in enumerate(zip(slots, phys, levels)):
+            t = (lv.points_table[0] if len(lv.points_table) else DEFAULT_POINTS_TABLE).astype(np.int32)
+            idx = [j for j, u in enumerate(self.points_table) if np.array_equal(t, u)]
+            if not idx:
+                raise ValueError("the new level's points table is not one of the pool's (the score tables are built once)")
+            if lv.rng_words is None and lv.seed is None:
+                lv = Level(lv.board, lv.goals, lv.agent_locs, lv.spawn_prob, lv.min_performance,
+                           lv.points_table, seed=self._seq.spawn(1)[0])
+            self.pool_board[p], self.pool_goals[p] = lv.board, lv.goals
+            self.pool_agent_loc[p] = lv.agent_locs[0] if len(lv.agent_locs) else (-1, -1)
+            self.pool_exit_locs[p] = -1
+            self.pool_exit_locs[p, :len(lv.exit_locs)] = lv.exit_locs
+            self.pool_spawn_prob[p] = lv.spawn_prob
+            self.pool_rng[p] = lv.initial_rng_words()
+            self.pool_table_idx[p] = idx[0]
+            self.initial_counts[p] = counts[i]
+            table = self.points_table[idx[0]].astype(np.int64)
+            self.pool_initial_points[p] = int((table * counts[i]).sum())
+            avail = available_points(table, counts[i], initial_colors(lv.board))
+            self.pool_required_reset[p] = required_points(lv.min_performance, avail)
+            self.pool_required_step[p] = required_points(np.float64(lv.min_performance) * self._frac, avail)
+            self.levels[l] = lv
+            self.bank[l] = 1 - self.bank[l]
+        return phys
 
 
 def empty_env_arrays(pool, num_envs):

@@ -55,7 +55,7 @@ class RewardGather(object):
 
     RECORD_BYTES = 16
 
-    def __init__(self, env, every=32, world=1, rank=0, group=None, backend=None):
+    def __init__(self, env, every=32, world=1, rank=0, group=None, backend=None, force=None):
         import torch
         self.torch = torch
         self.env, self.every, self.world, self.rank, self.group = env, int(every), int(world), int(rank), group
@@ -63,7 +63,7 @@ class RewardGather(object):
         shape = (self.every, B, 4)
         self.cuda = torch.device(env.device).type == "cuda"
         # SAFELIFE_FORCE_GATHER=1 runs the exchange even with one rank (exercises the RCCL path on a one-GPU box)
-        self.force = os.environ.get("SAFELIFE_FORCE_GATHER", "0") == "1"
+        self.force = (os.environ.get("SAFELIFE_FORCE_GATHER", "0") == "1") if force is None else bool(force)
         self.collective = self.world > 1 or self.force     # False: one rank, nothing to gather
         if backend is None:
             backend = os.environ.get("SAFELIFE_GATHER_BACKEND") or ("rccl" if self.cuda else "torch")

@@ -24,6 +24,15 @@ from .levels import LevelPool
 _DEFAULT_CHANNELS = tuple(range(16)) + (25, 26, 27)      # safelife_env.py:71
 
 
+class _EventSet(object):
+    def __init__(self, events):
+        self.events = list(events)
+
+    def synchronize(self):
+        for e in self.events:
+            e.synchronize()
+
+
 class SideEffectBatch(object):
     """What one ``side_effects_flush()`` produced, still on the device.
 
@@ -34,15 +43,23 @@ class SideEffectBatch(object):
     ``keys`` / ``life_dist`` / ``type_masks``: the distributions of :111-130 (include/safelife_hip.h)
     """
 
-    def __init__(self, env, queue_bufs, out, num_samples):
+    def __init__(self, env, queue_bufs, out, num_samples, done=None):
         self.env, self.num_samples = env, num_samples
         self.count, self.rec_tensor, self.boards = queue_bufs["count"], queue_bufs["records"], queue_bufs["boards"]
         self.counts, self.keys = out["counts"], out["keys"]
         self.life_dist, self.type_masks = out["life_dist"], out["type_masks"]
         self._keep = out
+        self._done = done       # event behind the pass when it ran on the env's side stream (overlap=True)
+
+    def wait(self):
+        """The caller's current stream waits for the pass (a no-op for a pass that ran on that stream); host reads
+        through this class do it themselves."""
+        if self._done is not None:
+            self.env.torch.cuda.current_stream().wait_event(self._done)
 
     def __len__(self):
         """Valid entries (synchronises)."""
+        self.wait()
         return min(int(self.count.item()), self.rec_tensor.shape[0])
 
     def records(self):
@@ -57,10 +74,12 @@ class SideEffectBatch(object):
 
     def dropped(self):
         """Episodes that ended while the queue was full (they were not recorded)."""
+        self.wait()
         return max(0, int(self.count.item()) - self.rec_tensor.shape[0])
 
     def distributions(self, i):
         """(inaction, action): ``{cell type: float64 [H,W]}`` of entry i, as side_effects.py:113-130 builds them."""
+        self.wait()
         rec = self.rec_tensor[i].cpu().numpy()
         n_types = int(rec[7:8].copy().view(np.uint8)[2])
         if n_types > _hip.SL_SE_MAX_KEYS - 8:
@@ -193,14 +212,7 @@ class SafeLifeVectorEnv(object):
         t["pool_exit_locs"] = torch.from_numpy(np.ascontiguousarray(pa["pool_exit_locs"])).to(dev)
         t["pool_rng"] = torch.from_numpy(np.ascontiguousarray(pa["pool_rng"]).view(np.int64)).to(dev)
         t["points_table"] = torch.from_numpy(np.ascontiguousarray(pa["points_table"], dtype=np.int32)).to(dev)
-        lv = np.zeros((len(pool), 8), np.int32)
-        lv[:, 0:2] = pa["pool_agent_loc"]
-        lv[:, 2] = pa["pool_required_reset"]
-        lv[:, 3] = pa["pool_required_step"]
-        lv[:, 4] = pa["pool_initial_points"]
-        lv[:, 5] = pa["pool_table_idx"]
-        lv[:, 6] = pa["pool_spawn_prob"].astype(np.float32).view(np.int32)
-        t["pool_scalars"] = torch.from_numpy(lv).to(dev)
+        t["pool_scalars"] = torch.from_numpy(self._level_scalars(pa, slice(None))).to(dev)
         vh, vw = self.view_shape
         if not with_obs:
             self.obs = None
@@ -232,10 +244,20 @@ class SafeLifeVectorEnv(object):
         s.view_h, s.view_w, s.n_channels = vh, vw, len(chans)
         for i, c in enumerate(chans):
             s.channels[i] = int(c)
-        s.L, s.level_stride = len(pool), int(level_stride)
+        s.L, s.level_stride = pool.n_slots, int(level_stride)
+        # a refreshable pool (levels.LevelPool(refreshable=True)): the successor table instead of the stride rule, two
+        # copies that pool_commit() alternates
+        self._pool_next = None
+        self._pool_refresh = None
+        if getattr(pool, "refreshable", False):
+            nt = torch.from_numpy(pool.next_table(level_stride)).to(dev)
+            self._pool_next = [nt, nt.clone()]
+            self._pool_refresh = {"which": 0, "staged": None, "fence": None, "stream": None}
         s.spawner_free = int(not pool.has_spawner)
         s.stream_salt = 1 + int(env_offset) if episode_streams else 0
         t["score_lut"] = torch.zeros((s.n_tables, 4096 + 65536), dtype=torch.int8, device=dev)
+        if self._pool_next is not None:
+            s.pool_next = self._pool_next[0].data_ptr()
         for name in _hip.ENV_STATE_PTRS + _hip.ENV_POOL_PTRS + _hip.ENV_OUT_PTRS:
             if name == "obs":
                 s.obs = None if self.obs is None else self.obs.data_ptr()
@@ -281,6 +303,7 @@ class SafeLifeVectorEnv(object):
         self._caller_ahead = True        # the caller's stream holds work the slice streams have not been fenced against
         self._queues = None              # step_queues(): the library's own AQL queues (opened on first use)
         self._queues_pending = False     # steps dispatched there since the last queues_sync()
+        self.steps_dispatched = 0        # steps handed to the device so far, whatever the launcher
         self._queue_refs = []            # action tensors of those steps (kept alive until the sync)
         self._stream_ptrs = (C.c_void_p * max(1, n_sl))(*[st.cuda_stream for st in self._slice_streams])
         self._primary_ptr = C.c_void_p(self._primary.cuda_stream)
@@ -301,6 +324,114 @@ class SafeLifeVectorEnv(object):
                 t["goal_cache"] = torch.zeros(total // 4, dtype=torch.int32, device=dev)
                 s.goal_cache = t["goal_cache"].data_ptr()
                 self.goal_cache_group = int(group.value)
+
+    @staticmethod
+    def _level_scalars(pa, sel):
+        """``struct sl_level_scalars`` rows (int32 [n,8]) of the pool slots `sel` from the pool's host arrays."""
+        n = len(pa["pool_table_idx"][sel])
+        lv = np.zeros((n, 8), np.int32)
+        lv[:, 0:2] = pa["pool_agent_loc"][sel]
+        lv[:, 2] = pa["pool_required_reset"][sel]
+        lv[:, 3] = pa["pool_required_step"][sel]
+        lv[:, 4] = pa["pool_initial_points"][sel]
+        lv[:, 5] = pa["pool_table_idx"][sel]
+        lv[:, 6] = pa["pool_spawn_prob"][sel].astype(np.float32).view(np.int32)
+        return lv
+
+    # ---- level-pool refresh while the envs step (levels.LevelPool(refreshable=True)) -------------------------------
+    # The reference hands every reset a NEW level (level_iterator.py:200-223, safelife_env.py:203-218); a device-resident
+    # pool that never changes makes 8192 envs cycle the same few dozen levels for ever.  pool_stage() takes new levels
+    # for some of the pool's logical slots at any time: they are written into those slots' SPARE physical slots (host
+    # arrays at once, device copies from pinned memory on a side stream) together with the successor table that names
+    # them -- nothing an env can load refers to a spare slot, so the copies need no ordering against the steps.
+    # pool_commit() makes them current: it waits for the copies' event (long past, normally) and hands the new table to
+    # every step launched FROM THEN ON -- a kernel argument, patched per dispatch by the queue launcher -- so the switch
+    # falls between two steps of the stepping thread's program order, deterministically, with no queue drain.
+
+    def pool_stage(self, slots, levels):
+        """New levels for the logical pool slots `slots`, staged (see above).  One staging at a time."""
+        rf = self._pool_refresh
+        if rf is None:
+            raise ValueError("the env's pool was not built with refreshable=True")
+        if rf["staged"] is not None:
+            raise ValueError("pool_stage(): the previous staging has not been committed")
+        torch, dev = self.torch, self.device
+        w = self.struct.wrap
+        if self._se is not None or (w.flags & _hip.WRAP_SIDE_EFFECT and not (w.flags & _hip.WRAP_INACTION)):
+            # these read their level's slot long after the reset that loaded it (the episode-end pass takes the
+            # starting board from it, the starting-state baseline its rows): a slot must outlive the episodes on it
+            last = rf.setdefault("last_replaced", {})
+            for l in slots:
+                if self.steps_dispatched - last.get(int(l), -10 ** 9) < self.time_limit:
+                    raise ValueError("pool slot %d was replaced less than one time limit ago: envs may still be playing "
+                                     "its previous content, which this env's side-effect machinery reads from the pool"
+                                     % int(l))
+        # the spare slots about to be overwritten were current until the commit before last at the latest; every step
+        # dispatched before the last commit has long completed -- make sure (a marker taken at that commit)
+        fence = rf["fence"]
+        if fence is not None:
+            kind, what = fence
+            if kind == "queues":
+                self.queues_wait(what)
+            else:
+                what.synchronize()
+            rf["fence"] = None
+        phys = self.pool.replace(slots, levels)
+        pa = self.pool.arrays()
+        sel = np.asarray(phys, np.int64)
+        side = rf["stream"]
+        if side is None:
+            side = rf["stream"] = torch.cuda.Stream(device=dev)
+        idx = torch.from_numpy(sel).to(dev)
+        keep = []                                   # pinned staging buffers, alive until the commit
+
+        def up(host, dst):
+            h = torch.from_numpy(np.ascontiguousarray(host)).pin_memory()
+            keep.append(h)
+            dst.index_copy_(0, idx, h.to(dev, non_blocking=True))
+
+        nxt = 1 - rf["which"]
+        side.wait_stream(torch.cuda.current_stream())       # (idx was uploaded there)
+        with torch.cuda.stream(side):
+            up(pa["pool_board"][sel].view(np.int16), self.t["pool_board"])
+            up(pa["pool_goals"][sel].view(np.int16), self.t["pool_goals"])
+            up(pa["pool_exit_locs"][sel], self.t["pool_exit_locs"])
+            up(pa["pool_rng"][sel].view(np.int64), self.t["pool_rng"])
+            up(self._level_scalars(pa, sel), self.t["pool_scalars"])
+            table = torch.from_numpy(self.pool.next_table(self.struct.level_stride)).pin_memory()
+            keep.append(table)
+            self._pool_next[nxt].copy_(table, non_blocking=True)
+            if w.flags & _hip.WRAP_SIDE_EFFECT and not (w.flags & _hip.WRAP_INACTION):
+                rc = self._lib.slhip_pool_baseline(self._sref, C.c_void_p(side.cuda_stream))
+                _hip.check(rc)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        rf["staged"] = (ev, nxt, keep, [int(l) for l in slots])
+        return phys
+
+    def pool_commit(self):
+        """Make the staged levels current for every step dispatched from now on (no-op without a staging)."""
+        rf = self._pool_refresh
+        if rf is None or rf["staged"] is None:
+            return
+        ev, nxt, keep, slots = rf["staged"]
+        ev.synchronize()
+        rf["staged"] = None
+        rf["which"] = nxt
+        self.struct.pool_next = self._pool_next[nxt].data_ptr()
+        for l in slots:
+            rf.setdefault("last_replaced", {})[l] = self.steps_dispatched
+        # what was current until now may be overwritten by the staging after next: not before every step dispatched so
+        # far is through
+        if self._queues is not None and self._queues_pending:
+            rf["fence"] = ("queues", self.queues_marker())
+        else:
+            evs = []
+            for st in list(self._slice_streams) + [self.torch.cuda.current_stream()]:
+                e = self.torch.cuda.Event()
+                e.record(st)
+                evs.append(e)
+            rf["fence"] = ("events", _EventSet(evs))
 
     def goal_cache_flags(self):
         """Per group of ``goal_cache_group`` consecutive envs: 1 where the group currently steps on cached goal words
@@ -355,7 +486,7 @@ class SafeLifeVectorEnv(object):
         t["move_table"] = torch.from_numpy(table).to(dev)
         t["wrap_state"] = torch.zeros((B, 12), dtype=torch.int32, device=dev)         # struct sl_wrap_state
         t["shaped_reward"] = torch.zeros(B, dtype=torch.float64, device=dev)
-        t["pool_baseline"] = torch.zeros((len(self.pool), H, (W + 1) // 2), dtype=torch.int32, device=dev)
+        t["pool_baseline"] = torch.zeros((self.pool.n_slots, H, (W + 1) // 2), dtype=torch.int32, device=dev)
         w.move_period, w.move_table_len = period, n_tab
         w.move_bonus = float(bonus or 0.0)
         w.exit_bonus = float(cfg.get("exit_bonus") or 0.0)
@@ -417,6 +548,7 @@ class SafeLifeVectorEnv(object):
         rc = self._lib.slhip_env_step(self._sref, _hip.ptr(a), _hip.current_stream_ptr())
         _hip.check(rc)
         self._caller_ahead = True
+        self.steps_dispatched += 1
         return self.obs, self.reward, self.done, self.info
 
     # ---- sliced stepping (slices > 1): no implicit ordering against the caller's stream
@@ -566,6 +698,7 @@ class SafeLifeVectorEnv(object):
         if rc:
             _hip.check(rc)
         self._queues_pending = True
+        self.steps_dispatched += int(n_steps)
 
     def queues_marker(self):
         """A system-scope release behind every queue step dispatched so far; returns a ticket at once (-1: nothing was
@@ -627,6 +760,7 @@ class SafeLifeVectorEnv(object):
             rc = self._lib.slhip_env_step(self._sref, ptr, _hip.current_stream_ptr())
         if rc:
             _hip.check(rc)
+        self.steps_dispatched += 1
 
     def step_slice(self, i, actions):
         """One step of slice i only (envs ``slice_bounds[i] .. slice_bounds[i+1]``), one launch on the slice's own
@@ -668,6 +802,7 @@ class SafeLifeVectorEnv(object):
         self.struct.wrap.shaped_reward_t = None
         _hip.check(rc)
         self._caller_ahead = True
+        self.steps_dispatched += T
         return reward_out, done_out
 
     def set_step_outputs(self, out_ptr):
@@ -716,15 +851,54 @@ class SafeLifeVectorEnv(object):
         q.count, q.records, q.boards = (bufs[k].data_ptr() for k in ("count", "records", "boards"))
         return q, bufs
 
-    def side_effects_flush(self):
-        """Run the episode-end pass (``slhip_side_effects``) over the episodes queued since the last flush, on the
-        caller's current stream, and switch the step kernels to the other queue.  Nothing is read back: the
-        returned ``SideEffectBatch`` takes the queue's buffers along (a fresh queue replaces it) next to the pass's
-        outputs, all device tensors sized by the capacity, plus the device-side entry count; its ``records()`` / ``scores()`` synchronise when (and only when) the host wants the numbers."""
+    def _side_stream(self):
+        """A stream for work that runs UNDER the steps (the episode-end pass): one that shares a hardware queue with
+        none of the slice streams -- HIP multiplexes streams onto four of them, and a 10 ms kernel on a shared one
+        holds that slice's launches up for as long."""
+        se = self._se
+        if se.get("stream") is None:
+            torch = self.torch
+            pick = None
+            for _ in range(12):
+                cand = torch.cuda.Stream(device=self.device)
+                ok = C.c_int(1)
+                for st in [self._primary] + list(self._slice_streams):
+                    _hip.check(self._lib.slhip_streams_concurrent(st.cuda_stream, cand.cuda_stream, C.byref(ok)))
+                    if not ok.value:
+                        break
+                if ok.value:
+                    pick = cand
+                    break
+                se.setdefault("spare_streams", []).append(cand)     # (kept: a released stream's queue slot is handed out again)
+            se["stream"] = pick if pick is not None else torch.cuda.Stream(device=self.device)
+        return se["stream"]
+
+    def side_effects_flush(self, overlap=False):
+        """Run the episode-end pass (``slhip_side_effects``) over the episodes queued since the last flush and switch the
+        step kernels to the other queue.  Nothing is read back: the returned ``SideEffectBatch`` takes the queue's
+        buffers along (a fresh queue replaces it) next to the pass's outputs, all device tensors sized by the capacity,
+        plus the device-side entry count; its ``records()`` / ``scores()`` synchronise when (and only when) the host wants
+        the numbers.
+
+        ``overlap=False``: the pass runs on the caller's current stream, behind every step enqueued so far, and later
+        steps wait for it.  ``overlap=True``: it runs on a side stream of the env, behind the steps enqueued so far, and
+        the steps that FOLLOW do not wait for it (nothing they touch is shared with it: the queue it reads has been
+        replaced, the level pool is read-only) -- ``side_effects_join()`` / the batch's accessors order against it."""
         if self._se is None:
             raise ValueError("construct the env with side_effects=dict(capacity=...) first")
         torch, se = self.torch, self._se
-        self._settle()                                # the queue was filled on the slice streams
+        side = None
+        if overlap and self.device.type == "cuda":
+            side = self._side_stream()
+            if self._queues_pending:
+                self.queues_sync()                    # (queue steps: their fence is a host wait)
+            # the queue was filled by the steps enqueued so far: the side stream waits for them, nobody waits for it
+            before = list(self._slice_streams) + [torch.cuda.current_stream()]
+            b = (C.c_void_p * len(before))(*[st.cuda_stream for st in before])
+            a = (C.c_void_p * 1)(side.cuda_stream)
+            _hip.check(self._lib.slhip_streams_order(b, len(before), a, 1))
+        else:
+            self._settle()                            # the queue was filled on the slice streams
         q, bufs = se["queue"]
         se["queue"] = self._new_queue()               # the step kernels fill a fresh queue from here on
         self.struct.finished = se["queue"][0]
@@ -746,15 +920,30 @@ class SafeLifeVectorEnv(object):
                              life_dist=torch.empty((cap, 2, 8, H, W), dtype=torch.float64, device=dev),
                              type_masks=torch.empty((cap, 2, K - 8, H, W), dtype=torch.uint8, device=dev)))
             out = sets[-1]
+            if side is not None:                      # (first use: the allocations above happened on the caller's stream)
+                side.wait_stream(torch.cuda.current_stream())
         else:
             out = sets[se["flushes"] % len(sets)]
         se["flushes"] = se.get("flushes", 0) + 1
+        stream_ptr = _hip.current_stream_ptr() if side is None else C.c_void_p(side.cuda_stream)
         rc = self._lib.slhip_side_effects(self._sref, C.byref(q), se["num_samples"], 1,
                                           *[_hip.ptr(out[k]) for k in ("work_boards", "work_prob", "work_steps", "work_rng",
                                                                        "counts", "keys", "life_dist", "type_masks")],
-                                          _hip.current_stream_ptr())
+                                          stream_ptr)
         _hip.check(rc)
-        return SideEffectBatch(self, bufs, out, se["num_samples"])
+        done = None
+        if side is not None:
+            for tns in bufs.values():                 # (the allocator must not hand these to someone else while the pass runs)
+                tns.record_stream(side)
+            done = torch.cuda.Event()
+            done.record(side)
+            se["last_done"] = done
+        return SideEffectBatch(self, bufs, out, se["num_samples"], done)
+
+    def side_effects_join(self):
+        """The caller's current stream waits for the last overlapped episode-end pass."""
+        if self._se is not None and self._se.get("last_done") is not None:
+            self.torch.cuda.current_stream().wait_event(self._se["last_done"])
 
     def side_effect_occupancy(self, env_ids, rng, num_samples=1000):
         """The two ``life_occupancy`` tensors of ``side_effect_score`` (side_effects.py:103-111) for the

@@ -169,3 +169,45 @@ def test_every_shipped_benchmark_level():
     got, want = util.bulk_levels_digests(util.OracleBackend, util.oracle_counts)
     assert len(want) == 830
     assert np.array_equal(got, want), np.flatnonzero(got != want)[:10]
+
+
+def test_refreshable_pool_on_the_oracle():
+    """levels.LevelPool(refreshable=True): a replacement goes into the level's spare slot, the successor table names it
+    from then on, and the oracle env that follows the table loads exactly the new content at its next reset -- while an
+    env that is still playing the old content keeps it (its slot is untouched until the same level is replaced again)."""
+    from safelife_amd.levels import LevelPool
+    pool0, _ = util.pool_from_fixture("prune_still_25", util.oracle_counts)
+    levels = list(pool0.levels)
+    L = 8
+    pool = LevelPool(levels[:L], counts_fn=util.oracle_counts, refreshable=True)
+    assert len(pool) == L and pool.n_slots == 2 * L
+    nt = pool.next_table(3)
+    assert np.array_equal(nt[:L], (np.arange(L) + 3) % L) and np.array_equal(nt[L:], nt[:L])
+    B = 2 * L
+    first = np.arange(B) % L
+    kw = dict(auto_reset=True, level_stride=3, time_limit=5, with_obs=False)
+    cpu = util.OracleBackend(pool, B, first_level=first, **kw)
+    cpu.env.set_pool_next(pool.next_table(3))
+    cpu.env.reset()
+    assert np.array_equal(cpu.get("level_idx"), first)
+    old4 = pool.pool_board[4].copy()
+    phys = pool.replace([4, 6], [levels[20], levels[21]])
+    assert phys == [4 + L, 6 + L] and pool.slot_of(4) == 4 + L and pool.slot_of(5) == 5
+    assert np.array_equal(pool.pool_board[4], old4) and np.array_equal(pool.pool_board[4 + L], levels[20].board)
+    cpu.env.set_pool_next(pool.next_table(3))
+    noop = np.zeros(B, np.int32)
+    for t in range(5):              # time limit 5: every env resets at the fifth step, onto (level + 3) % L
+        cpu.env.step(noop)
+    lvl = cpu.get("level_idx")
+    want = (first + 3) % L
+    want = np.where(want == 4, 4 + L, np.where(want == 6, 6 + L, want))
+    assert np.array_equal(lvl, want)
+    e = int(np.nonzero(lvl == 4 + L)[0][0])
+    got = cpu.get("board")[e]
+    keep = (levels[20].board & 256) == 0            # (exit cells are repainted by the reset)
+    assert np.array_equal(got[keep], levels[20].board[keep])
+    # replacing level 4 AGAIN goes back to slot 4; envs on slot 4 + L keep their content
+    phys = pool.replace([4], [levels[22]])
+    assert phys == [4] and np.array_equal(pool.pool_board[4 + L], levels[20].board)
+    with pytest.raises(ValueError):
+        LevelPool(levels[:L], counts_fn=util.oracle_counts).replace([0], [levels[9]])

@@ -10,7 +10,7 @@ for rep in 1 2 3; do
       python3 -c "
 import json,sys
 d=json.loads(sys.argv[1]); r=d['roofline']
-print('%-40s K=%-3d %7.3f us/step  device %.3f us  host %.2f us' % (sys.argv[2], d['steps'], d['ms_per_step']*1e3, r['launch_ms']*1e3, r['host_enqueue_ms_per_step']*1e3))" "$line" "$lib"
+print('%-40s K=%-3d %7.3f us/step  device %.3f us  host %.2f us' % (sys.argv[2], d['steps'], d['ms_per_step']*1e3, r.get('stream_leg_launch_ms', r.get('device_launch_ms', 0))*1e3, r['host_enqueue_ms_per_step']*1e3))" "$line" "$lib"
     done
   done
 done

@@ -73,7 +73,7 @@ while time.time() < t_end:
                 kw={k: v for k, v in kw.items() if k != "first_level"})
     if plain:
         dev.env.reset()
-        cpu.reset()
+        cpu.env.reset()
     else:
         assert np.array_equal(dev.reset(), cpu.reset()), ("reset obs", desc)
     T = int(rng.integers(5, 40))
@@ -82,8 +82,8 @@ while time.time() < t_end:
         if plain:
             dev.env.step(a)
             o1, r1, d1 = None, dev.get("reward"), dev.get("done")
-            o2, r2, d2 = cpu.step(a)
-            o2 = None
+            cpu.env.step(a)
+            o2, r2, d2 = None, cpu.get("reward"), cpu.get("done")
             if rng.random() < 0.1:      # a masked reset in the middle (lowers flags of the cache)
                 mask = (rng.random(B) < 0.3).astype(np.uint8)
                 dev.env.reset(mask)
@@ -112,9 +112,9 @@ while time.time() < t_end:
         r_t, d_t = dev.env.rollout(a)
         want_r, want_d, want_s = [], [], []
         for t in range(T2):
-            _, r2, d2 = cpu.step(a[t])
-            want_r.append(r2)
-            want_d.append(d2)
+            cpu.env.step(a[t])
+            want_r.append(cpu.get("reward"))
+            want_d.append(cpu.get("done"))
             if wrappers:
                 want_s.append(cpu.get("shaped_reward"))
         assert np.array_equal(r_t.cpu().numpy(), np.stack(want_r)) and np.array_equal(d_t.cpu().numpy(), np.stack(want_d)), ("rollout", desc)
