@@ -361,7 +361,9 @@ def main():
                         free = [0, 1, 2, 3]
                     queue_ids[0] = free[:3] if 3 <= len(free) < 4 else [0, 1, 2, 3]
                 ids = queue_ids[0] if ((gather.collective and n_queues == 4) or os.environ.get("SAFELIFE_BENCH_QUEUE_IDS")) else None
-                env.queues_open(len(ids) if ids else n_queues, release_free=(fences == "none"), queue_ids=ids)
+                # (recover=False: this bench has its own answer to a refused placement -- the whole run again with a
+                #  stream's fences -- and keeps the env's per-sync state copy out of the timed region)
+                env.queues_open(len(ids) if ids else n_queues, release_free=(fences == "none"), queue_ids=ids, recover=False)
                 res["use_queues"], res["queues_why"] = True, None
                 res["fences"] = "none" if env.queue_release_free else "agent"
                 if fences == "none" and not env.queue_release_free:
@@ -775,6 +777,21 @@ def main():
         us = e0.elapsed_time(e1) / 200 * 1e3
         extra["c2_advance_board_1024x25x25_us_per_launch"] = us
         extra["c2_advance_board_board_steps_per_s"] = 1024 / (us * 1e-6)
+        # the floor of that figure: the SAME launch (same kernel, grid, arguments, stream, back to back) with zero CA
+        # steps -- rows in, rows out: what one dependent launch of this shape costs on a HIP stream before any rule is
+        # evaluated.  1024 boards are 512 one-wave workgroups on 256 CUs and 2.56 MB: the number is launch latency.
+        c2_floor = c2_args[:6] + (0,) + c2_args[7:]
+        for _ in range(10):
+            c2_fn(*c2_floor)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(200):
+            c2_fn(*c2_floor)
+        e1.record()
+        torch.cuda.synchronize()
+        extra["c2_launch_floor_us_per_launch"] = e0.elapsed_time(e1) / 200 * 1e3
+        extra["c2_launch_floor_note"] = ("slhip_advance_board with n_steps = 0 (load, no step, store), 200 launches back to "
+                                         "back on one stream under HIP events, as the line above")
         # ... and the reference's own C advance_board (oracle/_ref: its sources compiled by oracle/Makefile) on the
         # same 1024 boards, one host core, next to it (cpu_baseline kind "reference" for C2)
         if args.cpu_baseline:

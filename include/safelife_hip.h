@@ -295,7 +295,8 @@ int slhip_env_prepare(const sl_env_batch *env, void *stream);
  * slhip_env_prepare does once, synchronously): after pool slots have been rewritten. */
 int slhip_pool_baseline(const sl_env_batch *env, void *stream);
 
-/* Bytes of env->goal_cache for this batch (0: the board shape has no row kernels -- leave goal_cache NULL).
+/* Bytes of env->goal_cache for this batch as described by *env -- call it with the observation, wrapper and queue fields
+ * already set (0: no step kernel of this batch keeps a cache -- leave goal_cache NULL).
  * *boards_per_block (optional): the cache is one block of bytes / ceil(B / boards_per_block) bytes per group of that many
  * consecutive envs; a block's first 32-bit word is its flag (1: the group steps on cached goal words). */
 size_t slhip_goal_cache_bytes(const sl_env_batch *env, int *boards_per_block);

@@ -371,7 +371,11 @@ int slhip_pool_baseline(const sl_env_batch *env, void *stream) {
 
 size_t slhip_goal_cache_bytes(const sl_env_batch *env, int *boards_per_block) {
     if (boards_per_block) *boards_per_block = 0;
-    if (!env || env->B <= 0 || force_generic()) return 0;
+    if (!env || env->B <= 0 || force_generic() || !env->score_lut) return 0;
+    // only the plain step kernels keep the cache: no observation, no wrappers, and a finished-episode queue only where
+    // the shape's plain kernels serve one (the 64-cell rows of C5)
+    if (env->wrap.flags || env->obs || env->policy_obs) return 0;
+    if (env->finished.capacity > 0 && !sl::rowlane_lean_takes_queue(env->H, env->W)) return 0;
     return sl::rowlane_goal_cache_bytes(env->H, env->W, env->B, boards_per_block);
 }
 

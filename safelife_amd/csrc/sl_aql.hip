@@ -479,7 +479,12 @@ hipError_t emit(Device &d, const Hsa &h, int queue, hipFunction_t f, unsigned gr
                 const AqlPatch *patch = nullptr) {
     const KernelInfo *k = kernel_info(d, f);
     if (!k) return hipErrorNotFound;
-    if (arg_bytes > k->kernarg || k->kernarg > KARG_SLOT || k->priv != 0) return hipErrorInvalidValue;
+    if (arg_bytes > k->kernarg || k->kernarg > KARG_SLOT || k->priv != 0) {
+        // (never expected: say which -- a kernel that spills has private memory, which these packets do not set up)
+        fprintf(stderr, "libsafelife_hip: AQL dispatch refused: argument block %zu bytes, kernel takes %u (slot %zu), private "
+                        "segment %u bytes\n", arg_bytes, (unsigned)k->kernarg, KARG_SLOT, (unsigned)k->priv);
+        return hipErrorInvalidValue;
+    }
     Queue &q = d.queues[queue];
     // the argument block: explicit arguments, zeros where hidden ones would follow (the step kernels have none)
     const unsigned si = (unsigned)(q.karg_next++ % KARG_SLOTS);

@@ -628,19 +628,28 @@ __device__ void resolve_draws(const RowWords<H, W> &b, RowWords<H, W> &n, const 
 // increment's share C_k * inc, k = lane << log2c) instead of fetching the table entry from global memory and
 // multiplying it out at every step: one 128-bit multiply and one L2 round trip less on the step's critical chain.
 struct JumpCache {
-    int log2c = -1;
-    U128 mult = {0, 0}, plus_inc = {0, 0};
+    int log2c = -1;             // (wave-uniform) the deal the cached jumps belong to
+    u64 *lds = nullptr;         // this wave's [4][64] u64: mult hi / lo, (plus * inc) hi / lo of every lane -- in LDS, not in
+                                // registers: eight more registers per lane cost life_occupancy a wave per SIMD at 64x64
 };
 __device__ __forceinline__ U128 pcg_jump_cached(const Jump *__restrict__ table, int k, int log2c, U128 state, U128 inc,
                                                 JumpCache *jc) {
     if (!jc) return pcg_jump(table, k, state, inc);
-    if (jc->log2c != log2c) {           // (wave-uniform: log2c is)
-        const Jump j = table[k];
-        jc->mult = U128{j.mult_hi, j.mult_lo};
-        jc->plus_inc = mul128(U128{j.plus_hi, j.plus_lo}, inc);
-        jc->log2c = log2c;
-    }
-    return add128(mul128(jc->mult, state), jc->plus_inc);
+    const int lane = (int)__lane_id();
+    return add128(mul128(U128{jc->lds[lane], jc->lds[64 + lane]}, state), U128{jc->lds[128 + lane], jc->lds[192 + lane]});
+}
+// (wave-uniform; called by every lane of the wave when the deal changes -- idle lanes included: their k stays inside the
+//  table, 63 << 5 at most)
+__device__ __forceinline__ void pcg_jump_refresh(const Jump *__restrict__ table, int k, int log2c, U128 inc, JumpCache *jc) {
+    if (!jc || jc->log2c == log2c) return;
+    const int lane = (int)__lane_id();
+    const Jump j = table[k];
+    const U128 pi = mul128(U128{j.plus_hi, j.plus_lo}, inc);
+    jc->lds[lane] = j.mult_hi;
+    jc->lds[64 + lane] = j.mult_lo;
+    jc->lds[128 + lane] = pi.hi;
+    jc->lds[192 + lane] = pi.lo;
+    jc->log2c = log2c;
 }
 
 template <int H, int W, int NW>
@@ -697,6 +706,7 @@ __device__ pl::Pl<NW> resolve_draws_planes(const pl::Pl<NW> &elig, u64 *rng_lds,
             const u32 bthr_lo = __builtin_amdgcn_readlane((u32)thr, LaneMap<H, W>::first_lane(0) + 1);
             const u64 bthr = ((u64)bthr_hi << 32) | bthr_lo;
             u32 bits = 0;
+            pcg_jump_refresh(jump, first, log2c, inc, jc);
             if (n_here > 0) {
                 U128 cur = pcg_jump_cached(jump, first, log2c, st, inc, jc);
                 for (int i = 0; i < n_here; ++i) {
@@ -758,6 +768,7 @@ __device__ pl::Pl<NW> resolve_draws_planes(const pl::Pl<NW> &elig, u64 *rng_lds,
             const u32 th1 = __builtin_amdgcn_readlane((u32)(thr >> 32), LaneMap<H, W>::first_lane(1) + 1);
             const u64 wthr = wq ? (((u64)th1 << 32) | tl1) : (((u64)th0 << 32) | tl0);
             u32 bits = 0;
+            pcg_jump_refresh(jump, first, log2c, winc, jc);
             if (n_here > 0) {
                 U128 cur = pcg_jump_cached(jump, first, log2c, wst, winc, jc);
                 for (int i = 0; i < n_here; ++i) {
@@ -1386,7 +1397,8 @@ struct OccGeom {
     static constexpr bool DIRECT = SL_OCC_DIRECT && CB == 8 && use_planes_multi<H, W>();
     static constexpr int OFF_CNT = 0;
     static constexpr int OFF_RNG = DIRECT ? 0 : 64 * PITCH * 4;         // G x 4 u64
-    static constexpr int LDS_BYTES = OFF_RNG + Gm::G * 32;
+    static constexpr int OFF_JUMP = OFF_RNG + ((Gm::G * 32 + 63) & ~63);  // the lanes' cached jumps (JumpCache): 4 x 64 u64
+    static constexpr int LDS_BYTES = OFF_JUMP + 4 * 64 * 8;
     static constexpr int FLUSH_EVERY = (CB == 8 && !DIRECT) ? 255 : 0x7FFFFFFF;
 };
 
@@ -1509,6 +1521,7 @@ __global__ __launch_bounds__(64) void k_occupancy_rowlane(const u16 *__restrict_
     wave_sync();
     int since_drain = 0;
     JumpCache jcache;
+    jcache.lds = (u64 *)(smem + Oc::OFF_JUMP);
     // rows of up to 28 cells, or 64: the row stays in bit-plane form for all the steps (sl_planes.h) -- one
     // transposition at the start, the CA on whole rows, and the counting visits only the cells that ARE alive
     // (a handful per row) instead of every cell position
@@ -2493,7 +2506,11 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     typedef __attribute__((address_space(3))) int *lds_int;       // (a generic volatile pointer would go through FLAT)
     lds_int dirty_flag = (lds_int)(smem + Gm::OFF_GOALS);              // in the region's leading pad
     if (tid == 0) *dirty_flag = 0;
-    const bool has_queue = !LEAN && env.finished.capacity > 0;
+    // (the finished-episode queue is also compiled into the LEAN kernels of the wide shapes -- two waves per SIMD, registers
+    //  to spare: C5's envs then step on the LEAN kernel, goal-word cache and all, with half the LDS per workgroup, which is
+    //  what lets the episode-end pass run beside them)
+    constexpr bool QUEUE_OK = !LEAN || Gm::WAVES_PER_SIMD < 4;
+    const bool has_queue = QUEUE_OK && env.finished.capacity > 0;
     const bool hand_over = env.auto_reset || has_queue;           // (uniform) leaders may ask the rows for something
     // Round 4, single-step launches: the leaders decide the move HERE, in front of the load barrier (their four cells
     // came from global memory, two dependent round trips that run under the bulk loads), and leave what is to be
@@ -2565,7 +2582,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     auto hand_over_block = [&]() {
         const int any = box[0].any;
         if (any & 1) any_reset = true;
-        if (!LEAN && (any & 2)) {
+        if ((!LEAN || Gm::WAVES_PER_SIMD < 4) && (any & 2)) {
             // the step that ended an episode queued it for the side-effect pass (include/safelife_hip.h): the board
             // as the agent left it, from the LDS image, before any reset reloads the slot
             const int slot = rowl ? box[gb].qslot : -1;
@@ -3262,7 +3279,7 @@ template <int H, int W>
 hipError_t pick_rollout_t(const sl_env_batch &env, int T, void **kernel, hipFunction_t *f_out, unsigned *threads_out, int *lds_out,
                           bool *gcache_ok) {
     using Gm = Geom<H, W>;
-    const bool lean = !env.wrap.flags && !env.obs && !env.policy_obs && env.finished.capacity == 0;
+    const bool lean = !env.wrap.flags && !env.obs && !env.policy_obs && (env.finished.capacity == 0 || Gm::WAVES_PER_SIMD < 4);
     const int variant = (env.n_tables == 1 ? 1 : 0) | (env.spawner_free ? 2 : 0) | (env.wrap.flags ? 4 : (lean ? 8 : 0));
     typedef void (*kernel_t)(const u16 *, const u16 *, const sl_pcg64 *, sl_env_scalars *, u32 *,
                              const int32_t *, int, int, const int8_t *, sl_env_batch, int, int, int, sl_step_out *, float *,
@@ -3422,6 +3439,13 @@ int rowlane_policy_room(int H, int W) {
     SL_ROWLANE_SHAPES(X)
 #undef X
     return 0;
+}
+
+bool rowlane_lean_takes_queue(int H, int W) {
+#define X(h, w) if (H == h && W == w) return rl::Geom<h, w>::WAVES_PER_SIMD < 4;
+    SL_ROWLANE_SHAPES(X)
+#undef X
+    return false;
 }
 
 size_t rowlane_goal_cache_bytes(int H, int W, int B, int *boards_per_block) {

@@ -305,6 +305,7 @@ class SafeLifeVectorEnv(object):
         self._queues_pending = False     # steps dispatched there since the last queues_sync()
         self.steps_dispatched = 0        # steps handed to the device so far, whatever the launcher
         self._queue_refs = []            # action tensors of those steps (kept alive until the sync)
+        self._rf_recover, self._rf_ckpt, self._queue_log, self._queue_open_args = False, None, [], None
         self._stream_ptrs = (C.c_void_p * max(1, n_sl))(*[st.cuda_stream for st in self._slice_streams])
         self._primary_ptr = C.c_void_p(self._primary.cuda_stream)
         rc = self._lib.slhip_env_prepare(self._sref, _hip.current_stream_ptr())
@@ -316,8 +317,7 @@ class SafeLifeVectorEnv(object):
         # wrappers, no finished-episode queue -- whose boards have static goals step without moving the goal array.
         # SAFELIFE_GOAL_CACHE=0 leaves it out (A/B runs).
         self.goal_cache_group = 0           # envs per block of the cache (one block per workgroup of the batch), 0 = none
-        plain = not (wrappers or side_effects or self.obs is not None or self.policy_tensor is not None)
-        if plain and s.score_lut and os.environ.get("SAFELIFE_GOAL_CACHE", "1") != "0":
+        if s.score_lut and os.environ.get("SAFELIFE_GOAL_CACHE", "1") != "0":     # (the library says which batches keep one)
             group = C.c_int(0)
             total = int(self._lib.slhip_goal_cache_bytes(self._sref, C.byref(group)))
             if total > 0:
@@ -605,7 +605,10 @@ class SafeLifeVectorEnv(object):
     # ---- sliced stepping on the library's own AQL queues (csrc/sl_aql.hip, slhip_queues_*): what step_async() does
     # ---- with stream slices, without HIP's per-launch host cost -- three to six slices per step become affordable
 
-    def queues_open(self, slices=None, release_free=None, queue_ids=None):
+    _CKPT_NAMES = ("board", "goals", "rng", "scalars", "exit_locs", "out", "wrap_state", "inaction_board", "inaction_rng",
+                   "shaped_reward")
+
+    def queues_open(self, slices=None, release_free=None, queue_ids=None, recover=True):
         """Open one AQL queue per slice (default: SAFELIFE_QUEUE_SLICES or 4).  Raises SafeLifeHipError when the
         batch or the runtime does not support it -- callers keep to step_async() then.
 
@@ -615,10 +618,18 @@ class SafeLifeVectorEnv(object):
         ``release_free`` (default: True only if SAFELIFE_QUEUE_FENCES=none): OPT-IN to steps without a release fence
         (include/safelife_hip.h, SL_QUEUES_RELEASE_FREE) -- ~0.9 us faster per C3 step, valid only while a workgroup
         index keeps its XCD; the library probes that when the queues are opened (``queue_release_free`` tells whether
-        it was granted, ``queue_mode_note`` why not) and every step verifies it: a violation makes ``queues_sync()``
-        raise, and the envs' state since the queues were opened is then lost.  The default keeps a stream's fences."""
+        it was granted, ``queue_mode_note`` why not) and every step verifies it.  The default keeps a stream's fences.
+
+        ``recover`` (release-free stepping only): the env keeps a device-side copy of its state as of the last
+        successful ``queues_sync()`` (one asynchronous copy per sync: 21 MB at C3) and a log of the step calls since.
+        If a step then finds itself on the wrong XCD -- the placement is a property of the process's set of hardware
+        queues: a stream or an RCCL communicator created after the queues were opened can change it -- the sync does
+        not fail: it puts the copy back, reopens the queues with a stream's fences, replays the logged calls and
+        warns; the run continues bit for bit as if the steps had carried fences all along.  ``recover=False``: the
+        sync raises instead and the state since the previous sync is not valid."""
         if self._queues is not None:
             return
+        self._rf_recover, self._rf_ckpt, self._queue_log = False, None, []
         B = self.num_envs
         n = int(slices if slices is not None else (len(queue_ids) if queue_ids is not None else
                                                    os.environ.get("SAFELIFE_QUEUE_SLICES", "4")))
@@ -643,6 +654,58 @@ class SafeLifeVectorEnv(object):
             import warnings
             warnings.warn("safelife_amd: release-free queue stepping was asked for and not granted (%s); stepping with "
                           "agent-scope fences" % self.queue_mode_note, RuntimeWarning, stacklevel=2)
+        self._queue_open_args = dict(slices=n, queue_ids=queue_ids)
+        if self.queue_release_free and recover:
+            self._rf_recover = True
+            self._settle()
+            self._rf_checkpoint()
+
+    def _rf_checkpoint(self):
+        """Device-side copy of everything a step changes, on the caller's stream (release-free stepping with recovery:
+        taken when the queues are opened and after every successful sync)."""
+        names = [k for k in self._CKPT_NAMES if k in self.t]
+        if self._rf_ckpt is None:
+            self._rf_ckpt = {k: self.torch.empty_like(self.t[k]) for k in names}
+        for k in names:
+            self._rf_ckpt[k].copy_(self.t[k], non_blocking=True)
+        if self._se is not None:
+            self._rf_ckpt["se_count"] = self._se["queue"][1]["count"].clone()
+        self._queue_log = []
+        self._caller_ahead = True
+
+    def _rf_recover_now(self, message):
+        """The placement check fired: back to the last good state, stream fences from here on, the logged calls again."""
+        import warnings
+        log, args = self._queue_log, self._queue_open_args
+        self._lib.slhip_queues_close(self._queues)
+        self._queues, self._queues_pending = None, False
+        self.torch.cuda.synchronize(self.device)
+        for k, v in self._rf_ckpt.items():
+            if k == "se_count":
+                self._se["queue"][1]["count"].copy_(v)
+            else:
+                self.t[k].copy_(v)
+        if self.goal_cache_group:
+            self.t["goal_cache"].zero_()
+        self.torch.cuda.synchronize(self.device)
+        self._caller_ahead = True
+        self._rf_recover, self._rf_ckpt = False, None
+        warnings.warn("safelife_amd: release-free queue stepping was refused by its placement check (%s); restored the "
+                      "state of the last sync, reopened the queues with agent-scope fences and replayed %d step call(s)"
+                      % (message.split(";")[0][:200], len(log)), RuntimeWarning, stacklevel=3)
+        self.queues_open(args["slices"], release_free=False, queue_ids=args["queue_ids"])
+        self.steps_dispatched -= sum(c[2] for c in log)
+        keep_out = self.struct.out
+        for actions, ptr, n_steps, stride, out_stride, out_ptr in log:
+            self.struct.out = out_ptr
+            self.step_queues_many(actions if actions is not None else ptr, n_steps, stride, out_stride)
+        self.struct.out = keep_out
+        self._queues_pending = False
+        try:
+            _hip.check(self._lib.slhip_queues_sync(self._queues))
+        finally:
+            self._queue_refs, self._queue_log = [], []
+            self._caller_ahead = True
 
     def _queue_head(self, assume_ordered):
         """1 if the next queue step must take a system-scope acquire behind a device synchronize: HIP streams have
@@ -699,6 +762,9 @@ class SafeLifeVectorEnv(object):
             _hip.check(rc)
         self._queues_pending = True
         self.steps_dispatched += int(n_steps)
+        if self._rf_recover:
+            self._queue_log.append((None if isinstance(actions, int) else actions, ptr, int(n_steps), stride, int(out_stride),
+                                    self.struct.out))
 
     def queues_marker(self):
         """A system-scope release behind every queue step dispatched so far; returns a ticket at once (-1: nothing was
@@ -722,9 +788,16 @@ class SafeLifeVectorEnv(object):
         if self._queues is not None:
             try:
                 _hip.check(self._lib.slhip_queues_sync(self._queues))
+            except _hip.SafeLifeHipError as e:
+                if not (self._rf_recover and "another XCD" in str(e)):
+                    raise
+                self._rf_recover_now(str(e))
+                return
             finally:
                 self._queue_refs = []
                 self._caller_ahead = True
+            if self._rf_recover:
+                self._rf_checkpoint()
 
     def queues_close(self):
         if self._queues is not None:

@@ -912,10 +912,10 @@ def test_sliced_stepping_soak(pool_name, B):
                 assert np.array_equal(env.numpy(name), ref), (trial, n, name)
 
 
-def _queues_or_skip(env, slices=None, release_free=False, queue_ids=None):
+def _queues_or_skip(env, slices=None, release_free=False, queue_ids=None, recover=True):
     from safelife_amd._hip import SafeLifeHipError
     try:
-        env.queues_open(slices, release_free=release_free, queue_ids=queue_ids)
+        env.queues_open(slices, release_free=release_free, queue_ids=queue_ids, recover=recover)
     except SafeLifeHipError as e:           # no HSA queue to be had (not an MI355X box as the driver's): say why
         pytest.skip("AQL queues unavailable: %s" % e)
     if release_free and not env.queue_release_free:
@@ -1109,7 +1109,7 @@ def test_queue_stepping_with_misplaced_workgroups():
 
     dev = util.DeviceBackend(pool, B, **common)
     env = dev.env
-    _queues_or_skip(env, 4, release_free=True)
+    _queues_or_skip(env, 4, release_free=True, recover=False)
     env.reset()
     env.step_queues_many(d_acts[:10])       # honest placement first: nothing to refuse
     env.queues_sync()
@@ -1636,6 +1636,57 @@ def test_goal_word_cache_vs_oracle(pool_name, B, kw):
     static = cpu.get("goals_static") == 1
     for w in np.nonzero(f)[0]:
         assert static[w * nb:(w + 1) * nb].all(), w
+
+
+def test_release_free_stepping_recovers_from_a_misplacement():
+    """Release-free queue stepping that a trainer survives: the env keeps a device-side copy of its state as of the last
+    good sync and a log of the step calls since; when steps then run on the wrong XCD (the self-test hook that swaps the
+    queues: a REAL misplacement, the check fires, boards are wrong) the sync restores the copy, reopens the queues with a
+    stream's fences, replays the log and warns -- and the run goes on bit for bit with the oracle, training wrappers'
+    state included."""
+    import torch
+    from safelife_amd import _hip
+    B, T = 4096 + 11, 75
+    pool, _ = util.pool_from_fixture("prune_still_25", _device_counts, min_performance_fraction=0.05)
+    wr = dict(movement_bonus=0.1, movement_bonus_power=1e-100, movement_bonus_period=4, as_penalty=True, exit_bonus=0.5,
+              penalty_coef=0.3)
+    for wrappers in (None, wr):
+        common = dict(first_level=np.arange(B) % len(pool), auto_reset=True, level_stride=3, time_limit=25, view_shape=(9, 9),
+                      with_obs=False, wrappers=wrappers)
+        cpu = util.OracleBackend(pool, B, **common)
+        cpu.env.reset()
+        acts = np.random.default_rng(14).integers(0, 9, (T, B)).astype(np.int32)
+        d_acts = torch.from_numpy(acts).to("cuda")
+        dev = util.DeviceBackend(pool, B, **common)
+        env = dev.env
+        _queues_or_skip(env, 4, release_free=True)          # (recover=True is the default)
+        assert env._rf_recover
+        env.reset()
+        env.step_queues_many(d_acts[:25])
+        env.queues_sync()                                   # a good sync: the state copy is taken here
+        for t in range(25):
+            cpu.env.step(acts[t], n_threads=8)
+        assert np.array_equal(dev.get("board"), cpu.get("board"))
+        _hip.check(env._lib.slhip_queues_selftest(env._queues, _hip.QUEUES_SELFTEST_SWAP, 1))
+        env.step_queues_many(d_acts[25:40])                 # two calls in the log
+        env.step_queues_many(d_acts[40:50])
+        with pytest.warns(RuntimeWarning, match="placement check"):
+            env.queues_sync()
+        assert not env.queue_release_free and env._queues is not None
+        for t in range(25, 50):
+            cpu.env.step(acts[t], n_threads=8)
+        names = ("reward", "done", "board", "goals", "rng", "agent_loc", "episode_idx", "level_idx", "num_steps")
+        for name in names:
+            assert np.array_equal(dev.get(name), cpu.get(name)), ("after the recovery", name)
+        if wrappers:
+            assert np.array_equal(dev.get("shaped_reward"), cpu.get("shaped_reward"))
+        env.step_queues_many(d_acts[50:])                   # and on, with a stream's fences
+        env.queues_sync()
+        for t in range(50, T):
+            cpu.env.step(acts[t], n_threads=8)
+        for name in names:
+            assert np.array_equal(dev.get(name), cpu.get(name)), ("after the recovery, later", name)
+        env.queues_close()
 
 
 @pytest.mark.parametrize("pool_name,B,wrappers", [
