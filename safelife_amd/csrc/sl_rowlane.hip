@@ -627,34 +627,28 @@ __device__ void resolve_draws(const RowWords<H, W> &b, RowWords<H, W> &n, const 
 // power of two -- hardly ever changes from one step to the next.  So the lane keeps ITS jump (the multiplier A^k and the
 // increment's share C_k * inc, k = lane << log2c) instead of fetching the table entry from global memory and
 // multiplying it out at every step: one 128-bit multiply and one L2 round trip less on the step's critical chain.
-struct JumpCache {
-    int log2c = -1;             // (wave-uniform) the deal the cached jumps belong to
-    u64 *lds = nullptr;         // this wave's [4][64] u64: mult hi / lo, (plus * inc) hi / lo of every lane -- in LDS, not in
-                                // registers: eight more registers per lane cost life_occupancy a wave per SIMD at 64x64
+struct JumpCache {             // (in registers: kept in LDS instead -- 2 KB per wave, four 8-byte reads per step -- the
+    int log2c = -1;             //  pass of C5 ran 13.9 instead of 12.6 ms, slower than without any cache, 13.4)
+    U128 mult = {0, 0}, plus_inc = {0, 0};
 };
 __device__ __forceinline__ U128 pcg_jump_cached(const Jump *__restrict__ table, int k, int log2c, U128 state, U128 inc,
                                                 JumpCache *jc) {
     if (!jc) return pcg_jump(table, k, state, inc);
-    const int lane = (int)__lane_id();
-    return add128(mul128(U128{jc->lds[lane], jc->lds[64 + lane]}, state), U128{jc->lds[128 + lane], jc->lds[192 + lane]});
-}
-// (wave-uniform; called by every lane of the wave when the deal changes -- idle lanes included: their k stays inside the
-//  table, 63 << 5 at most)
-__device__ __forceinline__ void pcg_jump_refresh(const Jump *__restrict__ table, int k, int log2c, U128 inc, JumpCache *jc) {
-    if (!jc || jc->log2c == log2c) return;
-    const int lane = (int)__lane_id();
-    const Jump j = table[k];
-    const U128 pi = mul128(U128{j.plus_hi, j.plus_lo}, inc);
-    jc->lds[lane] = j.mult_hi;
-    jc->lds[64 + lane] = j.mult_lo;
-    jc->lds[128 + lane] = pi.hi;
-    jc->lds[192 + lane] = pi.lo;
-    jc->log2c = log2c;
+    if (jc->log2c != log2c) {
+        const Jump j = table[k];
+        jc->mult = U128{j.mult_hi, j.mult_lo};
+        jc->plus_inc = mul128(U128{j.plus_hi, j.plus_lo}, inc);
+        jc->log2c = log2c;
+    }
+    return add128(mul128(jc->mult, state), jc->plus_inc);
 }
 
-template <int H, int W, int NW>
+// (JC is a template parameter, not just a null pointer: the extra argument alone cost the fused step's spawner
+//  variants five registers -- and the 25x25 one its scratch-free build, which the queue launcher relies on)
+template <int H, int W, int NW, bool JC = false>
 __device__ pl::Pl<NW> resolve_draws_planes(const pl::Pl<NW> &elig, u64 *rng_lds, int g, double p,
-                                           const Jump *__restrict__ jump, JumpCache *jc = nullptr) {
+                                           const Jump *__restrict__ jump, JumpCache *jc_arg = nullptr) {
+    JumpCache *const jc = JC ? jc_arg : nullptr;
     using Gm = Geom<H, W>;
     int mine = 0;
 #pragma unroll
@@ -706,7 +700,6 @@ __device__ pl::Pl<NW> resolve_draws_planes(const pl::Pl<NW> &elig, u64 *rng_lds,
             const u32 bthr_lo = __builtin_amdgcn_readlane((u32)thr, LaneMap<H, W>::first_lane(0) + 1);
             const u64 bthr = ((u64)bthr_hi << 32) | bthr_lo;
             u32 bits = 0;
-            pcg_jump_refresh(jump, first, log2c, inc, jc);
             if (n_here > 0) {
                 U128 cur = pcg_jump_cached(jump, first, log2c, st, inc, jc);
                 for (int i = 0; i < n_here; ++i) {
@@ -768,7 +761,6 @@ __device__ pl::Pl<NW> resolve_draws_planes(const pl::Pl<NW> &elig, u64 *rng_lds,
             const u32 th1 = __builtin_amdgcn_readlane((u32)(thr >> 32), LaneMap<H, W>::first_lane(1) + 1);
             const u64 wthr = wq ? (((u64)th1 << 32) | tl1) : (((u64)th0 << 32) | tl0);
             u32 bits = 0;
-            pcg_jump_refresh(jump, first, log2c, winc, jc);
             if (n_here > 0) {
                 U128 cur = pcg_jump_cached(jump, first, log2c, wst, winc, jc);
                 for (int i = 0; i < n_here; ++i) {
@@ -1397,8 +1389,7 @@ struct OccGeom {
     static constexpr bool DIRECT = SL_OCC_DIRECT && CB == 8 && use_planes_multi<H, W>();
     static constexpr int OFF_CNT = 0;
     static constexpr int OFF_RNG = DIRECT ? 0 : 64 * PITCH * 4;         // G x 4 u64
-    static constexpr int OFF_JUMP = OFF_RNG + ((Gm::G * 32 + 63) & ~63);  // the lanes' cached jumps (JumpCache): 4 x 64 u64
-    static constexpr int LDS_BYTES = OFF_JUMP + 4 * 64 * 8;
+    static constexpr int LDS_BYTES = OFF_RNG + Gm::G * 32;
     static constexpr int FLUSH_EVERY = (CB == 8 && !DIRECT) ? 255 : 0x7FFFFFFF;
 };
 
@@ -1521,7 +1512,6 @@ __global__ __launch_bounds__(64) void k_occupancy_rowlane(const u16 *__restrict_
     wave_sync();
     int since_drain = 0;
     JumpCache jcache;
-    jcache.lds = (u64 *)(smem + Oc::OFF_JUMP);
     // rows of up to 28 cells, or 64: the row stays in bit-plane form for all the steps (sl_planes.h) -- one
     // transposition at the start, the CA on whole rows, and the counting visits only the cells that ARE alive
     // (a handful per row) instead of every cell position
@@ -1579,7 +1569,7 @@ __global__ __launch_bounds__(64) void k_occupancy_rowlane(const u16 *__restrict_
 #ifdef SL_OCC_NODRAW
                 return elig;
 #else
-                return resolve_draws_planes<H, W, NW>(elig, rng_lds, rowl ? g : 0, p, jump, &jcache);
+                return resolve_draws_planes<H, W, NW, true>(elig, rng_lds, rowl ? g : 0, p, jump, &jcache);
 #endif
             });
         } else {
@@ -2319,7 +2309,8 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
 #endif
     if (SL_PRIO_PROLOGUE) __builtin_amdgcn_s_setprio(SL_PRIO_PROLOGUE);
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = SL_SCALAR_WAVE ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
+    // (the plain single-step kernels only: the others sit at their register limit, and a scalar there tips them into scratch)
+    const int wave = (SL_SCALAR_WAVE && ONE && LEAN) ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
     // envs [hot_first, hot_end) of the batch: one slice (slhip_env_step_slices) or all of it
     const unsigned B = tstride;                        // row pitch of the [T, B] per-step arrays
     const int E = hot_E;
@@ -2368,7 +2359,9 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     u32 gsh_reg[GSH_REG ? WS : 1];
     u32 *gsh_lane = GSH_REG ? gsh_reg : (u32 *)(smem + Gm::OFF_GSH) + (wave * 64 + lane) * WS;
     // the goal-word cache (GoalCache above): LEAN kernels whose goal words live in registers
-    constexpr bool GCACHE = LEAN && GSH_REG && !LEADX;
+    // (single-step launches: the T-step instantiations sit at their register limit -- a T-step launch of a batch that
+    //  has a cache lowers every flag first, launch_rollout_t)
+    constexpr bool GCACHE = LEAN && GSH_REG && ONE && !LEADX;
     using Gc = GoalCache<H, W>;
     u32 *const gc_block = GCACHE && hot_gcache ? hot_gcache + (size_t)((unsigned)hot_first / Gm::NB + blockIdx.x) * Gc::BLOCK_DWORDS
                                                : nullptr;
@@ -2381,9 +2374,11 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     if (GCACHE && gc_flag && T > 0) gc_word = *(const u32 *)gc_flag;
     bool goals_free = false;
     auto gc_look = [&]() {      // (through a VGPR: an SGPR constraint here has tripped "illegal VGPR to SGPR copy" in the backend)
-        u32 seen = gc_word;
-        asm volatile("" : "+v"(seen));
-        goals_free = GCACHE && __builtin_amdgcn_readfirstlane(seen) == 1u;
+        if constexpr (GCACHE) {
+            u32 seen = gc_word;
+            asm volatile("" : "+v"(seen));
+            goals_free = __builtin_amdgcn_readfirstlane(seen) == 1u;
+        }
     };
     const int8_t *lds_lut = (const int8_t *)(smem + OFF_LUT_V);
     // wrappers: this wave's baseline rows, word k of lane l at [k * 64 + l] (the layout the b32 DMA writes)
@@ -2450,10 +2445,12 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
         const int dw = LEADX ? wave : wave - 1;
         dma_to_lds<Gm::NB * 32, false, DW>((const unsigned char *)(k_rng + e0b), smem + Gm::OFF_RNG, nbb * 32, lane, dw);
         dma_to_lds<Gm::NB * 64, false, DW>((const unsigned char *)(hot_scalars + e0b), smem + Gm::OFF_REC, nbb * 64, lane, dw);
+        // (the score table's pointer is not preloaded: where the flag is looked at anyway, its DMA goes behind that wait)
+        if (LDS_LUT && !GCACHE) dma_to_lds<4096, false, DW>((const unsigned char *)k_lut, smem + OFF_LUT_V, 4096, lane, dw);
         load_span<H, W, DW>(k_board + (size_t)e0b * HW, board, nbb, lane, dw);
         gc_look();
         if (!goals_free) load_span<H, W, DW>(k_goals + (size_t)e0b * HW, goals, nbb, lane, dw);
-        if (LDS_LUT) dma_to_lds<4096, false, DW>((const unsigned char *)k_lut, smem + OFF_LUT_V, 4096, lane, dw);
+        if (LDS_LUT && GCACHE) dma_to_lds<4096, false, DW>((const unsigned char *)k_lut, smem + OFF_LUT_V, 4096, lane, dw);
         if (WRAP) {
             dma_to_lds<Gm::NB * (int)sizeof(sl_wrap_state), false, DW>((const unsigned char *)(env.wrap.state + e0b),
                                                                        smem + Gm::OFF_WST,
@@ -2499,9 +2496,9 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     {
         const int a0 = env.time_limit, a1 = env.exit_points, a2 = env.auto_reset, a3 = env.L, a4 = env.level_stride;
         const void *p0 = out_rec, *p1 = env.pool_board, *p2 = env.pool_goals, *p3 = env.pool_exit_locs;
-        const void *p4 = env.pool_rng, *p5 = env.pool_scalars, *p6 = env.exit_locs, *p7 = env.pool_next;
+        const void *p4 = env.pool_rng, *p5 = env.pool_scalars, *p6 = env.exit_locs;
         asm volatile("" ::"s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(T), "s"(p0), "s"(p1), "s"(p2), "s"(p3),
-                     "s"(p4), "s"(p5), "s"(p6), "s"(p7), "s"(reward_t), "s"(done_t), "s"(xcd_base), "s"(xcd_flag));
+                     "s"(p4), "s"(p5), "s"(p6), "s"(reward_t), "s"(done_t), "s"(xcd_base), "s"(xcd_flag));
     }
     typedef __attribute__((address_space(3))) int *lds_int;       // (a generic volatile pointer would go through FLAT)
     lds_int dirty_flag = (lds_int)(smem + Gm::OFF_GOALS);              // in the region's leading pad
@@ -3298,7 +3295,7 @@ hipError_t pick_rollout_t(const sl_env_batch &env, int T, void **kernel, hipFunc
     const kernel_t fn = table[slot];
     const bool spawn = !(variant & 2), base_in_gsh = !spawn && Gm::WAVES_PER_SIMD == 4;
     // (the kernel's GCACHE: LEAN instantiations whose goal words live in registers)
-    *gcache_ok = (variant & 8) && gsh_in_registers<H, W>(spawn, true, T == 1) && !Gm::LEADX_OK;
+    *gcache_ok = (variant & 8) && T == 1 && gsh_in_registers<H, W>(spawn, true, true) && !Gm::LEADX_OK;
     const int lds_wrap = base_in_gsh ? Gm::LDS_WRAP_GSHREG : Gm::LDS_WRAP_GSHLDS;
     const int lds_plain = lean_lds<H, W>(spawn, (variant & 8) != 0, T == 1) ? lean_lds_bytes<H, W>() : Gm::LDS_BYTES;
     const int lds = !(variant & 4) ? lds_plain : lds_wrap + ((env.wrap.flags & SL_WRAP_INACTION) ? Gm::INACTION_BYTES : 0);

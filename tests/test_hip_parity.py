@@ -1049,7 +1049,7 @@ def test_queue_stepping_refuses_a_planted_placement_record():
     acts = torch.zeros((B,), dtype=torch.int32, device="cuda")
     kw = dict(auto_reset=True, time_limit=20, view_shape=(9, 9), with_obs=False)
     env = SafeLifeVectorEnv(pool, B, **kw)
-    _queues_or_skip(env, 2, release_free=True)
+    _queues_or_skip(env, 2, release_free=True, recover=False)
     env.reset()
     env.step_queues(acts)
     env.queues_sync()                       # an honest record: nothing to refuse
@@ -1755,7 +1755,8 @@ def test_level_pool_refresh_while_stepping(pool_name, B, wrappers):
             if wrappers:
                 assert np.array_equal(dev.get("shaped_reward"), cpu.get("shaped_reward")), t0 + CH
     assert cpu.get("episode_idx").min() >= 10
-    assert len(np.unique(cpu.get("level_idx"))) > 32        # both banks in use
+    lvl = cpu.get("level_idx")
+    assert (lvl >= 32).any() and (lvl < 32).any()           # both banks in use
     env.queues_close()
 
 
