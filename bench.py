@@ -1016,6 +1016,20 @@ def main():
                          stream_key + "_achieved": achieved_device, stream_key + "_frac": achieved_device / HBM_PEAK_GBS,
                          "host_enqueue_ms_per_step": (t_enqueued - t_start) / K * 1e3,
                          "measured_ceiling": ceiling,
+                         # the issue side next to the HBM side (C3, four waves per SIMD; counters and timing-only builds
+                         # committed under profiles/, not measured in this run)
+                         "issue_side": ({"valu_per_wave": 539, "salu_per_wave": 235, "lds_per_wave": 53, "waves_per_simd": 4,
+                                         "valu_cycles_each": [2, 4],
+                                         "valu_issue_us_per_step": [4 * 539 * 2 / 2.4e3, 4 * 539 * 4 / 2.4e3],
+                                         "hbm_floor_us_per_step": bytes_per_step * B / (HBM_PEAK_GBS * 1e3),
+                                         "timing_only_us_per_step": {"full": 6.4, "no_ca": 5.7, "no_scores": 6.2,
+                                                                     "no_leader_work": 6.1, "skeleton": 4.8},
+                                         "binds": "neither roofline: the step is one launch's latency chain (DMA issue, "
+                                                  "memory latency, three workgroup barriers, stores) plus the CP's "
+                                                  "boundary between launches; the SIMDs are at most half busy",
+                                         "source": "profiles/round5_i_queues4_none_pmc.txt, round5_a_c3_issue_pmc.txt, "
+                                                   "round5_f_timing_only.txt; DESIGN.md section 6"}
+                                        if args.pool == "prune_still_25" and B == 8192 and not args.obs else None),
                          "note": "frac = bytes_per_env_step x envs / ms_per_step / peak.  rocprofv3 serialises the queues' "
                                  "dispatches (its kernel trace gives per-launch durations only); the four queues' overlap "
                                  "is shown by the kernels' own clocks (tools/trace_overlap.py); traffic is null for "

@@ -718,6 +718,8 @@ __device__ pl::Pl<NW> resolve_draws_planes(const pl::Pl<NW> &elig, u64 *rng_lds,
             if (per > 4) v |= (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x101F);      // xor 4
             if (per > 8) v |= (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x201F);      // xor 8
             if (per > 16) v |= (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);     // xor 16
+            // (round 5, measured and dropped: DPP quad permutes and row mirrors for the steps inside a row of sixteen
+            //  lanes -- bit exact, and no faster: the pass of C5 12.0-12.1 ms either way, C4's step 8.04-8.14)
             // dword d of the outcome string sits in lanes [d per, (d + 1) per); mine start at bit `excl`
             const int w0 = excl >> 5, sh = excl & 31;
             const int log2per = 5 - log2c;
@@ -779,6 +781,8 @@ __device__ pl::Pl<NW> resolve_draws_planes(const pl::Pl<NW> &elig, u64 *rng_lds,
             if (per > 4) v |= (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x101F);      // xor 4
             if (per > 8) v |= (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x201F);      // xor 8
             if (per > 16) v |= (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);     // xor 16
+            // (round 5, measured and dropped: DPP quad permutes and row mirrors for the steps inside a row of sixteen
+            //  lanes -- bit exact, and no faster: the pass of C5 12.0-12.1 ms either way, C4's step 8.04-8.14)
             // dword d of board q's outcome string sits in lanes [32 q + d per, 32 q + (d + 1) per)
             const int w0 = excl >> 5, sh = excl & 31;
             const int log2per = 5 - log2c;
@@ -3446,12 +3450,17 @@ bool rowlane_lean_takes_queue(int H, int W) {
 }
 
 size_t rowlane_goal_cache_bytes(int H, int W, int B, int *boards_per_block) {
+    // (slices and queue slices start at multiples of 64 envs: shapes whose workgroups hold 12, 20 or 24 boards would have
+    //  launches off the blocks' grid -- they go without a cache)
 #define X(h, w)                                                         \
     if (H == h && W == w) {                                             \
+        if (64 % rl::Geom<h, w>::NB != 0) break;                        \
         if (boards_per_block) *boards_per_block = rl::Geom<h, w>::NB;   \
         return rl::GoalCache<h, w>::bytes(B);                           \
     }
-    SL_ROWLANE_SHAPES(X)
+    do {
+        SL_ROWLANE_SHAPES(X)
+    } while (false);
 #undef X
     if (boards_per_block) *boards_per_block = 0;
     return 0;
