@@ -280,7 +280,10 @@ typedef struct sl_env_batch {
                                     boards all have them there moves no goal array at all.  The kernels maintain it
                                     across steps, resets and slices; whoever writes `goals`, `scalars.goals_static` or
                                     `scalars.level_idx` from OUTSIDE the library zeroes it again.  Only batches without
-                                    observation, wrappers and finished-episode queue use it.  NULL = none */
+                                    observation and wrappers use it (with a finished-episode queue: the wide board shapes).
+                                    The kernels that keep it hold no goal image in LDS at all: WITHOUT the workspace
+                                    (NULL) they fetch every lane's goal row from global memory at every step -- correct,
+                                    and slower; give such batches their cache */
     sl_wrappers wrap;            /* training wrappers; wrap.flags == 0 => none */
     sl_episode_queue finished;   /* episodes that ended, for the side-effect pass; finished.capacity == 0 => none */
 } sl_env_batch;

@@ -349,6 +349,67 @@ __device__ __forceinline__ void write_row(unsigned char *region, int gb, int r, 
     }
 }
 
+// A row straight from / to GLOBAL memory (round 5: the plain single-step kernels keep no goal image in LDS; a goal row
+// is touched there only on the rare launches that find no cached goal words, or that evolve or reload a goal array).
+// Rows that are whole 16-byte chunks (and therefore 16-byte aligned) go as chunks, the others cell by cell.
+template <int H, int W>
+__device__ __forceinline__ void read_row_global(const u16 *__restrict__ row, RowWords<H, W> &b) {
+    using Gm = Geom<H, W>;
+    if constexpr (W % 8 == 0) {
+        u32 d[W / 2];
+#pragma unroll
+        for (int j = 0; j < W / 8; ++j) {
+            const u32x4 v = ((const u32x4 *)row)[j];
+            d[4 * j + 0] = v.x, d[4 * j + 1] = v.y, d[4 * j + 2] = v.z, d[4 * j + 3] = v.w;
+        }
+#pragma unroll
+        for (int k = 0; k < Gm::WS; ++k)
+            b[k] = __builtin_amdgcn_perm(d[(k + Gm::WS) >> 1], d[k >> 1], (k & 1) ? 0x07060302u : 0x05040100u);
+    } else {
+#pragma unroll
+        for (int k = 0; k < Gm::WS; ++k) {
+            const u32 lo = row[k];
+            const u32 hi = (Gm::ODD && k == Gm::WS - 1) ? 0u : (u32)row[k + Gm::WS];
+            b[k] = lo | (hi << 16);
+        }
+    }
+}
+template <int H, int W>
+__device__ __forceinline__ void write_row_global(u16 *__restrict__ row, const RowWords<H, W> &n) {
+    using Gm = Geom<H, W>;
+    if constexpr (W % 8 == 0) {
+#pragma unroll
+        for (int j = 0; j < W / 8; ++j) {
+            u32 q[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c0 = 2 * (4 * j + i);
+                q[i] = c0 < Gm::WS ? __builtin_amdgcn_perm(n[c0 + 1], n[c0], 0x05040100u)
+                                   : __builtin_amdgcn_perm(n[c0 + 1 - Gm::WS], n[c0 - Gm::WS], 0x07060302u);
+            }
+            ((u32x4 *)row)[j] = u32x4{q[0], q[1], q[2], q[3]};
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < Gm::WS; ++k) {
+            row[k] = (u16)n[k];
+            if (!(Gm::ODD && k == Gm::WS - 1)) row[k + Gm::WS] = (u16)(n[k] >> 16);
+        }
+    }
+}
+// the split-halves words of a row held as consecutive cell pairs: pair j = (cell 2j, cell 2j + 1), an odd row's last cell
+// alone in the low half of pair WS - 1
+template <int H, int W>
+__device__ __forceinline__ void words_from_pairs(const u32 (&tw)[Geom<H, W>::WS], RowWords<H, W> &b) {
+    using Gm = Geom<H, W>;
+#pragma unroll
+    for (int k = 0; k < Gm::WS; ++k) {
+        const u32 sel = ((k & 1) ? 0x0302u : 0x0100u) | ((((k + Gm::WS) & 1) ? 0x0706u : 0x0504u) << 16);
+        b[k] = (Gm::ODD && k == Gm::WS - 1) ? (tw[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu
+                                            : __builtin_amdgcn_perm(tw[(k + Gm::WS) >> 1], tw[k >> 1], sel);
+    }
+}
+
 // Left / right neighbour words of an array of per-cell words in the split layout.
 template <int H, int W>
 struct Seams {
@@ -2274,10 +2335,22 @@ constexpr bool lean_lds(bool spawn, bool lean, bool one) {
 }
 template <int H, int W>
 constexpr int lean_lds_bytes() { return Geom<H, W>::OFF_GSH + 4096 + Geom<H, W>::NB * 16; }
+// the plain single-step kernels whose goal words live in registers: goal-word cache, no goal image in LDS
+template <int H, int W>
+constexpr bool nogoals_lds(bool spawn, bool lean, bool one) {
+    return lean && one && !Geom<H, W>::LEADX_OK && gsh_in_registers<H, W>(spawn, lean, one);
+}
+template <int H, int W>
+constexpr int nogoals_shift() { return Geom<H, W>::REGION - 16; }
 
 template <int H, int W, bool LDS_LUT, bool SPAWN, bool WRAP, bool LEAN, bool ONE>
+#ifndef SL_WIDE_WAVES
+#define SL_WIDE_WAVES 3         /* A/B knob: waves per SIMD the plain single-step kernels of the wide shapes are compiled for (2: rounds 1-4) */
+#endif
 __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
-                             (leadx<H, W, LEAN>() ? 5 : Geom<H, W>::WAVES_PER_SIMD)) void k_env_rollout_rowlane(
+                             (leadx<H, W, LEAN>() ? 5
+                              : (Geom<H, W>::WAVES_PER_SIMD < 4 && nogoals_lds<H, W>(SPAWN, LEAN, ONE)) ? SL_WIDE_WAVES
+                                                                                                       : Geom<H, W>::WAVES_PER_SIMD)) void k_env_rollout_rowlane(
     // the eight arguments the prologue needs before anything else come first: with
     // -amdgpu-kernarg-preload-count=8 they arrive in SGPRs with the wave instead of behind an s_load
     const u16 *__restrict__ hot_board, const u16 *__restrict__ hot_goals, const sl_pcg64 *__restrict__ hot_rng,
@@ -2327,6 +2400,14 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     const bool live = rowl && lm.real;                 // owns row r of board gb
     const bool rlead = live && r == 0;                 // the row lane that writes the board's mailbox
     constexpr bool LEADX = leadx<H, W, LEAN>();
+    // The plain single-step kernels keep the lanes' goal words across launches (GoalCache) and NO goal image in LDS
+    // (NOGOALS): a launch on cached words needs none, and the rare launch that does need goal rows -- no cache yet, an
+    // evolving goal array, a level being loaded -- moves them between registers and global memory row by row.
+    // Everything behind the board image then sits one image lower (smem_hi), and the workgroup asks for that much less
+    // LDS (25x25: 24.4 -> 14.4 KB; 64x64: 70 -> 37 KB: four workgroups fit a CU instead of two).
+    constexpr bool NOGOALS = nogoals_lds<H, W>(SPAWN, LEAN, ONE);
+    static_assert(!NOGOALS || (LEAN && !WRAP), "the goal-image-free layout is the plain kernels'");
+    unsigned char *const smem_hi = smem - (NOGOALS ? Gm::REGION - 16 : 0);
     const bool lwave = wave == (LEADX ? WAVES : 0);    // the leader wave ...
 #ifndef SL_LEADER_PRIO
 #define SL_LEADER_PRIO 0        /* A/B knob: s_setprio of the leader wave (it holds rows AND leads: the wave its workgroup waits for) */
@@ -2349,9 +2430,9 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     unsigned char *board = smem + Gm::OFF_BOARD, *goals = smem + Gm::OFF_GOALS;
     u16 *board16 = (u16 *)(board + Gm::PAD) + (live ? gb : 0) * HW;
     u16 *lboard16 = (u16 *)(board + Gm::PAD) + lq * HW;
-    u64 *rng_lds = (u64 *)(smem + Gm::OFF_RNG) + 4 * Gm::G * wave;
-    u64 *lrng = (u64 *)(smem + Gm::OFF_RNG) + 4 * lq;
-    BoardBox *box = (BoardBox *)(smem + Gm::OFF_BOX);
+    u64 *rng_lds = (u64 *)(smem_hi + Gm::OFF_RNG) + 4 * Gm::G * wave;
+    u64 *lrng = (u64 *)(smem_hi + Gm::OFF_RNG) + 4 * lq;
+    BoardBox *box = (BoardBox *)(smem_hi + Gm::OFF_BOX);
     // goal colours of the lane's row, pre-shifted for the score index: in registers where the
     // budget allows (spawner-free variants; 64-wide boards run 2 waves/SIMD), else in LDS
     // (and the LEAN single-step instantiation of the spawner variant where it fits: 114 -> 125 VGPRs at 25x25, C4's
@@ -2361,11 +2442,12 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     constexpr bool SHRINK = lean_lds<H, W>(SPAWN, LEAN, ONE);
     constexpr int OFF_LUT_V = SHRINK ? Gm::OFF_GSH : Gm::OFF_LUT, OFF_MOVE_V = SHRINK ? Gm::OFF_GSH + 4096 : Gm::OFF_MOVE;
     u32 gsh_reg[GSH_REG ? WS : 1];
-    u32 *gsh_lane = GSH_REG ? gsh_reg : (u32 *)(smem + Gm::OFF_GSH) + (wave * 64 + lane) * WS;
+    u32 *gsh_lane = GSH_REG ? gsh_reg : (u32 *)(smem_hi + Gm::OFF_GSH) + (wave * 64 + lane) * WS;
     // the goal-word cache (GoalCache above): LEAN kernels whose goal words live in registers
     // (single-step launches: the T-step instantiations sit at their register limit -- a T-step launch of a batch that
     //  has a cache lowers every flag first, launch_rollout_t)
     constexpr bool GCACHE = LEAN && GSH_REG && ONE && !LEADX;
+    static_assert(GCACHE == NOGOALS, "the kernels that keep the cache are the ones without a goal image");
     using Gc = GoalCache<H, W>;
     u32 *const gc_block = GCACHE && hot_gcache ? hot_gcache + (size_t)((unsigned)hot_first / Gm::NB + blockIdx.x) * Gc::BLOCK_DWORDS
                                                : nullptr;
@@ -2384,18 +2466,18 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
             goals_free = __builtin_amdgcn_readfirstlane(seen) == 1u;
         }
     };
-    const int8_t *lds_lut = (const int8_t *)(smem + OFF_LUT_V);
+    const int8_t *lds_lut = (const int8_t *)(smem_hi + OFF_LUT_V);
     // wrappers: this wave's baseline rows, word k of lane l at [k * 64 + l] (the layout the b32 DMA writes)
     constexpr bool BASE_IN_GSH = GSH_REG && Gm::GSH_BYTES >= WAVES * 64 * WS * 4;
-    unsigned char *base_rows = smem + (BASE_IN_GSH ? Gm::OFF_GSH : Gm::OFF_BASE) + wave * 64 * WS * 4;
+    unsigned char *base_rows = smem_hi + (BASE_IN_GSH ? Gm::OFF_GSH : Gm::OFF_BASE) + wave * 64 * WS * 4;
     // SimpleSideEffectPenalty's "inaction" baseline (env_wrappers.py:179-180), folded into this kernel in round 4: the
     // baseline boards of the workgroup's envs in a third LDS image, advanced by one more pass of the CA loop below
     const bool inaction = WRAP && (env.wrap.flags & SL_WRAP_INACTION) != 0;
     constexpr int OFF_INB = BASE_IN_GSH ? Gm::LDS_WRAP_GSHREG : Gm::LDS_WRAP_GSHLDS;
-    unsigned char *inb = smem + OFF_INB;
-    u64 *irng_lds = (u64 *)(smem + OFF_INB + Gm::REGION) + 4 * Gm::G * wave;
-    sl_wrap_state *wst = (sl_wrap_state *)(smem + Gm::OFF_WST);
-    const double *mvt = (const double *)(smem + Gm::OFF_MVT);
+    unsigned char *inb = smem_hi + OFF_INB;
+    u64 *irng_lds = (u64 *)(smem_hi + OFF_INB + Gm::REGION) + 4 * Gm::G * wave;
+    sl_wrap_state *wst = (sl_wrap_state *)(smem_hi + Gm::OFF_WST);
+    const double *mvt = (const double *)(smem_hi + Gm::OFF_MVT);
     const int8_t *__restrict__ lut = env.score_lut + 4096;        // wide form of table t at + t * SCORE_LUT_BYTES
     const Consts cst = make_consts();
     const pl::PConsts pcst = pl::make_pconsts();
@@ -2418,7 +2500,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     // dozen per-board values held in registers for the whole launch cost every wave of the kernel those registers);
     // only the agent's location, which the move of step 0 needs before the copies have landed, is loaded directly.
     static_assert(sizeof(sl_env_scalars) == 64, "record stride");
-    sl_env_scalars *const lrec = (sl_env_scalars *)(smem + Gm::OFF_REC) + lq;
+    sl_env_scalars *const lrec = (sl_env_scalars *)(smem_hi + Gm::OFF_REC) + lq;
     int ly = -1, lx = 0, exit0 = -1, action = 0;
     bool pool_exits = false;                            // the board's exit table: its own row of env.exit_locs, or
                                                         // (after a reset in this launch) the pool level's
@@ -2447,25 +2529,25 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
         // everything bulky goes through the LDS DMA, issued by the waves that are not the leader
         constexpr int DW = LEADX ? WAVES : WAVES - 1;
         const int dw = LEADX ? wave : wave - 1;
-        dma_to_lds<Gm::NB * 32, false, DW>((const unsigned char *)(k_rng + e0b), smem + Gm::OFF_RNG, nbb * 32, lane, dw);
-        dma_to_lds<Gm::NB * 64, false, DW>((const unsigned char *)(hot_scalars + e0b), smem + Gm::OFF_REC, nbb * 64, lane, dw);
+        dma_to_lds<Gm::NB * 32, false, DW>((const unsigned char *)(k_rng + e0b), smem_hi + Gm::OFF_RNG, nbb * 32, lane, dw);
+        dma_to_lds<Gm::NB * 64, false, DW>((const unsigned char *)(hot_scalars + e0b), smem_hi + Gm::OFF_REC, nbb * 64, lane, dw);
         // (the score table's pointer is not preloaded: where the flag is looked at anyway, its DMA goes behind that wait)
-        if (LDS_LUT && !GCACHE) dma_to_lds<4096, false, DW>((const unsigned char *)k_lut, smem + OFF_LUT_V, 4096, lane, dw);
+        if (LDS_LUT && !GCACHE) dma_to_lds<4096, false, DW>((const unsigned char *)k_lut, smem_hi + OFF_LUT_V, 4096, lane, dw);
         load_span<H, W, DW>(k_board + (size_t)e0b * HW, board, nbb, lane, dw);
         gc_look();
-        if (!goals_free) load_span<H, W, DW>(k_goals + (size_t)e0b * HW, goals, nbb, lane, dw);
-        if (LDS_LUT && GCACHE) dma_to_lds<4096, false, DW>((const unsigned char *)k_lut, smem + OFF_LUT_V, 4096, lane, dw);
+        if (!NOGOALS) load_span<H, W, DW>(k_goals + (size_t)e0b * HW, goals, nbb, lane, dw);
+        if (LDS_LUT && GCACHE) dma_to_lds<4096, false, DW>((const unsigned char *)k_lut, smem_hi + OFF_LUT_V, 4096, lane, dw);
         if (WRAP) {
             dma_to_lds<Gm::NB * (int)sizeof(sl_wrap_state), false, DW>((const unsigned char *)(env.wrap.state + e0b),
-                                                                       smem + Gm::OFF_WST,
+                                                                       smem_hi + Gm::OFF_WST,
                                                                        nbb * (int)sizeof(sl_wrap_state), lane, dw);
             if (env.wrap.flags & SL_WRAP_MOVEMENT)
-                dma_to_lds<Gm::MVT_N * 8, false, DW>((const unsigned char *)env.wrap.move_table, smem + Gm::OFF_MVT,
+                dma_to_lds<Gm::MVT_N * 8, false, DW>((const unsigned char *)env.wrap.move_table, smem_hi + Gm::OFF_MVT,
                                                      min(env.wrap.move_table_len & ~1, Gm::MVT_N) * 8, lane, dw);
             if (inaction) {
                 load_span<H, W, DW>(env.wrap.inaction_board + (size_t)e0b * HW, inb, nbb, lane, dw);
                 dma_to_lds<Gm::NB * 32, false, DW>((const unsigned char *)(env.wrap.inaction_rng + e0b),
-                                                   smem + OFF_INB + Gm::REGION, nbb * 32, lane, dw);
+                                                   smem_hi + OFF_INB + Gm::REGION, nbb * 32, lane, dw);
             }
         }
     }
@@ -2519,7 +2601,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     // barrier, in front of its row reads (LDS operations of one wave stay in order), so no workgroup barrier stands
     // between the loads and the CA any more, and the leaders' serial section is off the rows' path.
     typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
-    u32x4_t *const move_box = (u32x4_t *)(smem + OFF_MOVE_V);
+    u32x4_t *const move_box = (u32x4_t *)(smem_hi + OFF_MOVE_V);
     if (MOVE_BOX && lwave) {
         u32x4_t mv = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
         if (lead && ly >= 0) pre_write = act_rule(pre_c, action, ly, lx, pre_y1, pre_x1);
@@ -2553,7 +2635,8 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     if (GCACHE && goals_free) gstatic = 1;           // (what the flag vouches for; the goal image does not exist in this launch)
     if (rwave) {
     if (live && !goals_free) {
-        read_row<H, W>(goals, gb, r, b);
+        if constexpr (NOGOALS) read_row_global<H, W>(k_goals + (size_t)e * HW + r * W, b);
+        else read_row<H, W>(goals, gb, r, b);
 #pragma unroll
         for (int k = 0; k < WS; ++k) gsh_lane[k] = goal_shift(b[k]);
     }
@@ -2579,7 +2662,6 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     // level -- is carried out behind the NEXT workgroup barrier: the one at the top of the following step, or the
     // one in front of the final stores.
     bool any_reset = false;             // (wave-uniform) some board of the workgroup loaded a level in this launch
-    bool goal_row_dirty = false;        // the lane's goal row in the image differs from global memory
     auto hand_over_block = [&]() {
         const int any = box[0].any;
         if (any & 1) any_reset = true;
@@ -2618,6 +2700,18 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
 #pragma unroll
                 for (int j = 0; j < W / 2; ++j) tw[j] = *(const u32_a2 *)(rows[a] + 2 * j);
                 if (Gm::ODD) tw[WS - 1] = rows[a][W - 1];
+                if (NOGOALS && a == 1) {
+                    // no goal image: the row goes to the env's goal array as it came, and into the registers the score reads
+                    u16 *grow = env.goals + (size_t)e * HW + r2 * W;
+#pragma unroll
+                    for (int j = 0; j < W / 2; ++j) *(u32_a2 *)(grow + 2 * j) = tw[j];
+                    if (Gm::ODD) grow[W - 1] = (u16)tw[WS - 1];
+                    RowWords<H, W> gw;
+                    words_from_pairs<H, W>(tw, gw);
+#pragma unroll
+                    for (int k = 0; k < WS; ++k) gsh_lane[k] = goal_shift(gw[k]);
+                    continue;
+                }
 #pragma unroll
                 for (int j = 0; j < W / 2; ++j) {
                     imgs[a][Gm::cell(r, 2 * j)] = (u16)tw[j];
@@ -2630,15 +2724,16 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
             if (r2 < 4) rng_lds[4 * g + r2] = ((const u64 *)(env.pool_rng + level))[r2];
             for (int k = r2; k < E; k += H)
                 env.exit_locs[(size_t)e * E + k] = env.pool_exit_locs[(size_t)level * E + k];
-            *dirty_flag = 1;                             // (any wave that changes its goals raises the flag)
-            goal_row_dirty = true;
+            if (!NOGOALS) *dirty_flag = 1;               // (any wave that changes its goals raises the flag)
             if (r2 == 0) box[gb].dirty = 1;              // (and the whole board is new)
         }
         wave_sync();
         if (mine) {
-            read_row<H, W>(goals, gb, r, b);
+            if constexpr (!NOGOALS) {
+                read_row<H, W>(goals, gb, r, b);
 #pragma unroll
-            for (int k = 0; k < WS; ++k) gsh_lane[k] = goal_shift(b[k]);
+                for (int k = 0; k < WS; ++k) gsh_lane[k] = goal_shift(b[k]);
+            }
             read_row<H, W>(board, gb, r, b);
         }
         const int s0 = group_total<H, W>(
@@ -2707,7 +2802,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
         if (WRAP && inaction) {
             // An env in the first step of an episode (num_steps == 0) takes its board as it stands now -- after the
             // reset, before this step's action -- as its baseline: what the wrapper's reset() copies.
-            const bool fresh = rowl && ((const sl_env_scalars *)(smem + Gm::OFF_REC))[gb].num_steps == 0;
+            const bool fresh = rowl && ((const sl_env_scalars *)(smem_hi + Gm::OFF_REC))[gb].num_steps == 0;
             if (rwave && __ballot(fresh)) {
                 if (fresh && live) {
                     read_row<H, W>(board, gb, r, b);
@@ -2761,7 +2856,12 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
             const bool mine = has && lm.real;
             unsigned char *img = pass == 0 ? board : (base ? inb : goals);
             u64 *const pass_rng = base ? irng_lds : rng_lds;
-            if (has) read_row<H, W>(img, gb, r, b);
+            u16 *const grow = NOGOALS ? env.goals + (size_t)e * HW + r * W : nullptr;      // the lane's goal row in global memory
+            const bool global_row = NOGOALS && pass == goal_pass;
+            if (has) {
+                if (global_row) read_row_global<H, W>(grow, b);
+                else read_row<H, W>(img, gb, r, b);
+            }
             bool changed = true;                             // (wave-uniform) some cell of the wave's rows changed
             if constexpr (use_planes<H, W>()) {
                 u32 row_changed = 0;
@@ -2806,7 +2906,8 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
                 if (mine) {
                     RowWords<H, W> old;
                     if (changed) {
-                        read_row<H, W>(img, gb, r, old);
+                        if (global_row) read_row_global<H, W>(grow, old);
+                        else read_row<H, W>(img, gb, r, old);
                     } else {
 #pragma unroll
                         for (int k = 0; k < WS; ++k) old[k] = b[k];
@@ -2820,11 +2921,13 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
                 if (mine) {
 #pragma unroll
                     for (int k = 0; k < WS; ++k) gsh_lane[k] = goal_shift(b[k]);
-                    *dirty_flag = 1;
-                    goal_row_dirty = true;
+                    if (!NOGOALS) *dirty_flag = 1;
                 }
             }
-            if (mine && changed) write_row<H, W>(img, gb, r, b);
+            if (mine && changed) {
+                if (global_row) write_row_global<H, W>(grow, b);
+                else write_row<H, W>(img, gb, r, b);
+            }
         }
         if (passes > 1) {                // board rows back into registers for scoring
             wave_sync();
@@ -3023,7 +3126,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
         int lane3 = lane;
         asm volatile("" : "+v"(lane3));
         for (int i = lane3; i < nbb * 4; i += 64)
-            ((u32x4 *)(env.scalars + e0b))[i] = ((const u32x4 *)(smem + Gm::OFF_REC))[i];
+            ((u32x4 *)(env.scalars + e0b))[i] = ((const u32x4 *)(smem_hi + Gm::OFF_REC))[i];
     }
     const int dirty = *dirty_flag;
     SL_STAMP(8);
@@ -3036,17 +3139,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     if (rwave) {
         if constexpr (SPARSE_STORE) store_span_dirty<H, W>(env.board + (size_t)e0b * HW, board, nbb, tid2, box);
         else store_span<H, W>(env.board + (size_t)e0b * HW, board, nbb, tid2);
-        if (dirty && !goals_free) store_span<H, W>(env.goals + (size_t)e0b * HW, goals, nbb, tid2);
-        if (GCACHE && dirty && goals_free && live && goal_row_dirty) {
-            // a launch without the goal span: only the rows this launch wrote exist in the image -- each goes to global
-            // memory by itself (rare: a board that reset)
-            int r3 = r;
-            asm volatile("" : "+v"(r3));
-            const u16 *src = (const u16 *)(goals + Gm::PAD) + gb * HW;
-            u16 *gdst = env.goals + (size_t)e * HW + r3 * W;
-#pragma unroll 1
-            for (int x = 0; x < W; ++x) gdst[x] = src[Gm::cell(r3, x)];
-        }
+        if (dirty && !NOGOALS) store_span<H, W>(env.goals + (size_t)e0b * HW, goals, nbb, tid2);
     }
     if (GCACHE && gc_flag && T != 0) {
         // GoalCache: a launch that had the goal span keeps the lanes' words if every board of the workgroup ends it with
@@ -3075,7 +3168,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
         }
     }
     if (lane2 < 4 * Gm::G && wave2 * Gm::G + (lane2 >> 2) < nbb)
-        ((u64 *)(env.rng + e0b + wave2 * Gm::G))[lane2] = ((const u64 *)(smem + Gm::OFF_RNG) + 4 * Gm::G * wave2)[lane2];
+        ((u64 *)(env.rng + e0b + wave2 * Gm::G))[lane2] = ((const u64 *)(smem_hi + Gm::OFF_RNG) + 4 * Gm::G * wave2)[lane2];
     if (WRAP)       // (10-row boards: 24 per workgroup, more state words than threads)
         for (int i = tid2; i < nbb * (int)(sizeof(sl_wrap_state) / 4); i += 64 * WAVES)
             ((u32 *)(env.wrap.state + e0b))[i] = ((const u32 *)wst)[i];
@@ -3083,7 +3176,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
         if (rwave) store_span<H, W>(env.wrap.inaction_board + (size_t)e0b * HW, inb, nbb, tid2);
         if (lane2 < 4 * Gm::G && wave2 * Gm::G + (lane2 >> 2) < nbb)
             ((u64 *)(env.wrap.inaction_rng + e0b + wave2 * Gm::G))[lane2] =
-                ((const u64 *)(smem + OFF_INB + Gm::REGION) + 4 * Gm::G * wave2)[lane2];
+                ((const u64 *)(smem_hi + OFF_INB + Gm::REGION) + 4 * Gm::G * wave2)[lane2];
     }
 
     SL_STAMP(9);
@@ -3099,7 +3192,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     // observation (safelife_env.py:105-146) from the LDS images of the final state
     if (!LEAN && (env.obs || env.policy_obs)) {
         // per board: view centre and, per exit slot, the view cell it is painted on + its board cell
-        int *par = (int *)(smem + Gm::OFF_GSH);                 // goal words are dead by now
+        int *par = (int *)(smem_hi + Gm::OFF_GSH);                 // goal words are dead by now
         if (lead) {
             int *pp = par + lq * OBS_PAR_INTS;
             const int32_t *obs_exits = pool_exits ? env.pool_exit_locs + (size_t)lrec->level_idx * E
@@ -3301,7 +3394,10 @@ hipError_t pick_rollout_t(const sl_env_batch &env, int T, void **kernel, hipFunc
     // (the kernel's GCACHE: LEAN instantiations whose goal words live in registers)
     *gcache_ok = (variant & 8) && T == 1 && gsh_in_registers<H, W>(spawn, true, true) && !Gm::LEADX_OK;
     const int lds_wrap = base_in_gsh ? Gm::LDS_WRAP_GSHREG : Gm::LDS_WRAP_GSHLDS;
-    const int lds_plain = lean_lds<H, W>(spawn, (variant & 8) != 0, T == 1) ? lean_lds_bytes<H, W>() : Gm::LDS_BYTES;
+    // (the plain single-step kernels keep no goal image: nogoals_lds)
+    const bool nogoals = (variant & 8) && T == 1 && nogoals_lds<H, W>(spawn, true, true);
+    const int lds_plain = (lean_lds<H, W>(spawn, (variant & 8) != 0, T == 1) ? lean_lds_bytes<H, W>() : Gm::LDS_BYTES) -
+                          (nogoals ? nogoals_shift<H, W>() : 0);
     const int lds = !(variant & 4) ? lds_plain : lds_wrap + ((env.wrap.flags & SL_WRAP_INACTION) ? Gm::INACTION_BYTES : 0);
     const int lds_limit = !(variant & 4) ? Gm::LDS_BYTES : lds_wrap + Gm::INACTION_BYTES;     // (set once per variant)
     // per (device, variant), once: raise the dynamic LDS limit and look up the module-level handle of the kernel
