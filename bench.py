@@ -1027,7 +1027,7 @@ def main():
                                          "binds": "neither roofline: the step is one launch's latency chain (DMA issue, "
                                                   "memory latency, three workgroup barriers, stores) plus the CP's "
                                                   "boundary between launches; the SIMDs are at most half busy",
-                                         "source": "profiles/round5_i_queues4_none_pmc.txt, round5_a_c3_issue_pmc.txt, "
+                                         "source": "profiles/round5_m_queues4_none_pmc.txt, round5_a_c3_issue_pmc.txt, "
                                                    "round5_f_timing_only.txt; DESIGN.md section 6"}
                                         if args.pool == "prune_still_25" and B == 8192 and not args.obs else None),
                          "note": "frac = bytes_per_env_step x envs / ms_per_step / peak.  rocprofv3 serialises the queues' "
