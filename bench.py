@@ -907,6 +907,31 @@ def main():
                                                       "region's last pass waited for in full (%d episodes: roll-forward + "
                                                       "2 x 1000-step life_occupancy + distributions); EMD on the host not "
                                                       "included" % (n_c5, n_meas, flush_every, n_eps))
+                # the same through the library's queues (the launcher of the headline line; wall clock: HIP events do
+                # not see the queues), whole windows of flush_every steps per call
+                if use_queues:
+                    try:
+                        env5.queues_open(4, release_free=(res["fences"] == "none"), recover=False)
+                        env5.side_effects_flush()
+                        torch.cuda.synchronize()
+                        batches = []
+                        t0 = time.perf_counter()
+                        for w0 in range(0, n_meas, flush_every):
+                            # (the fresh queue's buffers were zeroed on this stream: wait for THAT, not for the device --
+                            #  the pass of the window before is still running on its side stream, and may)
+                            torch.cuda.current_stream().synchronize()
+                            env5.step_queues_many(acts5[20 + w0:20 + w0 + flush_every], assume_ordered=True)
+                            batches.append(env5.side_effects_flush(overlap=True))      # (waits for the queues' fence first)
+                        env5.queues_sync()
+                        env5.side_effects_join()
+                        torch.cuda.synchronize()
+                        us = (time.perf_counter() - t0) / n_meas * 1e6
+                        extra["c5_with_side_effects_queues_us_per_step"] = us
+                        extra["c5_with_side_effects_queues_env_steps_per_s_per_gpu"] = n_c5 / (us * 1e-6)
+                        extra["c5_with_side_effects_queues_episodes_scored"] = sum(len(b) for b in batches)
+                        env5.queues_close()
+                    except _hip.SafeLifeHipError as e:
+                        extra["c5_with_side_effects_queues_error"] = str(e)
                 del env5, batches
 
     if rank == 0:
