@@ -748,6 +748,48 @@ def main():
                     pass
             return us_streams
 
+        # level-pool refresh while stepping (levels.LevelPool(refreshable=True), pool_stage / pool_commit): C3's batch through
+        # the queues in calls of `chunk` steps, with a sixth of the pool's levels replaced every call (staged one call
+        # ahead, committed between two calls) against the same calls without any refresh
+        if use_queues and args.pool == "prune_still_25":
+            try:
+                from safelife_amd.levels import LevelPool
+                lv_all = list(pool.levels)
+                n_half = len(lv_all) // 2
+                pool_r = LevelPool(lv_all[:n_half], counts_fn=_device_counts, refreshable=True)
+                env_r = SafeLifeVectorEnv(pool_r, B, time_limit=1000, view_shape=(25, 25), output_channels=TRAIN_CHANNELS,
+                                          auto_reset=True, with_obs=False, slices=args.slices)
+                env_r.reset()
+                chunk, n_calls = 100, 8
+                acts_r = torch.randint(0, 9, (chunk * (n_calls + 1), B), generator=gen, device=dev, dtype=torch.int32)
+                env_r.queues_open(n_queues, release_free=(res["fences"] == "none"), recover=False)
+                rr = np.random.default_rng(5)
+                env_r.pool_stage([0], [lv_all[n_half]])        # (untimed: the first staging pins its host buffers)
+                env_r.pool_commit()
+                for refresh in (False, True):
+                    env_r.step_queues_many(acts_r[:chunk])
+                    env_r.queues_sync()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for c in range(n_calls):
+                        if refresh:
+                            env_r.pool_commit()
+                        env_r.step_queues_many(acts_r[chunk * (c + 1):chunk * (c + 2)], assume_ordered=True)
+                        if refresh:         # (behind the call: what staging waits for -- the steps enqueued before the
+                            #                  last commit -- completes while the device works through this call)
+                            slots = rr.choice(n_half, n_half // 6, replace=False)
+                            env_r.pool_stage(slots, [lv_all[int(k)] for k in rr.integers(0, len(lv_all), len(slots))])
+                    env_r.queues_sync()
+                    us = (time.perf_counter() - t0) / (chunk * n_calls) * 1e6
+                    extra["pool_refresh_us_per_step" if refresh else "pool_static_us_per_step"] = us
+                extra["pool_refresh_note"] = ("8192 envs, %d-level refreshable pool, %d steps per queue call, %d levels "
+                                              "replaced per call (staged a call ahead, committed between calls; no queue "
+                                              "drain for the refresh)" % (n_half, chunk, n_half // 6))
+                env_r.queues_close()
+                del env_r
+            except _hip.SafeLifeHipError as e:
+                extra["pool_refresh_error"] = str(e)
+
         # C2 (BASELINE configs[1]): advance_board alone on 1024 random 25x25 boards (SURVEY 8d palette-like)
         from safelife_amd import speedups
         c2 = np.random.default_rng(1234)

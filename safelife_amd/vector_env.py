@@ -349,7 +349,10 @@ class SafeLifeVectorEnv(object):
     # falls between two steps of the stepping thread's program order, deterministically, with no queue drain.
 
     def pool_stage(self, slots, levels):
-        """New levels for the logical pool slots `slots`, staged (see above).  One staging at a time."""
+        """New levels for the logical pool slots `slots`, staged (see above).  One staging at a time.  The spare slots it
+        writes may still be read by resets of steps enqueued BEFORE the last ``pool_commit()``; it waits for those steps
+        (a marker taken at that commit) -- so call it behind the step call that follows a commit, not right behind the
+        commit: ``pool_commit(); step_queues_many(...); pool_stage(...)`` keeps the device busy meanwhile."""
         rf = self._pool_refresh
         if rf is None:
             raise ValueError("the env's pool was not built with refreshable=True")
@@ -379,28 +382,40 @@ class SafeLifeVectorEnv(object):
         phys = self.pool.replace(slots, levels)
         pa = self.pool.arrays()
         sel = np.asarray(phys, np.int64)
+        n = len(sel)
         side = rf["stream"]
         if side is None:
             side = rf["stream"] = torch.cuda.Stream(device=dev)
-        idx = torch.from_numpy(sel).to(dev)
-        keep = []                                   # pinned staging buffers, alive until the commit
+        # pinned staging buffers, allocated ONCE (pinning host memory costs milliseconds and stalls the device's queues:
+        # a fresh set per staging made a refreshed run ten times slower); sized for every level of the pool at once.
+        # One staging at a time, and a staging's copies have completed when it is committed: the buffers are free here.
+        pin = rf.get("pinned")
+        if pin is None:
+            Lg, (H, W), E = len(self.pool), self.pool.shape, self.pool.exit_slots
 
-        def up(host, dst):
-            h = torch.from_numpy(np.ascontiguousarray(host)).pin_memory()
-            keep.append(h)
-            dst.index_copy_(0, idx, h.to(dev, non_blocking=True))
+            def pinned(shape, dtype):
+                return torch.empty(shape, dtype=dtype).pin_memory()
+            pin = rf["pinned"] = dict(board=pinned((Lg, H, W), torch.int16), goals=pinned((Lg, H, W), torch.int16),
+                                      exits=pinned((Lg, E), torch.int32), rng=pinned((Lg, 4), torch.int64),
+                                      scalars=pinned((Lg, 8), torch.int32), idx=pinned((Lg,), torch.int64),
+                                      table=pinned((self.pool.n_slots,), torch.int32))
+        keep = []
+
+        def up(name, host, dst, idx_dev):
+            pin[name].numpy()[:n] = host
+            dst.index_copy_(0, idx_dev, pin[name][:n].to(dev, non_blocking=True))
 
         nxt = 1 - rf["which"]
-        side.wait_stream(torch.cuda.current_stream())       # (idx was uploaded there)
         with torch.cuda.stream(side):
-            up(pa["pool_board"][sel].view(np.int16), self.t["pool_board"])
-            up(pa["pool_goals"][sel].view(np.int16), self.t["pool_goals"])
-            up(pa["pool_exit_locs"][sel], self.t["pool_exit_locs"])
-            up(pa["pool_rng"][sel].view(np.int64), self.t["pool_rng"])
-            up(self._level_scalars(pa, sel), self.t["pool_scalars"])
-            table = torch.from_numpy(self.pool.next_table(self.struct.level_stride)).pin_memory()
-            keep.append(table)
-            self._pool_next[nxt].copy_(table, non_blocking=True)
+            pin["idx"].numpy()[:n] = sel
+            idx_dev = pin["idx"][:n].to(dev, non_blocking=True)
+            up("board", pa["pool_board"][sel].view(np.int16), self.t["pool_board"], idx_dev)
+            up("goals", pa["pool_goals"][sel].view(np.int16), self.t["pool_goals"], idx_dev)
+            up("exits", pa["pool_exit_locs"][sel], self.t["pool_exit_locs"], idx_dev)
+            up("rng", pa["pool_rng"][sel].view(np.int64), self.t["pool_rng"], idx_dev)
+            up("scalars", self._level_scalars(pa, sel), self.t["pool_scalars"], idx_dev)
+            pin["table"].numpy()[:] = self.pool.next_table(self.struct.level_stride)
+            self._pool_next[nxt].copy_(pin["table"], non_blocking=True)
             if w.flags & _hip.WRAP_SIDE_EFFECT and not (w.flags & _hip.WRAP_INACTION):
                 rc = self._lib.slhip_pool_baseline(self._sref, C.c_void_p(side.cuda_stream))
                 _hip.check(rc)
