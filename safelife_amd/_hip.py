@@ -20,7 +20,7 @@ SL_E_SHAPE, SL_E_ARG, SL_E_HIP, SL_E_UNSUPPORTED = -1, -2, -3, -4
 EXPORTS = (
     "slhip_abi_version", "slhip_last_error", "slhip_device_count",
     "slhip_advance_board", "slhip_advance_board_each", "slhip_life_occupancy", "slhip_alive_counts", "slhip_execute_actions",
-    "slhip_env_prepare", "slhip_pool_baseline", "slhip_goal_cache_bytes", "slhip_env_reset", "slhip_env_step", "slhip_env_step_slices", "slhip_env_step_range", "slhip_env_rollout",
+    "slhip_env_prepare", "slhip_pool_baseline", "slhip_pool_write", "slhip_goal_cache_bytes", "slhip_env_reset", "slhip_env_step", "slhip_env_step_slices", "slhip_env_step_range", "slhip_env_rollout",
     "slhip_streams_concurrent", "slhip_streams_order",
     "slhip_env_obs",
     "slhip_obs_to_policy", "slhip_sample_actions", "slhip_side_effects",
@@ -54,7 +54,7 @@ ENV_STATE_PTRS = ("board", "goals", "exit_locs", "rng", "scalars", "points_table
 ENV_POOL_PTRS = ("pool_board", "pool_goals", "pool_exit_locs", "pool_rng", "pool_scalars")
 ENV_POOL_TAIL = ("pool_next",)      # (optional: set by SafeLifeVectorEnv for refreshable pools)
 ENV_OUT_PTRS = ("out", "obs", "score_lut")
-SL_ABI_VERSION = 11
+SL_ABI_VERSION = 12
 
 #: int32 column of each field inside `struct sl_env_scalars` (64 bytes = 16 columns)
 SCALAR_COLS = {"agent_row": 0, "agent_col": 1, "num_steps": 2, "old_value": 3, "required_points": 4,
@@ -91,6 +91,13 @@ class EpisodeRecord(C.Structure):
     _fields_ = [("env", C.c_int32), ("level", C.c_int32), ("num_steps", C.c_int32), ("episode_idx", C.c_int32),
                 ("spawn_prob", C.c_float), ("episode_reward", C.c_float), ("episode_length", C.c_int32),
                 ("success", C.c_uint8), ("times_up", C.c_uint8), ("n_cell_types", C.c_uint8), ("reserved", C.c_uint8)]
+
+
+class PoolRows(C.Structure):
+    """``struct sl_pool_rows`` (slhip_pool_write)."""
+    _fields_ = [("n", C.c_int32), ("slot", C.c_void_p), ("board", C.c_void_p), ("goals", C.c_void_p),
+                ("exit_locs", C.c_void_p), ("rng", C.c_void_p), ("scalars", C.c_void_p), ("next", C.c_void_p),
+                ("next_dst", C.c_void_p)]
 
 
 class EpisodeQueue(C.Structure):
@@ -139,6 +146,8 @@ def lib():
         L.slhip_env_prepare.argtypes = [C.POINTER(EnvBatch), _p]
         if hasattr(L, "slhip_pool_baseline"):
             L.slhip_pool_baseline.argtypes = [C.POINTER(EnvBatch), _p]
+        if hasattr(L, "slhip_pool_write"):
+            L.slhip_pool_write.argtypes = [C.POINTER(EnvBatch), C.POINTER(PoolRows), _p]
         if hasattr(L, "slhip_goal_cache_bytes"):
             L.slhip_goal_cache_bytes.argtypes = [C.POINTER(EnvBatch), C.POINTER(C.c_int)]
             L.slhip_goal_cache_bytes.restype = C.c_size_t

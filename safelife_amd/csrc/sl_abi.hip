@@ -369,6 +369,43 @@ int slhip_pool_baseline(const sl_env_batch *env, void *stream) {
     return err == hipSuccess ? SL_OK : hip_fail(err, "pool_baseline launch");
 }
 
+// One workgroup per new level (plus one for the successor table): 2 x H*W cells, E exits, 32 B of generator, 32 B of
+// scalars -- a few KB each, fetched from wherever the rows lie (pinned host memory: no staging copy, no second launch).
+__global__ void __launch_bounds__(256) k_pool_write(sl_env_batch env, sl_pool_rows r) {
+    const int i = blockIdx.x, t = threadIdx.x;
+    if (i == r.n) {
+        for (int k = t; k < env.L; k += 256) r.next_dst[k] = r.next[k];
+        return;
+    }
+    const size_t cells = (size_t)env.H * env.W, s = (size_t)r.slot[i];
+    uint16_t *board = const_cast<uint16_t *>(env.pool_board) + s * cells;
+    uint16_t *goals = const_cast<uint16_t *>(env.pool_goals) + s * cells;
+    for (size_t k = t; k < cells; k += 256) {
+        board[k] = r.board[i * cells + k];
+        goals[k] = r.goals[i * cells + k];
+    }
+    for (int k = t; k < env.E; k += 256) const_cast<int32_t *>(env.pool_exit_locs)[s * env.E + k] = r.exit_locs[(size_t)i * env.E + k];
+    constexpr int RNG_WORDS = sizeof(sl_pcg64) / 4, SCALAR_WORDS = sizeof(sl_level_scalars) / 4;
+    if (t < RNG_WORDS)
+        ((uint32_t *)const_cast<sl_pcg64 *>(env.pool_rng + s))[t] = ((const uint32_t *)(r.rng + i))[t];
+    else if (t >= 64 && t < 64 + SCALAR_WORDS)
+        ((uint32_t *)const_cast<sl_level_scalars *>(env.pool_scalars + s))[t - 64] = ((const uint32_t *)(r.scalars + i))[t - 64];
+}
+
+int slhip_pool_write(const sl_env_batch *env, const sl_pool_rows *rows, void *stream) {
+    int rc = check_env(env);
+    if (rc) return rc;
+    if (!rows || rows->n < 0 || rows->n > env->L) return fail(SL_E_ARG, "pool_write: n outside 0..L");
+    if (rows->n && (!rows->slot || !rows->board || !rows->goals || !rows->exit_locs || !rows->rng || !rows->scalars))
+        return fail(SL_E_ARG, "pool_write: a row array is missing");
+    if ((rows->next != nullptr) != (rows->next_dst != nullptr)) return fail(SL_E_ARG, "pool_write: next and next_dst go together");
+    const int blocks = rows->n + (rows->next ? 1 : 0);
+    if (!blocks) return SL_OK;
+    hipLaunchKernelGGL(k_pool_write, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *env, *rows);
+    hipError_t err = hipGetLastError();
+    return err == hipSuccess ? SL_OK : hip_fail(err, "pool_write launch");
+}
+
 size_t slhip_goal_cache_bytes(const sl_env_batch *env, int *boards_per_block) {
     if (boards_per_block) *boards_per_block = 0;
     if (!env || env->B <= 0 || force_generic() || !env->score_lut) return 0;

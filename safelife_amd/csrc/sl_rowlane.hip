@@ -691,6 +691,7 @@ __device__ void resolve_draws(const RowWords<H, W> &b, RowWords<H, W> &n, const 
 struct JumpCache {             // (in registers: kept in LDS instead -- 2 KB per wave, four 8-byte reads per step -- the
     int log2c = -1;             //  pass of C5 ran 13.9 instead of 12.6 ms, slower than without any cache, 13.4)
     U128 mult = {0, 0}, plus_inc = {0, 0};
+    U128 plus64 = {0, 0};       // (the round-by-round deal: log2c == 64, mult / plus_inc the lane's jump by lane + 1)
 };
 __device__ __forceinline__ U128 pcg_jump_cached(const Jump *__restrict__ table, int k, int log2c, U128 state, U128 inc,
                                                 JumpCache *jc) {
@@ -749,6 +750,84 @@ __device__ pl::Pl<NW> resolve_draws_planes(const pl::Pl<NW> &elig, u64 *rng_lds,
         // of two; 32 / c neighbouring lanes' outcome bits make one dword (xor swizzles); a row's lane then pulls
         // the dwords that hold ITS draws' outcomes -- consecutive bits from its prefix offset on -- across the
         // wave and deals them to its flagged cells in order.
+#ifndef SL_STRIDE_DEAL
+#define SL_STRIDE_DEAL 1        /* A/B knob: 0 = the blocked deal below for every step */
+#endif
+        constexpr int MAXR = 8;
+        if (SL_STRIDE_DEAL && total <= 64 * MAXR) {
+            // Round 5: the deal goes ROUND by round -- lane j makes draws j, j + 64, j + 128 ... -- instead of in blocks
+            // of 2^log2c per lane.  A lane's first draw is a jump by j + 1 from the board's state, the SAME jump at
+            // every step (the cached multiplier never changes), every further one a step of 64 (the table's entry 64:
+            // wave-uniform); the outcome bits of round r ARE the compare's lane mask -- draw 64 r + j is bit j of a
+            // scalar pair -- so the outcome string needs no cross-lane assembly (was: five dependent LDS swizzles) and
+            // a row's lane shifts its window out of the two pairs that hold it.  ceil(total / 64) multiplies per lane
+            // instead of 1 + the next power of two.
+            const int lane = (int)__lane_id();
+            const int rounds = (total + 63) >> 6;
+            const u32 bthr_hi = __builtin_amdgcn_readlane((u32)(thr >> 32), LaneMap<H, W>::first_lane(0) + 1);
+            const u32 bthr_lo = __builtin_amdgcn_readlane((u32)thr, LaneMap<H, W>::first_lane(0) + 1);
+            const u64 bthr = ((u64)bthr_hi << 32) | bthr_lo;
+            u64 B[MAXR + 1];
+#pragma unroll
+            for (int r = 0; r <= MAXR; ++r) B[r] = 0;
+            if (total > 0) {
+                U128 cur = st, plus64 = {0, 0};
+                const bool in0 = lane < total;
+                if (jc) {
+                    if (jc->log2c != 64) {      // (every lane, whether it draws at this step or not)
+                        const Jump j = jump[lane + 1];
+                        jc->mult = U128{j.mult_hi, j.mult_lo};
+                        jc->plus_inc = mul128(U128{j.plus_hi, j.plus_lo}, inc);
+                        jc->plus64 = mul128(U128{jump[64].plus_hi, jump[64].plus_lo}, inc);
+                        jc->log2c = 64;
+                    }
+                    if (in0) cur = add128(mul128(jc->mult, st), jc->plus_inc);
+                    plus64 = jc->plus64;
+                } else {
+                    if (in0) cur = pcg_jump(jump, lane + 1, st, inc);
+                    if (rounds > 1) plus64 = mul128(U128{jump[64].plus_hi, jump[64].plus_lo}, inc);
+                }
+                B[0] = __ballot(in0 && pcg_output_u53(cur) < bthr);                 // advance_board.c:115
+                const U128 mult64 = {jump[64].mult_hi, jump[64].mult_lo};
+#pragma unroll
+                for (int r = 1; r < MAXR; ++r) {
+                    if (r < rounds) {
+                        const bool in = lane + 64 * r < total;
+                        if (in) cur = add128(mul128(mult64, cur), plus64);
+                        B[r] = __ballot(in && pcg_output_u53(cur) < bthr);
+                    }
+                }
+                if (lane == ((total - 1) & 63)) {       // the lane that made the board's last draw holds its new state
+                    rng_lds[4 * g + 0] = cur.hi;
+                    rng_lds[4 * g + 1] = cur.lo;
+                }
+            }
+            // my draws' outcomes: bits [excl, excl + mine) of the string B[0] | B[1] << 64 | ...
+            const int w0 = excl >> 6, sh = excl & 63;
+            u64 lo = B[0], hi = B[1];
+#pragma unroll
+            for (int r = 1; r < MAXR; ++r) {
+                if (r < rounds && w0 == r) {
+                    lo = B[r];
+                    hi = B[r + 1];
+                }
+            }
+            u64 R = lo >> sh;
+            if (sh) R |= hi << (64 - sh);
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                u32 todo = elig.w[i], got = 0;
+                while (todo) {
+                    const u32 bit = todo & (0u - todo);
+                    got |= (R & 1ull) ? bit : 0u;
+                    R >>= 1;
+                    todo ^= bit;
+                }
+                ok.w[i] = got;
+            }
+            wave_sync();
+            return ok;
+        }
         if (total <= 32 * 64) {
             const int lane = (int)__lane_id();
             const int need = (total + 63) >> 6;
@@ -1452,6 +1531,12 @@ struct OccGeom {
 #define SL_OCC_DIRECT 0
 #endif
     static constexpr bool DIRECT = SL_OCC_DIRECT && CB == 8 && use_planes_multi<H, W>();
+    // 64-cell rows (two plane words): the register counters are transposed into byte lanes and added four cells at a
+    // time, so a lane's counters are laid out [slot][plane word i][q] with byte j of that dword = cell 32 i + q + 8 j
+#ifndef SL_OCC_NIBBLE
+#define SL_OCC_NIBBLE 1         /* A/B knob: 0 = 64-cell rows walk their non-zero cells like the other shapes */
+#endif
+    static constexpr bool NIBBLE = SL_OCC_NIBBLE && CB == 8 && W == 64 && !DIRECT;
     static constexpr int OFF_CNT = 0;
     static constexpr int OFF_RNG = DIRECT ? 0 : 64 * PITCH * 4;         // G x 4 u64
     static constexpr int LDS_BYTES = OFF_RNG + Gm::G * 32;
@@ -1463,6 +1548,22 @@ struct OccGeom {
 template <int H, int W, int SLOTS>
 __device__ __forceinline__ void occ_drain(u32 *cnt, int32_t *dst, u32 inv) {
     using Oc = OccGeom<H, W, SLOTS>;
+    if constexpr (Oc::NIBBLE) {
+        for (int d = 0; d < SLOTS * 16; ++d) {
+            const u32 v = cnt[d];
+            if (v) {
+                const int slot = d >> 4, x0 = 32 * ((d >> 3) & 1) + (d & 7);
+                int32_t *cell = dst + ((inv >> (3 * slot)) & 7u);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = (v >> (8 * j)) & 0xFFu;
+                    if (c) cell[(x0 + 8 * j) * 8] += c;
+                }
+                cnt[d] = 0;
+            }
+        }
+        return;
+    }
     for (int x = 0; x < W; ++x) {
 #pragma unroll
         for (int q = 0; q < Oc::CELL_DWORDS; ++q) {
@@ -1518,34 +1619,44 @@ __global__ __launch_bounds__(64) void k_occupancy_rowlane(const u16 *__restrict_
         }
     }
     // colour bits in use on each board: those of its live cells and of its spawners
-    u32 used = 0;
+    u32 used = 0, lacks = 0;            // (lacks: colour bits some source of the row does NOT have)
 #pragma unroll
     for (int k = 0; k < WS; ++k) {
         const u32 c = b[k];
         const u32 src = (c | (c >> 7)) & 0x00010001u;                   // ALIVE or SPAWNING, per half
         used |= c & (src * 0x0E00u);
+        lacks |= ~c & (src * 0x0E00u);
     }
     used = (used | (used >> 16)) & 0x0E00u;
-    u32 bits = 0;                                                       // of the lane's own board, bit i = colour bit i
-    bool wave_compact = Oc::CB == 8;            // (only 64-wide boards are LDS-bound: see launch_occupancy_t)
+    lacks = (lacks | (lacks >> 16)) & 0x0E00u;
+    // A colour bit that is set in EVERY source is set in every cell they ever produce as well (a birth takes the bits
+    // seen in two of its three live neighbours, a spawned cell those plus its spawners' -- all of them sources), just
+    // as a bit no source has stays clear: only the bits that VARY between a board's sources tell its colours apart.
+    u32 bits = 0, fixed = 0;            // of the lane's own board: colour bits that vary / that every source has
+    int wave_vary = Oc::CB == 8 ? 0 : 3;        // (only 64-wide boards are LDS-bound: see launch_occupancy_t)
 #pragma unroll
     for (int q = 0; q < Gm::G; ++q) {
         const unsigned long long in_board = ((Gm::GL == 64 ? ~0ull : ((1ull << Gm::GL) - 1ull)) << (q * Gm::GL % 64));
-        u32 bq = 0;
+        u32 bq = 0, aq = 0;
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < 3; ++i) {
             if (__ballot(rowl && (used & (0x0200u << i))) & in_board) bq |= 1u << i;
-        if (q < nbb && __popc(bq) > 2) wave_compact = false;
-        if (g == q) bits = bq;
+            if (!(__ballot(rowl && (lacks & (0x0200u << i))) & in_board)) aq |= 1u << i;
+        }
+        aq &= bq;
+        if (q < nbb) wave_vary = max(wave_vary, __popc(bq & ~aq));
+        if (g == q) bits = bq & ~aq, fixed = aq;
     }
-    if (wave_compact != (SLOTS == 4)) return;       // the other instantiation takes this wavefront's boards
-    // colour -> slot (2 bits each) and slot -> colour (3 bits each) for the board's two colour bits
+    if ((wave_vary <= 2) != (SLOTS == 4)) return;   // the other instantiation takes this wavefront's boards
+    // (wave-uniform) the slots the wave's boards can tick at all: the rest are skipped, counting and flushing
+    const int n_active = SLOTS == 4 ? 1 << wave_vary : SLOTS;
+    // colour -> slot (2 bits each) and slot -> colour (3 bits each) for the board's varying colour bits
     u32 lut = 0, inv = 0;
     if (SLOTS == 4) {
         int next = 0;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            if ((c & ~bits) == 0) {                 // colour c only uses bits the board has
+            if ((c & ~(bits | fixed)) == 0 && (c & fixed) == fixed) {       // a colour the board can show
                 lut |= (u32)next << (2 * c);
                 inv |= (u32)c << (3 * next);
                 ++next;
@@ -1594,10 +1705,40 @@ __global__ __launch_bounds__(64) void k_occupancy_rowlane(const u16 *__restrict_
 #pragma unroll
             for (int i = 0; i < NW; ++i) mini[a][k][i] = 0;
     int mini_steps = 0;
-    // SLOTS == 4: which colour planes are the board's two colour bits (lowest first; 3 = none)
+    // SLOTS == 4: which colour planes are the board's two varying colour bits (lowest first; 3 = none)
     const int sel_lo = (bits & 1u) ? 0 : ((bits & 2u) ? 1 : ((bits & 4u) ? 2 : 3));
     const int sel_hi = (bits & 1u) ? ((bits & 2u) ? 1 : ((bits & 4u) ? 2 : 3)) : (((bits & 2u) && (bits & 4u)) ? 2 : 3);
-    auto flush_mini = [&]() {           // small counters -> LDS counters, visiting non-zero cells only
+    auto flush_mini = [&]() {           // small counters -> LDS counters
+        if constexpr (Oc::NIBBLE) {
+            // the four bit planes of a word's 32 counters -> eight dwords of four byte lanes each (cells q + 8 j of the
+            // word in dword q), added to the LDS counters with eight fire-and-forget adds: ~36 instructions per slot
+            // and word whatever the number of live cells, no loop, no divergence (the walk below ran as often as the
+            // wave's busiest row had live cells, ~25 instructions each time)
+            const u32 M5 = 0x55555555u, M3 = 0x33333333u, MF = 0x0F0F0F0Fu;
+#pragma unroll
+            for (int sl = 0; sl < SLOTS; ++sl) {
+                if (sl >= n_active) break;
+#pragma unroll
+                for (int i = 0; i < NW; ++i) {
+                    const u32 p0 = mini[sl][0][i], p1 = mini[sl][1][i], p2 = mini[sl][2][i], p3 = mini[sl][3][i];
+                    if (!__ballot((p0 | p1 | p2 | p3) != 0)) continue;
+                    const u32 a = (p0 & M5) | ((p1 << 1) & ~M5), bb = ((p0 >> 1) & M5) | (p1 & ~M5);     // 2-bit fields:
+                    const u32 c = (p2 & M5) | ((p3 << 1) & ~M5), d = ((p2 >> 1) & M5) | (p3 & ~M5);      // even / odd cells
+                    const u32 e[4] = {(a & M3) | ((c << 2) & ~M3), (bb & M3) | ((d << 2) & ~M3),          // nibble n of e[r]:
+                                      ((a >> 2) & M3) | (c & ~M3), ((bb >> 2) & M3) | (d & ~M3)};         // cell 4 n + r
+                    u32 *base = cnt + (sl * NW + i) * 8;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const u32 lo = e[r] & MF, hi = (e[r] >> 4) & MF;        // cells 8 j + r, cells 8 j + 4 + r
+                        if (lo) __hip_atomic_fetch_add(base + r, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        if (hi) __hip_atomic_fetch_add(base + 4 + r, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    }
+#pragma unroll
+                    for (int k = 0; k < MINI_BITS; ++k) mini[sl][k][i] = 0;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int sl = 0; sl < (PLANES ? SLOTS : 1); ++sl)
 #pragma unroll
@@ -1658,8 +1799,9 @@ __global__ __launch_bounds__(64) void k_occupancy_rowlane(const u16 *__restrict_
                 const u32 tick = counting ? (st.A.w[i] & ~st.G.w[i] & ~st.Z.w[i] & ~st.X.w[i] & pl::PG<W>::REAL) : 0u;
 #pragma unroll
                 for (int sl = 0; sl < SLOTS; ++sl) {
+                    if (sl >= n_active) break;          // (wave-uniform) a slot none of the wave's boards can tick
                     u32 carry;
-                    if (SLOTS == 4) {       // slot = the colour's two used bits, compressed
+                    if (SLOTS == 4) {       // slot = the colour's two varying bits, compressed
                         const u32 s0 = sel_lo == 0 ? st.C[0].w[i] : (sel_lo == 1 ? st.C[1].w[i] : (sel_lo == 2 ? st.C[2].w[i] : 0u));
                         const u32 s1 = sel_hi == 1 ? st.C[1].w[i] : (sel_hi == 2 ? st.C[2].w[i] : 0u);
                         carry = tick & ((sl & 1) ? s0 : ~s0) & ((sl & 2) ? s1 : ~s1);

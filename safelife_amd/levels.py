@@ -311,31 +311,35 @@ class LevelPool(object):
         succ = cur[(np.arange(self.n_slots) % L + int(level_stride)) % L]
         return succ.astype(np.int32)
 
-    def replace(self, slots, levels):
-        """New content for the logical levels `slots` (refreshable pools): written into each level's SPARE slot, which
-        becomes its current one.  Returns the physical slots written.  Host arrays only -- the device copy and the
-        switch of the successor table are ``SafeLifeVectorEnv.pool_stage`` / ``pool_commit``.  A new level must fit the
-        pool as built: same shape, no more exits than ``exit_slots``, a points table the pool already has, and no
-        spawner in a pool that was built without any (the kernels were chosen for that)."""
+    def prepare(self, levels):
+        """Everything ``replace`` needs of `levels`, computed now: the checks, the cell counts (the HIP kernel, one batch),
+        the points and the RNG words.  Level generation happens away from the stepping thread (the reference's level
+        iterator fills its queue ahead, level_iterator.py:200-223); this belongs with it -- ``replace`` / ``pool_stage``
+        of a PreparedLevels only copy.  ``take(idx)`` picks a subset."""
         if not self.refreshable:
             raise ValueError("build the pool with refreshable=True")
-        slots = [int(x) for x in slots]
         levels = list(levels)
-        if len(slots) != len(levels) or len(set(slots)) != len(slots):
-            raise ValueError("one new level per distinct slot")
-        L, E = len(self), self.exit_slots
-        for l, lv in zip(slots, levels):
-            if not 0 <= l < L:
-                raise ValueError("no such level slot: %d" % l)
+        n, E = len(levels), self.exit_slots
+        for lv in levels:
             if lv.shape != self.shape or len(lv.agent_locs) > 1 or len(lv.exit_locs) > E:
                 raise ValueError("the new level does not fit the pool (shape, agents or exit slots)")
             if not self.has_spawner and bool(((lv.board | lv.goals) & CellTypes.spawning).any()):
                 raise ValueError("a level with spawners cannot join a pool that was built spawner-free")
-        phys = [l + L * (1 - int(self.bank[l])) for l in slots]
-        boards = np.stack([lv.board for lv in levels])
-        goals = np.stack([lv.goals for lv in levels])
-        counts = np.asarray((self._counts_fn or _device_counts)(boards, goals), np.int64).reshape(len(levels), 8, 9)
-        for i, (l, p, lv) in enumerate(zip(slots, phys, levels)):
+        pl = PreparedLevels()
+        pl.pool_board = np.stack([lv.board for lv in levels])
+        pl.pool_goals = np.stack([lv.goals for lv in levels])
+        counts = np.asarray((self._counts_fn or _device_counts)(pl.pool_board, pl.pool_goals), np.int64).reshape(n, 8, 9)
+        pl.initial_counts = counts
+        pl.pool_agent_loc = np.full((n, 2), -1, np.int32)
+        pl.pool_exit_locs = np.full((n, E), -1, np.int32)
+        pl.pool_spawn_prob = np.array([lv.spawn_prob for lv in levels], np.float32)
+        pl.pool_rng = np.zeros((n, 4), np.uint64)
+        pl.pool_table_idx = np.zeros(n, np.int32)
+        pl.pool_initial_points = np.zeros(n, np.int32)
+        pl.pool_required_reset = np.zeros(n, np.int32)
+        pl.pool_required_step = np.zeros(n, np.int32)
+        pl.levels = []
+        for i, lv in enumerate(levels):
             t = (lv.points_table[0] if len(lv.points_table) else DEFAULT_POINTS_TABLE).astype(np.int32)
             idx = [j for j, u in enumerate(self.points_table) if np.array_equal(t, u)]
             if not idx:
@@ -343,22 +347,62 @@ class LevelPool(object):
             if lv.rng_words is None and lv.seed is None:
                 lv = Level(lv.board, lv.goals, lv.agent_locs, lv.spawn_prob, lv.min_performance,
                            lv.points_table, seed=self._seq.spawn(1)[0])
-            self.pool_board[p], self.pool_goals[p] = lv.board, lv.goals
-            self.pool_agent_loc[p] = lv.agent_locs[0] if len(lv.agent_locs) else (-1, -1)
-            self.pool_exit_locs[p] = -1
-            self.pool_exit_locs[p, :len(lv.exit_locs)] = lv.exit_locs
-            self.pool_spawn_prob[p] = lv.spawn_prob
-            self.pool_rng[p] = lv.initial_rng_words()
-            self.pool_table_idx[p] = idx[0]
-            self.initial_counts[p] = counts[i]
+            if len(lv.agent_locs):
+                pl.pool_agent_loc[i] = lv.agent_locs[0]
+            ex = lv.exit_locs
+            pl.pool_exit_locs[i, :len(ex)] = ex
+            pl.pool_rng[i] = lv.initial_rng_words()
+            pl.pool_table_idx[i] = idx[0]
             table = self.points_table[idx[0]].astype(np.int64)
-            self.pool_initial_points[p] = int((table * counts[i]).sum())
+            pl.pool_initial_points[i] = int((table * counts[i]).sum())
             avail = available_points(table, counts[i], initial_colors(lv.board))
-            self.pool_required_reset[p] = required_points(lv.min_performance, avail)
-            self.pool_required_step[p] = required_points(np.float64(lv.min_performance) * self._frac, avail)
+            pl.pool_required_reset[i] = required_points(lv.min_performance, avail)
+            pl.pool_required_step[i] = required_points(np.float64(lv.min_performance) * self._frac, avail)
+            pl.levels.append(lv)
+        return pl
+
+    def replace(self, slots, levels):
+        """New content for the logical levels `slots` (refreshable pools): written into each level's SPARE slot, which
+        becomes its current one.  Returns the physical slots written.  Host arrays only -- the device copy and the
+        switch of the successor table are ``SafeLifeVectorEnv.pool_stage`` / ``pool_commit``.  `levels`: a list of
+        Level, or what ``prepare`` made of one (then this only copies).  A new level must fit the pool as built: same
+        shape, no more exits than ``exit_slots``, a points table the pool already has, and no spawner in a pool that was
+        built without any (the kernels were chosen for that)."""
+        if not self.refreshable:
+            raise ValueError("build the pool with refreshable=True")
+        slots = np.asarray([int(x) for x in slots], np.int64)
+        pl = levels if isinstance(levels, PreparedLevels) else self.prepare(levels)
+        L = len(self)
+        if len(slots) != len(pl.levels) or len(set(slots.tolist())) != len(slots):
+            raise ValueError("one new level per distinct slot")
+        if len(slots) and (slots.min() < 0 or slots.max() >= L):
+            raise ValueError("no such level slot: %d" % (slots.min() if slots.min() < 0 else slots.max()))
+        phys = slots + L * (1 - self.bank[slots].astype(np.int64))
+        for k in PreparedLevels.ARRAYS:
+            getattr(self, k)[phys] = getattr(pl, k)
+        for l, lv in zip(slots.tolist(), pl.levels):
             self.levels[l] = lv
-            self.bank[l] = 1 - self.bank[l]
-        return phys
+        self.bank[slots] = 1 - self.bank[slots]
+        return phys.tolist()
+
+
+class PreparedLevels(object):
+    """``LevelPool.prepare``'s result: the rows the pool's arrays take for some new levels."""
+
+    ARRAYS = ("pool_board", "pool_goals", "pool_agent_loc", "pool_exit_locs", "pool_rng", "pool_spawn_prob",
+              "pool_required_reset", "pool_required_step", "pool_initial_points", "pool_table_idx", "initial_counts")
+
+    def __len__(self):
+        return len(self.levels)
+
+    def take(self, idx):
+        """The levels `idx` of this set (repeats allowed), as a PreparedLevels."""
+        idx = np.asarray(idx, np.int64)
+        out = PreparedLevels()
+        for k in self.ARRAYS:
+            setattr(out, k, getattr(self, k)[idx])
+        out.levels = [self.levels[int(i)] for i in idx]
+        return out
 
 
 def empty_env_arrays(pool, num_envs):

@@ -19,7 +19,7 @@ import os
 import numpy as np
 
 from . import _hip
-from .levels import LevelPool
+from .levels import LevelPool, PreparedLevels
 
 _DEFAULT_CHANNELS = tuple(range(16)) + (25, 26, 27)      # safelife_env.py:71
 
@@ -348,17 +348,23 @@ class SafeLifeVectorEnv(object):
     # every step launched FROM THEN ON -- a kernel argument, patched per dispatch by the queue launcher -- so the switch
     # falls between two steps of the stepping thread's program order, deterministically, with no queue drain.
 
-    def pool_stage(self, slots, levels):
+    def pool_stage(self, slots, levels, background=False):
         """New levels for the logical pool slots `slots`, staged (see above).  One staging at a time.  The spare slots it
         writes may still be read by resets of steps enqueued BEFORE the last ``pool_commit()``; it waits for those steps
         (a marker taken at that commit) -- so call it behind the step call that follows a commit, not right behind the
-        commit: ``pool_commit(); step_queues_many(...); pool_stage(...)`` keeps the device busy meanwhile."""
+        commit: ``pool_commit(); step_queues_many(...); pool_stage(...)`` keeps the device busy meanwhile.
+        ``background``: the work (the levels' cell counts through the HIP kernel, the host arrays, the copies) is done by
+        a helper thread of the env, so that the stepping thread -- whose enqueueing is what bounds queue stepping -- only
+        pays for handing it over; ``pool_commit()`` waits for it and re-raises what it raised.  Until then the caller
+        must not touch ``self.pool``."""
         rf = self._pool_refresh
         if rf is None:
             raise ValueError("the env's pool was not built with refreshable=True")
         if rf["staged"] is not None:
             raise ValueError("pool_stage(): the previous staging has not been committed")
-        torch, dev = self.torch, self.device
+        slots = [int(l) for l in slots]
+        if not isinstance(levels, PreparedLevels):
+            levels = list(levels)
         w = self.struct.wrap
         if self._se is not None or (w.flags & _hip.WRAP_SIDE_EFFECT and not (w.flags & _hip.WRAP_INACTION)):
             # these read their level's slot long after the reset that loaded it (the episode-end pass takes the
@@ -369,6 +375,19 @@ class SafeLifeVectorEnv(object):
                     raise ValueError("pool slot %d was replaced less than one time limit ago: envs may still be playing "
                                      "its previous content, which this env's side-effect machinery reads from the pool"
                                      % int(l))
+        if background:
+            pool = rf.get("helper")
+            if pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                pool = rf["helper"] = ThreadPoolExecutor(1, thread_name_prefix="safelife-pool-stage")
+            rf["staged"] = pool.submit(self._pool_stage_now, slots, levels)
+            return None
+        rf["staged"] = self._pool_stage_now(slots, levels)
+        return rf["staged"][4]
+
+    def _pool_stage_now(self, slots, levels):
+        rf, torch, dev, w = self._pool_refresh, self.torch, self.device, self.struct.wrap
+        torch.cuda.set_device(dev)              # (the helper thread starts on device 0)
         # the spare slots about to be overwritten were current until the commit before last at the latest; every step
         # dispatched before the last commit has long completed -- make sure (a marker taken at that commit)
         fence = rf["fence"]
@@ -386,50 +405,63 @@ class SafeLifeVectorEnv(object):
         side = rf["stream"]
         if side is None:
             side = rf["stream"] = torch.cuda.Stream(device=dev)
-        # pinned staging buffers, allocated ONCE (pinning host memory costs milliseconds and stalls the device's queues:
-        # a fresh set per staging made a refreshed run ten times slower); sized for every level of the pool at once.
-        # One staging at a time, and a staging's copies have completed when it is committed: the buffers are free here.
+        # ONE pinned staging buffer, allocated once (pinning host memory costs milliseconds and stalls the device's
+        # queues: a fresh set per staging made a refreshed run ten times slower), with a section per pool array sized for
+        # every level of the pool at once; slhip_pool_write's single kernel reads it where it lies and scatters the rows
+        # (and the successor table) into the pool.  One staging at a time, and a staging's kernel has completed when it
+        # is committed: the buffer is free here.
         pin = rf.get("pinned")
         if pin is None:
             Lg, (H, W), E = len(self.pool), self.pool.shape, self.pool.exit_slots
-
-            def pinned(shape, dtype):
-                return torch.empty(shape, dtype=dtype).pin_memory()
-            pin = rf["pinned"] = dict(board=pinned((Lg, H, W), torch.int16), goals=pinned((Lg, H, W), torch.int16),
-                                      exits=pinned((Lg, E), torch.int32), rng=pinned((Lg, 4), torch.int64),
-                                      scalars=pinned((Lg, 8), torch.int32), idx=pinned((Lg,), torch.int64),
-                                      table=pinned((self.pool.n_slots,), torch.int32))
+            spec = [("board", (Lg, H, W), np.int16), ("goals", (Lg, H, W), np.int16), ("exits", (Lg, E), np.int32),
+                    ("rng", (Lg, 4), np.int64), ("scalars", (Lg, 8), np.int32), ("slot", (Lg,), np.int32),
+                    ("table", (self.pool.n_slots,), np.int32)]
+            off, at = 0, {}
+            for name, shape, ndt in spec:
+                nbytes = int(np.prod(shape)) * np.dtype(ndt).itemsize
+                at[name] = (off, nbytes, shape, ndt)
+                off += -(-nbytes // 16) * 16
+            host = torch.empty(off, dtype=torch.uint8).pin_memory()
+            pin = rf["pinned"] = dict(host=host, h={}, ptr={})
+            for name, (o, nbytes, shape, ndt) in at.items():
+                pin["h"][name] = host.numpy()[o:o + nbytes].view(ndt).reshape(shape)
+                pin["ptr"][name] = host.data_ptr() + o
+        h, ptr = pin["h"], pin["ptr"]
         keep = []
-
-        def up(name, host, dst, idx_dev):
-            pin[name].numpy()[:n] = host
-            dst.index_copy_(0, idx_dev, pin[name][:n].to(dev, non_blocking=True))
-
         nxt = 1 - rf["which"]
-        with torch.cuda.stream(side):
-            pin["idx"].numpy()[:n] = sel
-            idx_dev = pin["idx"][:n].to(dev, non_blocking=True)
-            up("board", pa["pool_board"][sel].view(np.int16), self.t["pool_board"], idx_dev)
-            up("goals", pa["pool_goals"][sel].view(np.int16), self.t["pool_goals"], idx_dev)
-            up("exits", pa["pool_exit_locs"][sel], self.t["pool_exit_locs"], idx_dev)
-            up("rng", pa["pool_rng"][sel].view(np.int64), self.t["pool_rng"], idx_dev)
-            up("scalars", self._level_scalars(pa, sel), self.t["pool_scalars"], idx_dev)
-            pin["table"].numpy()[:] = self.pool.next_table(self.struct.level_stride)
-            self._pool_next[nxt].copy_(pin["table"], non_blocking=True)
-            if w.flags & _hip.WRAP_SIDE_EFFECT and not (w.flags & _hip.WRAP_INACTION):
-                rc = self._lib.slhip_pool_baseline(self._sref, C.c_void_p(side.cuda_stream))
-                _hip.check(rc)
-            ev = torch.cuda.Event()
-            ev.record(side)
-        rf["staged"] = (ev, nxt, keep, [int(l) for l in slots])
-        return phys
+        h["slot"][:n] = sel
+        h["board"][:n] = pa["pool_board"][sel].view(np.int16)
+        h["goals"][:n] = pa["pool_goals"][sel].view(np.int16)
+        h["exits"][:n] = pa["pool_exit_locs"][sel]
+        h["rng"][:n] = pa["pool_rng"][sel].view(np.int64)
+        h["scalars"][:n] = self._level_scalars(pa, sel)
+        h["table"][:] = self.pool.next_table(self.struct.level_stride)
+        rows = _hip.PoolRows(n=n, slot=ptr["slot"], board=ptr["board"], goals=ptr["goals"], exit_locs=ptr["exits"],
+                             rng=ptr["rng"], scalars=ptr["scalars"], next=ptr["table"],
+                             next_dst=self._pool_next[nxt].data_ptr())
+        _hip.check(self._lib.slhip_pool_write(self._sref, C.byref(rows), C.c_void_p(side.cuda_stream)))
+        if w.flags & _hip.WRAP_SIDE_EFFECT and not (w.flags & _hip.WRAP_INACTION):
+            _hip.check(self._lib.slhip_pool_baseline(self._sref, C.c_void_p(side.cuda_stream)))
+        ev = torch.cuda.Event()
+        ev.record(side)
+        return (ev, nxt, keep, slots, phys)
 
-    def pool_commit(self):
-        """Make the staged levels current for every step dispatched from now on (no-op without a staging)."""
+    def pool_commit(self, wait=True):
+        """Make the staged levels current for every step dispatched from now on.  Returns True when it did (or there was
+        nothing staged).  ``wait=False``: if the staging is still on its way (the helper thread, the copy kernel), leave
+        it staged and return False instead of waiting for it -- for a stepping loop that does not care at WHICH call the
+        new levels arrive and tries again at the next one."""
         rf = self._pool_refresh
         if rf is None or rf["staged"] is None:
-            return
-        ev, nxt, keep, slots = rf["staged"]
+            return True
+        staged = rf["staged"]
+        if hasattr(staged, "result"):
+            if not wait and not staged.done():
+                return False
+            staged = rf["staged"] = staged.result()     # (a background staging: re-raises what the helper raised)
+        ev, nxt, keep, slots, _ = staged
+        if not wait and not ev.query():
+            return False
         ev.synchronize()
         rf["staged"] = None
         rf["which"] = nxt
@@ -447,6 +479,7 @@ class SafeLifeVectorEnv(object):
                 e.record(st)
                 evs.append(e)
             rf["fence"] = ("events", _EventSet(evs))
+        return True
 
     def goal_cache_flags(self):
         """Per group of ``goal_cache_group`` consecutive envs: 1 where the group currently steps on cached goal words

@@ -153,6 +153,43 @@ def test_life_occupancy_vs_oracle(sp, shape, B, n_step, kind):
     assert np.array_equal(sp._to_host(d_rng, np.uint64), w_cpu)
 
 
+@pytest.mark.parametrize("shape,n_step", [((64, 64), 300), ((48, 48), 120), ((40, 40), 60), ((25, 25), 60)])
+def test_life_occupancy_colour_classes(sp, shape, n_step):
+    """The counters-per-cell classes of the wide occupancy kernels (sl_rowlane.hip, OccGeom): a board takes two, four
+    or eight colour slots by the colour bits that VARY between its live and spawner cells.  One batch mixes boards of
+    every class -- a single colour, two colours one bit apart, a bit every source has next to varying ones, all eight --
+    and walls whose colours belong to no source; more than 255 steps at 64x64 so that the 8-bit counters drain."""
+    import torch
+    H, W = shape
+    rng = np.random.default_rng(1234 + H)
+    sets = [[3], [2, 3], [6], [5, 7], [1, 2], [4, 5, 6, 7], [0, 7], [0, 1, 2, 3, 4, 5, 6, 7], [0], [1, 3, 5, 7], [2, 4]]
+    boards = np.zeros((2 * len(sets), H, W), np.uint16)
+    for k in range(len(boards)):
+        cols = np.array(sets[k % len(sets)])
+        pick = lambda n: (cols[rng.integers(0, len(cols), n)].astype(np.uint16) << 9)
+        b = boards[k].reshape(-1)
+        alive = rng.random(H * W) < 0.3
+        b[alive] = 9 | pick(int(alive.sum()))
+        for _ in range(6):
+            b[rng.integers(0, H * W)] = 152 | pick(1)[0]                   # a spawner of one of the board's colours
+        for _ in range(5):
+            b[rng.integers(0, H * W)] = 17 | pick(1)[0]                    # frozen life: a source as well
+        walls = rng.random(H * W) < 0.03
+        b[walls] = 16 | (rng.integers(0, 8, int(walls.sum())).astype(np.uint16) << 9)   # any colour: not a source
+    B = len(boards)
+    words = util.random_rng_words(rng, B)
+    p = rng.choice([0.3, 0.05, 1.0], B).astype(np.float32)
+    w_cpu = words.copy()
+    want = oracle.life_occupancy_batch(boards, p, n_step, w_cpu, n_threads=8)
+    d_rng = sp._to_device(words.copy(), np.uint64)
+    got = sp.life_occupancy_batch(sp._to_device(boards, np.uint16), torch.from_numpy(p).to(d_rng.device), d_rng, n_step)
+    got = got.cpu().numpy()
+    for k in range(B):
+        assert np.array_equal(got[k], want[k]), (k, sets[k % len(sets)])
+    assert np.array_equal(sp._to_host(d_rng, np.uint64), w_cpu)
+    assert want.sum() > 0
+
+
 def test_alive_counts_and_actions_vs_oracle(sp):
     import torch
     rng = np.random.default_rng(11)
@@ -1689,18 +1726,21 @@ def test_release_free_stepping_recovers_from_a_misplacement():
         env.queues_close()
 
 
-@pytest.mark.parametrize("pool_name,B,wrappers", [
-    ("prune_still_25", 2048 + 5, None),
-    ("append_spawn_25", 515, None),
+@pytest.mark.parametrize("pool_name,B,wrappers,background", [
+    ("prune_still_25", 2048 + 5, None, False),
+    ("prune_still_25", 2048 + 5, None, True),
+    ("append_spawn_25", 515, None, False),
+    ("append_spawn_25", 515, None, True),
     ("prune_still_25", 300, dict(movement_bonus=0.1, movement_bonus_power=1e-100, movement_bonus_period=4, as_penalty=True,
-                                 exit_bonus=0.5, penalty_coef=None)),
+                                 exit_bonus=0.5, penalty_coef=None), False),
 ])
-def test_level_pool_refresh_while_stepping(pool_name, B, wrappers):
+def test_level_pool_refresh_while_stepping(pool_name, B, wrappers, background):
     """levels.LevelPool(refreshable=True) + SafeLifeVectorEnv.pool_stage / pool_commit (level_iterator.py:200-223,
     safelife_env.py:203-218: every reset takes a fresh level): half of the pool's levels are replaced every ten steps
     while the envs step through the library's queues -- staged ten steps ahead, committed between two queue calls, no
     queue drain for the refresh itself -- and the oracle, given the same replacements at the same steps, agrees bit
-    for bit after 200 steps (state compared every fifty)."""
+    for bit after 200 steps (state compared every fifty).  ``background``: the staging is handed to the env's helper
+    thread BEHIND the step call (the order bench.py measures), while the queues are stepping."""
     import torch
     from safelife_amd import _hip
     _, _ = util.pool_from_fixture(pool_name, _device_counts, n=1)
@@ -1740,12 +1780,15 @@ def test_level_pool_refresh_while_stepping(pool_name, B, wrappers):
         slots = rng.choice(32, 16, replace=False)
         news = [levels[int(k)] for k in rng.integers(0, len(levels), 16)]
         staged = (slots, news)
-        env.pool_stage(slots, news)
+        if not background:
+            env.pool_stage(slots, news)
         if use_queues:
             env.step_queues_many(d_acts[t0:t0 + CH])
         else:
             for t in range(t0, t0 + CH):
                 env.step_async(d_acts[t])
+        if background:
+            assert env.pool_stage(slots, pool_dev.prepare(news), background=True) is None
         for t in range(t0, t0 + CH):
             cpu.env.step(acts[t])
         if (t0 + CH) % 50 == 0:
