@@ -320,6 +320,18 @@ bool open_queue(Device &d, Queue &q) {
         return false;
     }
     if (d.timeline) (void)h.hsa_amd_profiling_set_profiler_enabled(q.q, 1);
+    // SL_AQL_PRIORITY=1 (an experiment's knob): the step queues at HIGH priority (optional entry point, looked up on
+    // its own) -- for runs that put long-lived kernels of other queues beside the steps (the episode-end pass of C5
+    // under them: no gain measured, profiles/round5_p_c5_overlap.txt)
+    if (env_int("SL_AQL_PRIORITY", 0) > 0) {
+        static auto set_priority = [] {
+            std::string path;
+            dl_iterate_phdr(find_loaded_hsa, &path);
+            void *lib = path.empty() ? nullptr : dlopen(path.c_str(), RTLD_NOW | RTLD_NOLOAD);
+            return lib ? (decltype(&::hsa_amd_queue_set_priority))dlsym(lib, "hsa_amd_queue_set_priority") : nullptr;
+        }();
+        if (set_priority) (void)set_priority(q.q, HSA_AMD_QUEUE_PRIORITY_HIGH);
+    }
     st = h.hsa_signal_create(0, 0, nullptr, &q.fence);
     if (st != HSA_STATUS_SUCCESS) {
         d.why = hsa_err("hsa_signal_create", st);

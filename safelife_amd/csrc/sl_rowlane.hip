@@ -692,6 +692,8 @@ struct JumpCache {             // (in registers: kept in LDS instead -- 2 KB per
     int log2c = -1;             //  pass of C5 ran 13.9 instead of 12.6 ms, slower than without any cache, 13.4)
     U128 mult = {0, 0}, plus_inc = {0, 0};
     U128 plus64 = {0, 0};       // (the round-by-round deal: log2c == 64, mult / plus_inc the lane's jump by lane + 1)
+    // (round 5, measured and dropped: the board's generator itself kept in registers from step to step, handed round by
+    //  v_readlane from the lane of the last draw instead of through LDS -- 10.4-10.6 ms either way for the pass of C5)
 };
 __device__ __forceinline__ U128 pcg_jump_cached(const Jump *__restrict__ table, int k, int log2c, U128 state, U128 inc,
                                                 JumpCache *jc) {
@@ -703,6 +705,60 @@ __device__ __forceinline__ U128 pcg_jump_cached(const Jump *__restrict__ table, 
         jc->log2c = log2c;
     }
     return add128(mul128(jc->mult, state), jc->plus_inc);
+}
+
+// A lane's draw outcomes -> its flagged cells: bit k of R is the outcome of the lane's k-th flagged cell in row-major
+// order (ascending bits, word 0 first).  Round 5: the words of a plane are dealt SIDE BY SIDE, two cells of each per trip
+// (word 1's outcomes start popc(word 0) bits into R; a word that has run out of cells idles: its lowest bit is 0) -- the
+// wave loops ceil(busiest word / 2) times instead of once per cell and word, and the trips' chains are independent.
+// The loop is the longest serial stretch of a spawner board's step: 64x64 navigation, ~8 + ~8 flagged cells in the
+// busiest row's two words: 16 trips -> 4.
+#ifndef SL_DEAL_PAIRS
+#define SL_DEAL_PAIRS 2         /* cells of each word per trip (0: the words one after the other, a cell per trip; 4: no faster) */
+#endif
+#ifndef SL_STRIDE_DEAL
+#define SL_STRIDE_DEAL 1        /* A/B knob: 0 = the blocked deal for every step */
+#endif
+template <int NW>
+__device__ __forceinline__ void deal_outcomes(const pl::Pl<NW> &elig, u64 R, pl::Pl<NW> &ok) {
+    if constexpr (SL_DEAL_PAIRS && NW <= 2) {
+        u32 t[NW], g[NW], r[NW];
+        t[0] = elig.w[0], g[0] = 0, r[0] = (u32)R;
+        if constexpr (NW == 2) {
+            t[1] = elig.w[1], g[1] = 0;
+            r[1] = (u32)(R >> __popc(t[0]));    // (popc <= 32; the window holds the lane's <= 64 outcomes)
+        }
+        u32 any = t[0];
+        if constexpr (NW == 2) any |= t[1];
+        while (any) {
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+#pragma unroll
+                for (int k = 0; k < SL_DEAL_PAIRS; ++k) {
+                    const u32 bit = t[i] & (0u - t[i]);
+                    g[i] |= (0u - (r[i] & 1u)) & bit;
+                    r[i] >>= 1;
+                    t[i] ^= bit;
+                }
+            }
+            any = t[0];
+            if constexpr (NW == 2) any |= t[1];
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) ok.w[i] = g[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            u32 todo = elig.w[i], got = 0;
+            while (todo) {
+                const u32 bit = todo & (0u - todo);
+                got |= (R & 1ull) ? bit : 0u;
+                R >>= 1;
+                todo ^= bit;
+            }
+            ok.w[i] = got;
+        }
+    }
 }
 
 // (JC is a template parameter, not just a null pointer: the extra argument alone cost the fused step's spawner
@@ -729,6 +785,8 @@ __device__ pl::Pl<NW> resolve_draws_planes(const pl::Pl<NW> &elig, u64 *rng_lds,
         }
     }
     const int excl = incl - mine - before;
+    constexpr int MAXR = 8;             // rounds of the round-by-round deal (below)
+    const bool stride_now = Gm::G == 1 && SL_STRIDE_DEAL && total <= 64 * MAXR;        // (wave-uniform)
     const U128 st = {rng_lds[4 * g + 0], rng_lds[4 * g + 1]}, inc = {rng_lds[4 * g + 2], rng_lds[4 * g + 3]};
     // two boards per wave: lanes 0-31 make the draws of board 0, lanes 32-63 those of board 1 (below), whatever
     // rows they hold
@@ -750,11 +808,7 @@ __device__ pl::Pl<NW> resolve_draws_planes(const pl::Pl<NW> &elig, u64 *rng_lds,
         // of two; 32 / c neighbouring lanes' outcome bits make one dword (xor swizzles); a row's lane then pulls
         // the dwords that hold ITS draws' outcomes -- consecutive bits from its prefix offset on -- across the
         // wave and deals them to its flagged cells in order.
-#ifndef SL_STRIDE_DEAL
-#define SL_STRIDE_DEAL 1        /* A/B knob: 0 = the blocked deal below for every step */
-#endif
-        constexpr int MAXR = 8;
-        if (SL_STRIDE_DEAL && total <= 64 * MAXR) {
+        if (stride_now) {
             // Round 5: the deal goes ROUND by round -- lane j makes draws j, j + 64, j + 128 ... -- instead of in blocks
             // of 2^log2c per lane.  A lane's first draw is a jump by j + 1 from the board's state, the SAME jump at
             // every step (the cached multiplier never changes), every further one a step of 64 (the table's entry 64:
@@ -814,17 +868,7 @@ __device__ pl::Pl<NW> resolve_draws_planes(const pl::Pl<NW> &elig, u64 *rng_lds,
             }
             u64 R = lo >> sh;
             if (sh) R |= hi << (64 - sh);
-#pragma unroll
-            for (int i = 0; i < NW; ++i) {
-                u32 todo = elig.w[i], got = 0;
-                while (todo) {
-                    const u32 bit = todo & (0u - todo);
-                    got |= (R & 1ull) ? bit : 0u;
-                    R >>= 1;
-                    todo ^= bit;
-                }
-                ok.w[i] = got;
-            }
+            deal_outcomes<NW>(elig, R, ok);
             wave_sync();
             return ok;
         }
@@ -867,17 +911,7 @@ __device__ pl::Pl<NW> resolve_draws_planes(const pl::Pl<NW> &elig, u64 *rng_lds,
             const u32 d2 = bperm(4 * min(63, (w0 + 2) << log2per), v);
             u64 R = (((u64)d1 << 32) | d0) >> sh;
             if (sh) R |= (u64)d2 << (64 - sh);
-#pragma unroll
-            for (int i = 0; i < NW; ++i) {
-                u32 todo = elig.w[i], got = 0;
-                while (todo) {
-                    const u32 bit = todo & (0u - todo);
-                    got |= (R & 1ull) ? bit : 0u;
-                    R >>= 1;
-                    todo ^= bit;
-                }
-                ok.w[i] = got;
-            }
+            deal_outcomes<NW>(elig, R, ok);
             wave_sync();
             return ok;
         }
@@ -932,17 +966,7 @@ __device__ pl::Pl<NW> resolve_draws_planes(const pl::Pl<NW> &elig, u64 *rng_lds,
             const u32 d2 = bperm(4 * (base + min(31, (w0 + 2) << log2per)), v);
             u64 R = (((u64)d1 << 32) | d0) >> sh;
             if (sh) R |= (u64)d2 << (64 - sh);
-#pragma unroll
-            for (int i = 0; i < NW; ++i) {
-                u32 todo = elig.w[i], got = 0;
-                while (todo) {
-                    const u32 bit = todo & (0u - todo);
-                    got |= (R & 1ull) ? bit : 0u;
-                    R >>= 1;
-                    todo ^= bit;
-                }
-                ok.w[i] = got;
-            }
+            deal_outcomes<NW>(elig, R, ok);
             wave_sync();
             return ok;
         }
@@ -3564,7 +3588,16 @@ hipError_t pick_rollout_t(const sl_env_batch &env, int T, void **kernel, hipFunc
     }
     *kernel = (void *)fn;
     *f_out = ce.fn.load(std::memory_order_relaxed);
-    *lds_out = lds;
+    // SAFELIFE_STEP_LDS_MIN (bytes, read once; an experiment's knob): ask for at least that much LDS per step workgroup,
+    // up to the kernel's limit -- i.e. FEWER step workgroups per CU than the kernel's own needs would allow, to leave
+    // the wavefronts of the episode-end pass of C5 (side_effects_flush(overlap=True)) room beside the steps.  Measured
+    // (profiles/round5_p_c5_overlap.txt): two step workgroups per CU instead of three cost the steps 24.3 -> 27.7 us
+    // and the pass under them gives nothing back -- 46.7 against 44.4 us per step; left at 0.
+    static const int lds_min = [] {
+        const char *e = getenv("SAFELIFE_STEP_LDS_MIN");
+        return e ? atoi(e) : 0;
+    }();
+    *lds_out = lds_min > lds ? (lds_min < lds_limit ? lds_min : lds_limit) : lds;
     return hipSuccess;
 }
 

@@ -55,6 +55,7 @@ class SideEffectBatch(object):
         """The caller's current stream waits for the pass (a no-op for a pass that ran on that stream); host reads
         through this class do it themselves."""
         if self._done is not None:
+            self.env.side_effects_launch()          # (a deferred pass nobody has launched yet)
             self.env.torch.cuda.current_stream().wait_event(self._done)
 
     def __len__(self):
@@ -994,7 +995,7 @@ class SafeLifeVectorEnv(object):
             se["stream"] = pick if pick is not None else torch.cuda.Stream(device=self.device)
         return se["stream"]
 
-    def side_effects_flush(self, overlap=False):
+    def side_effects_flush(self, overlap=False, defer=False):
         """Run the episode-end pass (``slhip_side_effects``) over the episodes queued since the last flush and switch the
         step kernels to the other queue.  Nothing is read back: the returned ``SideEffectBatch`` takes the queue's
         buffers along (a fresh queue replaces it) next to the pass's outputs, all device tensors sized by the capacity,
@@ -1004,10 +1005,13 @@ class SafeLifeVectorEnv(object):
         ``overlap=False``: the pass runs on the caller's current stream, behind every step enqueued so far, and later
         steps wait for it.  ``overlap=True``: it runs on a side stream of the env, behind the steps enqueued so far, and
         the steps that FOLLOW do not wait for it (nothing they touch is shared with it: the queue it reads has been
-        replaced, the level pool is read-only) -- ``side_effects_join()`` / the batch's accessors order against it."""
+        replaced, the level pool is read-only) -- ``side_effects_join()`` / the batch's accessors order against it.
+        ``defer=True`` (with overlap): everything but the launch -- ``side_effects_launch()`` makes it, so that the caller
+        can put its next steps in front of the pass in the device's queues (it is also made by the next flush / join)."""
         if self._se is None:
             raise ValueError("construct the env with side_effects=dict(capacity=...) first")
         torch, se = self.torch, self._se
+        self.side_effects_launch()
         side = None
         if overlap and self.device.type == "cuda":
             side = self._side_stream()
@@ -1047,23 +1051,37 @@ class SafeLifeVectorEnv(object):
             out = sets[se["flushes"] % len(sets)]
         se["flushes"] = se.get("flushes", 0) + 1
         stream_ptr = _hip.current_stream_ptr() if side is None else C.c_void_p(side.cuda_stream)
-        rc = self._lib.slhip_side_effects(self._sref, C.byref(q), se["num_samples"], 1,
-                                          *[_hip.ptr(out[k]) for k in ("work_boards", "work_prob", "work_steps", "work_rng",
-                                                                       "counts", "keys", "life_dist", "type_masks")],
-                                          stream_ptr)
-        _hip.check(rc)
-        done = None
+        done = torch.cuda.Event() if side is not None else None
+
+        def launch():
+            rc = self._lib.slhip_side_effects(self._sref, C.byref(q), se["num_samples"], 1,
+                                              *[_hip.ptr(out[k]) for k in ("work_boards", "work_prob", "work_steps",
+                                                                           "work_rng", "counts", "keys", "life_dist",
+                                                                           "type_masks")],
+                                              stream_ptr)
+            _hip.check(rc)
+            if side is not None:
+                for tns in bufs.values():             # (the allocator must not hand these to someone else while the pass runs)
+                    tns.record_stream(side)
+                done.record(side)
+        if defer and side is not None:
+            se["deferred"] = launch
+        else:
+            launch()
         if side is not None:
-            for tns in bufs.values():                 # (the allocator must not hand these to someone else while the pass runs)
-                tns.record_stream(side)
-            done = torch.cuda.Event()
-            done.record(side)
             se["last_done"] = done
         return SideEffectBatch(self, bufs, out, se["num_samples"], done)
+
+    def side_effects_launch(self):
+        """Launch the pass a ``side_effects_flush(overlap=True, defer=True)`` left prepared (no-op otherwise)."""
+        if self._se is not None and self._se.get("deferred") is not None:
+            launch, self._se["deferred"] = self._se["deferred"], None
+            launch()
 
     def side_effects_join(self):
         """The caller's current stream waits for the last overlapped episode-end pass."""
         if self._se is not None and self._se.get("last_done") is not None:
+            self.side_effects_launch()
             self.torch.cuda.current_stream().wait_event(self._se["last_done"])
 
     def side_effect_occupancy(self, env_ids, rng, num_samples=1000):

@@ -211,3 +211,19 @@ def test_refreshable_pool_on_the_oracle():
     assert phys == [4] and np.array_equal(pool.pool_board[4 + L], levels[20].board)
     with pytest.raises(ValueError):
         LevelPool(levels[:L], counts_fn=util.oracle_counts).replace([0], [levels[9]])
+    # prepared levels (LevelPool.prepare: counts, points, RNG words ahead of time; replace only copies) == plain ones
+    a = LevelPool(levels[:L], counts_fn=util.oracle_counts, refreshable=True, seed=5)
+    b = LevelPool(levels[:L], counts_fn=util.oracle_counts, refreshable=True, seed=5)
+    ready = b.prepare(levels[10:30])
+    assert len(ready) == 20 and len(ready.take([3, 3, 7])) == 3
+    for slots, idx in (([1, 5, 2], [0, 7, 19]), ([5, 0], [4, 4])):
+        assert a.replace(slots, [levels[10 + k] for k in idx]) == b.replace(slots, ready.take(idx))
+        for k in LevelPool.ARRAYS:
+            if k != "pool_rng":         # (levels without a generator of their own draw theirs from the pool's seed, in the
+                #                          order they are prepared: the words differ by construction here)
+                assert np.array_equal(getattr(a, k), getattr(b, k)), k
+        assert np.array_equal(a.bank, b.bank) and np.array_equal(a.initial_counts, b.initial_counts)
+    with pytest.raises(ValueError):
+        b.replace([1, 1], ready.take([0, 1]))
+    with pytest.raises(ValueError):
+        b.replace([L], ready.take([0]))
