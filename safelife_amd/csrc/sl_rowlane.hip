@@ -719,6 +719,11 @@ __device__ __forceinline__ U128 pcg_jump_cached(const Jump *__restrict__ table, 
 #ifndef SL_STRIDE_DEAL
 #define SL_STRIDE_DEAL 1        /* A/B knob: 0 = the blocked deal for every step */
 #endif
+#ifndef SL_STRIDE_ROUNDS2
+#define SL_STRIDE_ROUNDS2 4     /* two boards per wave: rounds (of 32 draws per board) the round-by-round deal takes; a step
+                                   with more draws goes row by row (below) -- the blocked deal is not kept beside it: both
+                                   together cost the 25x25 step kernels the registers of their scratch-free build */
+#endif
 template <int NW>
 __device__ __forceinline__ void deal_outcomes(const pl::Pl<NW> &elig, u64 R, pl::Pl<NW> &ok) {
     if constexpr (SL_DEAL_PAIRS && NW <= 2) {
@@ -923,6 +928,74 @@ __device__ pl::Pl<NW> resolve_draws_planes(const pl::Pl<NW> &elig, u64 *rng_lds,
         // q (one c for both boards); the xor swizzles stay inside a half; a row's lane pulls its dwords from the
         // half of its OWN board.
         const int tmax = max(tot_q[0], tot_q[1]);
+        constexpr int MAXR2 = SL_STRIDE_ROUNDS2;     // (more rounds cost the 25x25 step kernels registers they do not have)
+        if (SL_STRIDE_DEAL && tmax <= 32 * MAXR2) {
+            // the round-by-round deal on the two halves: lane j of half q makes draws j, j + 32, ... of board q -- a jump
+            // by j + 1, then steps of 32 (the table's entry 32) -- and round r's outcomes are the compare's lane mask,
+            // board 0's in its low dword, board 1's in its high one.  A 25x25 board with a spawner or two draws ~10
+            // times a step: one round, i.e. the jump alone (was: jump + one step + five swizzles + three bpermutes).
+            const int lane = (int)__lane_id(), j = lane & 31;
+            const int rounds = (tmax + 31) >> 5;
+            const int total_w = wq ? tot_q[1] : tot_q[0];
+            const u32 tl0 = __builtin_amdgcn_readlane((u32)thr, LaneMap<H, W>::first_lane(0) + 1);
+            const u32 th0 = __builtin_amdgcn_readlane((u32)(thr >> 32), LaneMap<H, W>::first_lane(0) + 1);
+            const u32 tl1 = __builtin_amdgcn_readlane((u32)thr, LaneMap<H, W>::first_lane(1) + 1);
+            const u32 th1 = __builtin_amdgcn_readlane((u32)(thr >> 32), LaneMap<H, W>::first_lane(1) + 1);
+            const u64 wthr = wq ? (((u64)th1 << 32) | tl1) : (((u64)th0 << 32) | tl0);
+            u64 B[MAXR2];
+#pragma unroll
+            for (int r = 0; r < MAXR2; ++r) B[r] = 0;
+            if (tmax > 0) {
+                U128 cur = wst, plus32 = {0, 0};
+                const bool in0 = j < total_w;
+                if (jc) {
+                    if (jc->log2c != 32) {      // (every lane, whether it draws at this step or not)
+                        const Jump jj = jump[j + 1];
+                        jc->mult = U128{jj.mult_hi, jj.mult_lo};
+                        jc->plus_inc = mul128(U128{jj.plus_hi, jj.plus_lo}, winc);
+                        jc->plus64 = mul128(U128{jump[32].plus_hi, jump[32].plus_lo}, winc);
+                        jc->log2c = 32;
+                    }
+                    if (in0) cur = add128(mul128(jc->mult, wst), jc->plus_inc);
+                    plus32 = jc->plus64;
+                } else {
+                    if (in0) cur = pcg_jump(jump, j + 1, wst, winc);
+                    if (rounds > 1) plus32 = mul128(U128{jump[32].plus_hi, jump[32].plus_lo}, winc);
+                }
+                B[0] = __ballot(in0 && pcg_output_u53(cur) < wthr);                 // advance_board.c:115
+                const U128 mult32 = {jump[32].mult_hi, jump[32].mult_lo};
+#pragma unroll
+                for (int r = 1; r < MAXR2; ++r) {
+                    if (r < rounds) {
+                        const bool in = j + 32 * r < total_w;
+                        if (in) cur = add128(mul128(mult32, cur), plus32);
+                        B[r] = __ballot(in && pcg_output_u53(cur) < wthr);
+                    }
+                }
+                if (total_w > 0 && j == ((total_w - 1) & 31)) {     // the lane that made its board's last draw
+                    rng_lds[4 * wq + 0] = cur.hi;
+                    rng_lds[4 * wq + 1] = cur.lo;
+                }
+            }
+            // my draws' outcomes: bits [excl, excl + mine) of MY board's string, dword r = my board's half of B[r]
+            const int w0 = excl >> 5, sh = excl & 31;
+            u32 d0 = 0, d1 = 0, d2 = 0;
+#pragma unroll
+            for (int r = 0; r < MAXR2; ++r) {
+                if (r < rounds) {
+                    const u32 v = g ? (u32)(B[r] >> 32) : (u32)B[r];
+                    if (w0 == r) d0 = v;
+                    if (w0 + 1 == r) d1 = v;
+                    if (w0 + 2 == r) d2 = v;
+                }
+            }
+            u64 R = (((u64)d1 << 32) | d0) >> sh;
+            if (sh) R |= (u64)d2 << (64 - sh);
+            deal_outcomes<NW>(elig, R, ok);
+            wave_sync();
+            return ok;
+        }
+#if !SL_STRIDE_DEAL
         if (tmax <= 32 * 32) {
             const int lane = (int)__lane_id(), j = lane & 31;
             const int need = (tmax + 31) >> 5;
@@ -970,6 +1043,7 @@ __device__ pl::Pl<NW> resolve_draws_planes(const pl::Pl<NW> &elig, u64 *rng_lds,
             wave_sync();
             return ok;
         }
+#endif
     }
     if (mine > 0) {
         U128 cur = pcg_jump(jump, excl, st, inc);
