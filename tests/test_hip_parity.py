@@ -773,6 +773,61 @@ def test_side_effect_queue_end_to_end(sp, pool_name, n_levels, B, time_limit, ca
     assert len(dev.env.side_effects_flush()) == 0          # the fresh queue starts empty
 
 
+def test_side_effects_flush_overlapped_and_deferred():
+    """side_effects_flush(overlap=True) -- the pass on the env's side stream, later steps not waiting for it -- and
+    defer=True + side_effects_launch() -- the launch itself left until the caller has put further steps in front of it --
+    return what the plain flush returns (records, boards, counts, keys, distributions), and the steps that went in
+    between are the same steps: two envs, same pool, same actions, one flushed each way."""
+    import torch
+    from safelife_amd.vector_env import SafeLifeVectorEnv
+    pool, _ = util.pool_from_fixture("append_spawn_25", _device_counts, n=6, min_performance_fraction=0.05)
+    B, T = 40, 31
+    kw = dict(auto_reset=True, level_stride=1, time_limit=7, view_shape=(9, 9), slices=2,
+              side_effects=dict(capacity=256, num_samples=40))
+    envs = [SafeLifeVectorEnv(pool, B, **kw) for _ in range(3)]
+    for e in envs:
+        e.reset()
+    rng = np.random.default_rng(8)
+    acts = torch.from_numpy(rng.integers(0, 9, (T + 12, B)).astype(np.int32)).to(envs[0].device)
+
+    def same(a, b, what):
+        assert len(a) == len(b) and len(a) > 0, what
+        ra, rb = a.records(), b.records()
+        order_a = np.lexsort((ra["episode_idx"], ra["env"]))
+        order_b = np.lexsort((rb["episode_idx"], rb["env"]))
+        for k in ("env", "episode_idx", "level", "num_steps"):
+            assert np.array_equal(ra[k][order_a], rb[k][order_b]), (what, k)
+        n = len(a)
+        for name in ("boards", "keys", "life_dist"):
+            x = getattr(a, name).cpu().numpy()[:n][order_a]
+            y = getattr(b, name).cpu().numpy()[:n][order_b]
+            assert np.array_equal(x, y), (what, name)
+        ca, cb = a.counts.cpu().numpy(), b.counts.cpu().numpy()
+        assert np.array_equal(ca[:, :n][:, order_a], cb[:, :n][:, order_b]), (what, "counts")
+
+    for t in range(T):
+        for e in envs:
+            e.step_async(acts[t])
+    plain = envs[0].side_effects_flush()
+    over = envs[1].side_effects_flush(overlap=True)
+    late = envs[2].side_effects_flush(overlap=True, defer=True)
+    for t in range(T, T + 6):
+        for e in envs:
+            e.step_async(acts[t])
+    envs[2].side_effects_launch()
+    for t in range(T + 6, T + 12):
+        for e in envs:
+            e.step_async(acts[t])
+    same(plain, over, "overlapped")
+    same(plain, late, "deferred")
+    # the second window: the deferred one is never launched by hand -- the flush / the accessors do it
+    p2 = envs[0].side_effects_flush()
+    l2 = envs[2].side_effects_flush(overlap=True, defer=True)
+    same(p2, l2, "second window")
+    for name in ("board", "rng"):
+        assert torch.equal(envs[0].t[name], envs[2].t[name]), name
+
+
 def test_vector_env_side_effect_occupancy(sp):
     """Batched device pipeline of side_effect_score for finished episodes == the one-env pipeline
     (advance_board(b0, n) -> life_occupancy x2 under one generator), env by env, generator state included."""
