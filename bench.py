@@ -570,30 +570,56 @@ def main():
             g2.flush()
             g2.close()
             queue_ids[0] = None
-        except _hip.SafeLifeHipError as e:
-            extra["forced_gather_error"] = str(e)
+        except Exception as e:          # noqa: BLE001  (an extra: reported, never fatal to the headline line)
+            extra["forced_gather_error"] = "%s: %s" % (type(e).__name__, e)
         env.set_step_outputs(None)
     if args.rollout > 0:
-        T = args.rollout
-        reps = max(1, K // T)
-        a = actions[:T].contiguous()
-        env.rollout(a)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
+        try:
+            T = args.rollout
+            reps = max(1, K // T)
+            a = actions[:T].contiguous()
             env.rollout(a)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
-        extra["rollout_T"] = T
-        extra["rollout_env_steps_per_s_per_gpu"] = B * T / (ms * 1e-3)
-        extra["rollout_us_per_step"] = ms * 1e3 / T
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                env.rollout(a)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            extra["rollout_T"] = T
+            extra["rollout_env_steps_per_s_per_gpu"] = B * T / (ms * 1e-3)
+            extra["rollout_us_per_step"] = ms * 1e3 / T
+        except Exception as e:          # noqa: BLE001
+            extra["rollout_error"] = "%s: %s" % (type(e).__name__, e)
     if args.extras and world == 1:
-        # the same step with the two observation formats of the reference (SafeLifeEnv.output_channels)
-        for tag, chans in (("obs_u8_25x25x15", TRAIN_CHANNELS), ("obs_u32_view_25x25", None)):
-            env2 = SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25), output_channels=chans,
-                                     auto_reset=True, level_stride=1, with_obs=True)
+        # (an extra that fails must not take the headline line with it: the error is reported in its place)
+        try:
+            # the same step with the two observation formats of the reference (SafeLifeEnv.output_channels)
+            for tag, chans in (("obs_u8_25x25x15", TRAIN_CHANNELS), ("obs_u32_view_25x25", None)):
+                env2 = SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25), output_channels=chans,
+                                         auto_reset=True, level_stride=1, with_obs=True)
+                env2.reset()
+                for t in range(20):
+                    env2.step(actions[t])
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                n = min(K, 200)
+                e0.record()
+                for t in range(n):
+                    env2.step(actions[t])
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) / n * 1e3
+                extra[tag + "_us_per_step"] = us
+                extra[tag + "_env_steps_per_s"] = B / (us * 1e-6)
+                obs_b = H * Wd * (len(chans) if chans else 4)           # step bytes + observation bytes
+                extra[tag + "_roofline_frac"] = (3 * H * Wd * 2 + obs_b) * B / (us * 1e-6) / (HBM_PEAK_GBS * 1e9)
+                del env2
+
+            # f4: the observation written by the step kernel in the policy network's layout ([B,C,W,H] uint8), no (h,w,c) tensor
+            env2 = SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25), output_channels=TRAIN_CHANNELS,
+                                     auto_reset=True, level_stride=1, with_obs=False, policy_layout="uint8")
             env2.reset()
             for t in range(20):
                 env2.step(actions[t])
@@ -605,383 +631,370 @@ def main():
                 env2.step(actions[t])
             e1.record()
             torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) / n * 1e3
-            extra[tag + "_us_per_step"] = us
-            extra[tag + "_env_steps_per_s"] = B / (us * 1e-6)
-            obs_b = H * Wd * (len(chans) if chans else 4)           # step bytes + observation bytes
-            extra[tag + "_roofline_frac"] = (3 * H * Wd * 2 + obs_b) * B / (us * 1e-6) / (HBM_PEAK_GBS * 1e9)
+            extra["obs_policy_layout_u8_25x25x15_us_per_step"] = e0.elapsed_time(e1) / n * 1e3
             del env2
 
-        # f4: the observation written by the step kernel in the policy network's layout ([B,C,W,H] uint8), no (h,w,c) tensor
-        env2 = SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25), output_channels=TRAIN_CHANNELS,
-                                 auto_reset=True, level_stride=1, with_obs=False, policy_layout="uint8")
-        env2.reset()
-        for t in range(20):
-            env2.step(actions[t])
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        n = min(K, 200)
-        e0.record()
-        for t in range(n):
-            env2.step(actions[t])
-        e1.record()
-        torch.cuda.synchronize()
-        extra["obs_policy_layout_u8_25x25x15_us_per_step"] = e0.elapsed_time(e1) / n * 1e3
-        del env2
+            # f4 closed loop (training/base_algo.py:152-244, ppo.py:61-73, models.py:80-109): observation (policy layout,
+            # uint8, written by the step kernel) -> policy -> one categorical draw per env on the device -> step, nothing on
+            # the host.  Serial (VectorRunner: one stream, one launch per step) and pipelined (PipelinedRunner: two groups
+            # of 4096 envs, each group's policy / draw / step on the group's own stream, the groups overlapping), with a
+            # trivial policy (uniform probabilities, no arithmetic: what is left is the plumbing) and with a network of
+            # the reference's SafeLifePolicyNetwork shape (stock torch convolutions, float32, random weights: NOT part of
+            # this build's kernels).  Wall clock, device idle before and after.
+            from safelife_amd.runner import VectorRunner, PipelinedRunner
 
-        # f4 closed loop (training/base_algo.py:152-244, ppo.py:61-73, models.py:80-109): observation (policy layout,
-        # uint8, written by the step kernel) -> policy -> one categorical draw per env on the device -> step, nothing on
-        # the host.  Serial (VectorRunner: one stream, one launch per step) and pipelined (PipelinedRunner: two groups
-        # of 4096 envs, each group's policy / draw / step on the group's own stream, the groups overlapping), with a
-        # trivial policy (uniform probabilities, no arithmetic: what is left is the plumbing) and with a network of
-        # the reference's SafeLifePolicyNetwork shape (stock torch convolutions, float32, random weights: NOT part of
-        # this build's kernels).  Wall clock, device idle before and after.
-        from safelife_amd.runner import VectorRunner, PipelinedRunner
+            class TrivialPolicy(object):
+                def __init__(self):
+                    self.cache = {}
 
-        class TrivialPolicy(object):
-            def __init__(self):
-                self.cache = {}
+                def __call__(self, obs):
+                    n = obs.shape[0]
+                    if n not in self.cache:
+                        self.cache[n] = (torch.zeros(n, device=dev), torch.full((n, 9), 1.0 / 9.0, device=dev))
+                    return self.cache[n]
 
-            def __call__(self, obs):
-                n = obs.shape[0]
-                if n not in self.cache:
-                    self.cache[n] = (torch.zeros(n, device=dev), torch.full((n, 9), 1.0 / 9.0, device=dev))
-                return self.cache[n]
+            class RefShapedPolicy(torch.nn.Module):
+                def __init__(self, c):
+                    super().__init__()
+                    nn = torch.nn
+                    self.cnn = nn.Sequential(nn.Conv2d(c, 32, 5, 2), nn.ReLU(), nn.Conv2d(32, 64, 3, 2), nn.ReLU(),
+                                             nn.Conv2d(64, 64, 3, 1), nn.ReLU())
+                    self.dense = nn.Sequential(nn.Linear(64 * 3 * 3, 512), nn.ReLU())
+                    self.logits, self.value = nn.Linear(512, 9), nn.Linear(512, 1)
 
-        class RefShapedPolicy(torch.nn.Module):
-            def __init__(self, c):
-                super().__init__()
-                nn = torch.nn
-                self.cnn = nn.Sequential(nn.Conv2d(c, 32, 5, 2), nn.ReLU(), nn.Conv2d(32, 64, 3, 2), nn.ReLU(),
-                                         nn.Conv2d(64, 64, 3, 1), nn.ReLU())
-                self.dense = nn.Sequential(nn.Linear(64 * 3 * 3, 512), nn.ReLU())
-                self.logits, self.value = nn.Linear(512, 9), nn.Linear(512, 1)
+                def forward(self, obs):
+                    x = self.dense(self.cnn(obs.to(torch.float32)).flatten(1))
+                    return self.value(x)[..., 0], torch.softmax(self.logits(x), dim=-1)
 
-            def forward(self, obs):
-                x = self.dense(self.cnn(obs.to(torch.float32)).flatten(1))
-                return self.value(x)[..., 0], torch.softmax(self.logits(x), dim=-1)
+            def wall(fn, n, warm=5):
+                for _ in range(warm):
+                    fn()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / n * 1e6
 
-        def wall(fn, n, warm=5):
-            for _ in range(warm):
-                fn()
+            def loop_env(slices):
+                e = SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25), output_channels=TRAIN_CHANNELS,
+                                      auto_reset=True, level_stride=1, with_obs=False, policy_layout="uint8", slices=slices)
+                return e
+            cnn = RefShapedPolicy(len(TRAIN_CHANNELS)).to(dev).eval()
+            cl = {}
+            for pname, pol, n in (("trivial", TrivialPolicy(), 200), ("refshaped_cnn", cnn, 20)):
+                r1 = VectorRunner(loop_env(1), pol, copy_obs=False, cast_obs=False)
+                cl["serial_%s_us_per_step" % pname] = wall(r1.take_one_step, n)
+                r2 = PipelinedRunner(loop_env(2), pol)
+                r2.start()
+                cl["pipelined_%s_us_per_step" % pname] = wall(lambda: r2.run(1), n)
+                r2.finish()
+                del r1, r2
+            # the parts, each by itself: the two-group step with the policy-layout observation, the draw, the forward pass
+            e2 = loop_env(2)
+            e2.reset()
+            e2.fence()
+            fixed = torch.randint(0, 9, (B,), device=dev, dtype=torch.int32)
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(n):
-                fn()
+
+            def both_groups():
+                e2.step_slice(0, fixed)
+                e2.step_slice(1, fixed)
+            cl["parts_step_two_groups_us"] = wall(both_groups, 200)
+            e2.join()
+            uni = torch.full((B, 9), 1.0 / 9.0, device=dev)
+            acts_buf = torch.zeros(B, dtype=torch.int32, device=dev)
+            cl["parts_draw_torch_multinomial_us"] = wall(lambda: acts_buf.copy_(torch.multinomial(uni, 1).view(-1)), 200)
+            st_ptr = _hip.current_stream_ptr()
+            cl["parts_draw_us"] = wall(lambda: _hip.lib().slhip_sample_actions(uni.data_ptr(), B, 9, 1, 2, acts_buf.data_ptr(), st_ptr), 200)
+            obs_f = e2.policy_tensor
+            with torch.no_grad():
+                cl["parts_refshaped_cnn_forward_us"] = wall(lambda: cnn(obs_f), 20)
+            cl["note"] = ("8192 envs, 25x25x15 uint8 observation in the policy layout written by the step kernel; serial = "
+                          "VectorRunner (one stream), pipelined = PipelinedRunner (two groups of 4096 envs on two streams); the "
+                          "network has the reference's SafeLifePolicyNetwork shape (conv 5x5/2-32, 3x3/2-64, 3x3-64, dense 512), "
+                          "stock torch float32 kernels, random weights")
+            extra["closed_loop"] = cl
+            del e2, cnn
+
+            def time_steps(env3, n_envs, n=200):
+                acts = torch.randint(0, 9, (n + 20, n_envs), generator=gen, device=dev, dtype=torch.int32)
+                env3.reset()
+                torch.cuda.synchronize()
+                for t in range(20):
+                    env3.step_async(acts[t])
+                env3.join()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for t in range(20, 20 + n):
+                    env3.step_async(acts[t])
+                env3.join()
+                e1.record()
+                torch.cuda.synchronize()
+                us_streams = e0.elapsed_time(e1) / n * 1e3
+                # the same steps through the library's AQL queues (wall clock around n steps + their fence), where the
+                # timed region ran on them
+                env3.last_queues_us = None
+                if use_queues:
+                    try:
+                        env3.queues_open(n_queues, release_free=(res["fences"] == "none"))
+                        for t in range(20):
+                            env3.step_queues(acts[t])
+                        env3.queues_sync()
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        for t in range(20, 20 + n):
+                            env3.step_queues(acts[t])
+                        env3.queues_sync()
+                        env3.last_queues_us = (time.perf_counter() - t0) / n * 1e6
+                        env3.queues_close()
+                    except _hip.SafeLifeHipError:
+                        pass
+                return us_streams
+
+            # level-pool refresh while stepping (levels.LevelPool(refreshable=True), pool_stage / pool_commit): C3's batch through
+            # the queues in calls of `chunk` steps, with a sixth of the pool's levels replaced every call (staged one call
+            # ahead, committed between two calls) against the same calls without any refresh
+            if use_queues and args.pool == "prune_still_25":
+                try:
+                    from safelife_amd.levels import LevelPool
+                    lv_all = list(pool.levels)
+                    n_half = len(lv_all) // 2
+                    pool_r = LevelPool(lv_all[:n_half], counts_fn=_device_counts, refreshable=True)
+                    env_r = SafeLifeVectorEnv(pool_r, B, time_limit=1000, view_shape=(25, 25), output_channels=TRAIN_CHANNELS,
+                                              auto_reset=True, with_obs=False, slices=args.slices)
+                    env_r.reset()
+                    chunk, n_calls = 100, 8
+                    acts_r = torch.randint(0, 9, (chunk * (n_calls + 1), B), generator=gen, device=dev, dtype=torch.int32)
+                    env_r.queues_open(n_queues, release_free=(res["fences"] == "none"), recover=False)
+                    rr = np.random.default_rng(5)
+                    env_r.pool_stage([0], [lv_all[n_half]])        # (untimed: the first staging pins its host buffers)
+                    # new levels come prepared (LevelPool.prepare: checks, cell counts, points, RNG words) -- part of making
+                    # a level, which the reference does away from the stepping thread too (level_iterator.py:200-223)
+                    ready = pool_r.prepare(lv_all)
+                    env_r.pool_commit()
+                    for refresh in (False, True):
+                        env_r.step_queues_many(acts_r[:chunk])
+                        env_r.queues_sync()
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        n_committed = 0
+                        for c in range(n_calls):
+                            free = refresh and env_r.pool_commit(wait=False)    # (not yet there: next call)
+                            n_committed += int(free)
+                            env_r.step_queues_many(acts_r[chunk * (c + 1):chunk * (c + 2)], assume_ordered=True)
+                            if free:            # (behind the call: what staging waits for -- the steps enqueued before the
+                                #                  last commit -- completes while the device works through this call)
+                                slots = rr.choice(n_half, n_half // 6, replace=False)
+                                env_r.pool_stage(slots, ready.take(rr.integers(0, len(ready), len(slots))), background=True)
+                        env_r.queues_sync()
+                        us = (time.perf_counter() - t0) / (chunk * n_calls) * 1e6
+                        extra["pool_refresh_us_per_step" if refresh else "pool_static_us_per_step"] = us
+                        if refresh:
+                            extra["pool_refresh_commits"] = "%d of %d calls" % (n_committed, n_calls)
+                        env_r.pool_commit()
+                    extra["pool_refresh_note"] = ("8192 envs, %d-level refreshable pool, %d steps per queue call, %d levels "
+                                                  "replaced per call (prepared levels, staged a call ahead by the env's helper thread, committed "
+                                                  "between calls; no queue drain for the refresh)" % (n_half, chunk, n_half // 6))
+                    env_r.queues_close()
+                    del env_r
+                except _hip.SafeLifeHipError as e:
+                    extra["pool_refresh_error"] = str(e)
+
+            # C2 (BASELINE configs[1]): advance_board alone on 1024 random 25x25 boards (SURVEY 8d palette-like)
+            from safelife_amd import speedups
+            c2 = np.random.default_rng(1234)
+            pal = np.array([0] * 10 + [9] * 4 + [1, 16, 17, 32788, 152, 152 | 0x200, 144, 48, 53, 85, 32884, 272, 9 | 0x200,
+                                          9 | 0x400, 9 | 0x800, 122], np.uint16)
+            c2_boards = torch.from_numpy(pal[c2.integers(0, len(pal), (1024, 25, 25))].view(np.int16)).to(dev)
+            c2_prob = torch.full((1024,), 0.3, dtype=torch.float32, device=dev)
+            c2_rng = torch.arange(4096, dtype=torch.int64, device=dev).reshape(1024, 4) * 2 + 1
+            c2_out = torch.empty_like(c2_boards)
+            for _ in range(10):
+                speedups.advance_board_batch(c2_boards, c2_prob, c2_rng, 1, out=c2_out)
             torch.cuda.synchronize()
-            return (time.perf_counter() - t0) / n * 1e6
-
-        def loop_env(slices):
-            e = SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25), output_channels=TRAIN_CHANNELS,
-                                  auto_reset=True, level_stride=1, with_obs=False, policy_layout="uint8", slices=slices)
-            return e
-        cnn = RefShapedPolicy(len(TRAIN_CHANNELS)).to(dev).eval()
-        cl = {}
-        for pname, pol, n in (("trivial", TrivialPolicy(), 200), ("refshaped_cnn", cnn, 20)):
-            r1 = VectorRunner(loop_env(1), pol, copy_obs=False, cast_obs=False)
-            cl["serial_%s_us_per_step" % pname] = wall(r1.take_one_step, n)
-            r2 = PipelinedRunner(loop_env(2), pol)
-            r2.start()
-            cl["pipelined_%s_us_per_step" % pname] = wall(lambda: r2.run(1), n)
-            r2.finish()
-            del r1, r2
-        # the parts, each by itself: the two-group step with the policy-layout observation, the draw, the forward pass
-        e2 = loop_env(2)
-        e2.reset()
-        e2.fence()
-        fixed = torch.randint(0, 9, (B,), device=dev, dtype=torch.int32)
-        torch.cuda.synchronize()
-
-        def both_groups():
-            e2.step_slice(0, fixed)
-            e2.step_slice(1, fixed)
-        cl["parts_step_two_groups_us"] = wall(both_groups, 200)
-        e2.join()
-        uni = torch.full((B, 9), 1.0 / 9.0, device=dev)
-        acts_buf = torch.zeros(B, dtype=torch.int32, device=dev)
-        cl["parts_draw_torch_multinomial_us"] = wall(lambda: acts_buf.copy_(torch.multinomial(uni, 1).view(-1)), 200)
-        st_ptr = _hip.current_stream_ptr()
-        cl["parts_draw_us"] = wall(lambda: _hip.lib().slhip_sample_actions(uni.data_ptr(), B, 9, 1, 2, acts_buf.data_ptr(), st_ptr), 200)
-        obs_f = e2.policy_tensor
-        with torch.no_grad():
-            cl["parts_refshaped_cnn_forward_us"] = wall(lambda: cnn(obs_f), 20)
-        cl["note"] = ("8192 envs, 25x25x15 uint8 observation in the policy layout written by the step kernel; serial = "
-                      "VectorRunner (one stream), pipelined = PipelinedRunner (two groups of 4096 envs on two streams); the "
-                      "network has the reference's SafeLifePolicyNetwork shape (conv 5x5/2-32, 3x3/2-64, 3x3-64, dense 512), "
-                      "stock torch float32 kernels, random weights")
-        extra["closed_loop"] = cl
-        del e2, cnn
-
-        def time_steps(env3, n_envs, n=200):
-            acts = torch.randint(0, 9, (n + 20, n_envs), generator=gen, device=dev, dtype=torch.int32)
-            env3.reset()
-            torch.cuda.synchronize()
-            for t in range(20):
-                env3.step_async(acts[t])
-            env3.join()
+            # (the launch through the C-ABI with its arguments bound once: the Python shim's per-call work -- pointer
+            #  objects, the current-stream lookup -- is ~8 us, more than the kernel)
+            c2_fn = _hip.lib().slhip_advance_board
+            c2_args = (_hip.ptr(c2_boards), _hip.ptr(c2_out), 1024, 25, 25, _hip.ptr(c2_prob), 1, _hip.ptr(c2_rng),
+                       _hip.current_stream_ptr())
+            for _ in range(10):
+                c2_fn(*c2_args)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for t in range(20, 20 + n):
-                env3.step_async(acts[t])
-            env3.join()
+            for _ in range(200):
+                c2_fn(*c2_args)
             e1.record()
             torch.cuda.synchronize()
-            us_streams = e0.elapsed_time(e1) / n * 1e3
-            # the same steps through the library's AQL queues (wall clock around n steps + their fence), where the
-            # timed region ran on them
-            env3.last_queues_us = None
-            if use_queues:
-                try:
-                    env3.queues_open(n_queues, release_free=(res["fences"] == "none"))
+            us = e0.elapsed_time(e1) / 200 * 1e3
+            extra["c2_advance_board_1024x25x25_us_per_launch"] = us
+            extra["c2_advance_board_board_steps_per_s"] = 1024 / (us * 1e-6)
+            # the floor of that figure: the SAME launch (same kernel, grid, arguments, stream, back to back) with zero CA
+            # steps -- rows in, rows out: what one dependent launch of this shape costs on a HIP stream before any rule is
+            # evaluated.  1024 boards are 512 one-wave workgroups on 256 CUs and 2.56 MB: the number is launch latency.
+            c2_floor = c2_args[:6] + (0,) + c2_args[7:]
+            for _ in range(10):
+                c2_fn(*c2_floor)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(200):
+                c2_fn(*c2_floor)
+            e1.record()
+            torch.cuda.synchronize()
+            extra["c2_launch_floor_us_per_launch"] = e0.elapsed_time(e1) / 200 * 1e3
+            extra["c2_launch_floor_note"] = ("slhip_advance_board with n_steps = 0 (load, no step, store), 200 launches back to "
+                                             "back on one stream under HIP events, as the line above")
+            # ... and the reference's own C advance_board (oracle/_ref: its sources compiled by oracle/Makefile) on the
+            # same 1024 boards, one host core, next to it (cpu_baseline kind "reference" for C2)
+            if args.cpu_baseline:
+                import oracle
+                ref = oracle.load_ref()
+                if ref is not None:
+                    host_boards = pal[np.random.default_rng(1234).integers(0, len(pal), (1024, 25, 25))]
+                    c2_bg = np.random.PCG64(1234)          # (kept alive: the module holds a borrowed pointer)
+                    ref.set_bit_generator(c2_bg)
+                    t0 = time.perf_counter()
+                    reps = 0
+                    while time.perf_counter() - t0 < 1.0:
+                        oracle.ref_advance_batch(ref, host_boards, 0.3, 1)
+                        reps += 1
+                    dt = time.perf_counter() - t0
+                    extra["c2_cpu_reference_board_steps_per_s"] = 1024 * reps / dt
+                    extra["c2_cpu_reference_note"] = ("safelife/speedups_src advance_board_nstep compiled with gcc -O3 (oracle/_ref), "
+                                                      "1 core of %s (the reference draws from one process-wide generator), "
+                                                      "called per board from a C loop: no interpreter or wrapper time" % cpu_model())
+
+            # the same step with the training wrappers of env_factory.py:277-283 fused in (float64 shaped reward)
+            envw = SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25), output_channels=TRAIN_CHANNELS,
+                                     auto_reset=True, with_obs=False, slices=args.slices,
+                                     wrappers=dict(movement_bonus=0.1, exit_bonus=0.5, penalty_coef=0.3))
+            us = time_steps(envw, B)
+            extra["training_wrappers_us_per_step"] = us
+            if envw.last_queues_us:
+                extra["training_wrappers_queues_us_per_step"] = envw.last_queues_us
+            del envw
+            # ... with SimpleSideEffectPenalty's "inaction" baseline (env_wrappers.py:179-180): a CA step of every env's
+            # baseline board per step, a third pass of the step kernel's CA loop
+            envi = SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25), output_channels=TRAIN_CHANNELS,
+                                     auto_reset=True, with_obs=False, slices=args.slices,
+                                     wrappers=dict(movement_bonus=0.1, exit_bonus=0.5, penalty_coef=0.3,
+                                                   baseline="inaction", inaction_seed=11))
+            extra["training_wrappers_inaction_baseline_us_per_step"] = time_steps(envi, B)
+            if envi.last_queues_us:
+                extra["training_wrappers_inaction_baseline_queues_us_per_step"] = envi.last_queues_us
+            del envi
+            # per-GPU shares of the sharded configs of BASELINE.json (C4: append-spawn 25x25, C5: navigation 64x64)
+            # (and the shape the reference's own random-level YAMLs use, levels/random/*.yaml: board_shape [26, 26])
+            for tag, pname, n_envs in (("c4_append_spawn_25", "append_spawn_25", 8192), ("c5_navigation_64", "navigation_64", 4096),
+                                       ("append_still_26x26", "append_still_26", 8192)):
+                if not os.path.exists(os.path.join(REPO, "tests", "golden", "pool_%s.npz" % pname)):
+                    continue
+                p2 = load_pool(pname, _device_counts)
+                envc = SafeLifeVectorEnv(p2, n_envs, time_limit=1000, view_shape=(25, 25), slices=args.slices,
+                                         output_channels=TRAIN_CHANNELS, auto_reset=True, with_obs=False)
+                us = time_steps(envc, n_envs)
+                extra[tag + "_us_per_step"] = us
+                extra[tag + "_env_steps_per_s_per_gpu"] = n_envs / (us * 1e-6)
+                if envc.last_queues_us:
+                    extra[tag + "_queues_us_per_step"] = envc.last_queues_us
+                    extra[tag + "_queues_env_steps_per_s_per_gpu"] = n_envs / (envc.last_queues_us * 1e-6)
+                del envc
+                if pname == "navigation_64":
+                    # side_effects.py:109-111 runs life_occupancy(board, n_step=1000) twice at every episode end
+                    from safelife_amd import speedups
+                    nb = 4096
+                    boards = env3_boards = torch.from_numpy(
+                        np.ascontiguousarray(p2.arrays()["pool_board"][np.arange(nb) % len(p2)]).view(np.int16)).to(dev)
+                    probs = torch.full((nb,), 0.3, dtype=torch.float32, device=dev)
+                    rngs = torch.arange(nb * 4, dtype=torch.int64, device=dev).reshape(nb, 4) * 2 + 1
+                    speedups.life_occupancy_batch(boards[:8], probs[:8], rngs[:8].clone(), 10)
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    speedups.life_occupancy_batch(boards, probs, rngs, 1000)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ms = e0.elapsed_time(e1)
+                    extra["life_occupancy_64x64_1000steps_boards_per_s"] = nb / (ms * 1e-3)
+                    extra["life_occupancy_64x64_board_steps_per_s"] = nb * 1000 / (ms * 1e-3)
+                    # C5 as BASELINE.json states it: navigation WITH the side-effect score.  Episode ends are spread
+                    # evenly (every env starts at a different point of its 1000-step episode), the step kernels queue
+                    # the finished episodes, and every `flush_every` steps the episode-end pass of side_effect_score
+                    # (roll-forward by the episode's length + 2 x 1000-step occupancy + distributions) runs on the
+                    # device for whatever the queue holds -- all inside the timed region; the earth-mover distances
+                    # (host, pyemd: parity unpinned) are not.
+                    n_c5, flush_every, n_meas = n_envs, 512, 2048
+                    env5 = SafeLifeVectorEnv(p2, n_c5, time_limit=1000, view_shape=(25, 25), output_channels=TRAIN_CHANNELS,
+                                             auto_reset=True, with_obs=False, slices=args.slices,
+                                             side_effects=dict(capacity=2 * (n_c5 * flush_every // 1000 + 64), num_samples=1000))
+                    env5.reset()
+                    env5.t["scalars"][:, _hip.SCALAR_COLS["num_steps"]] = (
+                        torch.arange(n_c5, device=dev, dtype=torch.int32) * 997) % 1000
+                    acts5 = torch.randint(0, 9, (n_meas + 20, n_c5), generator=gen, device=dev, dtype=torch.int32)
+                    torch.cuda.synchronize()
                     for t in range(20):
-                        env3.step_queues(acts[t])
-                    env3.queues_sync()
+                        env5.step_async(acts5[t])
+                    env5.side_effects_flush()
                     torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    for t in range(20, 20 + n):
-                        env3.step_queues(acts[t])
-                    env3.queues_sync()
-                    env3.last_queues_us = (time.perf_counter() - t0) / n * 1e6
-                    env3.queues_close()
-                except _hip.SafeLifeHipError:
-                    pass
-            return us_streams
-
-        # level-pool refresh while stepping (levels.LevelPool(refreshable=True), pool_stage / pool_commit): C3's batch through
-        # the queues in calls of `chunk` steps, with a sixth of the pool's levels replaced every call (staged one call
-        # ahead, committed between two calls) against the same calls without any refresh
-        if use_queues and args.pool == "prune_still_25":
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    batches = []
+                    e0.record()
+                    for t in range(20, 20 + n_meas):
+                        env5.step_async(acts5[t])
+                        if (t - 19) % flush_every == 0:
+                            # (round 5) the pass runs on a stream of its own UNDER the steps that follow; the last one of the
+                            # region has nothing to hide under and is waited for in full
+                            batches.append(env5.side_effects_flush(overlap=True))
+                    env5.join()
+                    env5.side_effects_join()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ms = e0.elapsed_time(e1)
+                    n_eps = sum(len(b) for b in batches)
+                    extra["c5_with_side_effects_us_per_step"] = ms * 1e3 / n_meas
+                    extra["c5_with_side_effects_env_steps_per_s_per_gpu"] = n_c5 * n_meas / (ms * 1e-3)
+                    extra["c5_with_side_effects_episodes_scored"] = n_eps
+                    extra["c5_with_side_effects_note"] = ("%d envs x 64x64 navigation, %d steps, episode-end pass every %d steps "
+                                                          "on the device, on a side stream under the following steps, the "
+                                                          "region's last pass waited for in full (%d episodes: roll-forward + "
+                                                          "2 x 1000-step life_occupancy + distributions); EMD on the host not "
+                                                          "included" % (n_c5, n_meas, flush_every, n_eps))
+                    # the same through the library's queues (the launcher of the headline line; wall clock: HIP events do
+                    # not see the queues), whole windows of flush_every steps per call
+                    if use_queues:
+                        try:
+                            env5.queues_open(4, release_free=(res["fences"] == "none"), recover=False)
+                            env5.side_effects_flush()
+                            torch.cuda.synchronize()
+                            batches = []
+                            t0 = time.perf_counter()
+                            for w0 in range(0, n_meas, flush_every):
+                                # (the fresh queue's buffers were zeroed on this stream: wait for THAT, not for the device --
+                                #  the pass of the window before is still running on its side stream, and may)
+                                torch.cuda.current_stream().synchronize()
+                                env5.step_queues_many(acts5[20 + w0:20 + w0 + flush_every], assume_ordered=True)
+                                batches.append(env5.side_effects_flush(overlap=True))      # (waits for the queues' fence first)
+                            env5.queues_sync()
+                            env5.side_effects_join()
+                            torch.cuda.synchronize()
+                            us = (time.perf_counter() - t0) / n_meas * 1e6
+                            extra["c5_with_side_effects_queues_us_per_step"] = us
+                            extra["c5_with_side_effects_queues_env_steps_per_s_per_gpu"] = n_c5 / (us * 1e-6)
+                            extra["c5_with_side_effects_queues_episodes_scored"] = sum(len(b) for b in batches)
+                            env5.queues_close()
+                        except _hip.SafeLifeHipError as e:
+                            extra["c5_with_side_effects_queues_error"] = str(e)
+                    del env5, batches
+        except Exception as e:          # noqa: BLE001
+            import traceback
+            extra["extras_error"] = "%s: %s" % (type(e).__name__, e)
+            print("bench: an extra failed:\n" + traceback.format_exc(), file=sys.stderr)
             try:
-                from safelife_amd.levels import LevelPool
-                lv_all = list(pool.levels)
-                n_half = len(lv_all) // 2
-                pool_r = LevelPool(lv_all[:n_half], counts_fn=_device_counts, refreshable=True)
-                env_r = SafeLifeVectorEnv(pool_r, B, time_limit=1000, view_shape=(25, 25), output_channels=TRAIN_CHANNELS,
-                                          auto_reset=True, with_obs=False, slices=args.slices)
-                env_r.reset()
-                chunk, n_calls = 100, 8
-                acts_r = torch.randint(0, 9, (chunk * (n_calls + 1), B), generator=gen, device=dev, dtype=torch.int32)
-                env_r.queues_open(n_queues, release_free=(res["fences"] == "none"), recover=False)
-                rr = np.random.default_rng(5)
-                env_r.pool_stage([0], [lv_all[n_half]])        # (untimed: the first staging pins its host buffers)
-                # new levels come prepared (LevelPool.prepare: checks, cell counts, points, RNG words) -- part of making
-                # a level, which the reference does away from the stepping thread too (level_iterator.py:200-223)
-                ready = pool_r.prepare(lv_all)
-                env_r.pool_commit()
-                for refresh in (False, True):
-                    env_r.step_queues_many(acts_r[:chunk])
-                    env_r.queues_sync()
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    n_committed = 0
-                    for c in range(n_calls):
-                        free = refresh and env_r.pool_commit(wait=False)    # (not yet there: next call)
-                        n_committed += int(free)
-                        env_r.step_queues_many(acts_r[chunk * (c + 1):chunk * (c + 2)], assume_ordered=True)
-                        if free:            # (behind the call: what staging waits for -- the steps enqueued before the
-                            #                  last commit -- completes while the device works through this call)
-                            slots = rr.choice(n_half, n_half // 6, replace=False)
-                            env_r.pool_stage(slots, ready.take(rr.integers(0, len(ready), len(slots))), background=True)
-                    env_r.queues_sync()
-                    us = (time.perf_counter() - t0) / (chunk * n_calls) * 1e6
-                    extra["pool_refresh_us_per_step" if refresh else "pool_static_us_per_step"] = us
-                    if refresh:
-                        extra["pool_refresh_commits"] = "%d of %d calls" % (n_committed, n_calls)
-                    env_r.pool_commit()
-                extra["pool_refresh_note"] = ("8192 envs, %d-level refreshable pool, %d steps per queue call, %d levels "
-                                              "replaced per call (prepared levels, staged a call ahead by the env's helper thread, committed "
-                                              "between calls; no queue drain for the refresh)" % (n_half, chunk, n_half // 6))
-                env_r.queues_close()
-                del env_r
-            except _hip.SafeLifeHipError as e:
-                extra["pool_refresh_error"] = str(e)
-
-        # C2 (BASELINE configs[1]): advance_board alone on 1024 random 25x25 boards (SURVEY 8d palette-like)
-        from safelife_amd import speedups
-        c2 = np.random.default_rng(1234)
-        pal = np.array([0] * 10 + [9] * 4 + [1, 16, 17, 32788, 152, 152 | 0x200, 144, 48, 53, 85, 32884, 272, 9 | 0x200,
-                                      9 | 0x400, 9 | 0x800, 122], np.uint16)
-        c2_boards = torch.from_numpy(pal[c2.integers(0, len(pal), (1024, 25, 25))].view(np.int16)).to(dev)
-        c2_prob = torch.full((1024,), 0.3, dtype=torch.float32, device=dev)
-        c2_rng = torch.arange(4096, dtype=torch.int64, device=dev).reshape(1024, 4) * 2 + 1
-        c2_out = torch.empty_like(c2_boards)
-        for _ in range(10):
-            speedups.advance_board_batch(c2_boards, c2_prob, c2_rng, 1, out=c2_out)
-        torch.cuda.synchronize()
-        # (the launch through the C-ABI with its arguments bound once: the Python shim's per-call work -- pointer
-        #  objects, the current-stream lookup -- is ~8 us, more than the kernel)
-        c2_fn = _hip.lib().slhip_advance_board
-        c2_args = (_hip.ptr(c2_boards), _hip.ptr(c2_out), 1024, 25, 25, _hip.ptr(c2_prob), 1, _hip.ptr(c2_rng),
-                   _hip.current_stream_ptr())
-        for _ in range(10):
-            c2_fn(*c2_args)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(200):
-            c2_fn(*c2_args)
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) / 200 * 1e3
-        extra["c2_advance_board_1024x25x25_us_per_launch"] = us
-        extra["c2_advance_board_board_steps_per_s"] = 1024 / (us * 1e-6)
-        # the floor of that figure: the SAME launch (same kernel, grid, arguments, stream, back to back) with zero CA
-        # steps -- rows in, rows out: what one dependent launch of this shape costs on a HIP stream before any rule is
-        # evaluated.  1024 boards are 512 one-wave workgroups on 256 CUs and 2.56 MB: the number is launch latency.
-        c2_floor = c2_args[:6] + (0,) + c2_args[7:]
-        for _ in range(10):
-            c2_fn(*c2_floor)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(200):
-            c2_fn(*c2_floor)
-        e1.record()
-        torch.cuda.synchronize()
-        extra["c2_launch_floor_us_per_launch"] = e0.elapsed_time(e1) / 200 * 1e3
-        extra["c2_launch_floor_note"] = ("slhip_advance_board with n_steps = 0 (load, no step, store), 200 launches back to "
-                                         "back on one stream under HIP events, as the line above")
-        # ... and the reference's own C advance_board (oracle/_ref: its sources compiled by oracle/Makefile) on the
-        # same 1024 boards, one host core, next to it (cpu_baseline kind "reference" for C2)
-        if args.cpu_baseline:
-            import oracle
-            ref = oracle.load_ref()
-            if ref is not None:
-                host_boards = pal[np.random.default_rng(1234).integers(0, len(pal), (1024, 25, 25))]
-                c2_bg = np.random.PCG64(1234)          # (kept alive: the module holds a borrowed pointer)
-                ref.set_bit_generator(c2_bg)
-                t0 = time.perf_counter()
-                reps = 0
-                while time.perf_counter() - t0 < 1.0:
-                    oracle.ref_advance_batch(ref, host_boards, 0.3, 1)
-                    reps += 1
-                dt = time.perf_counter() - t0
-                extra["c2_cpu_reference_board_steps_per_s"] = 1024 * reps / dt
-                extra["c2_cpu_reference_note"] = ("safelife/speedups_src advance_board_nstep compiled with gcc -O3 (oracle/_ref), "
-                                                  "1 core of %s (the reference draws from one process-wide generator), "
-                                                  "called per board from a C loop: no interpreter or wrapper time" % cpu_model())
-
-        # the same step with the training wrappers of env_factory.py:277-283 fused in (float64 shaped reward)
-        envw = SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25), output_channels=TRAIN_CHANNELS,
-                                 auto_reset=True, with_obs=False, slices=args.slices,
-                                 wrappers=dict(movement_bonus=0.1, exit_bonus=0.5, penalty_coef=0.3))
-        us = time_steps(envw, B)
-        extra["training_wrappers_us_per_step"] = us
-        if envw.last_queues_us:
-            extra["training_wrappers_queues_us_per_step"] = envw.last_queues_us
-        del envw
-        # ... with SimpleSideEffectPenalty's "inaction" baseline (env_wrappers.py:179-180): a CA step of every env's
-        # baseline board per step, a third pass of the step kernel's CA loop
-        envi = SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25), output_channels=TRAIN_CHANNELS,
-                                 auto_reset=True, with_obs=False, slices=args.slices,
-                                 wrappers=dict(movement_bonus=0.1, exit_bonus=0.5, penalty_coef=0.3,
-                                               baseline="inaction", inaction_seed=11))
-        extra["training_wrappers_inaction_baseline_us_per_step"] = time_steps(envi, B)
-        if envi.last_queues_us:
-            extra["training_wrappers_inaction_baseline_queues_us_per_step"] = envi.last_queues_us
-        del envi
-        # per-GPU shares of the sharded configs of BASELINE.json (C4: append-spawn 25x25, C5: navigation 64x64)
-        # (and the shape the reference's own random-level YAMLs use, levels/random/*.yaml: board_shape [26, 26])
-        for tag, pname, n_envs in (("c4_append_spawn_25", "append_spawn_25", 8192), ("c5_navigation_64", "navigation_64", 4096),
-                                   ("append_still_26x26", "append_still_26", 8192)):
-            if not os.path.exists(os.path.join(REPO, "tests", "golden", "pool_%s.npz" % pname)):
-                continue
-            p2 = load_pool(pname, _device_counts)
-            envc = SafeLifeVectorEnv(p2, n_envs, time_limit=1000, view_shape=(25, 25), slices=args.slices,
-                                     output_channels=TRAIN_CHANNELS, auto_reset=True, with_obs=False)
-            us = time_steps(envc, n_envs)
-            extra[tag + "_us_per_step"] = us
-            extra[tag + "_env_steps_per_s_per_gpu"] = n_envs / (us * 1e-6)
-            if envc.last_queues_us:
-                extra[tag + "_queues_us_per_step"] = envc.last_queues_us
-                extra[tag + "_queues_env_steps_per_s_per_gpu"] = n_envs / (envc.last_queues_us * 1e-6)
-            del envc
-            if pname == "navigation_64":
-                # side_effects.py:109-111 runs life_occupancy(board, n_step=1000) twice at every episode end
-                from safelife_amd import speedups
-                nb = 4096
-                boards = env3_boards = torch.from_numpy(
-                    np.ascontiguousarray(p2.arrays()["pool_board"][np.arange(nb) % len(p2)]).view(np.int16)).to(dev)
-                probs = torch.full((nb,), 0.3, dtype=torch.float32, device=dev)
-                rngs = torch.arange(nb * 4, dtype=torch.int64, device=dev).reshape(nb, 4) * 2 + 1
-                speedups.life_occupancy_batch(boards[:8], probs[:8], rngs[:8].clone(), 10)
                 torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                speedups.life_occupancy_batch(boards, probs, rngs, 1000)
-                e1.record()
-                torch.cuda.synchronize()
-                ms = e0.elapsed_time(e1)
-                extra["life_occupancy_64x64_1000steps_boards_per_s"] = nb / (ms * 1e-3)
-                extra["life_occupancy_64x64_board_steps_per_s"] = nb * 1000 / (ms * 1e-3)
-                # C5 as BASELINE.json states it: navigation WITH the side-effect score.  Episode ends are spread
-                # evenly (every env starts at a different point of its 1000-step episode), the step kernels queue
-                # the finished episodes, and every `flush_every` steps the episode-end pass of side_effect_score
-                # (roll-forward by the episode's length + 2 x 1000-step occupancy + distributions) runs on the
-                # device for whatever the queue holds -- all inside the timed region; the earth-mover distances
-                # (host, pyemd: parity unpinned) are not.
-                n_c5, flush_every, n_meas = n_envs, 512, 2048
-                env5 = SafeLifeVectorEnv(p2, n_c5, time_limit=1000, view_shape=(25, 25), output_channels=TRAIN_CHANNELS,
-                                         auto_reset=True, with_obs=False, slices=args.slices,
-                                         side_effects=dict(capacity=2 * (n_c5 * flush_every // 1000 + 64), num_samples=1000))
-                env5.reset()
-                env5.t["scalars"][:, _hip.SCALAR_COLS["num_steps"]] = (
-                    torch.arange(n_c5, device=dev, dtype=torch.int32) * 997) % 1000
-                acts5 = torch.randint(0, 9, (n_meas + 20, n_c5), generator=gen, device=dev, dtype=torch.int32)
-                torch.cuda.synchronize()
-                for t in range(20):
-                    env5.step_async(acts5[t])
-                env5.side_effects_flush()
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                batches = []
-                e0.record()
-                for t in range(20, 20 + n_meas):
-                    env5.step_async(acts5[t])
-                    if (t - 19) % flush_every == 0:
-                        # (round 5) the pass runs on a stream of its own UNDER the steps that follow; the last one of the
-                        # region has nothing to hide under and is waited for in full
-                        batches.append(env5.side_effects_flush(overlap=True))
-                env5.join()
-                env5.side_effects_join()
-                e1.record()
-                torch.cuda.synchronize()
-                ms = e0.elapsed_time(e1)
-                n_eps = sum(len(b) for b in batches)
-                extra["c5_with_side_effects_us_per_step"] = ms * 1e3 / n_meas
-                extra["c5_with_side_effects_env_steps_per_s_per_gpu"] = n_c5 * n_meas / (ms * 1e-3)
-                extra["c5_with_side_effects_episodes_scored"] = n_eps
-                extra["c5_with_side_effects_note"] = ("%d envs x 64x64 navigation, %d steps, episode-end pass every %d steps "
-                                                      "on the device, on a side stream under the following steps, the "
-                                                      "region's last pass waited for in full (%d episodes: roll-forward + "
-                                                      "2 x 1000-step life_occupancy + distributions); EMD on the host not "
-                                                      "included" % (n_c5, n_meas, flush_every, n_eps))
-                # the same through the library's queues (the launcher of the headline line; wall clock: HIP events do
-                # not see the queues), whole windows of flush_every steps per call
-                if use_queues:
-                    try:
-                        env5.queues_open(4, release_free=(res["fences"] == "none"), recover=False)
-                        env5.side_effects_flush()
-                        torch.cuda.synchronize()
-                        batches = []
-                        t0 = time.perf_counter()
-                        for w0 in range(0, n_meas, flush_every):
-                            # (the fresh queue's buffers were zeroed on this stream: wait for THAT, not for the device --
-                            #  the pass of the window before is still running on its side stream, and may)
-                            torch.cuda.current_stream().synchronize()
-                            env5.step_queues_many(acts5[20 + w0:20 + w0 + flush_every], assume_ordered=True)
-                            batches.append(env5.side_effects_flush(overlap=True))      # (waits for the queues' fence first)
-                        env5.queues_sync()
-                        env5.side_effects_join()
-                        torch.cuda.synchronize()
-                        us = (time.perf_counter() - t0) / n_meas * 1e6
-                        extra["c5_with_side_effects_queues_us_per_step"] = us
-                        extra["c5_with_side_effects_queues_env_steps_per_s_per_gpu"] = n_c5 / (us * 1e-6)
-                        extra["c5_with_side_effects_queues_episodes_scored"] = sum(len(b) for b in batches)
-                        env5.queues_close()
-                    except _hip.SafeLifeHipError as e:
-                        extra["c5_with_side_effects_queues_error"] = str(e)
-                del env5, batches
+            except Exception:           # noqa: BLE001
+                pass
 
     if rank == 0:
         obs_bytes = {0: 0, 1: H * Wd * len(TRAIN_CHANNELS), 2: H * Wd * 4}[args.obs]
