@@ -15,7 +15,8 @@ env = SafeLifeVectorEnv(p2, n, time_limit=1000, view_shape=(25, 25), output_chan
                         with_obs=False, slices=nsl)
 env.reset()
 dev = env.device
-env.t["scalars"][:, _hip.SCALAR_COLS["num_steps"]] = (torch.arange(n, device=dev, dtype=torch.int32) * 997) % 1000
+if os.environ.get("NO_SPREAD") != "1":        # episode ends spread evenly over the envs (else: none within the run)
+    env.t["scalars"][:, _hip.SCALAR_COLS["num_steps"]] = (torch.arange(n, device=dev, dtype=torch.int32) * 997) % 1000
 acts = torch.randint(0, 9, (440, n), device=dev, dtype=torch.int32)
 env.queues_open(min(nsl, 4), release_free=True, recover=False)
 env.step_queues_many(acts[:40]); env.queues_sync(); torch.cuda.synchronize()
