@@ -2917,6 +2917,15 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
         }
         if (!(any & 1)) return;
         // on-device auto-reset (training/base_algo.py:231-236 calls env.reset() after a done step)
+        // (the leaders' own fetches -- the level's constants and its first exit -- go out FIRST, beside the rows' below,
+        //  not behind them: one memory round trip less on the chain a reloading workgroup holds its launch up with)
+        const bool l_reset = lead && box[lq].reset_level >= 0;
+        sl_level_scalars lv_pre = {};
+        int exit0_pre = -1;
+        if (l_reset) {
+            lv_pre = env.pool_scalars[box[lq].reset_level];
+            exit0_pre = env.pool_exit_locs[(size_t)box[lq].reset_level * E];
+        }
         const int new_level = rowl ? box[gb].reset_level : -1;
         const bool mine = live && new_level >= 0;
         if (rowl && new_level >= 0) gstatic = 0;
@@ -2994,8 +3003,8 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
             }
             pool_exits = true;                                  // (the pool's table: never written by this launch)
             const int32_t *exits = env.pool_exit_locs + (size_t)l_level * E;
-            exit0 = exits[0];
-            const sl_level_scalars lv = env.pool_scalars[l_level];
+            exit0 = exit0_pre;
+            const sl_level_scalars lv = lv_pre;
             ly = lv.agent_row;
             lx = lv.agent_col;
             const int fresh = box[lq].score0;
