@@ -885,6 +885,31 @@ def main():
             if envi.last_queues_us:
                 extra["training_wrappers_inaction_baseline_queues_us_per_step"] = envi.last_queues_us
             del envi
+            # C3 in a training run's steady state: the timed region starts behind a reset of ALL envs and sees no episode
+            # end; here the envs are spread evenly over their 1000-step episodes (~B / 1000 in-kernel resets per step),
+            # 400 steps through the same queues, one call
+            if use_queues:
+                try:
+                    envs_ss = SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25), slices=args.slices,
+                                                output_channels=TRAIN_CHANNELS, auto_reset=True, with_obs=False)
+                    envs_ss.reset()
+                    envs_ss.t["scalars"][:, _hip.SCALAR_COLS["num_steps"]] = (
+                        torch.arange(B, device=dev, dtype=torch.int32) * 997) % 1000
+                    acts_ss = torch.randint(0, 9, (440, B), generator=gen, device=dev, dtype=torch.int32)
+                    envs_ss.queues_open(n_queues, release_free=(res["fences"] == "none"), recover=False)
+                    envs_ss.step_queues_many(acts_ss[:40])
+                    envs_ss.queues_sync()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    envs_ss.step_queues_many(acts_ss[40:], assume_ordered=True)
+                    envs_ss.queues_sync()
+                    extra["c3_steady_state_us_per_step"] = (time.perf_counter() - t0) / 400 * 1e6
+                    extra["c3_steady_state_note"] = ("%d envs spread evenly over their 1000-step episodes (about %d in-kernel "
+                                                     "resets per step), 400 steps in one queue call" % (B, B // 1000))
+                    envs_ss.queues_close()
+                    del envs_ss, acts_ss
+                except _hip.SafeLifeHipError as e:
+                    extra["c3_steady_state_error"] = str(e)
             # per-GPU shares of the sharded configs of BASELINE.json (C4: append-spawn 25x25, C5: navigation 64x64)
             # (and the shape the reference's own random-level YAMLs use, levels/random/*.yaml: board_shape [26, 26])
             for tag, pname, n_envs in (("c4_append_spawn_25", "append_spawn_25", 8192), ("c5_navigation_64", "navigation_64", 4096),
