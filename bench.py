@@ -60,7 +60,15 @@ def cpu_model():
     return "unknown CPU"
 
 
-def parity_replay(pool, actions, n_envs, device_env, checkpoints, threads):
+def spread_num_steps(n_envs, first=0, time_limit=1000):
+    """The episode phase every env of the timed run starts in (C3 is defined with episode ends and resets
+    inside the run): env e has played (e * 997) mod time_limit steps of its first episode, so ~n_envs / time_limit
+    envs reach their time limit -- and load their next level inside the step kernel -- at EVERY step, as in a training
+    run's steady state, instead of none for the first 1000 steps."""
+    return ((np.arange(first, first + n_envs, dtype=np.int64) * 997) % time_limit).astype(np.int32)
+
+
+def parity_replay(pool, actions, n_envs, device_env, checkpoints, threads, spread=True):
     """Checker use of the oracle inside the cpu_baseline leg ('all boards for B <= 8192, every step
     for the first K steps and at the end'): replay ALL envs of the measured run on the CPU -- same levels, same
     action stream, every step since the reset.  `checkpoints`: {step count: device state snapshot taken after
@@ -72,6 +80,8 @@ def parity_replay(pool, actions, n_envs, device_env, checkpoints, threads):
     env = oracle.OracleEnv(arrays, time_limit=1000, auto_reset=True, level_stride=1, view_shape=(25, 25),
                            output_channels=TRAIN_CHANNELS, with_obs=False, stream_salt=1)
     env.reset()
+    if spread:
+        arrays["num_steps"][:] = spread_num_steps(n_envs)
     names = ("board", "goals", "agent_loc", "rng", "num_steps", "episode_idx", "episode_length", "level_idx")
     ok, checked = True, []
     for t, a in enumerate(actions):
@@ -84,7 +94,8 @@ def parity_replay(pool, actions, n_envs, device_env, checkpoints, threads):
     for name in names:
         ok = ok and bool(np.array_equal(device_env.numpy(name)[:n_envs], arrays[name]))
     return {"envs": n_envs, "steps": len(actions), "every_step_until": max(checked) if checked else 0,
-            "and_at_the_end": True, "bit_exact": ok}
+            "and_at_the_end": True, "bit_exact": ok,
+            "episodes_ended_in_the_run": int((arrays["episode_idx"] > 0).sum()) if "episode_idx" in arrays else None}
 
 
 def cpu_baseline(pool, envs, steps, seed):
@@ -107,6 +118,7 @@ def cpu_baseline(pool, envs, steps, seed):
     env = oracle.OracleEnv(arrays, time_limit=1000, auto_reset=True, level_stride=1,
                            view_shape=(25, 25), output_channels=TRAIN_CHANNELS, with_obs=False, stream_salt=1)
     env.reset()
+    arrays["num_steps"][:] = spread_num_steps(envs)
     rng = np.random.default_rng(seed)
     acts = rng.integers(0, 9, (steps, envs)).astype(np.int32)
     env.step(acts[0], n_threads=threads)            # warm
@@ -266,6 +278,14 @@ def main():
                          "(SL_QUEUES_RELEASE_FREE: ~0.9 us per step faster; valid only while a workgroup index keeps its "
                          "XCD, which the library probes at open and every step verifies -- on a violation the run is "
                          "repeated with 'agent', on every rank).  config.queue_fences says which mode produced the line")
+    ap.add_argument("--queue-chained", type=int, default=int(os.environ.get("SAFELIFE_BENCH_CHAINED", "1")),
+                    help="release-free queue stepping only: 1 = also OPT IN to chained stepping (SL_QUEUES_CHAINED: no barrier "
+                         "bit between the steps of a queue, every workgroup waits for its own predecessor); 0 = barrier bit on "
+                         "every step.  config.queue_chained says what the line ran with")
+    ap.add_argument("--spread", type=int, default=1,
+                    help="1 (default): the timed region starts with the envs spread evenly over their 1000-step episodes, so "
+                         "that ~envs/1000 episodes end -- and reset inside the kernel -- at every step (SURVEY 8d); 0: straight "
+                         "behind a reset of all envs (no episode end within the first 1000 steps: rounds 1-5's region)")
     ap.add_argument("--stream-leg", type=int, default=1,
                     help="queue stepping only: 1 = also run K steps of the same kernel through the stream slices under HIP "
                          "events (roofline.stream_leg_*); 0 = leave it out (profiling runs: only the queues' launches in the trace)")
@@ -312,8 +332,10 @@ def main():
     gen.manual_seed(7 + rank)
     # P checkpointed steps for the parity replay, then W warm-up steps, then the K timed ones
     P = 8 if (args.cpu_baseline and world == 1) else 0
-    actions = torch.randint(0, 9, (P + W + K, B), generator=gen, device=dev, dtype=torch.int32)
-    act_ptr = [actions[t].data_ptr() for t in range(P + W + K)]
+    # (rows beyond P + W + K: the K = 400 repetition of the region reported as roofline.k400_us)
+    n_rows = max(P + W + K, 440 if (args.extras and world == 1) else 0)
+    actions = torch.randint(0, 9, (n_rows, B), generator=gen, device=dev, dtype=torch.int32)
+    act_ptr = [actions[t].data_ptr() for t in range(n_rows)]
     # N > 1: the window is cut so that at least one closes -- one RCCL exchange is issued -- inside the timed steps
     forced = os.environ.get("SAFELIFE_FORCE_GATHER", "0") == "1"         # one rank, exchange on (RCCL to itself)
     every_used = gather_window(args.gather_every, K) if (world > 1 or forced) else args.gather_every
@@ -339,14 +361,19 @@ def main():
 
     queue_ids = [None]
 
-    def attempt(fences, gather=gather, P=P, shift=shift):
+    def attempt(fences, gather=gather, P=P, shift=shift, spread=bool(args.spread), chained=bool(args.queue_chained), K=K, W=W):
         """Reset, P checkpointed steps, W warm-up steps, the K timed steps.  Returns the measurements, or None when
         release-free queue stepping was refused by its placement check on ANY rank (the caller repeats with 'agent').
-        (`gather`, `P`, `shift`: the extras below repeat the region with another exchange and without checkpoints.)"""
+        (`gather`, `P`, `shift`, `spread`, `chained`, `K`, `W`: the variants reported in `roofline` repeat the region
+        with another exchange, regime or length, without checkpoints.)"""
         every = gather.every
-        res = {"use_queues": False, "queues_why": "switched off", "fences": None}
+        res = {"use_queues": False, "queues_why": "switched off", "fences": None, "chained": False, "queue_slices": None,
+               "queue_ids": None, "spread": spread, "K": K, "W": W}
         env.queues_close()
         env.reset()
+        if spread:
+            env.t["scalars"][:, _hip.SCALAR_COLS["num_steps"]] = torch.from_numpy(spread_num_steps(B, first=rank * B)).to(dev)
+            torch.cuda.synchronize()
         if n_queues > 0:
             try:
                 # N > 1 (or the forced one-rank exchange): the step queue that RCCL's kernel would hold up is left
@@ -363,9 +390,14 @@ def main():
                 ids = queue_ids[0] if ((gather.collective and n_queues == 4) or os.environ.get("SAFELIFE_BENCH_QUEUE_IDS")) else None
                 # (recover=False: this bench has its own answer to a refused placement -- the whole run again with a
                 #  stream's fences -- and keeps the env's per-sync state copy out of the timed region)
-                env.queues_open(len(ids) if ids else n_queues, release_free=(fences == "none"), queue_ids=ids, recover=False)
+                env.queues_open(len(ids) if ids else n_queues, release_free=(fences == "none"), queue_ids=ids, recover=False,
+                                chained=(chained and fences == "none"))
                 res["use_queues"], res["queues_why"] = True, None
                 res["fences"] = "none" if env.queue_release_free else "agent"
+                # what THIS attempt steps with (the JSON line is built from these, not from whatever a later attempt
+                # leaves in `env`)
+                res["chained"] = bool(getattr(env, "queue_chained", False))
+                res["queue_slices"], res["queue_ids"] = int(env.queue_slices), list(env.queue_ids)
                 if fences == "none" and not env.queue_release_free:
                     print("bench: release-free queue stepping not granted (%s): agent-scope fences" % env.queue_mode_note,
                           file=sys.stderr)
@@ -382,7 +414,7 @@ def main():
             try:
                 env.queues_sync()
             except _hip.SafeLifeHipError as e:
-                if "another XCD" not in str(e):
+                if "another XCD" not in str(e) and "in vain" not in str(e):
                     raise
                 print("bench: %s" % e, file=sys.stderr)
                 refused[0] = True
@@ -481,11 +513,16 @@ def main():
         return res
 
     res = attempt(args.queue_fences)
+    if res is None and args.queue_fences == "none" and args.queue_chained:
+        print("bench: repeating the run without chained stepping", file=sys.stderr)
+        res = attempt("none", chained=False)
     if res is None:
         print("bench: repeating the run with agent-scope fences", file=sys.stderr)
         res = attempt("agent")
         if res is None:
             raise SystemExit("bench: placement check failed with agent-scope fences -- cannot happen")
+    if res["use_queues"]:
+        assert res["queue_slices"] == len(res["queue_ids"]), (res["queue_slices"], res["queue_ids"])
     use_queues, queues_why = res["use_queues"], res["queues_why"]
     elapsed, t_start, t_enqueued = res["elapsed"], res["t_start"], res["t_enqueued"]
     checkpoints, evs, streams = res["checkpoints"], res["evs"], res["streams"]
@@ -513,7 +550,7 @@ def main():
     if args.cpu_baseline and world == 1:
         # the state the timed launches left behind against a CPU replay of the same envs and actions
         threads = max(1, min(16, len(os.sched_getaffinity(0))))
-        parity = parity_replay(pool, actions[:P + W + K].cpu().numpy(), B, env, checkpoints, threads)
+        parity = parity_replay(pool, actions[:P + W + K].cpu().numpy(), B, env, checkpoints, threads, spread=res["spread"])
     stream_wall_ms = None
     if use_queues and args.stream_leg:
         # the timed steps ran on the library's queues, not on a HIP stream.  The same kernel through the stream
@@ -535,18 +572,36 @@ def main():
         kernel_ms = evs[0][0].elapsed_time(evs[0][1]) / K
 
     extra = {}
+    variants = {}       # short numeric fields of `roofline` (the driver keeps `roofline` and drops `extra`)
     if use_queues and args.extras and world == 1 and not gather.collective:
-        # What the driver's one-GPU line does not show (outside the timed region; same K, same warm-up, no checkpoints):
+        # What the driver's one-GPU line does not show (outside the timed region; same warm-up, no checkpoints; every
+        # variant the median of three repetitions of the whole region):
         # (a) the library's DEFAULT fences -- what SafeLifeVectorEnv.queues_open() gives a user;
-        # (b) the step as every N > 1 run takes it: the RCCL exchange on (one rank, to itself), three slices on the three
+        # (b) release-free stepping with the barrier bit on every step (rounds 4-5's launcher), where the line is chained;
+        # (c) the region straight behind a reset of all envs -- no episode end inside it (rounds 1-5's region);
+        # (d) the same region 400 steps long: what the fixed cost of a 20-step region (first doorbell, the queues'
+        #     staggered pick-up, the closing fence) hides;
+        # (e) the step as every N > 1 run takes it: the RCCL exchange on (one rank, to itself), three slices on the three
         #     queues the exchange does not hold up, one window closing inside the region.
+        def median_us(n=3, **kw):
+            fences = kw.pop("fences", res["fences"])
+            kw.setdefault("chained", res["chained"])
+            kw.setdefault("spread", res["spread"])
+            vals = []
+            for _ in range(n):
+                r = attempt(fences, P=0, **kw)
+                if r is None or r["fences"] != fences or r["chained"] != kw["chained"]:
+                    return None
+                vals.append(r["elapsed"] / r["K"] * 1e6)
+            return sorted(vals)[len(vals) // 2]
         try:
-            if res["fences"] != "agent":
-                r2 = attempt("agent", P=0)
-                if r2 is not None:
-                    extra["queue_fences_agent_us_per_step"] = r2["elapsed"] / K * 1e6
-            else:
-                extra["queue_fences_agent_us_per_step"] = elapsed / K * 1e6
+            variants["agent_fences_us"] = median_us(fences="agent", chained=False) if res["fences"] != "agent" else elapsed / K * 1e6
+            extra["queue_fences_agent_us_per_step"] = variants["agent_fences_us"]
+            if res["chained"]:
+                variants["unchained_us"] = median_us(chained=False)
+            variants["no_reset_us" if res["spread"] else "steady_state_us"] = median_us(spread=not res["spread"])
+            variants["k400_us"] = median_us(K=400, W=40)
+            variants["k20_median_us"] = median_us(n=5)
             env.queues_close()
             g2 = RewardGather(env, every=gather_window(args.gather_every, K), world=1, rank=0, force=True)
             g2.prime()
@@ -558,8 +613,8 @@ def main():
             if r3 is None:
                 r3 = attempt("agent", gather=g2, P=0, shift=shift2)
             if r3 is not None:
-                extra["forced_gather_us_per_step"] = r3["elapsed"] / K * 1e6
-                extra["forced_gather_queue_ids"] = list(getattr(env, "queue_ids", []))
+                extra["forced_gather_us_per_step"] = variants["forced_gather_us"] = r3["elapsed"] / K * 1e6
+                extra["forced_gather_queue_ids"] = r3["queue_ids"]
                 extra["forced_gather_windows_in_region"] = r3["gather_windows"]
                 extra["forced_gather_fences"] = r3["fences"]
                 extra["forced_gather_note"] = ("the same %d-step region with the RCCL exchange forced on for one rank "
@@ -720,6 +775,8 @@ def main():
             def time_steps(env3, n_envs, n=200):
                 acts = torch.randint(0, 9, (n + 20, n_envs), generator=gen, device=dev, dtype=torch.int32)
                 env3.reset()
+                if res["spread"]:       # (the headline's regime: episode ends at every step)
+                    env3.t["scalars"][:, _hip.SCALAR_COLS["num_steps"]] = torch.from_numpy(spread_num_steps(n_envs)).to(dev)
                 torch.cuda.synchronize()
                 for t in range(20):
                     env3.step_async(acts[t])
@@ -738,7 +795,7 @@ def main():
                 env3.last_queues_us = None
                 if use_queues:
                     try:
-                        env3.queues_open(n_queues, release_free=(res["fences"] == "none"))
+                        env3.queues_open(n_queues, release_free=(res["fences"] == "none"), chained=res["chained"])
                         for t in range(20):
                             env3.step_queues(acts[t])
                         env3.queues_sync()
@@ -767,7 +824,7 @@ def main():
                     env_r.reset()
                     chunk, n_calls = 100, 8
                     acts_r = torch.randint(0, 9, (chunk * (n_calls + 1), B), generator=gen, device=dev, dtype=torch.int32)
-                    env_r.queues_open(n_queues, release_free=(res["fences"] == "none"), recover=False)
+                    env_r.queues_open(n_queues, release_free=(res["fences"] == "none"), recover=False, chained=res["chained"])
                     rr = np.random.default_rng(5)
                     env_r.pool_stage([0], [lv_all[n_half]])        # (untimed: the first staging pins its host buffers)
                     # new levels come prepared (LevelPool.prepare: checks, cell counts, points, RNG words) -- part of making
@@ -885,31 +942,6 @@ def main():
             if envi.last_queues_us:
                 extra["training_wrappers_inaction_baseline_queues_us_per_step"] = envi.last_queues_us
             del envi
-            # C3 in a training run's steady state: the timed region starts behind a reset of ALL envs and sees no episode
-            # end; here the envs are spread evenly over their 1000-step episodes (~B / 1000 in-kernel resets per step),
-            # 400 steps through the same queues, one call
-            if use_queues:
-                try:
-                    envs_ss = SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25), slices=args.slices,
-                                                output_channels=TRAIN_CHANNELS, auto_reset=True, with_obs=False)
-                    envs_ss.reset()
-                    envs_ss.t["scalars"][:, _hip.SCALAR_COLS["num_steps"]] = (
-                        torch.arange(B, device=dev, dtype=torch.int32) * 997) % 1000
-                    acts_ss = torch.randint(0, 9, (440, B), generator=gen, device=dev, dtype=torch.int32)
-                    envs_ss.queues_open(n_queues, release_free=(res["fences"] == "none"), recover=False)
-                    envs_ss.step_queues_many(acts_ss[:40])
-                    envs_ss.queues_sync()
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    envs_ss.step_queues_many(acts_ss[40:], assume_ordered=True)
-                    envs_ss.queues_sync()
-                    extra["c3_steady_state_us_per_step"] = (time.perf_counter() - t0) / 400 * 1e6
-                    extra["c3_steady_state_note"] = ("%d envs spread evenly over their 1000-step episodes (about %d in-kernel "
-                                                     "resets per step), 400 steps in one queue call" % (B, B // 1000))
-                    envs_ss.queues_close()
-                    del envs_ss, acts_ss
-                except _hip.SafeLifeHipError as e:
-                    extra["c3_steady_state_error"] = str(e)
             # per-GPU shares of the sharded configs of BASELINE.json (C4: append-spawn 25x25, C5: navigation 64x64)
             # (and the shape the reference's own random-level YAMLs use, levels/random/*.yaml: board_shape [26, 26])
             for tag, pname, n_envs in (("c4_append_spawn_25", "append_spawn_25", 8192), ("c5_navigation_64", "navigation_64", 4096),
@@ -934,16 +966,27 @@ def main():
                         np.ascontiguousarray(p2.arrays()["pool_board"][np.arange(nb) % len(p2)]).view(np.int16)).to(dev)
                     probs = torch.full((nb,), 0.3, dtype=torch.float32, device=dev)
                     rngs = torch.arange(nb * 4, dtype=torch.int64, device=dev).reshape(nb, 4) * 2 + 1
-                    speedups.life_occupancy_batch(boards[:8], probs[:8], rngs[:8].clone(), 10)
+                    # (the 537 MB result is allocated and touched BEFORE the first event, the warm-up runs at full size, and
+                    #  the figure is the median of three launches: round 5's one-shot timing had a cold allocation of that
+                    #  size between its two events)
+                    occ_out = torch.zeros((nb, 64, 64, 8), dtype=torch.int32, device=dev)
+                    speedups.life_occupancy_batch(boards, probs, rngs.clone(), 100, out=occ_out)
                     torch.cuda.synchronize()
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    speedups.life_occupancy_batch(boards, probs, rngs, 1000)
-                    e1.record()
-                    torch.cuda.synchronize()
-                    ms = e0.elapsed_time(e1)
+                    occ_ms = []
+                    for _ in range(3):
+                        r_rep = rngs.clone()
+                        torch.cuda.synchronize()
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        speedups.life_occupancy_batch(boards, probs, r_rep, 1000, out=occ_out)
+                        e1.record()
+                        torch.cuda.synchronize()
+                        occ_ms.append(e0.elapsed_time(e1))
+                    ms = sorted(occ_ms)[1]
+                    del occ_out
                     extra["life_occupancy_64x64_1000steps_boards_per_s"] = nb / (ms * 1e-3)
-                    extra["life_occupancy_64x64_board_steps_per_s"] = nb * 1000 / (ms * 1e-3)
+                    extra["life_occupancy_64x64_board_steps_per_s"] = variants["life_occupancy_64x64_board_steps_per_s"] = nb * 1000 / (ms * 1e-3)
+                    extra["life_occupancy_64x64_ms_of_three"] = occ_ms
                     # C5 as BASELINE.json states it: navigation WITH the side-effect score.  Episode ends are spread
                     # evenly (every env starts at a different point of its 1000-step episode), the step kernels queue
                     # the finished episodes, and every `flush_every` steps the episode-end pass of side_effect_score
@@ -959,9 +1002,16 @@ def main():
                         torch.arange(n_c5, device=dev, dtype=torch.int32) * 997) % 1000
                     acts5 = torch.randint(0, 9, (n_meas + 20, n_c5), generator=gen, device=dev, dtype=torch.int32)
                     torch.cuda.synchronize()
+                    # (warm-up at full size: one whole window of steps and its episode-end pass, so that the pass's work and
+                    #  output buffers -- 560 MB -- exist and have been touched before the first event; round 5 measured them
+                    #  being allocated inside the region: 102 us per step on the driver's box against 48 here)
                     for t in range(20):
                         env5.step_async(acts5[t])
-                    env5.side_effects_flush()
+                    for t in range(20, 20 + flush_every):
+                        env5.step_async(acts5[t])
+                    env5.side_effects_flush(overlap=True)
+                    env5.join()
+                    env5.side_effects_join()
                     torch.cuda.synchronize()
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     batches = []
@@ -978,7 +1028,7 @@ def main():
                     torch.cuda.synchronize()
                     ms = e0.elapsed_time(e1)
                     n_eps = sum(len(b) for b in batches)
-                    extra["c5_with_side_effects_us_per_step"] = ms * 1e3 / n_meas
+                    extra["c5_with_side_effects_us_per_step"] = variants["c5_with_side_effects_streams_us"] = ms * 1e3 / n_meas
                     extra["c5_with_side_effects_env_steps_per_s_per_gpu"] = n_c5 * n_meas / (ms * 1e-3)
                     extra["c5_with_side_effects_episodes_scored"] = n_eps
                     extra["c5_with_side_effects_note"] = ("%d envs x 64x64 navigation, %d steps, episode-end pass every %d steps "
@@ -990,8 +1040,15 @@ def main():
                     # not see the queues), whole windows of flush_every steps per call
                     if use_queues:
                         try:
-                            env5.queues_open(4, release_free=(res["fences"] == "none"), recover=False)
+                            env5.queues_open(4, release_free=(res["fences"] == "none"), recover=False, chained=res["chained"])
                             env5.side_effects_flush()
+                            torch.cuda.synchronize()
+                            # (one untimed window first, as above)
+                            torch.cuda.current_stream().synchronize()
+                            env5.step_queues_many(acts5[20:20 + flush_every], assume_ordered=True)
+                            env5.side_effects_flush(overlap=True)
+                            env5.queues_sync()
+                            env5.side_effects_join()
                             torch.cuda.synchronize()
                             batches = []
                             t0 = time.perf_counter()
@@ -1005,7 +1062,7 @@ def main():
                             env5.side_effects_join()
                             torch.cuda.synchronize()
                             us = (time.perf_counter() - t0) / n_meas * 1e6
-                            extra["c5_with_side_effects_queues_us_per_step"] = us
+                            extra["c5_with_side_effects_queues_us_per_step"] = variants["c5_with_side_effects_us"] = us
                             extra["c5_with_side_effects_queues_env_steps_per_s_per_gpu"] = n_c5 / (us * 1e-6)
                             extra["c5_with_side_effects_queues_episodes_scored"] = sum(len(b) for b in batches)
                             env5.queues_close()
@@ -1059,15 +1116,26 @@ def main():
         achieved = bytes_per_step * B / (elapsed / K) / 1e9
         achieved_device = bytes_per_step * B / (kernel_ms * 1e-3) / 1e9
         stream_key = "stream_leg" if use_queues else "device"
-        traffic = None
+        traffic, traffic_note, traffic_agent = None, None, None
         try:    # HBM bytes per launch from the committed PMC passes (tools/pmc_run.sh), if they match this run
             with open(os.path.join(REPO, "profiles", "traffic_latest.json")) as f:
                 tj = json.load(f)
             # (only a PMC run of the SAME stepping mode counts: launches per step and, for the queues, the fences)
-            same = (tj.get("slices", 1) == (env.queue_slices if use_queues else env.slices)
+            same = (tj.get("slices", 1) == (res["queue_slices"] if use_queues else env.slices)
                     and tj.get("queue_fences") == (res["fences"] if use_queues else None))
-            if tj.get("envs_per_gpu") == B and tj.get("obs") == args.obs and same:
-                traffic = tj.get("hbm_bytes_per_step", tj["hbm_bytes_per_launch"])      # all launches of one step
+            if tj.get("envs_per_gpu") == B and tj.get("obs") == args.obs:
+                if same:
+                    traffic = tj.get("hbm_bytes_per_step", tj["hbm_bytes_per_launch"])      # all launches of one step
+                else:
+                    # the same kernel on the same batch, counted with a stream's fences: per-dispatch counters cannot
+                    # attribute a release-free step's traffic (the profiler serialises the dispatches and flushes the
+                    # L2s around each: every launch starts cold and its write-back falls outside its window)
+                    traffic_agent = tj.get("hbm_bytes_per_step", tj["hbm_bytes_per_launch"])
+                    traffic_note = ("null for this stepping mode (per-dispatch counters cannot attribute release-free "
+                                    "steps); traffic_agent_fences = PMC bytes per step of the same kernel and batch "
+                                    "stepped with agent-scope fences (%s), %.3f x the algorithmic bytes"
+                                    % (tj.get("source", "profiles/traffic_latest.json"),
+                                       traffic_agent / float((3 * H * Wd * 2 + obs_bytes) * B)))
         except (OSError, ValueError, KeyError):
             pass
         out = {
@@ -1091,15 +1159,22 @@ def main():
                                                                    ("%d slice(s) per GPU, one dispatch each on an AQL queue of "
                                                                     "the library's own (barrier bit; fences: see "
                                                                     "queue_fences), all K steps enqueued by one C call"
-                                                                    % env.queue_slices) if use_queues
+                                                                    % res["queue_slices"]) if use_queues
                                                                    else ("%d slice(s) per GPU, one launch and one stream each"
                                                                          % env.slices)),
                        "stepping": "aql-queues" if use_queues else "hip-streams",
                        "gather_window_closes_steps_before_end": (window_ahead if gather.collective else None),
-                       "queue_ids": (getattr(env, "queue_ids", None) if use_queues else None),
+                       "queue_ids": (res["queue_ids"] if use_queues else None),
                        "queue_ids_note": ("the step queue RCCL's exchange kernel would hold up is left out (probed: "
                                           "slhip_gather_stream_shares)" if (use_queues and gather.collective and
-                                                                            len(getattr(env, "queue_ids", [])) == 3) else None),
+                                                                            len(res["queue_ids"]) == 3) else None),
+                       "queue_chained": ("chained: bench opted in to SL_QUEUES_CHAINED -- no barrier bit between the steps of "
+                                         "a queue; every workgroup waits for the workgroup that stepped its boards last "
+                                         "(a per-workgroup counter), verified per step like the placement"
+                                         if res["chained"] else "barrier bit on every step") if use_queues else None,
+                       "episode_phase": ("spread: env e starts (e x 997) mod 1000 steps into its first episode -- about %d "
+                                         "episodes end and reset inside the kernel at every timed step (SURVEY 8d)" % (B // 1000)
+                                         if res["spread"] else "all envs straight behind a reset: no episode end in the region"),
                        "queue_fences": ({"none": "none: bench opted in to release-free stepping (SL_QUEUES_RELEASE_FREE) -- "
                                                  "agent-scope acquire, NO release between the steps of a queue; placement "
                                                  "probed at open and verified by every step",
@@ -1108,14 +1183,15 @@ def main():
                        "queue_fences_requested": args.queue_fences if use_queues else None,
                        "queues_unavailable": queues_why},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+                         "traffic_agent_fences": traffic_agent,
                          "kernel": "fused env step", "bytes_per_env_step": bytes_per_step,
                          "time_base": "wall clock of the timed region (ms_per_step): first launch from an idle GPU to "
                                       "the return of the closing synchronize",
                          # device time of one step (HIP events on slice 0's stream over the same region): the slice
                          # launches of a step run concurrently, each stream back to back, so a step costs one
                          # stream's launch-to-launch time
-                         "launches_per_step": env.queue_slices if use_queues else env.slices,
+                         "launches_per_step": res["queue_slices"] if use_queues else env.slices,
                          # queue stepping: a SEPARATE leg behind the timed region -- K steps of the same kernel through
                          # the HIP-stream slices under HIP events (events cannot see the library's queues).  It describes
                          # another launcher and may well exceed ms_per_step; stream stepping: the events bracket the
@@ -1127,6 +1203,21 @@ def main():
                          if stream_wall_ms is not None else "HIP events over the timed region (slice 0's stream)",
                          stream_key + "_achieved": achieved_device, stream_key + "_frac": achieved_device / HBM_PEAK_GBS,
                          "host_enqueue_ms_per_step": (t_enqueued - t_start) / K * 1e3,
+                         # the same region under other launchers / regimes / lengths, measured in this run behind the
+                         # timed region (us per step, medians of three repetitions; null: not measured in this run):
+                         #   agent_fences_us   the library's DEFAULT queue fences (a stream's acquire and release per step)
+                         #   unchained_us      release-free stepping with the barrier bit on every step (rounds 4-5's launcher)
+                         #   no_reset_us       the region straight behind a reset of all envs: no episode end inside it
+                         #                     (rounds 1-5's region; steady_state_us is its counterpart with --spread 0)
+                         #   k400_us           the same region 400 steps long (what a 20-step region's fixed cost hides)
+                         #   k20_median_us     this line's own region again, median of five
+                         #   forced_gather_us  one rank with the RCCL exchange forced on (what every N > 1 rank runs)
+                         #   c5_with_side_effects_us  C5's per-GPU share with the episode-end pass in the region (queues)
+                         **{k: variants.get(k) for k in ("agent_fences_us", "unchained_us", "no_reset_us", "steady_state_us", "k400_us",
+                                                         "k20_median_us", "forced_gather_us", "c5_with_side_effects_us",
+                                                         "c5_with_side_effects_streams_us", "life_occupancy_64x64_board_steps_per_s")},
+                         "scaling_curve": "not measured by this build (no multi-GPU node was available to it): the 1-to-N curve "
+                                          "is the driver's",
                          "measured_ceiling": ceiling,
                          # the issue side next to the HBM side (C3, four waves per SIMD; counters and timing-only builds
                          # committed under profiles/, not measured in this run)

@@ -144,10 +144,19 @@ def advance_board_batch(boards, spawn_prob, rng, n_step=1, out=None):
     return out
 
 
-def life_occupancy_batch(boards, spawn_prob, rng, n_step=1000):
+def life_occupancy_batch(boards, spawn_prob, rng, n_step=1000, out=None):
+    """int32 [B,H,W,8] occupancy counts of `n_step` steps per board (advance_board.c:153-189); `rng` advanced in place.
+    ``out``: a caller-owned int32 tensor [B,H,W,8] to write into (every element is written) instead of a new one --
+    at 4096 boards of 64x64 the result is 537 MB, and a fresh allocation of that size is not free."""
     torch = _torch()
     B, H, W = boards.shape
-    counts = torch.empty((B, H, W, 8), dtype=torch.int32, device=boards.device)
+    if out is None:
+        counts = torch.empty((B, H, W, 8), dtype=torch.int32, device=boards.device)
+    else:
+        counts = out
+        if (counts.dtype != torch.int32 or tuple(counts.shape) != (B, H, W, 8) or not counts.is_contiguous()
+                or counts.device != boards.device):
+            raise ValueError("out must be a contiguous int32 tensor [B,H,W,8] on the boards' device")
     rc = _hip.lib().slhip_life_occupancy(_hip.ptr(boards), _hip.ptr(counts), B, H, W, _hip.ptr(spawn_prob),
                                          int(n_step), _hip.ptr(rng), _hip.current_stream_ptr())
     _hip.check(rc, "Board must be at least 3x3.")

@@ -27,6 +27,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("steps", nargs="?", type=int, default=6)
 ap.add_argument("--queues", type=int, default=0)
 ap.add_argument("--fences", default="agent")
+ap.add_argument("--chained", type=int, default=0, help="queue mode, fences none: SL_QUEUES_CHAINED (no barrier bit between steps)")
+ap.add_argument("--spread", type=int, default=0, help="1: envs spread over their episodes (resets at every step)")
 ap.add_argument("--gather-every", type=int, default=0,
                 help="queue mode: hand a window of this many steps to the RCCL exchange (one rank, to itself) inside the trace")
 args = ap.parse_args()
@@ -36,9 +38,11 @@ pool = bench.load_pool("prune_still_25", _device_counts)
 env = SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25), output_channels=bench.TRAIN_CHANNELS,
                         auto_reset=True, with_obs=False, slices=2 if args.queues else SL)
 env.reset()
+if args.spread:
+    env.t["scalars"][:, _hip.SCALAR_COLS["num_steps"]] = (torch.arange(B, device=env.device, dtype=torch.int32) * 997) % 1000
 if args.queues:
-    env.queues_open(args.queues, release_free=(args.fences == "none"))
-    print("AQL queues: %d, release-free: %s" % (env.queue_slices, env.queue_release_free))
+    env.queues_open(args.queues, release_free=(args.fences == "none"), chained=bool(args.chained), recover=False)
+    print("AQL queues: %d, release-free: %s, chained: %s" % (env.queue_slices, env.queue_release_free, env.queue_chained))
 acts = torch.randint(0, 9, (64 + N, B), device=env.device, dtype=torch.int32)
 ptrs = [acts[t].data_ptr() for t in range(64 + N)]      # (addresses: the loop below is all the host does per step)
 step = env.step_queues if args.queues else env.step_async
@@ -106,3 +110,13 @@ for i, n in enumerate(names):
     print("  %-24s %6.0f %6.0f %6.0f" % (n, v.mean(), np.percentile(v, 50), np.percentile(v, 90)))
 life = (st[:, :, 10] - st[:, :, 0]).reshape(-1)
 print("  %-24s %6.0f %6.0f %6.0f" % ("wave lifetime", life.mean(), np.percentile(life, 50), np.percentile(life, 90)))
+
+# chained stepping: the wait for the workgroup's predecessor (stamp 13 - stamp 0), and what a CU slot does between two
+# workgroups: a wave's start against the end (stores acknowledged) of the same wave index of the same slice one step earlier
+wait = (tr[2 * SL:, :, 13] - tr[2 * SL:, :, 0]).astype(np.float64).reshape(-1) * 10.0
+print("  %-24s %6.0f %6.0f %6.0f   (inside 'loads issued')" % ("chain wait", wait.mean(), np.percentile(wait, 50), np.percentile(wait, 90)))
+succ = (tr[3 * SL:, :, 0] - tr[2 * SL:-SL, :, 10]).astype(np.float64).reshape(-1) * 10.0      # (same workgroup: same XCD, same clock)
+print("  %-24s %6.0f %6.0f %6.0f   (same workgroup, one step earlier: its stores acknowledged -> this wave's start)"
+      % ("successor starts after", succ.mean(), np.percentile(succ, 50), np.percentile(succ, 90)))
+cyc = (tr[3 * SL:, :, 0] - tr[2 * SL:-SL, :, 0]).astype(np.float64).reshape(-1) * 10.0
+print("  %-24s %6.0f %6.0f %6.0f   (start to start of the same workgroup's consecutive steps)" % ("workgroup cycle", cyc.mean(), np.percentile(cyc, 50), np.percentile(cyc, 90)))
