@@ -278,10 +278,6 @@ def main():
                          "(SL_QUEUES_RELEASE_FREE: ~0.9 us per step faster; valid only while a workgroup index keeps its "
                          "XCD, which the library probes at open and every step verifies -- on a violation the run is "
                          "repeated with 'agent', on every rank).  config.queue_fences says which mode produced the line")
-    ap.add_argument("--queue-chained", type=int, default=int(os.environ.get("SAFELIFE_BENCH_CHAINED", "1")),
-                    help="release-free queue stepping only: 1 = also OPT IN to chained stepping (SL_QUEUES_CHAINED: no barrier "
-                         "bit between the steps of a queue, every workgroup waits for its own predecessor); 0 = barrier bit on "
-                         "every step.  config.queue_chained says what the line ran with")
     ap.add_argument("--spread", type=int, default=1,
                     help="1 (default): the timed region starts with the envs spread evenly over their 1000-step episodes, so "
                          "that ~envs/1000 episodes end -- and reset inside the kernel -- at every step (SURVEY 8d); 0: straight "
@@ -361,13 +357,13 @@ def main():
 
     queue_ids = [None]
 
-    def attempt(fences, gather=gather, P=P, shift=shift, spread=bool(args.spread), chained=bool(args.queue_chained), K=K, W=W):
+    def attempt(fences, gather=gather, P=P, shift=shift, spread=bool(args.spread), K=K, W=W):
         """Reset, P checkpointed steps, W warm-up steps, the K timed steps.  Returns the measurements, or None when
         release-free queue stepping was refused by its placement check on ANY rank (the caller repeats with 'agent').
-        (`gather`, `P`, `shift`, `spread`, `chained`, `K`, `W`: the variants reported in `roofline` repeat the region
+        (`gather`, `P`, `shift`, `spread`, `K`, `W`: the variants reported in `roofline` repeat the region
         with another exchange, regime or length, without checkpoints.)"""
         every = gather.every
-        res = {"use_queues": False, "queues_why": "switched off", "fences": None, "chained": False, "queue_slices": None,
+        res = {"use_queues": False, "queues_why": "switched off", "fences": None, "queue_slices": None,
                "queue_ids": None, "spread": spread, "K": K, "W": W}
         env.queues_close()
         env.reset()
@@ -390,13 +386,11 @@ def main():
                 ids = queue_ids[0] if ((gather.collective and n_queues == 4) or os.environ.get("SAFELIFE_BENCH_QUEUE_IDS")) else None
                 # (recover=False: this bench has its own answer to a refused placement -- the whole run again with a
                 #  stream's fences -- and keeps the env's per-sync state copy out of the timed region)
-                env.queues_open(len(ids) if ids else n_queues, release_free=(fences == "none"), queue_ids=ids, recover=False,
-                                chained=(chained and fences == "none"))
+                env.queues_open(len(ids) if ids else n_queues, release_free=(fences == "none"), queue_ids=ids, recover=False)
                 res["use_queues"], res["queues_why"] = True, None
                 res["fences"] = "none" if env.queue_release_free else "agent"
                 # what THIS attempt steps with (the JSON line is built from these, not from whatever a later attempt
                 # leaves in `env`)
-                res["chained"] = bool(getattr(env, "queue_chained", False))
                 res["queue_slices"], res["queue_ids"] = int(env.queue_slices), list(env.queue_ids)
                 if fences == "none" and not env.queue_release_free:
                     print("bench: release-free queue stepping not granted (%s): agent-scope fences" % env.queue_mode_note,
@@ -414,7 +408,7 @@ def main():
             try:
                 env.queues_sync()
             except _hip.SafeLifeHipError as e:
-                if "another XCD" not in str(e) and "in vain" not in str(e):
+                if "another XCD" not in str(e):
                     raise
                 print("bench: %s" % e, file=sys.stderr)
                 refused[0] = True
@@ -513,9 +507,6 @@ def main():
         return res
 
     res = attempt(args.queue_fences)
-    if res is None and args.queue_fences == "none" and args.queue_chained:
-        print("bench: repeating the run without chained stepping", file=sys.stderr)
-        res = attempt("none", chained=False)
     if res is None:
         print("bench: repeating the run with agent-scope fences", file=sys.stderr)
         res = attempt("agent")
@@ -577,7 +568,6 @@ def main():
         # What the driver's one-GPU line does not show (outside the timed region; same warm-up, no checkpoints; every
         # variant the median of three repetitions of the whole region):
         # (a) the library's DEFAULT fences -- what SafeLifeVectorEnv.queues_open() gives a user;
-        # (b) release-free stepping with the barrier bit on every step (rounds 4-5's launcher), where the line is chained;
         # (c) the region straight behind a reset of all envs -- no episode end inside it (rounds 1-5's region);
         # (d) the same region 400 steps long: what the fixed cost of a 20-step region (first doorbell, the queues'
         #     staggered pick-up, the closing fence) hides;
@@ -585,20 +575,17 @@ def main():
         #     queues the exchange does not hold up, one window closing inside the region.
         def median_us(n=3, **kw):
             fences = kw.pop("fences", res["fences"])
-            kw.setdefault("chained", res["chained"])
             kw.setdefault("spread", res["spread"])
             vals = []
             for _ in range(n):
                 r = attempt(fences, P=0, **kw)
-                if r is None or r["fences"] != fences or r["chained"] != kw["chained"]:
+                if r is None or r["fences"] != fences:
                     return None
                 vals.append(r["elapsed"] / r["K"] * 1e6)
             return sorted(vals)[len(vals) // 2]
         try:
-            variants["agent_fences_us"] = median_us(fences="agent", chained=False) if res["fences"] != "agent" else elapsed / K * 1e6
+            variants["agent_fences_us"] = median_us(fences="agent") if res["fences"] != "agent" else elapsed / K * 1e6
             extra["queue_fences_agent_us_per_step"] = variants["agent_fences_us"]
-            if res["chained"]:
-                variants["unchained_us"] = median_us(chained=False)
             variants["no_reset_us" if res["spread"] else "steady_state_us"] = median_us(spread=not res["spread"])
             variants["k400_us"] = median_us(K=400, W=40)
             variants["k20_median_us"] = median_us(n=5)
@@ -795,7 +782,7 @@ def main():
                 env3.last_queues_us = None
                 if use_queues:
                     try:
-                        env3.queues_open(n_queues, release_free=(res["fences"] == "none"), chained=res["chained"])
+                        env3.queues_open(n_queues, release_free=(res["fences"] == "none"))
                         for t in range(20):
                             env3.step_queues(acts[t])
                         env3.queues_sync()
@@ -824,7 +811,7 @@ def main():
                     env_r.reset()
                     chunk, n_calls = 100, 8
                     acts_r = torch.randint(0, 9, (chunk * (n_calls + 1), B), generator=gen, device=dev, dtype=torch.int32)
-                    env_r.queues_open(n_queues, release_free=(res["fences"] == "none"), recover=False, chained=res["chained"])
+                    env_r.queues_open(n_queues, release_free=(res["fences"] == "none"), recover=False)
                     rr = np.random.default_rng(5)
                     env_r.pool_stage([0], [lv_all[n_half]])        # (untimed: the first staging pins its host buffers)
                     # new levels come prepared (LevelPool.prepare: checks, cell counts, points, RNG words) -- part of making
@@ -1040,7 +1027,7 @@ def main():
                     # not see the queues), whole windows of flush_every steps per call
                     if use_queues:
                         try:
-                            env5.queues_open(4, release_free=(res["fences"] == "none"), recover=False, chained=res["chained"])
+                            env5.queues_open(4, release_free=(res["fences"] == "none"), recover=False)
                             env5.side_effects_flush()
                             torch.cuda.synchronize()
                             # (one untimed window first, as above)
@@ -1168,10 +1155,6 @@ def main():
                        "queue_ids_note": ("the step queue RCCL's exchange kernel would hold up is left out (probed: "
                                           "slhip_gather_stream_shares)" if (use_queues and gather.collective and
                                                                             len(res["queue_ids"]) == 3) else None),
-                       "queue_chained": ("chained: bench opted in to SL_QUEUES_CHAINED -- no barrier bit between the steps of "
-                                         "a queue; every workgroup waits for the workgroup that stepped its boards last "
-                                         "(a per-workgroup counter), verified per step like the placement"
-                                         if res["chained"] else "barrier bit on every step") if use_queues else None,
                        "episode_phase": ("spread: env e starts (e x 997) mod 1000 steps into its first episode -- about %d "
                                          "episodes end and reset inside the kernel at every timed step (SURVEY 8d)" % (B // 1000)
                                          if res["spread"] else "all envs straight behind a reset: no episode end in the region"),
@@ -1206,14 +1189,13 @@ def main():
                          # the same region under other launchers / regimes / lengths, measured in this run behind the
                          # timed region (us per step, medians of three repetitions; null: not measured in this run):
                          #   agent_fences_us   the library's DEFAULT queue fences (a stream's acquire and release per step)
-                         #   unchained_us      release-free stepping with the barrier bit on every step (rounds 4-5's launcher)
                          #   no_reset_us       the region straight behind a reset of all envs: no episode end inside it
                          #                     (rounds 1-5's region; steady_state_us is its counterpart with --spread 0)
                          #   k400_us           the same region 400 steps long (what a 20-step region's fixed cost hides)
                          #   k20_median_us     this line's own region again, median of five
                          #   forced_gather_us  one rank with the RCCL exchange forced on (what every N > 1 rank runs)
                          #   c5_with_side_effects_us  C5's per-GPU share with the episode-end pass in the region (queues)
-                         **{k: variants.get(k) for k in ("agent_fences_us", "unchained_us", "no_reset_us", "steady_state_us", "k400_us",
+                         **{k: variants.get(k) for k in ("agent_fences_us", "no_reset_us", "steady_state_us", "k400_us",
                                                          "k20_median_us", "forced_gather_us", "c5_with_side_effects_us",
                                                          "c5_with_side_effects_streams_us", "life_occupancy_64x64_board_steps_per_s")},
                          "scaling_curve": "not measured by this build (no multi-GPU node was available to it): the 1-to-N curve "

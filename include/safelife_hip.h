@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SL_ABI_VERSION 13       /* 13: SL_QUEUES_CHAINED, slhip_goal_cache_lead_bytes; 12: slhip_pool_write; 11: sl_env_batch.goal_cache, slhip_goal_cache_bytes; 10: slhip_queues_open_on, slhip_queues_stream_shares, slhip_gather_stream_shares, slhip_gather_poke */
+#define SL_ABI_VERSION 12       /* 12: slhip_pool_write; 11: sl_env_batch.goal_cache, slhip_goal_cache_bytes; 10: slhip_queues_open_on, slhip_queues_stream_shares, slhip_gather_stream_shares, slhip_gather_poke */
 #define SL_MAX_CELLS 16384        /* H*W limit of one board */
 #define SL_MAX_CHANNELS 32
 
@@ -320,9 +320,6 @@ int slhip_pool_write(const sl_env_batch *env, const sl_pool_rows *rows, void *st
  * *boards_per_block (optional): the cache is one block of bytes / ceil(B / boards_per_block) bytes per group of that many
  * consecutive envs; a block's first 32-bit word is its flag (1: the group steps on cached goal words). */
 size_t slhip_goal_cache_bytes(const sl_env_batch *env, int *boards_per_block);
-/* Bytes the caller allocates -- zeroed, contiguous -- IN FRONT of env->goal_cache for SL_QUEUES_CHAINED stepping (one
- * 128-byte counter line per block of the cache; 0: the batch keeps no cache).  Zeroing the cache itself leaves them alone. */
-size_t slhip_goal_cache_lead_bytes(const sl_env_batch *env);
 
 /* SafeLifeEnv.reset() for the envs with mask[e] != 0 (mask NULL = all): an env that has never been loaded
  * takes pool level level_idx[e]; any other moves on to (level_idx[e] + level_stride) % L and counts an
@@ -409,21 +406,8 @@ int slhip_env_step_range(const sl_env_batch *env, int first, int count, const in
  * SL_QUEUES_SELFTEST_SWAP (arg 1 / 0: on / off) dispatches step t's slice i on queue (i + t) mod n behind a host-side
  * drain of all queues that carries no release, so that every env is stepped -- in order -- by a workgroup of another
  * QUEUE than the step before, which on MI355X means another XCD -- harmless with a stream's fences, a real misplacement
- * for release-free stepping (tests/test_hip_parity.py shows both).
- *
- * SL_QUEUES_CHAINED (open's flags; OPT-IN, on top of SL_QUEUES_RELEASE_FREE and ignored without it; round 6): the steps of
- * a queue go without the BARRIER BIT as well.  A dispatch then starts while its predecessor is still running -- its
- * workgroups take the CU slots the predecessor's leave one by one, no launch drains, no packet-processor boundary between
- * steps, and a workgroup that reloads a level holds up its own successor only.  Order is kept per workgroup: workgroup i's
- * boards are touched by workgroup i of every dispatch and nobody else; every wave of it counts itself in on the
- * workgroup's counter once its stores are acknowledged, and workgroup i of the next dispatch waits for that count before its
- * first fetch (sl_rowlane.hip: ChainWait).  Needs env->goal_cache with slhip_goal_cache_lead_bytes() zeroed bytes in front
- * of it (the counters; open zeroes them).  Rests on the same placement as release-free stepping, verified by every step,
- * and on a queue launching its dispatches' workgroups in order; a wait that does not end within ~0.1 s gives up and raises
- * the same host-visible word: wait / sync return SL_E_HIP.  The first step of every steps() call and every 16th
- * dispatch of a queue keep the barrier bit. */
+ * for release-free stepping (tests/test_hip_parity.py shows both). */
 #define SL_QUEUES_RELEASE_FREE 1
-#define SL_QUEUES_CHAINED 2
 #define SL_QUEUES_SELFTEST_PLANT 1
 #define SL_QUEUES_SELFTEST_SWAP 2
 int slhip_queues_open(const sl_env_batch *env, int n_slices, const int32_t *bounds, int flags, void **handle);

@@ -20,7 +20,7 @@ SL_E_SHAPE, SL_E_ARG, SL_E_HIP, SL_E_UNSUPPORTED = -1, -2, -3, -4
 EXPORTS = (
     "slhip_abi_version", "slhip_last_error", "slhip_device_count",
     "slhip_advance_board", "slhip_advance_board_each", "slhip_life_occupancy", "slhip_alive_counts", "slhip_execute_actions",
-    "slhip_env_prepare", "slhip_pool_baseline", "slhip_pool_write", "slhip_goal_cache_bytes", "slhip_goal_cache_lead_bytes", "slhip_env_reset", "slhip_env_step", "slhip_env_step_slices", "slhip_env_step_range", "slhip_env_rollout",
+    "slhip_env_prepare", "slhip_pool_baseline", "slhip_pool_write", "slhip_goal_cache_bytes", "slhip_env_reset", "slhip_env_step", "slhip_env_step_slices", "slhip_env_step_range", "slhip_env_rollout",
     "slhip_streams_concurrent", "slhip_streams_order",
     "slhip_env_obs",
     "slhip_obs_to_policy", "slhip_sample_actions", "slhip_side_effects",
@@ -30,7 +30,7 @@ EXPORTS = (
     "slhip_queues_open", "slhip_queues_open_on", "slhip_queues_stream_shares", "slhip_gather_stream_shares", "slhip_gather_poke", "slhip_queues_mode", "slhip_queues_steps", "slhip_queues_step", "slhip_queues_marker",
     "slhip_queues_wait", "slhip_queues_sync", "slhip_queues_close", "slhip_queues_selftest",
 )
-QUEUES_RELEASE_FREE, QUEUES_CHAINED = 1, 2
+QUEUES_RELEASE_FREE = 1
 QUEUES_SELFTEST_PLANT, QUEUES_SELFTEST_SWAP = 1, 2
 SL_GATHER_ID_BYTES = 128
 SL_SE_MAX_KEYS = 24
@@ -54,7 +54,7 @@ ENV_STATE_PTRS = ("board", "goals", "exit_locs", "rng", "scalars", "points_table
 ENV_POOL_PTRS = ("pool_board", "pool_goals", "pool_exit_locs", "pool_rng", "pool_scalars")
 ENV_POOL_TAIL = ("pool_next",)      # (optional: set by SafeLifeVectorEnv for refreshable pools)
 ENV_OUT_PTRS = ("out", "obs", "score_lut")
-SL_ABI_VERSION = 13
+SL_ABI_VERSION = 12
 
 #: int32 column of each field inside `struct sl_env_scalars` (64 bytes = 16 columns)
 SCALAR_COLS = {"agent_row": 0, "agent_col": 1, "num_steps": 2, "old_value": 3, "required_points": 4,
@@ -151,9 +151,6 @@ def lib():
         if hasattr(L, "slhip_goal_cache_bytes"):
             L.slhip_goal_cache_bytes.argtypes = [C.POINTER(EnvBatch), C.POINTER(C.c_int)]
             L.slhip_goal_cache_bytes.restype = C.c_size_t
-        if hasattr(L, "slhip_goal_cache_lead_bytes"):
-            L.slhip_goal_cache_lead_bytes.argtypes = [C.POINTER(EnvBatch)]
-            L.slhip_goal_cache_lead_bytes.restype = C.c_size_t
         L.slhip_env_reset.argtypes = [C.POINTER(EnvBatch), _p, _p]
         L.slhip_env_step.argtypes = [C.POINTER(EnvBatch), _p, _p]
         L.slhip_env_step_slices.argtypes = [C.POINTER(EnvBatch), C.c_int, _p, _p, _p]

@@ -416,12 +416,6 @@ size_t slhip_goal_cache_bytes(const sl_env_batch *env, int *boards_per_block) {
     return sl::rowlane_goal_cache_bytes(env->H, env->W, env->B, boards_per_block);
 }
 
-size_t slhip_goal_cache_lead_bytes(const sl_env_batch *env) {
-    int group = 0;
-    const size_t bytes = slhip_goal_cache_bytes(env, &group);
-    return bytes && group ? (size_t)128 * (size_t)((env->B + group - 1) / group) : 0;
-}
-
 // A launch of the size-generic kernels on a batch that carries a goal-word cache: they load levels without keeping its
 // flags, so every flag goes down first (the row kernels' launcher does the same for its own odd launches).
 static hipError_t drop_goal_cache(const sl_env_batch *env, hipStream_t st) {
@@ -636,10 +630,6 @@ struct StepQueues {
     // SL_QUEUES_RELEASE_FREE (opt-in): no release fence between the steps of a queue; the placement this rests on is
     // probed when the queues are opened and verified by every step (sl_rowlane.hip: xcd_base / xcd_flag).
     bool release_free = false;
-    // SL_QUEUES_CHAINED (opt-in on top of release-free): dispatches without the barrier bit; chain_steps = steps this
-    // handle has dispatched = what every workgroup's counter reads (x waves) when its next step may start
-    bool chained = false;
-    long long chain_steps = 0;
     int base[8] = {};               // queue i runs workgroup w of a dispatch on XCD (base[i] + w) mod 8 (probed at open)
     uint32_t *flag = nullptr;       // host memory: raised by a step kernel that finds itself on another XCD
     bool pending = false;           // steps dispatched since this handle last waited for a marker of its own
@@ -775,7 +765,7 @@ int slhip_queues_open_on(const sl_env_batch *env, int n_slices, const int32_t *b
             n_phys = std::max(n_phys, queue_ids[i] + 1);
         }
     }
-    if (flags & ~(SL_QUEUES_RELEASE_FREE | SL_QUEUES_CHAINED)) return fail(SL_E_ARG, "unknown queue flags");
+    if (flags & ~SL_QUEUES_RELEASE_FREE) return fail(SL_E_ARG, "unknown queue flags");
     if (bounds[0] != 0 || bounds[n_slices] != env->B) return fail(SL_E_ARG, "slice bounds must run from 0 to B");
     for (int i = 0; i < n_slices; ++i) {
         if (bounds[i + 1] < bounds[i]) return fail(SL_E_ARG, "slice bounds must not decrease");
@@ -814,22 +804,6 @@ int slhip_queues_open_on(const sl_env_batch *env, int n_slices, const int32_t *b
             for (int i = 0; i < n_slices; ++i) c->base[i] = phys_base[c->qmap[i]];
         }
     }
-    if ((flags & SL_QUEUES_CHAINED) && c->release_free) {
-        // the workgroups' counters (in front of the goal-word cache) start at zero with this handle's step count; the
-        // caller vouches that nothing steps these envs right now
-        const size_t lead = slhip_goal_cache_lead_bytes(env);
-        if (!lead || !env->goal_cache) {
-            c->downgraded = "chained stepping needs the goal-word cache (plain batches of a shape that keeps one)";
-        } else if (hipMemset((unsigned char *)env->goal_cache - lead, 0, lead) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-            (void)hipGetLastError();
-            c->downgraded = "the chain counters could not be zeroed";
-        } else {
-            c->chained = true;
-        }
-    } else if (flags & SL_QUEUES_CHAINED) {
-        c->downgraded += c->downgraded.empty() ? "chained stepping rests on release-free stepping, which was not asked for"
-                                               : " (chained stepping rests on release-free stepping)";
-    }
     *handle = c;
     return SL_OK;
 }
@@ -838,7 +812,7 @@ int slhip_queues_mode(void *handle, const char **why_not) {
     StepQueues *c = (StepQueues *)handle;
     if (!c) return fail(SL_E_ARG, "null pointer");
     if (why_not) *why_not = c->downgraded.empty() ? nullptr : c->downgraded.c_str();
-    return (c->release_free ? SL_QUEUES_RELEASE_FREE : 0) | (c->chained ? SL_QUEUES_CHAINED : 0);
+    return c->release_free ? SL_QUEUES_RELEASE_FREE : 0;
 }
 
 int slhip_queues_selftest(void *handle, int what, int arg) {
@@ -901,7 +875,6 @@ int slhip_queues_steps(void *handle, const sl_env_batch *env, const int32_t *act
         memcpy(ps[i].args + ps[i].off_actions, &none, sizeof(void *));
         memcpy(ps[i].args + ps[i].off_out, &none, sizeof(void *));
         memcpy(ps[i].args + ps[i].off_next, &none, sizeof(void *));
-        if (c->chained && !ps[i].chain_ok) return fail(SL_E_UNSUPPORTED, "chained stepping: this batch's step kernel keeps no goal-word cache");
         if (c->last_bytes[i] != ps[i].arg_bytes || memcmp(c->last_args[i], ps[i].args, ps[i].arg_bytes)) {
             memcpy(c->last_args[i], ps[i].args, ps[i].arg_bytes);
             c->last_bytes[i] = ps[i].arg_bytes;
@@ -937,13 +910,9 @@ int slhip_queues_steps(void *handle, const sl_env_batch *env, const int32_t *act
             memcpy(p.args + p.off_actions, &a_t, sizeof(void *));
             memcpy(p.args + p.off_out, &o_t, sizeof(void *));
             memcpy(p.args + p.off_next, &env->pool_next, sizeof(void *));
-            const int expect[2] = {c->chained ? (int)c->chain_steps : -1, 0};
-            memcpy(p.args + p.off_expect, expect, sizeof(expect));
             const int queue = c->qmap[c->swap ? (int)((i + c->steps) % c->n_slices) : i];
-            // (chained: the first step of a call keeps the barrier bit -- one boundary per call orders it behind whatever
-            //  the call before left in flight, markers included)
-            const sl::AqlLaunch a{queue, head != 0 && t == 0, c->release_free, c->chained && t > 0 && !c->swap};
-            sl::AqlPatch patch{c->serial * 8u + (uint32_t)i, c->version[i], 4, {p.off_actions, p.off_out, p.off_next, p.off_expect}};
+            const sl::AqlLaunch a{queue, head != 0 && t == 0, c->release_free};
+            sl::AqlPatch patch{c->serial * 8u + (uint32_t)i, c->version[i], 3, {p.off_actions, p.off_out, p.off_next}};
 #ifdef SL_TRACE
             if (g_trace_base && g_trace_next < g_trace_slots) {
                 float *trace = (float *)(g_trace_base + g_trace_bytes * g_trace_next++);
@@ -955,7 +924,6 @@ int slhip_queues_steps(void *handle, const sl_env_batch *env, const int32_t *act
             if (err != hipSuccess) return hip_fail(err, "AQL dispatch");
         }
         ++c->steps;
-        ++c->chain_steps;
         // A flush of the argument ring (sfence + read-back) and the doorbells cost ~1.5 us; a step's four dispatches
         // ~1-3 us of host time, and the device needs the next step ~6 us after the last.  So the first steps go out one
         // by one (the device starts at once and is never left waiting while a batch is being written: with eight steps
@@ -971,10 +939,6 @@ int slhip_queues_step(void *handle, const sl_env_batch *env, const int32_t *acti
 }
 
 static int queues_flag(StepQueues *c) {
-    if (c->release_free && (*(volatile uint32_t *)c->flag & 2u))
-        return fail(SL_E_HIP, "queue stepping: a chained step waited for its predecessor in vain (another XCD, or dispatches of a "
-                              "queue launched out of order) -- the envs' state since the queues were opened is not valid; open "
-                              "the queues without SL_QUEUES_CHAINED");
     if (c->release_free && *(volatile uint32_t *)c->flag)
         return fail(SL_E_HIP, "queue stepping: envs were stepped by a workgroup on another XCD than the step before, so a step "
                               "without a release fence may have read stale state -- the envs' state since the queues were "

@@ -50,10 +50,8 @@ constexpr int MAX_QUEUES = 8;
 constexpr uint32_t QUEUE_PACKETS = 1024;
 constexpr size_t KARG_SLOT = 1024;              // bytes per argument block
 // Argument blocks per queue: a short ring.  A slot is written again only when the packet that used it last has
-// COMPLETED: the read index has passed a LATER packet that carries the barrier bit (such a packet is taken off the ring
-// only when everything in front of it has completed -- Queue::passed()).  Every step packet carries the bit, except
-// the chained ones (AqlLaunch::chained), of which every CHAIN_BARRIER_EVERY-th does; so the host runs at most
-// KARG_SLOTS - 2 dispatches ahead of a queue (KARG_SLOTS - CHAIN_BARRIER_EVERY - 1 when chained).  A slot that already holds the block of the same slice of
+// COMPLETED (the read index has passed the packet behind it: every step packet carries the barrier bit), so the host
+// runs at most KARG_SLOTS - 2 dispatches ahead of a queue.  A slot that already holds the block of the same slice of
 // the same batch (AqlPatch; aql_warm() writes it into every idle slot when a batch first steps) only has the words that
 // change from step to step sent across the PCIe aperture again: two pointers instead of ~600 bytes, i.e. 0.6 us of a
 // dispatch's 0.7 us of host time.
@@ -137,22 +135,7 @@ struct Queue {
         uint32_t owner = 0, version = 0;    // whose argument block it holds (AqlPatch), 0 = nobody's
     } slots[KARG_SLOTS];
     bool dirty = false;             // dispatched since the last marker
-    // packets with the barrier bit that may still be on the ring, oldest first; done_upto: every packet with a smaller
-    // index has completed (= the youngest barrier-bit packet the read index has passed)
-    uint64_t bars[QUEUE_PACKETS] = {};
-    uint64_t bar_head = 0, bar_tail = 0, done_upto = 0;
-    uint64_t since_barrier = 0;     // chained dispatches since the last packet with the barrier bit
-    void passed() {                 // (after read_seen has been refreshed)
-        while (bar_head < bar_tail && bars[bar_head % QUEUE_PACKETS] < read_seen) done_upto = bars[bar_head++ % QUEUE_PACKETS];
-    }
-    void barrier_at(uint64_t idx) {     // (claim() keeps fewer than QUEUE_PACKETS packets on the ring: entries of packets the
-        passed();                       //  read index has passed go first)
-        if (bar_tail - bar_head == QUEUE_PACKETS) done_upto = bars[bar_head++ % QUEUE_PACKETS];
-        bars[bar_tail++ % QUEUE_PACKETS] = idx;
-    }
-    bool slot_free(const Slot &sl) const { return !sl.used || sl.packet < done_upto; }
 };
-constexpr uint64_t CHAIN_BARRIER_EVERY = 16;
 
 // A marker: one barrier packet per queue (system-scope release, completion signal) behind everything dispatched so
 // far.  Issued without waiting; whoever needs the results waits for its signals (the stepping thread in
@@ -519,24 +502,11 @@ hipError_t emit(Device &d, const Hsa &h, int queue, hipFunction_t f, unsigned gr
     const unsigned si = (unsigned)(q.karg_next++ % KARG_SLOTS);
     Queue::Slot &sl = q.slots[si];
     unsigned char *slot = q.karg + si * KARG_SLOT;
-    if (!q.slot_free(sl)) {
-        q.read_seen = h.hsa_queue_load_read_index_scacquire(q.q);
-        q.passed();
-        if (!q.slot_free(sl)) {
-            // the slot's last dispatch may still be reading it: hand over what is pending (it may be that very packet)
-            // and wait until a barrier-bit packet BEHIND it has been taken off the ring
-            publish(d, h);
-            const auto t0 = std::chrono::steady_clock::now();
-            while (!q.slot_free(sl)) {
-                _mm_pause();
-                q.read_seen = h.hsa_queue_load_read_index_scacquire(q.q);
-                q.passed();
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) {
-                    d.poisoned = true;
-                    return hipErrorLaunchTimeOut;
-                }
-            }
-        }
+    if (sl.used && q.read_seen < sl.packet + 2 && (q.read_seen = h.hsa_queue_load_read_index_scacquire(q.q)) < sl.packet + 2) {
+        // the slot's last dispatch may still be reading it: hand over what is pending (it may be that very packet) and
+        // wait until the packet BEHIND it has been taken off the ring
+        publish(d, h);
+        while ((q.read_seen = h.hsa_queue_load_read_index_scacquire(q.q)) < sl.packet + 2) _mm_pause();
     }
     const size_t total = (k->kernarg + 63) & ~(size_t)63;
     if (patch && patch->owner && sl.owner == patch->owner && sl.version == patch->version) {
@@ -572,12 +542,6 @@ hipError_t emit(Device &d, const Hsa &h, int queue, hipFunction_t f, unsigned gr
     p->completion_signal = completion;
     const uint16_t setup = 3 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
     q.dirty = true;
-    if ((hd >> HSA_PACKET_HEADER_BARRIER) & 1) {
-        q.barrier_at(idx);
-        q.since_barrier = 0;
-    } else {
-        ++q.since_barrier;
-    }
     const uint32_t head_word = (uint32_t)hd | ((uint32_t)setup << 16);
     if (may_batch && d.batching) {
         if (d.n_pending == Device::MAX_PENDING) publish(d, h);
@@ -595,8 +559,6 @@ void barrier(Device &d, const Hsa &h, int queue, const hsa_signal_t *deps, int n
     Queue &q = d.queues[queue];
     uint64_t idx;
     hsa_barrier_and_packet_t *p = (hsa_barrier_and_packet_t *)claim(h, q, &idx);
-    q.barrier_at(idx);
-    q.since_barrier = 0;
     memset((unsigned char *)p + 4, 0, 60);
     for (int i = 0; i < n_deps && i < 5; ++i) p->dep_signal[i] = deps[i];
     p->completion_signal = completion;
@@ -617,12 +579,7 @@ hipError_t aql_dispatch(const AqlLaunch &a, hipFunction_t f, unsigned grid, unsi
     // workgroup i of this queue keeps its XCD, which every step verifies itself (sl_rowlane.hip: xcd_base / xcd_flag).
     // Otherwise agent scope on both sides, as a HIP stream.
     const int release = a.release_free ? HSA_FENCE_SCOPE_NONE : d->step_release;
-    // chained (opt-in on top of release-free): no barrier bit -- the step kernel's workgroups wait for their predecessors
-    // themselves (sl_rowlane.hip: ChainWait).  The first step after stream work and every CHAIN_BARRIER_EVERY-th
-    // dispatch of a queue keep the bit: the latter bounds how far completion lags behind the read index, which is what
-    // the argument ring's slots are recycled by.
-    const bool chained = a.chained && a.release_free && !a.head && d->queues[a.queue].since_barrier + 1 < CHAIN_BARRIER_EVERY;
-    const uint16_t hd = header(HSA_PACKET_TYPE_KERNEL_DISPATCH, !chained, a.head ? HSA_FENCE_SCOPE_SYSTEM : d->step_acquire, release);
+    const uint16_t hd = header(HSA_PACKET_TYPE_KERNEL_DISPATCH, true, a.head ? HSA_FENCE_SCOPE_SYSTEM : d->step_acquire, release);
     return emit(*d, h, a.queue, f, grid, threads, lds, args, arg_bytes, hd, hsa_signal_t{0}, true, patch);
 }
 
@@ -638,9 +595,7 @@ void aql_warm(int queue, hipFunction_t f, const void *args, size_t arg_bytes, co
     const uint64_t read = q.read_seen = h.hsa_queue_load_read_index_scacquire(q.q);
     for (size_t si = 0; si < KARG_SLOTS; ++si) {
         Queue::Slot &sl = q.slots[si];
-        (void)read;
-        q.passed();
-        if (!q.slot_free(sl)) continue;                         // still (possibly) being read: rewritten when its turn comes
+        if (sl.used && read < sl.packet + 2) continue;          // still (possibly) being read: rewritten when its turn comes
         if (sl.owner == patch.owner && sl.version == patch.version) continue;
         unsigned char *slot = q.karg + si * KARG_SLOT;
         memcpy(slot, args, arg_bytes);

@@ -67,8 +67,6 @@ struct AqlLaunch {
     bool head;              // first step after work of HIP streams: system-scope acquire
     bool release_free;      // opt-in: no release fence behind this step (valid while workgroup i of the slice's queue keeps
                             // its XCD: the kernel checks itself against the placement found when the queues were opened)
-    bool chained = false;   // opt-in on top of release_free: NO barrier bit -- the dispatch starts beside its predecessor and
-                            // its workgroups wait for theirs themselves (sl_rowlane.hip: ChainWait)
 };
 // A single-step launch of the fused kernel that is not issued but handed back: kernel handle, geometry and the packed
 // argument block with the offsets of the fields that change from step to step -- what the queues dispatch, any number
@@ -77,8 +75,7 @@ struct PreparedStep {
     hipFunction_t f;
     unsigned grid, threads, lds;
     size_t arg_bytes;
-    size_t off_actions, off_out, off_base, off_flag, off_trace, off_next, off_expect;
-    bool chain_ok;          // the kernel can run as a CHAINED dispatch (no barrier bit; it waits for its own predecessor)
+    size_t off_actions, off_out, off_base, off_flag, off_trace, off_next;
     alignas(16) unsigned char args[1024];
 };
 // prepared (optional, T == 1 only): fill it instead of launching
@@ -98,7 +95,7 @@ hipFunction_t rowlane_probe_function();             // any kernel of the library
 struct AqlPatch {
     uint32_t owner, version;
     int n;
-    size_t offset[5];
+    size_t offset[4];
 };
 hipError_t aql_dispatch(const AqlLaunch &a, hipFunction_t f, unsigned grid, unsigned threads, unsigned lds,
                         const void *args, size_t arg_bytes, const AqlPatch *patch = nullptr);

@@ -2593,18 +2593,13 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
                                                                                                        : Geom<H, W>::WAVES_PER_SIMD)) void k_env_rollout_rowlane(
     // the eight arguments the prologue needs before anything else come first: with
     // -amdgpu-kernarg-preload-count=8 they arrive in SGPRs with the wave instead of behind an s_load
-    const u16 *__restrict__ hot_board, const sl_pcg64 *__restrict__ hot_rng, sl_env_scalars *__restrict__ hot_scalars,
+    const u16 *__restrict__ hot_board, const u16 *__restrict__ hot_goals, const sl_pcg64 *__restrict__ hot_rng,
+    sl_env_scalars *__restrict__ hot_scalars,
     // the goal-word cache of the batch (GoalCache above), or null: its flag word is the kernel's first fetch
     u32 *__restrict__ hot_gcache,
     const int32_t *__restrict__ actions, int hot_first, int hot_end,
-    // CHAINED queue stepping (round 6, ChainWait below): >= 0 -- this dispatch carries NO barrier bit; the workgroup
-    // waits until the dispatch that stepped its boards last has stored them (its counter in front of the goal-word
-    // cache reads chain_expect x WAVES) and counts itself in at the end; -1 on every other launch
-    int chain_expect,
-    // (the preload ends here -- 13 SGPRs next to the kernarg pointer; the goal array's pointer left the set in round 6:
-    //  the plain single-step kernels fetch goal rows only on the rare launch without cached words.  The score table's
-    //  DMA is the last to be issued)
-    const u16 *__restrict__ hot_goals, const int8_t *__restrict__ hot_lut,
+    // (the preload ends here -- 14 SGPRs next to the kernarg pointer; the score table's DMA is the last to be issued)
+    const int8_t *__restrict__ hot_lut,
     // The batch constants travel by value.  (Measured alternative: the struct resident in device memory behind
     // a pointer -- ~100 bytes of arguments instead of ~700 -- is SLOWER, 12.1 vs 11.5 us per C3 step and 16.6 vs
     // 13.8 in the first steps after a reset: loads through a global pointer are not invariant for the compiler,
@@ -2701,48 +2696,6 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     // are in the cache.  Step launches only: a reset launch rewrites goals, an observation launch reads the image.
     // The flag is FETCHED here, first thing, and LOOKED AT where the goal span would be issued (gc_look below) -- behind
     // the record loads and the board's DMA instructions, so that its round trip runs under them.
-    // ---- ChainWait (round 6): chained queue stepping ---------------------------------------------------------------
-    // A dispatch WITHOUT the barrier bit starts while its queue's previous dispatch is still running: its workgroups
-    // take the CU slots the previous step's workgroups leave one by one, instead of waiting for the whole launch to
-    // drain and for the packet processor's boundary (~1.4 us per step and slice; and a workgroup that reloads a level
-    // holds up its own successor only, not its slice).  What orders step t + 1 behind step t is then per WORKGROUP: the
-    // boards of workgroup i are touched by workgroup i of every dispatch and by nobody else, a queue launches its
-    // dispatches' workgroups in order, and each wave of workgroup i counts itself in -- behind the acknowledgement of
-    // everything it stored -- on a counter of the workgroup's own (128 bytes apart, IN FRONT of the goal-word cache:
-    // zeroing the cache leaves it alone).  Workgroup i of the dispatch the host numbered chain_expect waits here, before
-    // its first fetch of anything a step writes, until chain_expect x WAVES waves have counted in.  Release-free stepping only (the data
-    // is found in the L2 of the XCD both workgroups run on, verified below as before).  A wait that does not end raises
-    // the host-visible word with bit 1 -- the run is invalid and says so -- instead of hanging the queue.
-#ifndef SL_CHAIN_SPINS
-#define SL_CHAIN_SPINS (1 << 18)
-#endif
-    // No cache action follows the wait.  What the predecessor stored sits in the XCD's L2; the vector L1 of this CU could
-    // only hold older copies of these lines if a workgroup read them here after this packet's own acquire (which ran
-    // before any workgroup of this dispatch was launched): that can only be the predecessor itself, and a CU's L1 follows
-    // the stores of its own waves.  (A wave-level buffer_inv sc1 costs 1.7-6.5 us on a loaded CU, MI355X_MICROARCH.md:
-    // more than the boundary this mode removes.  SL_CHAIN_INV=1 builds it in for A/B runs.)
-#ifndef SL_CHAIN_INV
-#define SL_CHAIN_INV 0
-#endif
-    SL_STAMP(0);
-    constexpr bool CHAIN = GCACHE;
-    auto chain_counter = [&]() -> u32 * {
-        return hot_gcache - 32 * (size_t)((unsigned)hot_first / Gm::NB + blockIdx.x + 1);
-    };
-    if (CHAIN && chain_expect >= 0) {
-        const u32 need = (u32)chain_expect * (u32)WAVES;
-        const u32 *ctr = chain_counter();
-        int spins = 0;
-        while ((int)(__builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - need) < 0) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > SL_CHAIN_SPINS) {
-                if (xcd_flag && lane == 0) __hip_atomic_fetch_or(xcd_flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                break;
-            }
-        }
-        if (SL_CHAIN_INV) asm volatile("buffer_inv sc1" ::: "memory");
-    }
-    SL_STAMP(13);
     u32 gc_word = 0;
     if (GCACHE && gc_flag && T > 0) gc_word = *(const u32 *)gc_flag;
     bool goals_free = false;
@@ -2770,6 +2723,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     const pl::PConsts pcst = pl::make_pconsts();
     const u32 cell_mask = vreg(LDS_LUT ? (SCORE_CELL_MASK & 0x7FFF7FFFu) : SCORE_CELL_MASK), c100 = vreg(0x01000100u);
 
+    SL_STAMP(0);
     // Prologue.  The kernel arguments the loads need are fetched in one batch (the compiler otherwise sinks each
     // s_load next to its first use: dependent scalar-cache round trips in a row).
     const u16 *k_board = hot_board, *k_goals = hot_goals;
@@ -2910,7 +2864,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     // the same comparison in FRONT of the loads cost a scalar-cache round trip before the first DMA instruction).
     if (xcd_flag && wave == 1 && (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u) != (((u32)xcd_base + blockIdx.x) & 7u) &&
         lane == 0)
-        __hip_atomic_fetch_or(xcd_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(xcd_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 
     RowWords<H, W> b;
     Elig elig;
@@ -3474,11 +3428,6 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
                 ((const u64 *)(smem_hi + OFF_INB + Gm::REGION) + 4 * Gm::G * wave2)[lane2];
     }
 
-    if (CHAIN && chain_expect >= 0) {
-        // ChainWait: this wave's stores are acknowledged (in the L2 its successor reads them from) -> count it in
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane2 == 0) __hip_atomic_fetch_add(chain_counter(), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     SL_STAMP(9);
 #ifdef SL_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -3648,14 +3597,12 @@ hipError_t launch_occupancy_t(const u16 *in, int32_t *counts, size_t counts_stri
 // library's own queues write it into their argument ring as it is.  Mirrors the kernel's parameter list (natural
 // alignment == the kernel-argument layout).
 struct RolloutArgs {
-    const u16 *board;
+    const u16 *board, *goals;
     const sl_pcg64 *rng;
     sl_env_scalars *scalars;
     u32 *gcache;
     const int32_t *actions;
     int first, end;
-    int chain_expect, pad0;
-    const u16 *goals;
     const int8_t *lut;
     sl_env_batch env;
     int E, tstride, T;
@@ -3677,8 +3624,8 @@ hipError_t pick_rollout_t(const sl_env_batch &env, int T, void **kernel, hipFunc
     using Gm = Geom<H, W>;
     const bool lean = !env.wrap.flags && !env.obs && !env.policy_obs && (env.finished.capacity == 0 || Gm::WAVES_PER_SIMD < 4);
     const int variant = (env.n_tables == 1 ? 1 : 0) | (env.spawner_free ? 2 : 0) | (env.wrap.flags ? 4 : (lean ? 8 : 0));
-    typedef void (*kernel_t)(const u16 *, const sl_pcg64 *, sl_env_scalars *, u32 *, const int32_t *, int, int, int,
-                             const u16 *, const int8_t *, sl_env_batch, int, int, int, sl_step_out *, float *,
+    typedef void (*kernel_t)(const u16 *, const u16 *, const sl_pcg64 *, sl_env_scalars *, u32 *,
+                             const int32_t *, int, int, const int8_t *, sl_env_batch, int, int, int, sl_step_out *, float *,
                              uint8_t *, double *, const Jump *, int, u32 *, const uint8_t *);
 #define SL_VARIANTS(ONE)                                                                                               \
     k_env_rollout_rowlane<H, W, false, true, false, false, ONE>, k_env_rollout_rowlane<H, W, true, true, false, false, ONE>,   \
@@ -3763,9 +3710,8 @@ hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, c
             return hipErrorNotSupported;        // (a prepared launch off the blocks' grid: the queues' slices never are)
         }
     }
-    RolloutArgs args = {env.board, env.rng, env.scalars, gcache, actions, e_first, e_first + e_count, -1, 0, env.goals,
-                        env.score_lut, env, env.E, tstride, T, env.out, reward_t, done_t, env.wrap.shaped_reward_t, jump, 0,
-                        nullptr, reset_mask};
+    RolloutArgs args = {env.board, env.goals, env.rng, env.scalars, gcache, actions, e_first, e_first + e_count, env.score_lut, env,
+                        env.E, tstride, T, env.out, reward_t, done_t, env.wrap.shaped_reward_t, jump, 0, nullptr, reset_mask};
     if (prepared) {
         // not launched: the argument block and the launch geometry, for the library's own queues (sl_aql.hip) to
         // dispatch any number of times with the per-step fields patched in
@@ -3782,9 +3728,6 @@ hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, c
         prepared->off_flag = offsetof(RolloutArgs, xcd_flag);
         prepared->off_trace = offsetof(RolloutArgs, reward_t);
         prepared->off_next = offsetof(RolloutArgs, env) + offsetof(sl_env_batch, pool_next);
-        static_assert(offsetof(RolloutArgs, chain_expect) % 8 == 0, "patched as an 8-byte word");
-        prepared->off_expect = offsetof(RolloutArgs, chain_expect);
-        prepared->chain_ok = gcache != nullptr;     // (the kernels that keep a goal-word cache are the ones that can wait)
         return hipSuccess;
     }
     if (f) {
@@ -3792,8 +3735,8 @@ hipError_t launch_rollout_t(const sl_env_batch &env, int e_first, int e_count, c
         void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
         return hipModuleLaunchKernel(f, grid, 1, 1, threads, 1, 1, (unsigned)lds, stream, nullptr, extra);
     }
-    void *params[] = {&args.board, &args.rng, &args.scalars, &args.gcache, &args.actions, &args.first, &args.end,
-                      &args.chain_expect, &args.goals, &args.lut, &args.env, &args.E, &args.tstride, &args.T, &args.out, &args.reward_t, &args.done_t, &args.shaped_t,
+    void *params[] = {&args.board, &args.goals, &args.rng, &args.scalars, &args.gcache, &args.actions, &args.first, &args.end,
+                      &args.lut, &args.env, &args.E, &args.tstride, &args.T, &args.out, &args.reward_t, &args.done_t, &args.shaped_t,
                       &args.jump, &args.xcd_base, &args.xcd_flag, &args.reset_mask};
     return hipLaunchKernel(kernel, dim3(grid), dim3(threads), params, (size_t)lds, stream);
 }

@@ -322,14 +322,9 @@ class SafeLifeVectorEnv(object):
             group = C.c_int(0)
             total = int(self._lib.slhip_goal_cache_bytes(self._sref, C.byref(group)))
             if total > 0:
-                # (in front of the cache: the workgroups' counters of chained queue stepping, SL_QUEUES_CHAINED -- one
-                #  allocation, the cache a view behind them, so that zeroing the cache leaves the counters alone)
-                lead = int(self._lib.slhip_goal_cache_lead_bytes(self._sref)) if hasattr(self._lib, "slhip_goal_cache_lead_bytes") else 0
-                self._goal_cache_raw = torch.zeros((lead + total) // 4, dtype=torch.int32, device=dev)
-                t["goal_cache"] = self._goal_cache_raw[lead // 4:]
+                t["goal_cache"] = torch.zeros(total // 4, dtype=torch.int32, device=dev)
                 s.goal_cache = t["goal_cache"].data_ptr()
                 self.goal_cache_group = int(group.value)
-                self.goal_cache_lead = lead
 
     @staticmethod
     def _level_scalars(pa, sel):
@@ -662,7 +657,7 @@ class SafeLifeVectorEnv(object):
     _CKPT_NAMES = ("board", "goals", "rng", "scalars", "exit_locs", "out", "wrap_state", "inaction_board", "inaction_rng",
                    "shaped_reward")
 
-    def queues_open(self, slices=None, release_free=None, queue_ids=None, recover=True, chained=None):
+    def queues_open(self, slices=None, release_free=None, queue_ids=None, recover=True):
         """Open one AQL queue per slice (default: SAFELIFE_QUEUE_SLICES or 4).  Raises SafeLifeHipError when the
         batch or the runtime does not support it -- callers keep to step_async() then.
 
@@ -673,11 +668,6 @@ class SafeLifeVectorEnv(object):
         (include/safelife_hip.h, SL_QUEUES_RELEASE_FREE) -- ~0.9 us faster per C3 step, valid only while a workgroup
         index keeps its XCD; the library probes that when the queues are opened (``queue_release_free`` tells whether
         it was granted, ``queue_mode_note`` why not) and every step verifies it.  The default keeps a stream's fences.
-
-        ``chained`` (default: True only if SAFELIFE_QUEUE_CHAINED=1; release-free stepping only, plain batches that
-        keep a goal-word cache): OPT-IN to steps without the barrier bit as well (SL_QUEUES_CHAINED) -- a step starts
-        while the one before is still running and every workgroup waits for its own predecessor; ``queue_chained`` tells
-        whether it was granted.  A wait that does not end is reported like a misplacement (and recovered from likewise).
 
         ``recover`` (release-free stepping only): the env keeps a device-side copy of its state as of the last
         successful ``queues_sync()`` (one asynchronous copy per sync: 21 MB at C3) and a log of the step calls since.
@@ -699,23 +689,15 @@ class SafeLifeVectorEnv(object):
         bounds = [min(B, i * per) for i in range(n)] + [B]
         if release_free is None:
             release_free = os.environ.get("SAFELIFE_QUEUE_FENCES", "agent") == "none"
-        if chained is None:
-            chained = os.environ.get("SAFELIFE_QUEUE_CHAINED", "0") == "1"
-        chained = bool(chained and release_free and self.goal_cache_group and getattr(self, "goal_cache_lead", 0))
-        if chained:
-            self._settle()
-            self.torch.cuda.synchronize(self.device)        # (open zeroes the workgroups' counters: nothing may be stepping)
         handle = C.c_void_p()
         ids = (C.c_int32 * n)(*[int(q) for q in queue_ids[:n]]) if queue_ids is not None else None
         _hip.check(self._lib.slhip_queues_open_on(self._sref, n, (C.c_int32 * (n + 1))(*bounds), ids,
-                                                  (_hip.QUEUES_RELEASE_FREE if release_free else 0) |
-                                                  (_hip.QUEUES_CHAINED if chained else 0), C.byref(handle)))
+                                                  _hip.QUEUES_RELEASE_FREE if release_free else 0, C.byref(handle)))
         self.queue_ids = list(queue_ids[:n]) if queue_ids is not None else list(range(n))
         why = C.c_char_p()
         mode = self._lib.slhip_queues_mode(handle, C.byref(why))
         self._queues, self.queue_slices = handle, n
         self.queue_release_free = bool(mode & _hip.QUEUES_RELEASE_FREE)
-        self.queue_chained = bool(mode & _hip.QUEUES_CHAINED)
         self.queue_mode_note = why.value.decode() if why.value else None
         if release_free and not self.queue_release_free:
             import warnings
@@ -856,7 +838,7 @@ class SafeLifeVectorEnv(object):
             try:
                 _hip.check(self._lib.slhip_queues_sync(self._queues))
             except _hip.SafeLifeHipError as e:
-                if not (self._rf_recover and ("another XCD" in str(e) or "in vain" in str(e))):
+                if not (self._rf_recover and "another XCD" in str(e)):
                     raise
                 self._rf_recover_now(str(e))
                 return

@@ -1004,19 +1004,17 @@ def test_sliced_stepping_soak(pool_name, B):
                 assert np.array_equal(env.numpy(name), ref), (trial, n, name)
 
 
-def _queues_or_skip(env, slices=None, release_free=False, queue_ids=None, recover=True, chained=False):
+def _queues_or_skip(env, slices=None, release_free=False, queue_ids=None, recover=True):
     from safelife_amd._hip import SafeLifeHipError
     try:
-        env.queues_open(slices, release_free=release_free, queue_ids=queue_ids, recover=recover, chained=chained)
+        env.queues_open(slices, release_free=release_free, queue_ids=queue_ids, recover=recover)
     except SafeLifeHipError as e:           # no HSA queue to be had (not an MI355X box as the driver's): say why
         pytest.skip("AQL queues unavailable: %s" % e)
     if release_free and not env.queue_release_free:
         pytest.skip("release-free stepping not granted on this box: %s" % env.queue_mode_note)
-    if chained and not env.queue_chained:
-        pytest.skip("chained stepping is for plain batches that keep a goal-word cache (%s)" % env.queue_mode_note)
 
 
-@pytest.mark.parametrize("release_free", [False, True, "chained"], ids=["agent-fences", "release-free", "chained"])
+@pytest.mark.parametrize("release_free", [False, True], ids=["agent-fences", "release-free"])
 @pytest.mark.parametrize("pool_name,B,queue_slices,kw", [
     ("prune_still_25", 700, 1, dict(time_limit=12, view_shape=(9, 9))),
     ("append_spawn_25", 1500, 4, dict(time_limit=20, view_shape=(25, 25), output_channels=tuple(range(15)))),
@@ -1040,14 +1038,12 @@ def test_queue_stepping_vs_oracle(pool_name, B, queue_slices, kw, release_free):
     dev = util.DeviceBackend(pool, B, **common)
     cpu = util.OracleBackend(pool, B, **common)
     env = dev.env
-    chained = release_free == "chained"         # (round 6: no barrier bit either, every workgroup waits for its own predecessor)
-    release_free = bool(release_free)
     if isinstance(queue_slices, tuple):
-        _queues_or_skip(env, None, release_free, queue_ids=list(queue_slices), chained=chained)
+        _queues_or_skip(env, None, release_free, queue_ids=list(queue_slices))
         assert env.queue_ids == list(queue_slices) and env.queue_slices == len(queue_slices)
     else:
-        _queues_or_skip(env, queue_slices, release_free, chained=chained)
-    assert env.queue_release_free == release_free and env.queue_chained == chained
+        _queues_or_skip(env, queue_slices, release_free)
+    assert env.queue_release_free == release_free
     dev.env.reset()
     cpu.env.reset()
     rng = np.random.default_rng(31)

@@ -2,7 +2,7 @@
 bracketed exactly like bench.py's region (device idle, one library call, torch.cuda.synchronize + queues_sync), for
 K = 1 .. 400, median of `reps` repetitions each; least-squares line  elapsed = fixed + per_step * K  over the K's.
 
-    python tools/exp/kfit.py [spread=0|1] [fences=none|agent] [reps] [chained=0|1] [queues]
+    python tools/exp/kfit.py [spread=0|1] [fences=none|agent] [reps] [queues]
 
 SAFELIFE_HIP_LIB=<other .so> runs the same against another build (A/B)."""
 import os, sys, time
@@ -18,8 +18,7 @@ from safelife_amd.vector_env import SafeLifeVectorEnv
 spread = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 fences = sys.argv[2] if len(sys.argv) > 2 else "none"
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 7
-chained = bool(int(sys.argv[4])) if len(sys.argv) > 4 else False
-nq = int(sys.argv[5]) if len(sys.argv) > 5 else 4
+nq = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 B = 8192
 pool = bench.load_pool("prune_still_25", _device_counts)
 env = SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25), output_channels=bench.TRAIN_CHANNELS, auto_reset=True,
@@ -29,8 +28,8 @@ dev = env.device
 if spread:
     env.t["scalars"][:, _hip.SCALAR_COLS["num_steps"]] = (torch.arange(B, device=dev, dtype=torch.int32) * 997) % 1000
 acts = torch.randint(0, 9, (440, B), device=dev, dtype=torch.int32)
-env.queues_open(nq, release_free=(fences == "none"), recover=False, chained=chained)
-print("queues %d release_free %s chained %s (%s)" % (env.queue_slices, env.queue_release_free, env.queue_chained, env.queue_mode_note))
+env.queues_open(nq, release_free=(fences == "none"), recover=False)
+print("queues %d release_free %s (%s)" % (env.queue_slices, env.queue_release_free, env.queue_mode_note))
 env.step_queues_many(acts[:40]); env.queues_sync(); torch.cuda.synchronize()
 Ks = (1, 2, 5, 10, 20, 50, 100, 400)
 med = {}
@@ -54,6 +53,6 @@ for K in Ks:
 x = np.array(Ks, float); y = np.array([med[K][0] for K in Ks])
 A = np.stack([np.ones_like(x), x], 1)
 (fixed, per), *_ = np.linalg.lstsq(A, y, rcond=None)
-print("%s spread=%d fences=%s chained=%d queues=%d: elapsed = %.1f us + %.3f us x K   (K=20 -> %.2f us/step)" % (
-    os.path.basename(os.environ.get("SAFELIFE_HIP_LIB", "tree")), spread, fences, int(env.queue_chained), env.queue_slices, fixed, per,
+print("%s spread=%d fences=%s queues=%d: elapsed = %.1f us + %.3f us x K   (K=20 -> %.2f us/step)" % (
+    os.path.basename(os.environ.get("SAFELIFE_HIP_LIB", "tree")), spread, fences, env.queue_slices, fixed, per,
     (fixed + 20 * per) / 20))

@@ -27,7 +27,6 @@ ap = argparse.ArgumentParser()
 ap.add_argument("steps", nargs="?", type=int, default=6)
 ap.add_argument("--queues", type=int, default=0)
 ap.add_argument("--fences", default="agent")
-ap.add_argument("--chained", type=int, default=0, help="queue mode, fences none: SL_QUEUES_CHAINED (no barrier bit between steps)")
 ap.add_argument("--spread", type=int, default=0, help="1: envs spread over their episodes (resets at every step)")
 ap.add_argument("--gather-every", type=int, default=0,
                 help="queue mode: hand a window of this many steps to the RCCL exchange (one rank, to itself) inside the trace")
@@ -41,8 +40,8 @@ env.reset()
 if args.spread:
     env.t["scalars"][:, _hip.SCALAR_COLS["num_steps"]] = (torch.arange(B, device=env.device, dtype=torch.int32) * 997) % 1000
 if args.queues:
-    env.queues_open(args.queues, release_free=(args.fences == "none"), chained=bool(args.chained), recover=False)
-    print("AQL queues: %d, release-free: %s, chained: %s" % (env.queue_slices, env.queue_release_free, env.queue_chained))
+    env.queues_open(args.queues, release_free=(args.fences == "none"))
+    print("AQL queues: %d, release-free: %s" % (env.queue_slices, env.queue_release_free))
 acts = torch.randint(0, 9, (64 + N, B), device=env.device, dtype=torch.int32)
 ptrs = [acts[t].data_ptr() for t in range(64 + N)]      # (addresses: the loop below is all the host does per step)
 step = env.step_queues if args.queues else env.step_async
@@ -111,11 +110,9 @@ for i, n in enumerate(names):
 life = (st[:, :, 10] - st[:, :, 0]).reshape(-1)
 print("  %-24s %6.0f %6.0f %6.0f" % ("wave lifetime", life.mean(), np.percentile(life, 50), np.percentile(life, 90)))
 
-# chained stepping: the wait for the workgroup's predecessor (stamp 13 - stamp 0), and what a CU slot does between two
-# workgroups: a wave's start against the end (stores acknowledged) of the same wave index of the same slice one step earlier
-wait = (tr[2 * SL:, :, 13] - tr[2 * SL:, :, 0]).astype(np.float64).reshape(-1) * 10.0
-print("  %-24s %6.0f %6.0f %6.0f   (inside 'loads issued')" % ("chain wait", wait.mean(), np.percentile(wait, 50), np.percentile(wait, 90)))
-succ = (tr[3 * SL:, :, 0] - tr[2 * SL:-SL, :, 10]).astype(np.float64).reshape(-1) * 10.0      # (same workgroup: same XCD, same clock)
+# what a workgroup's CU slot does between two steps: a wave's start against the end (stores acknowledged) of the same wave
+# of the same slice one step earlier (same workgroup: same XCD, same clock)
+succ = (tr[3 * SL:, :, 0] - tr[2 * SL:-SL, :, 10]).astype(np.float64).reshape(-1) * 10.0
 print("  %-24s %6.0f %6.0f %6.0f   (same workgroup, one step earlier: its stores acknowledged -> this wave's start)"
       % ("successor starts after", succ.mean(), np.percentile(succ, 50), np.percentile(succ, 90)))
 cyc = (tr[3 * SL:, :, 0] - tr[2 * SL:-SL, :, 0]).astype(np.float64).reshape(-1) * 10.0
