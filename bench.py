@@ -282,6 +282,11 @@ def main():
                     help="1 (default): the timed region starts with the envs spread evenly over their 1000-step episodes, so "
                          "that ~envs/1000 episodes end -- and reset inside the kernel -- at every step (SURVEY 8d); 0: straight "
                          "behind a reset of all envs (no episode end within the first 1000 steps: rounds 1-5's region)")
+    ap.add_argument("--stage", type=int, default=int(os.environ.get("SAFELIFE_BENCH_STAGE", "1")),
+                    help="queue stepping on one GPU: 1 = the timed steps (up to 48 of them) are STAGED before the clock starts -- "
+                         "argument blocks and packets written, nothing handed to the device (slhip_queues_stage) -- and the timed "
+                         "region opens with slhip_queues_go (one doorbell per queue), as a captured hipGraph would be launched; "
+                         "0 = everything is enqueued inside the region (roofline.unstaged_us either way)")
     ap.add_argument("--stream-leg", type=int, default=1,
                     help="queue stepping only: 1 = also run K steps of the same kernel through the stream slices under HIP "
                          "events (roofline.stream_leg_*); 0 = leave it out (profiling runs: only the queues' launches in the trace)")
@@ -357,14 +362,14 @@ def main():
 
     queue_ids = [None]
 
-    def attempt(fences, gather=gather, P=P, shift=shift, spread=bool(args.spread), K=K, W=W):
+    def attempt(fences, gather=gather, P=P, shift=shift, spread=bool(args.spread), K=K, W=W, stage=bool(args.stage)):
         """Reset, P checkpointed steps, W warm-up steps, the K timed steps.  Returns the measurements, or None when
         release-free queue stepping was refused by its placement check on ANY rank (the caller repeats with 'agent').
-        (`gather`, `P`, `shift`, `spread`, `K`, `W`: the variants reported in `roofline` repeat the region
+        (`gather`, `P`, `shift`, `spread`, `K`, `W`, `stage`: the variants reported in `roofline` repeat the region
         with another exchange, regime or length, without checkpoints.)"""
         every = gather.every
         res = {"use_queues": False, "queues_why": "switched off", "fences": None, "queue_slices": None,
-               "queue_ids": None, "spread": spread, "K": K, "W": W}
+               "queue_ids": None, "spread": spread, "K": K, "W": W, "staged": 0}
         env.queues_close()
         env.reset()
         if spread:
@@ -421,7 +426,9 @@ def main():
                 # thread is out of the loop (slhip_queues_steps).  ordered: the device has just been synchronised and
                 # no stream holds work on the envs (the warm-up and the timed region); the checkpointed steps are
                 # not -- their snapshots are still being copied on a stream -- and wait for the device themselves
-                gather.run_queued(t0, n, act_ptr[t0], B, shift, assume_ordered=ordered)
+                # ("untouched": between the sync that closed the steps before and this call nothing has written the envs,
+                #  these actions or the outputs -- the first step needs no more of an acquire than any other)
+                gather.run_queued(t0, n, act_ptr[t0], B, shift, assume_ordered="untouched" if ordered else False)
                 return
             if not gather.collective:        # one rank: records stay in the env's own tensor, no windows to rotate
                 for t in range(t0, t0 + n):
@@ -466,8 +473,19 @@ def main():
         if not use_queues:
             evs[0][0].record(streams[0])
         windows0, exposed0 = gather.windows, gather.exposed_s
+        # One GPU, queue stepping: the region's steps are STAGED before the clock starts (argument blocks and packets
+        # written, nothing handed over: slhip_queues_stage) and the region opens with slhip_queues_go -- host-side
+        # encoding ahead of time, every step's execution inside the bracket (a captured graph's instantiate / launch)
+        staged = 0
+        if stage and use_queues and not gather.collective and hasattr(env, "queues_go"):
+            staged = min(K, _hip.QUEUES_STAGE_MAX)
+            env.step_queues_many(act_ptr[P + W], staged, B, assume_ordered="untouched", defer=True)
+        res["staged"] = staged
         t_start = time.perf_counter()
-        run(P + W, K)
+        if staged:
+            env.queues_go()
+        if K > staged:
+            run(P + W + staged, K - staged)
         t_enqueued = time.perf_counter()
         if not use_queues:
             evs[0][1].record(streams[0])
@@ -588,6 +606,8 @@ def main():
             extra["queue_fences_agent_us_per_step"] = variants["agent_fences_us"]
             variants["no_reset_us" if res["spread"] else "steady_state_us"] = median_us(spread=not res["spread"])
             variants["k400_us"] = median_us(K=400, W=40)
+            if res["staged"]:
+                variants["unstaged_us"] = median_us(stage=False)
             variants["k20_median_us"] = median_us(n=5)
             env.queues_close()
             g2 = RewardGather(env, every=gather_window(args.gather_every, K), world=1, rank=0, force=True)
@@ -1155,6 +1175,10 @@ def main():
                        "queue_ids_note": ("the step queue RCCL's exchange kernel would hold up is left out (probed: "
                                           "slhip_gather_stream_shares)" if (use_queues and gather.collective and
                                                                             len(res["queue_ids"]) == 3) else None),
+                       "staged_steps": ("%d of the %d timed steps were staged before the clock started (slhip_queues_stage: argument "
+                                        "blocks and packets written, nothing handed to the device) and released inside the region "
+                                        "by slhip_queues_go; all %d steps execute inside the region" % (res["staged"], K, K)
+                                        if res["staged"] else 0) if use_queues else None,
                        "episode_phase": ("spread: env e starts (e x 997) mod 1000 steps into its first episode -- about %d "
                                          "episodes end and reset inside the kernel at every timed step (SURVEY 8d)" % (B // 1000)
                                          if res["spread"] else "all envs straight behind a reset: no episode end in the region"),
@@ -1192,10 +1216,11 @@ def main():
                          #   no_reset_us       the region straight behind a reset of all envs: no episode end inside it
                          #                     (rounds 1-5's region; steady_state_us is its counterpart with --spread 0)
                          #   k400_us           the same region 400 steps long (what a 20-step region's fixed cost hides)
+                         #   unstaged_us       the same region with every step enqueued INSIDE it (config.staged_steps = 0)
                          #   k20_median_us     this line's own region again, median of five
                          #   forced_gather_us  one rank with the RCCL exchange forced on (what every N > 1 rank runs)
                          #   c5_with_side_effects_us  C5's per-GPU share with the episode-end pass in the region (queues)
-                         **{k: variants.get(k) for k in ("agent_fences_us", "no_reset_us", "steady_state_us", "k400_us",
+                         **{k: variants.get(k) for k in ("agent_fences_us", "no_reset_us", "steady_state_us", "k400_us", "unstaged_us",
                                                          "k20_median_us", "forced_gather_us", "c5_with_side_effects_us",
                                                          "c5_with_side_effects_streams_us", "life_occupancy_64x64_board_steps_per_s")},
                          "scaling_curve": "not measured by this build (no multi-GPU node was available to it): the 1-to-N curve "

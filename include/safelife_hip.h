@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SL_ABI_VERSION 12       /* 12: slhip_pool_write; 11: sl_env_batch.goal_cache, slhip_goal_cache_bytes; 10: slhip_queues_open_on, slhip_queues_stream_shares, slhip_gather_stream_shares, slhip_gather_poke */
+#define SL_ABI_VERSION 13       /* 13: slhip_queues_stage / slhip_queues_go, sl_env_batch.pool_ready, sl_level_scalars.ready; 12: slhip_pool_write; 11: sl_env_batch.goal_cache, slhip_goal_cache_bytes; 10: slhip_queues_open_on, slhip_queues_stream_shares, slhip_gather_stream_shares, slhip_gather_poke */
 #define SL_MAX_CELLS 16384        /* H*W limit of one board */
 #define SL_MAX_CHANNELS 32
 
@@ -134,7 +134,10 @@ typedef struct sl_level_scalars {
     int32_t initial_points;
     int32_t table_idx;
     float spawn_prob;
-    int32_t reserved;
+    int32_t ready;                /* written by the library where sl_env_batch.pool_ready is kept (round 6), else unused:
+                                     (old_value << 1) | exit_open -- what SafeLifeEnv.reset() computes on this level
+                                     (safelife_env.py:203-218: the score of the fresh board + the exit bonus if the agent
+                                     stands on an open exit; whether update_exit_colors opened the exits) */
 } sl_level_scalars;
 
 /* Training-wrapper math of safelife/env_wrappers.py, applied per env inside the step in the order
@@ -284,11 +287,19 @@ typedef struct sl_env_batch {
                                     The kernels that keep it hold no goal image in LDS at all: WITHOUT the workspace
                                     (NULL) they fetch every lane's goal row from global memory at every step -- correct,
                                     and slower; give such batches their cache */
+    uint16_t *pool_ready;        /* optional workspace [L,H,W] (round 6): every pool level as an episode STARTS on it --
+                                    pool_board after the reset's update_exit_colors (safelife_game.py:537-552) -- kept by
+                                    slhip_env_prepare() and slhip_pool_write() together with pool_scalars[l].ready.
+                                    What a reset computes on a level depends on the level alone, so an env whose episode
+                                    ends inside a step kernel COPIES its next level from here instead of scoring and
+                                    repainting it (one pass over the board, the leaders' exit walk and a workgroup
+                                    barrier less on the chain of the one workgroup its whole launch waits for).
+                                    NULL: the step kernels work it out at every reset, as before */
     sl_wrappers wrap;            /* training wrappers; wrap.flags == 0 => none */
     sl_episode_queue finished;   /* episodes that ended, for the side-effect pass; finished.capacity == 0 => none */
 } sl_env_batch;
 
-/* Derive env->score_lut from env->points_table, and env->wrap.pool_baseline from the level pool
+/* Derive env->score_lut from env->points_table, and env->wrap.pool_baseline / env->pool_ready from the level pool
  * (call once, and again whenever points_table or the pool changes).
  * Synchronises the stream.  Returns SL_E_UNSUPPORTED when a table entry does not fit int8; the
  * caller then passes score_lut = NULL and every shape runs on the size-generic kernels. */
@@ -422,6 +433,15 @@ int slhip_queues_mode(void *handle, const char **why_not);
 int slhip_queues_steps(void *handle, const sl_env_batch *env, const int32_t *actions, long long action_stride,
                        long long out_stride, int n_steps, int head);
 int slhip_queues_step(void *handle, const sl_env_batch *env, const int32_t *actions, int head);
+/* steps() split in two (round 6): stage() writes the argument blocks and packets of all n_steps (<= SL_QUEUES_STAGE_MAX)
+ * WITHOUT handing anything to the device; go() makes them valid and rings one doorbell per queue.  The action buffers must
+ * exist when the region is staged, their contents when it goes -- a caller stages the next region while it still waits
+ * for the last one's results, and starts it with a few hundred nanoseconds of host work.  Nothing else is dispatched on
+ * the handle in between (a marker or a steps() call hands the staged packets over early: harmless, just not deferred). */
+#define SL_QUEUES_STAGE_MAX 48
+int slhip_queues_stage(void *handle, const sl_env_batch *env, const int32_t *actions, long long action_stride,
+                       long long out_stride, int n_steps, int head);
+int slhip_queues_go(void *handle);
 int slhip_queues_marker(void *handle, long long *ticket);
 int slhip_queues_wait(void *handle, long long ticket);
 int slhip_queues_sync(void *handle);

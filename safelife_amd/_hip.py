@@ -27,10 +27,11 @@ EXPORTS = (
     "slhip_gather_unique_id", "slhip_gather_init", "slhip_gather_window", "slhip_gather_destroy",
     "slhip_gather_window_async", "slhip_gather_done", "slhip_gather_wait_streams",
     "slhip_gather_window_queued",
-    "slhip_queues_open", "slhip_queues_open_on", "slhip_queues_stream_shares", "slhip_gather_stream_shares", "slhip_gather_poke", "slhip_queues_mode", "slhip_queues_steps", "slhip_queues_step", "slhip_queues_marker",
+    "slhip_queues_open", "slhip_queues_open_on", "slhip_queues_stream_shares", "slhip_gather_stream_shares", "slhip_gather_poke", "slhip_queues_mode", "slhip_queues_steps", "slhip_queues_step", "slhip_queues_stage", "slhip_queues_go", "slhip_queues_marker",
     "slhip_queues_wait", "slhip_queues_sync", "slhip_queues_close", "slhip_queues_selftest",
 )
 QUEUES_RELEASE_FREE = 1
+QUEUES_STAGE_MAX = 48
 QUEUES_SELFTEST_PLANT, QUEUES_SELFTEST_SWAP = 1, 2
 SL_GATHER_ID_BYTES = 128
 SL_SE_MAX_KEYS = 24
@@ -54,7 +55,7 @@ ENV_STATE_PTRS = ("board", "goals", "exit_locs", "rng", "scalars", "points_table
 ENV_POOL_PTRS = ("pool_board", "pool_goals", "pool_exit_locs", "pool_rng", "pool_scalars")
 ENV_POOL_TAIL = ("pool_next",)      # (optional: set by SafeLifeVectorEnv for refreshable pools)
 ENV_OUT_PTRS = ("out", "obs", "score_lut")
-SL_ABI_VERSION = 12
+SL_ABI_VERSION = 13
 
 #: int32 column of each field inside `struct sl_env_scalars` (64 bytes = 16 columns)
 SCALAR_COLS = {"agent_row": 0, "agent_col": 1, "num_steps": 2, "old_value": 3, "required_points": 4,
@@ -113,7 +114,7 @@ class EnvBatch(C.Structure):
         + [("L", C.c_int32), ("level_stride", C.c_int32)]
         + [(n, _p) for n in ENV_POOL_PTRS + ENV_POOL_TAIL]
         + [("out", _p), ("obs", _p), ("policy_obs", _p), ("policy_dtype", C.c_int32), ("reserved1", C.c_int32),
-           ("score_lut", _p), ("goal_cache", _p)]
+           ("score_lut", _p), ("goal_cache", _p), ("pool_ready", _p)]
         + [("wrap", Wrappers), ("finished", EpisodeQueue)]
     )
 
@@ -173,6 +174,9 @@ def lib():
         if hasattr(L, "slhip_queues_steps"):
             L.slhip_queues_mode.argtypes = [C.c_void_p, C.POINTER(C.c_char_p)]
             L.slhip_queues_steps.argtypes = [C.c_void_p, C.POINTER(EnvBatch), _p, C.c_longlong, C.c_longlong, C.c_int, C.c_int]
+            if hasattr(L, "slhip_queues_stage"):
+                L.slhip_queues_stage.argtypes = L.slhip_queues_steps.argtypes
+                L.slhip_queues_go.argtypes = [C.c_void_p]
             L.slhip_queues_marker.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
             L.slhip_queues_wait.argtypes = [C.c_void_p, C.c_longlong]
             L.slhip_queues_selftest.argtypes = [C.c_void_p, C.c_int, C.c_int]

@@ -343,6 +343,50 @@ int slhip_execute_actions(uint16_t *board, int B, int H, int W, int64_t *locs, c
     return err == hipSuccess ? SL_OK : hip_fail(err, "execute_actions launch");
 }
 
+// sl_env_batch.pool_ready: level `s` of the pool as an episode starts on it (SafeLifeEnv.reset(), safelife_env.py:203-218
+// on a level of its own: safelife_game.py:537-552 update_exit_colors, :684-687 current_points), by one 256-thread
+// workgroup -- the generic reset's arithmetic (sl_generic.hip: reset_block), whose result depends on the level alone.
+__device__ void pool_ready_level(const sl_env_batch &env, size_t s) {
+    __shared__ int wave_tot[4];
+    const int t = threadIdx.x, cells = env.H * env.W;
+    const uint16_t *board = env.pool_board + s * cells, *goals = env.pool_goals + s * cells;
+    uint16_t *ready = env.pool_ready + s * cells;
+    sl_level_scalars *lvp = const_cast<sl_level_scalars *>(env.pool_scalars + s);
+    const sl_level_scalars lv = *lvp;
+    const int32_t *table = env.points_table + 72 * lv.table_idx;
+    int sum = 0;
+    for (int k = t; k < cells; k += 256) {
+        const uint16_t b = board[k];
+        const int bin = sl::score_bin(b, goals[k]);
+        if (bin >= 0) sum += table[bin];
+        ready[k] = b;
+    }
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+    if ((t & 63) == 0) wave_tot[t >> 6] = sum;
+    __syncthreads();                // (also: the copy above is visible to thread 0 below)
+    if (t == 0) {
+        const int score = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        const int ly = lv.agent_row, lx = lv.agent_col;
+        bool open = false;
+        if (ly >= 0) {
+            uint16_t *cell = ready + ly * env.W + lx;
+            int earned = score - lv.initial_points + env.exit_points * (sl::has_exited(*cell) ? 1 : 0);
+            if (earned < 0) earned = 0;
+            open = (*cell & sl::AGENT) && earned >= lv.required_reset;
+            *cell = (uint16_t)((*cell & ~sl::EXIT) | (open ? sl::EXIT : 0u));
+        }
+        const uint16_t paint = (uint16_t)(sl::FROZEN | sl::EXIT | (open ? sl::COLOR_R : 0u));
+        for (int k = 0; k < env.E; ++k) {
+            const int ex = env.pool_exit_locs[s * env.E + k];
+            if (ex >= 0) ready[ex] = paint;
+        }
+        const int exited = ly >= 0 ? (sl::has_exited(ready[ly * env.W + lx]) ? 1 : 0) : 0;
+        lvp->ready = (int32_t)(((uint32_t)(score + env.exit_points * exited) << 1) | (open ? 1u : 0u));
+    }
+}
+
+__global__ void __launch_bounds__(256) k_pool_ready(sl_env_batch env) { pool_ready_level(env, blockIdx.x); }
+
 int slhip_env_prepare(const sl_env_batch *env, void *stream) {
     int rc = check_env(env);
     if (rc) return rc;
@@ -357,6 +401,10 @@ int slhip_env_prepare(const sl_env_batch *env, void *stream) {
     err = sl::launch_build_score_lut(env->points_table, env->n_tables, env->score_lut, (hipStream_t)stream);
     if (err == hipSuccess && env->wrap.pool_baseline)
         err = sl::launch_build_baseline(*env, (hipStream_t)stream);
+    if (err == hipSuccess && env->pool_ready && env->L > 0) {
+        hipLaunchKernelGGL(k_pool_ready, dim3(env->L), dim3(256), 0, (hipStream_t)stream, *env);
+        err = hipGetLastError();
+    }
     return err == hipSuccess ? SL_OK : hip_fail(err, "env_prepare launch");
 }
 
@@ -390,6 +438,10 @@ __global__ void __launch_bounds__(256) k_pool_write(sl_env_batch env, sl_pool_ro
         ((uint32_t *)const_cast<sl_pcg64 *>(env.pool_rng + s))[t] = ((const uint32_t *)(r.rng + i))[t];
     else if (t >= 64 && t < 64 + SCALAR_WORDS)
         ((uint32_t *)const_cast<sl_level_scalars *>(env.pool_scalars + s))[t - 64] = ((const uint32_t *)(r.scalars + i))[t - 64];
+    if (env.pool_ready) {           // the slot as an episode starts on it, by the workgroup that has just written it
+        __syncthreads();
+        pool_ready_level(env, s);
+    }
 }
 
 int slhip_pool_write(const sl_env_batch *env, const sl_pool_rows *rows, void *stream) {
@@ -838,8 +890,33 @@ int slhip_queues_selftest(void *handle, int what, int arg) {
     return fail(SL_E_ARG, "unknown self-test");
 }
 
+static int queues_steps(void *handle, const sl_env_batch *env, const int32_t *actions, long long action_stride,
+                        long long out_stride, int n_steps, int head, bool stage);
+
 int slhip_queues_steps(void *handle, const sl_env_batch *env, const int32_t *actions, long long action_stride,
                        long long out_stride, int n_steps, int head) {
+    return queues_steps(handle, env, actions, action_stride, out_stride, n_steps, head, false);
+}
+
+// A region of steps written ahead of time: argument blocks and packets of all n_steps are laid down, nothing is handed to
+// the device; slhip_queues_go() then makes the packets valid and rings one doorbell per queue -- what a hipGraph's
+// instantiate / launch split does for a stream.  The action BUFFERS must exist when the region is staged; their contents
+// only when it goes.  At most SL_QUEUES_STAGE_MAX steps (the queues' argument rings), nothing else may be dispatched on
+// the handle in between (a marker or a steps call hands the staged packets over early: harmless, just not deferred).
+int slhip_queues_stage(void *handle, const sl_env_batch *env, const int32_t *actions, long long action_stride,
+                       long long out_stride, int n_steps, int head) {
+    if (n_steps > SL_QUEUES_STAGE_MAX) return fail(SL_E_ARG, "queues_stage: more steps than the argument rings hold");
+    return queues_steps(handle, env, actions, action_stride, out_stride, n_steps, head, true);
+}
+
+int slhip_queues_go(void *handle) {
+    if (!handle) return fail(SL_E_ARG, "null pointer");
+    sl::aql_commit();
+    return SL_OK;
+}
+
+static int queues_steps(void *handle, const sl_env_batch *env, const int32_t *actions, long long action_stride,
+                        long long out_stride, int n_steps, int head, bool stage) {
     StepQueues *c = (StepQueues *)handle;
     if (!c || !env || !actions) return fail(SL_E_ARG, "null pointer");
     if (n_steps < 0) return fail(SL_E_ARG, "n_steps < 0");
@@ -893,9 +970,12 @@ int slhip_queues_steps(void *handle, const sl_env_batch *env, const int32_t *act
         c->have_prepared = true;
     }
     struct Batch {
-        Batch() { sl::aql_begin(); }
-        ~Batch() { sl::aql_commit(); }
-    } batch;
+        const bool keep;
+        explicit Batch(bool keep_) : keep(keep_) { sl::aql_begin(); }
+        ~Batch() {
+            if (!keep) sl::aql_commit();        // (a staged region stays pending until slhip_queues_go)
+        }
+    } batch(stage);
     c->pending = true;
     for (int t = 0; t < n_steps; ++t) {
         const int32_t *a_t = actions + (long long)t * action_stride;
@@ -929,7 +1009,7 @@ int slhip_queues_steps(void *handle, const sl_env_batch *env, const int32_t *act
         // by one (the device starts at once and is never left waiting while a batch is being written: with eight steps
         // per flush from the start the kernels' own clocks showed it idle for 7 us behind step 0), later ones -- the
         // host is ahead by then -- in fours.
-        if (t < 3 || (t & 3) == 3 || c->swap) sl::aql_flush();
+        if (!stage && (t < 3 || (t & 3) == 3 || c->swap)) sl::aql_flush();
     }
     return SL_OK;
 }

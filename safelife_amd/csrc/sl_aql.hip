@@ -170,7 +170,7 @@ struct Device {
         uint32_t head_word;
         uint64_t index;
     };
-    static constexpr int MAX_PENDING = 64;
+    static constexpr int MAX_PENDING = 512;     // (a staged region: up to KARG_SLOTS - 2 steps of up to eight slices)
     Pending pending[MAX_PENDING];
     int n_pending = 0;
     bool batching = false;
@@ -437,11 +437,22 @@ void publish(Device &d, const Hsa &h) {
     }
     d.last_tail = nullptr;
     if (d.n_pending) tl_mark(d, h, "doorbells");
+    // every pending packet becomes valid, then ONE doorbell per queue with the index of its youngest packet (the packet
+    // processor takes everything up to it); queues in the order of their first pending packet
+    uint64_t last[MAX_QUEUES];
+    int order[MAX_QUEUES], n_order = 0;
+    bool seen[MAX_QUEUES] = {};
     for (int i = 0; i < d.n_pending; ++i) {
         const Device::Pending &p = d.pending[i];
         __atomic_store_n(p.packet, p.head_word, __ATOMIC_RELEASE);
-        h.hsa_signal_store_screlease(d.queues[p.queue].q->doorbell_signal, (hsa_signal_value_t)p.index);
+        if (!seen[p.queue]) {
+            seen[p.queue] = true;
+            order[n_order++] = p.queue;
+        }
+        last[p.queue] = p.index;
     }
+    for (int i = 0; i < n_order; ++i)
+        h.hsa_signal_store_screlease(d.queues[order[i]].q->doorbell_signal, (hsa_signal_value_t)last[order[i]]);
     d.n_pending = 0;
 }
 

@@ -2919,10 +2919,14 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
         // on-device auto-reset (training/base_algo.py:231-236 calls env.reset() after a done step)
         // (the leaders' own fetches -- the level's constants and its first exit -- go out FIRST, beside the rows' below,
         //  not behind them: one memory round trip less on the chain a reloading workgroup holds its launch up with)
+#ifndef SL_TIMING_RESET
+#define SL_TIMING_RESET 0       /* TIMING-ONLY builds (wrong results): 1 = a reloading workgroup fetches nothing of its new level (what a prefetch under the step could save at most) */
+#endif
+        const bool ready_pool = env.pool_ready != nullptr;          // (uniform)
         const bool l_reset = lead && box[lq].reset_level >= 0;
         sl_level_scalars lv_pre = {};
         int exit0_pre = -1;
-        if (l_reset) {
+        if (l_reset && !(SL_TIMING_RESET & 1)) {
             lv_pre = env.pool_scalars[box[lq].reset_level];
             exit0_pre = env.pool_exit_locs[(size_t)box[lq].reset_level * E];
         }
@@ -2935,7 +2939,9 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
             int r2 = r;
             asm volatile("" : "+v"(r2));
             level = new_level;
-            const u16 *pb = env.pool_board + (size_t)level * HW, *pg = env.pool_goals + (size_t)level * HW;
+            // (round 6: where the batch keeps sl_env_batch.pool_ready the level comes as an episode starts on it --
+            //  exits painted, its value in pool_scalars[l].ready -- and is neither scored nor repainted below)
+            const u16 *pb = (ready_pool ? env.pool_ready : env.pool_board) + (size_t)level * HW, *pg = env.pool_goals + (size_t)level * HW;
             u16 *gdst = (u16 *)(goals + Gm::PAD) + gb * HW;
             // each lane copies its OWN row of the new level: W cells = one contiguous run, fetched as 4-byte
             // pairs (2-byte aligned: the hardware splits what it must) all issued before the first is used --
@@ -2947,8 +2953,8 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
             for (int a = 0; a < 2; ++a) {
                 u32 tw[WS];
 #pragma unroll
-                for (int j = 0; j < W / 2; ++j) tw[j] = *(const u32_a2 *)(rows[a] + 2 * j);
-                if (Gm::ODD) tw[WS - 1] = rows[a][W - 1];
+                for (int j = 0; j < W / 2; ++j) tw[j] = (SL_TIMING_RESET & 1) ? (u32)(r2 == j ? 9u : 0u) : *(const u32_a2 *)(rows[a] + 2 * j);
+                if (Gm::ODD) tw[WS - 1] = (SL_TIMING_RESET & 1) ? 0u : rows[a][W - 1];
                 if (NOGOALS && a == 1) {
                     // no goal image: the row goes to the env's goal array as it came, and into the registers the score reads
                     u16 *grow = env.goals + (size_t)e * HW + r2 * W;
@@ -2968,11 +2974,13 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
                 }
                 if (Gm::ODD) imgs[a][Gm::cell(r, W - 1)] = (u16)tw[WS - 1];
             }
+            if (!(SL_TIMING_RESET & 1)) {
             lut_base = (u32)env.pool_scalars[level].table_idx * (u32)SCORE_LUT_BYTES;
             p = (double)env.pool_scalars[level].spawn_prob;
             if (r2 < 4) rng_lds[4 * g + r2] = ((const u64 *)(env.pool_rng + level))[r2];
             for (int k = r2; k < E; k += H)
                 env.exit_locs[(size_t)e * E + k] = env.pool_exit_locs[(size_t)level * E + k];
+            }
             if (!NOGOALS) *dirty_flag = 1;               // (any wave that changes its goals raises the flag)
             if (r2 == 0) box[gb].dirty = 1;              // (and the whole board is new)
         }
@@ -2983,14 +2991,14 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
 #pragma unroll
                 for (int k = 0; k < WS; ++k) gsh_lane[k] = goal_shift(b[k]);
             }
-            read_row<H, W>(board, gb, r, b);
+            if (!ready_pool) read_row<H, W>(board, gb, r, b);
         }
-        const int s0 = group_total<H, W>(
-            mine ? row_score<H, W, LDS_LUT>(b, gsh_lane, lut, lut_base, lds_lut, cell_mask, c100) : 0, live ? g : 0);
-        if (rlead) {
-            box[gb].score0 = s0;
-            box[gb].gstat = gstatic;
+        if (!ready_pool) {
+            const int s0 = group_total<H, W>(
+                mine ? row_score<H, W, LDS_LUT>(b, gsh_lane, lut, lut_base, lds_lut, cell_mask, c100) : 0, live ? g : 0);
+            if (rlead) box[gb].score0 = s0;
         }
+        if (rlead) box[gb].gstat = gstatic;
         wg_sync();
         if (lead && box[lq].reset_level >= 0) {
             const int l_level = box[lq].reset_level;
@@ -3007,11 +3015,18 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
             const sl_level_scalars lv = lv_pre;
             ly = lv.agent_row;
             lx = lv.agent_col;
-            const int fresh = box[lq].score0;
-            const int open0 = recolor_exits_lds<H, W>(lboard16, ly, lx, exits, exit0, E, fresh, lv.initial_points,
-                                                      lv.required_reset, env.exit_points) ? 1 : 0;
+            int fresh, open0, exited;
+            if (ready_pool) {           // the level came painted; its value at the start of an episode with it
+                open0 = lv.ready & 1;
+                fresh = lv.ready >> 1;
+                exited = 0;
+            } else {
+                fresh = box[lq].score0;
+                open0 = recolor_exits_lds<H, W>(lboard16, ly, lx, exits, exit0, E, fresh, lv.initial_points,
+                                                lv.required_reset, env.exit_points) ? 1 : 0;
+                exited = ly >= 0 ? (has_exited(lboard16[Gm::cell(ly, lx)]) ? 1 : 0) : 0;
+            }
             if (WRAP) wrap_reset(wst[lq], ly, lx);
-            const int exited = ly >= 0 ? (has_exited(lboard16[Gm::cell(ly, lx)]) ? 1 : 0) : 0;
             sl_env_scalars rec;
             rec.agent_row = ly;
             rec.agent_col = lx;

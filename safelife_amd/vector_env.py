@@ -266,6 +266,12 @@ class SafeLifeVectorEnv(object):
                 s.policy_dtype = 0 if policy_layout != "float32" else 1
             else:
                 setattr(s, name, t[name].data_ptr())
+        # every pool level as an episode starts on it (sl_env_batch.pool_ready: kept by slhip_env_prepare and
+        # slhip_pool_write; in-kernel resets copy it instead of scoring and repainting the level).  SAFELIFE_POOL_READY=0
+        # leaves it out (A/B runs).
+        if os.environ.get("SAFELIFE_POOL_READY", "1") != "0":
+            t["pool_ready"] = torch.zeros_like(t["pool_board"])
+            s.pool_ready = t["pool_ready"].data_ptr()
         # views of the per-step output records (struct sl_step_out)
         out = t["out"]
         flags = out[:, 1:2].view(torch.uint8)                    # done, success, times_up, pad
@@ -759,8 +765,15 @@ class SafeLifeVectorEnv(object):
     def _queue_head(self, assume_ordered):
         """1 if the next queue step must take a system-scope acquire behind a device synchronize: HIP streams have
         touched the envs (reset, step(), rollout() ...) or may hold work on the actions / outputs (anything after a
-        queues_sync()) since the queues last ran."""
+        queues_sync()) since the queues last ran.  ``assume_ordered="untouched"``: the caller vouches that NOTHING
+        outside the queues has written the envs' state, the actions of the coming steps or their outputs since the last
+        ``queues_sync()`` (it only waited, or read) -- honoured only if this object itself has not put anything on a
+        stream since (a reset, a step(), a checkpoint copy): the first step then is a step like any other, without the
+        system-scope acquire (worth ~8 us: it drops every XCD's L2)."""
         if not (self._caller_ahead or self._async_pending):
+            return 0
+        if assume_ordered == "untouched" and self._caller_ahead == "sync" and not self._async_pending:
+            self._caller_ahead = False
             return 0
         if self._async_pending:
             self.join()
@@ -779,14 +792,17 @@ class SafeLifeVectorEnv(object):
         the device synchronize it would otherwise make."""
         self.step_queues_many(actions, 1, assume_ordered=assume_ordered)
 
-    def step_queues_many(self, actions, n_steps=None, action_stride=None, out_stride=0, assume_ordered=False):
+    def step_queues_many(self, actions, n_steps=None, action_stride=None, out_stride=0, assume_ordered=False, defer=False):
         """``n_steps`` consecutive steps, ALL enqueued by this one call (``slhip_queues_steps``: the packets and
         argument blocks of every step and slice are written on the C side, the device starts on the first step while
         the rest is being written; the call blocks only while the queue rings are full).  `actions`: int32 device
         tensor [T, B] (or [B] with n_steps=1), complete when the call is made -- or its address with ``n_steps`` and
         ``action_stride`` (int32 elements between consecutive steps).  ``out_stride``: sl_step_out records between
         the outputs of consecutive steps (0: every step overwrites the env's own record tensor; sharding.RewardGather
-        points it at a window).  Keeps a reference to `actions` until the next ``queues_sync()``."""
+        points it at a window).  Keeps a reference to `actions` until the next ``queues_sync()``.
+        ``defer=True`` (``slhip_queues_stage``, at most ``_hip.QUEUES_STAGE_MAX`` steps): the steps are written --
+        argument blocks, packets -- but not handed to the device until ``queues_go()``; the action buffers must exist
+        now, their contents only then.  What a hipGraph's instantiate / launch split does for a stream."""
         if isinstance(actions, int):
             ptr = actions
             if n_steps is None:
@@ -806,7 +822,8 @@ class SafeLifeVectorEnv(object):
         if self._queues is None:
             self.queues_open()
         head = self._queue_head(assume_ordered)
-        rc = self._lib.slhip_queues_steps(self._queues, self._sref, ptr, stride, int(out_stride), int(n_steps), head)
+        fn = self._lib.slhip_queues_stage if defer else self._lib.slhip_queues_steps
+        rc = fn(self._queues, self._sref, ptr, stride, int(out_stride), int(n_steps), head)
         if rc:
             _hip.check(rc)
         self._queues_pending = True
@@ -814,6 +831,11 @@ class SafeLifeVectorEnv(object):
         if self._rf_recover:
             self._queue_log.append((None if isinstance(actions, int) else actions, ptr, int(n_steps), stride, int(out_stride),
                                     self.struct.out))
+
+    def queues_go(self):
+        """Hand the steps staged by ``step_queues_many(..., defer=True)`` to the device (one doorbell per queue)."""
+        if self._queues is not None:
+            _hip.check(self._lib.slhip_queues_go(self._queues))
 
     def queues_marker(self):
         """A system-scope release behind every queue step dispatched so far; returns a ticket at once (-1: nothing was
@@ -844,7 +866,8 @@ class SafeLifeVectorEnv(object):
                 return
             finally:
                 self._queue_refs = []
-                self._caller_ahead = True
+                # ("sync": nothing but this wait has happened since the queues last ran -- _queue_head)
+                self._caller_ahead = self._caller_ahead or "sync"
             if self._rf_recover:
                 self._rf_checkpoint()
 

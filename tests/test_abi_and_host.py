@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     lib = _hip.lib()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.slhip_abi_version() == _hip.SL_ABI_VERSION == 12
+    assert lib.slhip_abi_version() == _hip.SL_ABI_VERSION == 13
 
 
 def _ctypes_layout(struct, prefix=""):

@@ -1064,7 +1064,13 @@ def test_queue_stepping_vs_oracle(pool_name, B, queue_slices, kw, release_free):
                 cpu.env.step(acts[t])
                 t += 1
         else:                                   # one call for the whole run
-            env.step_queues_many(d_acts[t:t + run])
+            if run == 40:
+                # staged, then released (slhip_queues_stage / _go), and -- nothing but waits and reads since the last sync --
+                # without the first step's system-scope acquire
+                env.step_queues_many(d_acts[t:t + run], assume_ordered="untouched", defer=True)
+                env.queues_go()
+            else:
+                env.step_queues_many(d_acts[t:t + run])
             for _ in range(run):
                 cpu.env.step(acts[t])
                 t += 1

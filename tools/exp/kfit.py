@@ -20,6 +20,8 @@ fences = sys.argv[2] if len(sys.argv) > 2 else "none"
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 7
 nq = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 B = 8192
+NO_HEAD = os.environ.get("KFIT_NO_HEAD") == "1"
+NO_TORCH_SYNC = os.environ.get("KFIT_NO_TORCH_SYNC") == "1"
 pool = bench.load_pool("prune_still_25", _device_counts)
 env = SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25), output_channels=bench.TRAIN_CHANNELS, auto_reset=True,
                         with_obs=False, slices=2)
@@ -39,10 +41,13 @@ for K in Ks:
     for rep in range(reps):
         env.step_queues_many(acts[:5], assume_ordered=True)         # the bench's warm-up, then idle
         env.queues_sync(); torch.cuda.synchronize()
+        if NO_HEAD:
+            env._caller_ahead = False           # (experiment: the first step of the region without its system-scope acquire)
         t0 = time.perf_counter()
         env.step_queues_many(acts[40:40 + K], assume_ordered=True)
         t1 = time.perf_counter()
-        torch.cuda.synchronize()
+        if not NO_TORCH_SYNC:
+            torch.cuda.synchronize()
         env.queues_sync()
         t2 = time.perf_counter()
         ts.append(((t2 - t0) * 1e6, (t1 - t0) * 1e6))
@@ -53,6 +58,6 @@ for K in Ks:
 x = np.array(Ks, float); y = np.array([med[K][0] for K in Ks])
 A = np.stack([np.ones_like(x), x], 1)
 (fixed, per), *_ = np.linalg.lstsq(A, y, rcond=None)
-print("%s spread=%d fences=%s queues=%d: elapsed = %.1f us + %.3f us x K   (K=20 -> %.2f us/step)" % (
-    os.path.basename(os.environ.get("SAFELIFE_HIP_LIB", "tree")), spread, fences, env.queue_slices, fixed, per,
+print("%s spread=%d fences=%s queues=%d%s%s: elapsed = %.1f us + %.3f us x K   (K=20 -> %.2f us/step)" % (
+    os.path.basename(os.environ.get("SAFELIFE_HIP_LIB", "tree")), spread, fences, env.queue_slices, " no-head" if NO_HEAD else "", " no-torch-sync" if NO_TORCH_SYNC else "", fixed, per,
     (fixed + 20 * per) / 20))
