@@ -465,14 +465,14 @@ size_t slhip_goal_cache_bytes(const sl_env_batch *env, int *boards_per_block) {
     // the shape's plain kernels serve one (the 64-cell rows of C5)
     if (env->wrap.flags || env->obs || env->policy_obs) return 0;
     if (env->finished.capacity > 0 && !sl::rowlane_lean_takes_queue(env->H, env->W)) return 0;
-    return sl::rowlane_goal_cache_bytes(env->H, env->W, env->B, boards_per_block);
+    return sl::rowlane_goal_cache_bytes(env->H, env->W, env->B, !env->spawner_free, boards_per_block);
 }
 
 // A launch of the size-generic kernels on a batch that carries a goal-word cache: they load levels without keeping its
 // flags, so every flag goes down first (the row kernels' launcher does the same for its own odd launches).
 static hipError_t drop_goal_cache(const sl_env_batch *env, hipStream_t st) {
     if (!env->goal_cache) return hipSuccess;
-    const size_t bytes = sl::rowlane_goal_cache_bytes(env->H, env->W, env->B);
+    const size_t bytes = sl::rowlane_goal_cache_bytes(env->H, env->W, env->B, !env->spawner_free);
     return bytes ? hipMemsetAsync(env->goal_cache, 0, bytes, st) : hipSuccess;
 }
 

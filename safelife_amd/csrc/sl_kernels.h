@@ -35,7 +35,8 @@ hipError_t launch_obs_to_policy(const u32 *view, int B, int vh, int vw, const sl
 // sl_rowlane.hip : row-per-lane SWAR kernels for the shapes listed in SL_ROWLANE_SHAPES
 bool rowlane_supports(int H, int W);
 // size of sl_env_batch.goal_cache for a batch of B boards (0: no row kernels for the shape); zeroing it lowers every flag
-size_t rowlane_goal_cache_bytes(int H, int W, int B, int *boards_per_block = nullptr);
+// (spawn: the pool holds spawners -- which plain step kernel the batch runs, and whether that one keeps a cache)
+size_t rowlane_goal_cache_bytes(int H, int W, int B, bool spawn, int *boards_per_block = nullptr);
 bool rowlane_lean_takes_queue(int H, int W);       // the shape's plain step kernels also serve a finished-episode queue
 int rowlane_policy_room(int H, int W);
 hipError_t launch_build_score_lut(const int32_t *points_table, int n_tables, int8_t *lut, hipStream_t stream);

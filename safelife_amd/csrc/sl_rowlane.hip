@@ -3812,12 +3812,14 @@ bool rowlane_lean_takes_queue(int H, int W) {
     return false;
 }
 
-size_t rowlane_goal_cache_bytes(int H, int W, int B, int *boards_per_block) {
+size_t rowlane_goal_cache_bytes(int H, int W, int B, bool spawn, int *boards_per_block) {
     // (slices and queue slices start at multiples of 64 envs: shapes whose workgroups hold 12, 20 or 24 boards would have
-    //  launches off the blocks' grid -- they go without a cache)
+    //  launches off the blocks' grid -- they go without a cache; and so do batches whose plain single-step kernel keeps
+    //  none -- the kernel's GCACHE: goal words in registers, no fifth leader wave)
 #define X(h, w)                                                         \
     if (H == h && W == w) {                                             \
         if (64 % rl::Geom<h, w>::NB != 0) break;                        \
+        if (!rl::gsh_in_registers<h, w>(spawn, true, true) || rl::Geom<h, w>::LEADX_OK) break; \
         if (boards_per_block) *boards_per_block = rl::Geom<h, w>::NB;   \
         return rl::GoalCache<h, w>::bytes(B);                           \
     }

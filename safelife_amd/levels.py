@@ -276,6 +276,7 @@ class LevelPool(object):
         self._frac, self._seq, self._counts_fn = frac, seq, counts_fn
         self.refreshable = bool(refreshable)
         self.bank = np.zeros(L, np.int8)              # refreshable: which of its two slots holds level l now
+        self.slot_version = np.zeros(2 * L, np.int64) # how often each PHYSICAL slot has been rewritten (replace())
         if self.refreshable:                          # slots L .. 2L-1: the spare bank (starts as a copy: valid content)
             for k in self.ARRAYS:
                 if k != "points_table":
@@ -380,10 +381,21 @@ class LevelPool(object):
         phys = slots + L * (1 - self.bank[slots].astype(np.int64))
         for k in PreparedLevels.ARRAYS:
             getattr(self, k)[phys] = getattr(pl, k)
+        self._replaced = (slots.copy(), [self.levels[l] for l in slots.tolist()])      # (for undo_replace)
         for l, lv in zip(slots.tolist(), pl.levels):
             self.levels[l] = lv
         self.bank[slots] = 1 - self.bank[slots]
+        self.slot_version[phys] += 1
         return phys.tolist()
+
+    def undo_replace(self):
+        """The last ``replace()`` did not reach the device (its copy failed): the levels' previous slots are current
+        again.  (The spare slots keep the new rows -- nothing refers to them.)"""
+        slots, old = self._replaced
+        self.bank[slots] = 1 - self.bank[slots]
+        for l, lv in zip(slots.tolist(), old):
+            self.levels[l] = lv
+        self._replaced = (np.zeros(0, np.int64), [])
 
 
 class PreparedLevels(object):

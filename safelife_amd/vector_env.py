@@ -50,6 +50,10 @@ class SideEffectBatch(object):
         self.life_dist, self.type_masks = out["life_dist"], out["type_masks"]
         self._keep = out
         self._done = done       # event behind the pass when it ran on the env's side stream (overlap=True)
+        # (the host fallback of distributions() reads an entry's starting board from the host pool by physical slot: which
+        #  rewrite of every slot this batch belongs to)
+        ver = getattr(env.pool, "slot_version", None)
+        self._pool_versions = None if ver is None else ver.copy()
 
     def wait(self):
         """The caller's current stream waits for the pass (a no-op for a pass that ran on that stream); host reads
@@ -87,6 +91,10 @@ class SideEffectBatch(object):
             # more frozen movable / destructible cell types on the starting board than the device-side key slots
             # hold: this entry's distributions are rebuilt on the host from the occupancy tensors (which are complete)
             from . import side_effects as se
+            if self._pool_versions is not None and (int(rec[1]) < len(self._pool_versions) and
+                                                    self.env.pool.slot_version[int(rec[1])] != self._pool_versions[int(rec[1])]):
+                raise RuntimeError("entry %d: pool slot %d has been replaced since this batch was flushed -- its starting "
+                                   "board is gone; evaluate a batch before its levels' slots are staged again" % (i, int(rec[1])))
             b0 = np.asarray(self.env.pool.arrays()["pool_board"][int(rec[1])], np.uint16)
             b2 = self.boards[i].cpu().numpy().view(np.uint16)
             found_in, found_act = se.distributions_from_counts(b0, b2, self.counts[:, i].cpu().numpy(), self.num_samples)
@@ -311,6 +319,7 @@ class SafeLifeVectorEnv(object):
         self._queues = None              # step_queues(): the library's own AQL queues (opened on first use)
         self._queues_pending = False     # steps dispatched there since the last queues_sync()
         self.steps_dispatched = 0        # steps handed to the device so far, whatever the launcher
+        self._slice_steps, self._slice_steps_min = [0] * max(1, n_sl), 0      # (step_slice(): per slice)
         self._queue_refs = []            # action tensors of those steps (kept alive until the sync)
         self._rf_recover, self._rf_ckpt, self._queue_log, self._queue_open_args = False, None, [], None
         self._stream_ptrs = (C.c_void_p * max(1, n_sl))(*[st.cuda_stream for st in self._slice_streams])
@@ -382,6 +391,21 @@ class SafeLifeVectorEnv(object):
                     raise ValueError("pool slot %d was replaced less than one time limit ago: envs may still be playing "
                                      "its previous content, which this env's side-effect machinery reads from the pool"
                                      % int(l))
+            if self._se is not None:
+                # ... and the episodes that ENDED on the previous content sit in the finished queue until a flush: the
+                # episode-end pass takes their starting boards from the pool when it RUNS.  So a flush must have been
+                # issued after the last of them ended, and its pass -- deferred, or still running on the side stream --
+                # must be through before the slot is written.
+                flushed_at = self._se.get("flushed_at", -1)
+                for l in slots:
+                    if l in last and flushed_at < last[int(l)] + self.time_limit:
+                        raise ValueError("pool slot %d: episodes that ended on its previous content may still be queued for the "
+                                         "episode-end pass, which reads their starting boards from the pool -- call "
+                                         "side_effects_flush() first" % int(l))
+                self.side_effects_launch()
+                ev = self._se.get("pass_done")
+                if ev is not None:
+                    ev.synchronize()
         if background:
             pool = rf.get("helper")
             if pool is None:
@@ -406,6 +430,14 @@ class SafeLifeVectorEnv(object):
                 what.synchronize()
             rf["fence"] = None
         phys = self.pool.replace(slots, levels)
+        try:
+            return self._pool_write_staged(slots, phys)
+        except Exception:
+            self.pool.undo_replace()        # (host and device pools stay the same: the copy did not happen)
+            raise
+
+    def _pool_write_staged(self, slots, phys):
+        rf, torch, dev, w = self._pool_refresh, self.torch, self.device, self.struct.wrap
         pa = self.pool.arrays()
         sel = np.asarray(phys, np.int64)
         n = len(sel)
@@ -679,9 +711,11 @@ class SafeLifeVectorEnv(object):
         successful ``queues_sync()`` (one asynchronous copy per sync: 21 MB at C3) and a log of the step calls since.
         If a step then finds itself on the wrong XCD -- the placement is a property of the process's set of hardware
         queues: a stream or an RCCL communicator created after the queues were opened can change it -- the sync does
-        not fail: it puts the copy back, reopens the queues with a stream's fences, replays the logged calls and
-        warns; the run continues bit for bit as if the steps had carried fences all along.  ``recover=False``: the
-        sync raises instead and the state since the previous sync is not valid."""
+        not fail: it puts the copy back, reopens the queues with a stream's fences, replays the logged calls (each
+        with the record destination and the pool's successor table it was made with) and warns; the run continues bit
+        for bit as if the steps had carried fences all along -- PROVIDED the action buffers of the logged calls are
+        unchanged (keep them until the next ``queues_sync()``).  ``recover=False``: the sync raises instead and the
+        state since the previous sync is not valid."""
         if self._queues is not None:
             return
         self._rf_recover, self._rf_ckpt, self._queue_log = False, None, []
@@ -725,6 +759,9 @@ class SafeLifeVectorEnv(object):
             self._rf_ckpt[k].copy_(self.t[k], non_blocking=True)
         if self._se is not None:
             self._rf_ckpt["se_count"] = self._se["queue"][1]["count"].clone()
+        # (the copies READ what the next queue steps write: those wait for this event whatever the caller vouches for)
+        self._rf_ckpt_event = self.torch.cuda.Event()
+        self._rf_ckpt_event.record()
         self._queue_log = []
         self._caller_ahead = True
 
@@ -732,9 +769,12 @@ class SafeLifeVectorEnv(object):
         """The placement check fired: back to the last good state, stream fences from here on, the logged calls again."""
         import warnings
         log, args = self._queue_log, self._queue_open_args
+        self._drain_staging()
         self._lib.slhip_queues_close(self._queues)
         self._queues, self._queues_pending = None, False
         self.torch.cuda.synchronize(self.device)
+        if self._pool_refresh is not None:
+            self._pool_refresh["fence"] = None      # (a ticket of the closed handle; the device is idle)
         for k, v in self._rf_ckpt.items():
             if k == "se_count":
                 self._se["queue"][1]["count"].copy_(v)
@@ -744,17 +784,18 @@ class SafeLifeVectorEnv(object):
             self.t["goal_cache"].zero_()
         self.torch.cuda.synchronize(self.device)
         self._caller_ahead = True
-        self._rf_recover, self._rf_ckpt = False, None
+        self._rf_recover, self._rf_ckpt, self._rf_ckpt_event = False, None, None
         warnings.warn("safelife_amd: release-free queue stepping was refused by its placement check (%s); restored the "
                       "state of the last sync, reopened the queues with agent-scope fences and replayed %d step call(s)"
                       % (message.split(";")[0][:200], len(log)), RuntimeWarning, stacklevel=3)
         self.queues_open(args["slices"], release_free=False, queue_ids=args["queue_ids"])
         self.steps_dispatched -= sum(c[2] for c in log)
-        keep_out = self.struct.out
-        for actions, ptr, n_steps, stride, out_stride, out_ptr in log:
-            self.struct.out = out_ptr
+        keep_out, keep_next = self.struct.out, self.struct.pool_next
+        for actions, ptr, n_steps, stride, out_stride, out_ptr, pool_next in log:
+            # (as the call was made: its records' destination and the successor table a pool_commit() has since replaced)
+            self.struct.out, self.struct.pool_next = out_ptr, pool_next
             self.step_queues_many(actions if actions is not None else ptr, n_steps, stride, out_stride)
-        self.struct.out = keep_out
+        self.struct.out, self.struct.pool_next = keep_out, keep_next
         self._queues_pending = False
         try:
             _hip.check(self._lib.slhip_queues_sync(self._queues))
@@ -770,6 +811,10 @@ class SafeLifeVectorEnv(object):
         ``queues_sync()`` (it only waited, or read) -- honoured only if this object itself has not put anything on a
         stream since (a reset, a step(), a checkpoint copy): the first step then is a step like any other, without the
         system-scope acquire (worth ~8 us: it drops every XCD's L2)."""
+        ev = getattr(self, "_rf_ckpt_event", None)
+        if ev is not None:          # the recovery copy of the last sync is still reading the state
+            ev.synchronize()
+            self._rf_ckpt_event = None
         if not (self._caller_ahead or self._async_pending):
             return 0
         if assume_ordered == "untouched" and self._caller_ahead == "sync" and not self._async_pending:
@@ -830,7 +875,7 @@ class SafeLifeVectorEnv(object):
         self.steps_dispatched += int(n_steps)
         if self._rf_recover:
             self._queue_log.append((None if isinstance(actions, int) else actions, ptr, int(n_steps), stride, int(out_stride),
-                                    self.struct.out))
+                                    self.struct.out, self.struct.pool_next))
 
     def queues_go(self):
         """Hand the steps staged by ``step_queues_many(..., defer=True)`` to the device (one doorbell per queue)."""
@@ -847,8 +892,20 @@ class SafeLifeVectorEnv(object):
         return ticket.value
 
     def queues_wait(self, ticket):
+        """Wait for a ``queues_marker()``.  With release-free stepping and ``recover=True`` a placement failure found here
+        is recovered from as in ``queues_sync()`` (which this then amounts to); on success the call log is KEPT -- steps
+        behind the marker may still be in flight -- so action buffers handed to ``step_queues*`` must stay unchanged until
+        the next ``queues_sync()`` while ``recover=True`` (the replay reads them again)."""
         if self._queues is not None:
-            _hip.check(self._lib.slhip_queues_wait(self._queues, int(ticket)))
+            try:
+                _hip.check(self._lib.slhip_queues_wait(self._queues, int(ticket)))
+            except _hip.SafeLifeHipError as e:
+                if not (self._rf_recover and "another XCD" in str(e)):
+                    raise
+                self._queues_pending = False
+                self._rf_recover_now(str(e))
+                self._queue_refs = []
+                self._caller_ahead = True
 
     def queues_sync(self):
         """Wait for every step dispatched on the queues so far (system-scope release behind them): afterwards their
@@ -871,8 +928,20 @@ class SafeLifeVectorEnv(object):
             if self._rf_recover:
                 self._rf_checkpoint()
 
+    def _drain_staging(self):
+        """A background pool staging waits on a marker of the CURRENT queue handle: let it finish before the handle goes
+        (its result, or what it raised, stays with pool_commit())."""
+        rf = self._pool_refresh
+        if rf is not None and hasattr(rf.get("staged"), "exception"):
+            rf["staged"].exception()
+
     def queues_close(self):
         if self._queues is not None:
+            self._drain_staging()
+            rf = self._pool_refresh
+            if rf is not None and rf.get("fence") is not None and rf["fence"][0] == "queues":
+                self._lib.slhip_queues_wait(self._queues, int(rf["fence"][1]))       # (a ticket of this handle: settle it now)
+                rf["fence"] = None
             self._lib.slhip_queues_close(self._queues)
             self._queues, self._queues_pending, self._queue_refs = None, False, []
 
@@ -924,6 +993,13 @@ class SafeLifeVectorEnv(object):
         self._async_pending = True
         if rc:
             _hip.check(rc)
+        # (steps_dispatched counts whole steps of the batch: the slowest slice's)
+        c = self._slice_steps
+        c[i] += 1
+        m = min(c)
+        if m > self._slice_steps_min:
+            self.steps_dispatched += m - self._slice_steps_min
+            self._slice_steps_min = m
 
     def slice_stream(self, i):
         """The torch stream slice i is stepped on."""
@@ -1076,6 +1152,10 @@ class SafeLifeVectorEnv(object):
         stream_ptr = _hip.current_stream_ptr() if side is None else C.c_void_p(side.cuda_stream)
         done = torch.cuda.Event() if side is not None else None
 
+        se["flushed_at"] = self.steps_dispatched
+        pass_done = torch.cuda.Event() if self.device.type == "cuda" else None
+        se["pass_done"] = pass_done         # (recorded behind the pass on whichever stream runs it: pool_stage waits for it)
+
         def launch():
             rc = self._lib.slhip_side_effects(self._sref, C.byref(q), se["num_samples"], 1,
                                               *[_hip.ptr(out[k]) for k in ("work_boards", "work_prob", "work_steps",
@@ -1087,6 +1167,8 @@ class SafeLifeVectorEnv(object):
                 for tns in bufs.values():             # (the allocator must not hand these to someone else while the pass runs)
                     tns.record_stream(side)
                 done.record(side)
+            if pass_done is not None:
+                pass_done.record(side if side is not None else torch.cuda.current_stream())
         if defer and side is not None:
             se["deferred"] = launch
         else:

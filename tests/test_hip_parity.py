@@ -1864,6 +1864,58 @@ def test_level_pool_refresh_while_stepping(pool_name, B, wrappers, background):
     env.queues_close()
 
 
+def test_pool_slot_reuse_waits_for_the_episode_end_pass():
+    """A refreshable pool under an env with the side-effect queue: the episode-end pass takes an episode's
+    STARTING board from the pool when it runs, so a slot may only be staged again once (a) a time limit of steps has
+    passed since its last replacement and (b) a flush has been issued since -- whose pass is waited for.  Also:
+    step_slice() rounds count as dispatched steps (the guard's clock under PipelinedRunner)."""
+    import torch
+    from safelife_amd import _hip
+    from safelife_amd.levels import LevelPool
+    p, _ = util.pool_from_fixture("prune_still_25", _device_counts)
+    levels = list(p.levels)
+    pool = LevelPool(levels[:8], counts_fn=_device_counts, refreshable=True, min_performance_fraction=0.05)
+    B, TL = 256, 6
+    env = util.DeviceBackend(pool, B, first_level=np.arange(B) % 8, slices=2, auto_reset=True, level_stride=1, view_shape=(9, 9),
+                             time_limit=TL, with_obs=False, side_effects=dict(capacity=1024, num_samples=20)).env
+    env.reset()
+    acts = torch.randint(0, 9, (B,), device=env.device, dtype=torch.int32)
+
+    def steps(n):
+        for _ in range(n):
+            env.step_slice(0, acts)
+            env.step_slice(1, acts)
+        env.join()
+    steps(1)
+    assert env.steps_dispatched == 1                    # one round of both slices = one step of the batch
+    env.pool_stage([0, 1], [levels[8], levels[9]])
+    env.pool_commit()
+    steps(2)
+    with pytest.raises(ValueError, match="less than one time limit ago"):
+        env.pool_stage([0], [levels[10]])
+    steps(TL)
+    with pytest.raises(ValueError, match="side_effects_flush"):
+        env.pool_stage([0], [levels[10]])               # ended episodes of the old content are still queued
+    batch = env.side_effects_flush(overlap=True, defer=True)
+    env.pool_stage([0], [levels[10]])                   # launches the deferred pass and waits for it, then writes the slot
+    env.pool_commit()
+    assert len(batch) > 0
+    rec = batch.records()
+    assert set(np.unique(rec["level"])) <= set(range(16))
+    # a staging whose device copy fails leaves the host pool as it was
+    bank = pool.bank.copy()
+    keep = env._lib.slhip_pool_write
+    try:
+        env._lib.slhip_pool_write = lambda *a: _hip.SL_E_HIP
+        steps(TL)
+        env.side_effects_flush()
+        with pytest.raises(_hip.SafeLifeHipError):
+            env.pool_stage([2], [levels[11]])
+    finally:
+        env._lib.slhip_pool_write = keep
+    assert np.array_equal(pool.bank, bank) and env._pool_refresh["staged"] is None
+
+
 def test_sharded_equals_unsharded():
     """env e behaves the same whichever rank owns it -- two half-size envs with
     env_offset 0 / B/2 (what ranks 0 and 1 of a 2-GPU run hold) against one env of size B."""
