@@ -817,6 +817,19 @@ def main():
                         pass
                 return us_streams
 
+            # the observation variants again as a trainer would step them: the batch in stream slices, and through the
+            # library's queues (the one-launch-per-step figures above are what SafeLifeVectorEnv.step() costs)
+            for tag, okw in (("obs_u8_25x25x15", dict(output_channels=TRAIN_CHANNELS, with_obs=True)),
+                             ("obs_u32_view_25x25", dict(output_channels=None, with_obs=True)),
+                             ("obs_policy_layout_u8_25x25x15", dict(output_channels=TRAIN_CHANNELS, with_obs=False,
+                                                                    policy_layout="uint8"))):
+                envo = SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25), auto_reset=True, level_stride=1,
+                                         slices=args.slices, **okw)
+                extra[tag + "_slices_us_per_step"] = time_steps(envo, B)
+                if envo.last_queues_us:
+                    extra[tag + "_queues_us_per_step"] = variants[tag.split("_25x25")[0] + "_queues_us"] = envo.last_queues_us
+                del envo
+
             # level-pool refresh while stepping (levels.LevelPool(refreshable=True), pool_stage / pool_commit): C3's batch through
             # the queues in calls of `chunk` steps, with a sixth of the pool's levels replaced every call (staged one call
             # ahead, committed between two calls) against the same calls without any refresh
@@ -1222,7 +1235,8 @@ def main():
                          #   c5_with_side_effects_us  C5's per-GPU share with the episode-end pass in the region (queues)
                          **{k: variants.get(k) for k in ("agent_fences_us", "no_reset_us", "steady_state_us", "k400_us", "unstaged_us",
                                                          "k20_median_us", "forced_gather_us", "c5_with_side_effects_us",
-                                                         "c5_with_side_effects_streams_us", "life_occupancy_64x64_board_steps_per_s")},
+                                                         "c5_with_side_effects_streams_us", "life_occupancy_64x64_board_steps_per_s",
+                                                         "obs_u8_queues_us", "obs_u32_view_queues_us", "obs_policy_layout_u8_queues_us")},
                          "scaling_curve": "not measured by this build (no multi-GPU node was available to it): the 1-to-N curve "
                                           "is the driver's",
                          "measured_ceiling": ceiling,

@@ -1,6 +1,7 @@
 // sl_abi.hip -- the extern "C" boundary declared in include/safelife_hip.h: argument validation,
 // the per-device PCG64 jump table, and dispatch to the gfx950 kernels.
 #include <cstdint>
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -778,8 +779,11 @@ int slhip_queues_stream_shares(int n_queues, void *stream, int *mask) {
         uint32_t *out;
     } args = {out};
     for (int q = 0; q < n_queues && err == hipSuccess; ++q) {
-        double best = 1e30;
-        for (int rep = 0; rep < 2 && err == hipSuccess; ++rep) {     // (the first pass also warms the kernels up)
+        // (a host-timer measurement on a shared box: one warm-up pass, then the MEDIAN of five -- a single fast or slow
+        //  outlier flags nothing)
+        double us_of[6];
+        int n_us = 0;
+        for (int rep = 0; rep < 6 && err == hipSuccess; ++rep) {
             err = hipStreamSynchronize(st);
             if (err == hipSuccess) err = sl::aql_fence(n_queues);
             if (err == hipSuccess) err = sl::launch_idle(ticks, st);
@@ -789,9 +793,10 @@ int slhip_queues_stream_shares(int n_queues, void *stream, int *mask) {
             if (err == hipSuccess) err = sl::aql_dispatch(sl::AqlLaunch{q, false, false}, f, 1, 256, 0, &args, sizeof(args));
             if (err == hipSuccess) err = sl::aql_fence(n_queues);
             const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
-            if (us < best) best = us;
+            if (rep > 0) us_of[n_us++] = us;
         }
-        if (best > 80.0) *mask |= 1 << q;           // (alone: a few microseconds; behind the long kernel: >= 150)
+        std::sort(us_of, us_of + n_us);
+        if (n_us && us_of[n_us / 2] > 80.0) *mask |= 1 << q;   // (alone: a few microseconds; behind the long kernel: >= 150)
     }
     if (err == hipSuccess) err = hipStreamSynchronize(st);
     (void)hipFree(out);
@@ -1163,22 +1168,30 @@ int slhip_gather_stream_shares(void *comm, int n_queues, void *stream, int *mask
         *us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
         probe_err = e;
     };
-    constexpr int REPS = 5;
+    constexpr int REPS = 6;                         // one that sets things up, then five that count
     double alone[8], behind[8];
     for (int q = 0; q < n_queues; ++q) {
-        alone[q] = behind[q] = 1e30;
+        double a_us[REPS], b_us[REPS];
+        int n = 0;
         for (int rep = 0; rep < REPS; ++rep) {
-            double us = 0;
+            double ua = 0, ub = 0;
             (void)hipStreamSynchronize(st);
             if (local_why.empty() && probe_err == hipSuccess) probe_err = sl::aql_fence(n_queues);
-            tiny(q, &us);
-            alone[q] = std::min(alone[q], us);
+            tiny(q, &ua);
             if (rc == SL_OK) rc = gather_issue(g, send, recv, bytes, st);      // (an RCCL error is every rank's error)
-            tiny(q, &us);
-            if (rep > 0) behind[q] = std::min(behind[q], us);      // (the first exchange of a stream sets things up)
+            tiny(q, &ub);
+            if (rep > 0) {                          // (the first exchange of a stream sets things up)
+                a_us[n] = ua;
+                b_us[n++] = ub;
+            }
         }
         // (measured: 9 us alone and 9-10 us behind the exchange on a queue it does not touch; 15 and 22 us on the one
-        //  that shares a pipe with the stream's hardware queue.  Minima over the repetitions: host noise only ever adds.)
+        //  that shares a pipe with the stream's hardware queue.  MEDIANS of the five repetitions: one quiet or one noisy
+        //  repetition decides nothing, on either side of the comparison.)
+        std::sort(a_us, a_us + n);
+        std::sort(b_us, b_us + n);
+        alone[q] = a_us[n / 2];
+        behind[q] = b_us[n / 2];
         if (local_why.empty() && probe_err == hipSuccess && rc == SL_OK && behind[q] > alone[q] + 3.0) *mask |= 1 << q;
     }
     err = hipStreamSynchronize(st);

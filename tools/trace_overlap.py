@@ -27,6 +27,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("steps", nargs="?", type=int, default=6)
 ap.add_argument("--queues", type=int, default=0)
 ap.add_argument("--fences", default="agent")
+ap.add_argument("--stage", type=int, default=0, help="queue mode: 1 = the steps are staged, then released by queues_go (bench.py's region)")
 ap.add_argument("--spread", type=int, default=0, help="1: envs spread over their episodes (resets at every step)")
 ap.add_argument("--gather-every", type=int, default=0,
                 help="queue mode: hand a window of this many steps to the RCCL exchange (one rank, to itself) inside the trace")
@@ -68,7 +69,13 @@ if args.queues and args.gather_every:
     env.queues_sync()
     print("windows of %d steps handed to the exchange: %d" % (args.gather_every, gather.windows))
 elif args.queues:
-    env.step_queues_many(acts[64:64 + N], assume_ordered=True)
+    if args.stage:
+        env.step_queues_many(acts[64:64 + N], assume_ordered="untouched", defer=True)
+        import time
+        time.sleep(0.001)
+        env.queues_go()
+    else:
+        env.step_queues_many(acts[64:64 + N], assume_ordered=True)
     env.queues_sync()
 else:
     for t in range(64, 64 + N):
