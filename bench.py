@@ -166,7 +166,7 @@ class _StandInEnv(object):
         self._ct = ctypes
         self.set_step_outputs(None)
 
-    def set_step_outputs(self, out_ptr):
+    def set_step_outputs(self, out_ptr, compact=False):
         self.out_ptr = self.own.ctypes.data if out_ptr is None else int(out_ptr)
 
     def step_async(self, t):

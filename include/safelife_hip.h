@@ -273,7 +273,9 @@ typedef struct sl_env_batch {
                                     channels[c] of the view word at (y,x); uint8 or float32 (policy_dtype).  Needs
                                     n_channels >= 1.  NULL = skip */
     int32_t policy_dtype;        /* 0 = uint8, 1 = float32 */
-    int32_t reserved1;
+    int32_t out_compact;         /* != 0: `out` takes 8-byte records -- the first half of sl_step_out: reward, done, success,
+                                    times_up -- instead of 16-byte ones (what a learner on another rank needs of every
+                                    step: half the bytes a gather window carries; sharding.RewardGather(record="compact")) */
     /* workspace */
     int8_t *score_lut;           /* [n_tables,4096+65536] per-cell score tables derived from points_table by
                                     slhip_env_prepare(); NULL => the size-generic kernels are used */

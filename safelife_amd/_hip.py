@@ -113,7 +113,7 @@ class EnvBatch(C.Structure):
         + [(n, _p) for n in ENV_STATE_PTRS]
         + [("L", C.c_int32), ("level_stride", C.c_int32)]
         + [(n, _p) for n in ENV_POOL_PTRS + ENV_POOL_TAIL]
-        + [("out", _p), ("obs", _p), ("policy_obs", _p), ("policy_dtype", C.c_int32), ("reserved1", C.c_int32),
+        + [("out", _p), ("obs", _p), ("policy_obs", _p), ("policy_dtype", C.c_int32), ("out_compact", C.c_int32),
            ("score_lut", _p), ("goal_cache", _p), ("pool_ready", _p)]
         + [("wrap", Wrappers), ("finished", EpisodeQueue)]
     )

@@ -984,7 +984,7 @@ static int queues_steps(void *handle, const sl_env_batch *env, const int32_t *ac
     c->pending = true;
     for (int t = 0; t < n_steps; ++t) {
         const int32_t *a_t = actions + (long long)t * action_stride;
-        sl_step_out *o_t = env->out + (long long)t * out_stride;
+        sl_step_out *o_t = (sl_step_out *)((char *)env->out + (long long)t * out_stride * (env->out_compact ? 8 : (long long)sizeof(sl_step_out)));
         if (c->swap) {
             const hipError_t err = sl::aql_drain(c->n_phys);
             if (err != hipSuccess) return hip_fail(err, "AQL drain (self-test)");

@@ -444,7 +444,11 @@ __global__ __launch_bounds__(GB_MAX) void k_env_rollout_generic(sl_env_batch env
             o.reserved = 0;
             o.episode_reward = ep_r;
             o.episode_length = ep_l;
-            env.out[e] = o;
+            if (env.out_compact)
+                ((unsigned long long *)env.out)[e] =
+                    (unsigned long long)__float_as_uint(reward) |
+                    ((unsigned long long)((done ? 1u : 0u) | ((success ? 1u : 0u) << 8) | ((times_up ? 1u : 0u) << 16)) << 32);
+            else env.out[e] = o;
             if (reward_t) reward_t[(size_t)t * env.B + e] = reward;
             if (done_t) done_t[(size_t)t * env.B + e] = done;
             ivar[2] = done;

@@ -3271,7 +3271,11 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
                 o.episode_length = ep_len;
                 unsigned e3 = el;
                 asm volatile("" : "+v"(e3));
-                out_rec[e3] = o;
+                if (env.out_compact)        // (the record's first half, assembled in registers: reward, then the three flag bytes)
+                    ((unsigned long long *)out_rec)[e3] =
+                        (unsigned long long)__float_as_uint(reward) |
+                        ((unsigned long long)((done ? 1u : 0u) | ((success ? 1u : 0u) << 8) | ((times_up ? 1u : 0u) << 16)) << 32);
+                else out_rec[e3] = o;
 #ifndef SL_TRACE
                 if (reward_t) reward_t[(size_t)t * B + el] = reward;
                 if (done_t) done_t[(size_t)t * B + el] = done;

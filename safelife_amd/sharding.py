@@ -55,12 +55,19 @@ class RewardGather(object):
 
     RECORD_BYTES = 16
 
-    def __init__(self, env, every=32, world=1, rank=0, group=None, backend=None, force=None):
+    def __init__(self, env, every=32, world=1, rank=0, group=None, backend=None, force=None, record="full"):
+        """``record``: "full" -- sl_step_out, 16 bytes per env and step (reward, done / success / times_up, episode reward
+        and length) -- or "compact": its first 8 bytes (reward and the three flags: SURVEY 5.8's record), which halves
+        what every window carries to rank 0 (seven peers' worth on an 8-GPU node)."""
         import torch
         self.torch = torch
         self.env, self.every, self.world, self.rank, self.group = env, int(every), int(world), int(rank), group
         self.B = B = env.num_envs
-        shape = (self.every, B, 4)
+        if record not in ("full", "compact"):
+            raise ValueError("record must be 'full' or 'compact'")
+        self.compact = record == "compact"
+        self.RECORD_BYTES = 8 if self.compact else 16
+        shape = (self.every, B, self.RECORD_BYTES // 4)
         self.cuda = torch.device(env.device).type == "cuda"
         # SAFELIFE_FORCE_GATHER=1 runs the exchange even with one rank (exercises the RCCL path on a one-GPU box)
         self.force = (os.environ.get("SAFELIFE_FORCE_GATHER", "0") == "1") if force is None else bool(force)
@@ -249,7 +256,7 @@ class RewardGather(object):
             self._wait(which, self._writer_streams())      # the buffer is free again
             self.work[which], self.busy[which] = None, False
             self.exposed_s += time.perf_counter() - t0
-        self.env.set_step_outputs(self._slot_ptr[which][slot])
+        self.env.set_step_outputs(self._slot_ptr[which][slot], compact=self.compact)
 
     def after_step(self, t):
         if t % self.every != self.every - 1:
@@ -289,7 +296,7 @@ class RewardGather(object):
                 self._wait(which, [])                       # the buffer is free again (the exchange of two windows ago)
                 self.work[which], self.busy[which] = None, False
                 self.exposed_s += time.perf_counter() - w0
-            env.set_step_outputs(self._slot_ptr[which][slot])
+            env.set_step_outputs(self._slot_ptr[which][slot], compact=self.compact)
             d0 = time.perf_counter()
             env.step_queues_many(action_ptr + 4 * action_stride * (t - t0), seg, action_stride, out_stride=B,
                                  assume_ordered=assume_ordered)
@@ -318,8 +325,8 @@ class RewardGather(object):
         self.env.set_step_outputs(None)
 
     def latest_records(self):
-        """Records of the last COMPLETED window, int32 [world, every, B, 4] (the exchange that filled it is
-        waited for on the current stream first)."""
+        """Records of the last COMPLETED window, int32 [world, every, B, 4] ("compact": [..., 2]) (the exchange that
+        filled it is waited for on the current stream first)."""
         if self.last is None:
             return None
         if self.work[self.last] is not None or self.busy[self.last]:

@@ -1026,11 +1026,13 @@ class SafeLifeVectorEnv(object):
         self.steps_dispatched += T
         return reward_out, done_out
 
-    def set_step_outputs(self, out_ptr):
+    def set_step_outputs(self, out_ptr, compact=False):
         """Redirect the per-step output records (``sl_step_out[B]``, 16 bytes per env) to caller-owned
         device memory; ``None`` restores the env's own tensor.  Used by sharding.RewardGather to have
-        the kernel fill a send buffer directly."""
+        the kernel fill a send buffer directly.  ``compact``: 8-byte records there -- reward, done, success,
+        times_up: ``sl_env_batch.out_compact`` -- (the env's own tensor always takes whole records)."""
         self.struct.out = self.t["out"].data_ptr() if out_ptr is None else int(out_ptr)
+        self.struct.out_compact = 1 if (compact and out_ptr is not None) else 0
 
 
     def get_obs(self):

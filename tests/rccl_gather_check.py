@@ -30,8 +30,9 @@ kw = dict(time_limit=12, view_shape=(9, 9), auto_reset=True, with_obs=False)
 env = SafeLifeVectorEnv(pool, B, slices=2, **kw)
 ref = SafeLifeVectorEnv(pool, B, **kw)          # same envs, outputs read directly every step
 env.reset(), ref.reset()
-gather = RewardGather(env, every=every, world=1, rank=0)
+gather = RewardGather(env, every=every, world=1, rank=0, record=os.environ.get("SL_GATHER_RECORD", "full"))
 assert gather.backend == "rccl" and gather.collective
+assert gather.buf[0].shape[-1] == (2 if gather.compact else 4)
 gather.prime()
 rng = np.random.default_rng(3)
 want_r, want_d = [], []

@@ -1087,11 +1087,15 @@ def test_queue_stepping_vs_oracle(pool_name, B, queue_slices, kw, release_free):
     assert cpu.get("episode_idx").min() >= 1
 
 
-def test_queue_steps_write_one_record_set_per_step():
+@pytest.mark.parametrize("compact", [False, True], ids=["16-byte records", "8-byte records"])
+def test_queue_steps_write_one_record_set_per_step(compact):
     """slhip_queues_steps with out_stride: step t's sl_step_out records land in slot t of a caller-owned window (what
-    sharding.RewardGather hands to RCCL), against the oracle's reward / done of every step."""
+    sharding.RewardGather hands to RCCL), against the oracle's reward / done of every step.  compact: the 8-byte
+    record -- reward + flags, sl_env_batch.out_compact -- that halves what a window carries to rank 0; also through
+    one launch per step on a stream, and through the size-generic kernels."""
     import torch
     B, T = 512, 24
+    W = 2 if compact else 4
     pool, _ = util.pool_from_fixture("prune_still_25", _device_counts, min_performance_fraction=0.05)
     common = dict(first_level=np.arange(B) % len(pool), auto_reset=True, level_stride=3, time_limit=10, view_shape=(9, 9),
                   with_obs=False)
@@ -1103,17 +1107,23 @@ def test_queue_steps_write_one_record_set_per_step():
     cpu.env.reset()
     acts = np.random.default_rng(8).integers(0, 9, (T, B)).astype(np.int32)
     d_acts = torch.from_numpy(acts).to(env.device)
-    window = torch.zeros((T, B, 4), dtype=torch.int32, device=env.device)
+    window = torch.full((T + 1, B, W), -1, dtype=torch.int32, device=env.device)
     torch.cuda.synchronize()
-    env.set_step_outputs(window.data_ptr())
-    env.step_queues_many(d_acts, out_stride=B)
+    env.set_step_outputs(window.data_ptr(), compact=compact)
+    env.step_queues_many(d_acts[:T - 4], out_stride=B)
     env.queues_sync()
+    for t in range(T - 4, T):           # the last steps one launch at a time on the caller's stream, same records
+        env.set_step_outputs(window[t].data_ptr(), compact=compact)
+        env.step_async(d_acts[t])
+    env.join()
     env.set_step_outputs(None)
     rec = window.cpu().numpy()
+    assert (rec[T] == -1).all()         # nothing written past the last step's slot
     for t in range(T):
         cpu.env.step(acts[t])
         assert np.array_equal(rec[t, :, 0].view(np.float32), cpu.get("reward")), t
         assert np.array_equal(rec[t, :, 1].astype(np.uint32) & 0xFF, cpu.get("done").astype(np.uint32)), t
+    assert env.struct.out_compact == 0
 
 
 def test_queues_stream_shares_probe():
@@ -1320,13 +1330,15 @@ def test_manual_reset_moves_on_and_episode_streams():
     assert episodes.min() >= 2 and np.array_equal(dev.get("level_idx"), (2 * episodes) % len(pool))
 
 
-def test_reward_gather_through_rccl():
+@pytest.mark.parametrize("record", ["full", "compact"])
+def test_reward_gather_through_rccl(record):
     """The real env (two slices, outputs redirected into the gather windows) + RewardGather with the RCCL
     collective forced on for a single rank (SAFELIFE_FORCE_GATHER=1): every window against the rewards / dones
-    of an identical env read directly.  Own process: it initialises torch.distributed with the nccl backend."""
+    of an identical env read directly.  Own process: it initialises torch.distributed with the nccl backend.
+    record: whole sl_step_out records, or their first 8 bytes (sl_env_batch.out_compact)."""
     import subprocess, sys
     out = subprocess.check_output([sys.executable, os.path.join(util.REPO, "tests", "rccl_gather_check.py")],
-                                  stderr=subprocess.STDOUT, timeout=300).decode()
+                                  env=dict(os.environ, SL_GATHER_RECORD=record), stderr=subprocess.STDOUT, timeout=300).decode()
     assert "rccl gather ok" in out, out
 
 

@@ -33,23 +33,27 @@ class _FakeEnv(object):
         self.own = np.zeros((B, 4), np.int32)
         self.set_step_outputs(None)
 
-    def set_step_outputs(self, out_ptr):
+    def set_step_outputs(self, out_ptr, compact=False):
         self.out_ptr = self.own.ctypes.data if out_ptr is None else int(out_ptr)
+        self.compact = bool(compact and out_ptr is not None)
 
     def step(self, t, rank):
-        rec = np.ctypeslib.as_array(C.cast(self.out_ptr, C.POINTER(C.c_int32)), (self.num_envs, 4))
+        words = 2 if self.compact else 4            # (sl_env_batch.out_compact: the record's first 8 bytes only)
+        rec = np.ctypeslib.as_array(C.cast(self.out_ptr, C.POINTER(C.c_int32)), (self.num_envs, words))
         rec[:, 0] = (1000.0 * rank + t + np.arange(self.num_envs) / 64.0).astype(np.float32).view(np.int32)
         rec[:, 1] = ((np.arange(self.num_envs) + t + rank) % 3 == 0).astype(np.int32)      # done in byte 0
-        rec[:, 2] = np.float32(t).view(np.int32)
-        rec[:, 3] = t
+        if not self.compact:
+            rec[:, 2] = np.float32(t).view(np.int32)
+            rec[:, 3] = t
 
 
-def _worker(rank, world, port, B, every, steps, out_q):
+def _worker(rank, world, port, B, every, steps, out_q, record="full"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     env = _FakeEnv(B)
-    gather = RewardGather(env, every=every, world=world, rank=rank)
+    gather = RewardGather(env, every=every, world=world, rank=rank, record=record)
+    assert gather.buf[0].shape == (every, B, 2 if record == "compact" else 4)
     seen = []
     for t in range(steps):
         gather.before_step(t)
@@ -67,14 +71,15 @@ def _worker(rank, world, port, B, every, steps, out_q):
     dist.destroy_process_group()
 
 
-def test_reward_gather_world2():
+@pytest.mark.parametrize("record", ["full", "compact"])
+def test_reward_gather_world2(record):
     world, B, every, steps = 2, 48, 4, 12
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, B, every, steps, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, B, every, steps, q, record)) for r in range(world)]
     for p in procs:
         p.start()
     seen = q.get(timeout=120)
