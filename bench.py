@@ -9,16 +9,21 @@ bench.py -- env-steps/s of the batched SafeLife step() on MI355X (BASELINE.json 
 Workload (BASELINE.json configs[2]): 8192 envs x 25x25 per GPU,
 levels from the reference's `prune-still` procgen (fixture pool, cycled), uniform random actions,
 full step = execute_actions + advance_board + exit colours + score/reward/done + episode
-accounting + on-device auto-reset.  One "step" = ONE launch of the fused kernel over all envs of
-a rank.  Inputs are resident in HBM before the timed region.  Weak scaling: every rank owns 8192
-envs; the only cross-GPU traffic is the gather of (reward, done) to rank 0, batched every
---gather-every steps on a side stream.
+accounting + on-device auto-reset.  One "step" = every env of a rank stepped once (four slice
+launches of the fused kernel on the library's AQL queues).  Inputs are resident in HBM before the
+timed region, which starts with the envs spread over their 1000-step episodes (episode
+ends -- about envs/1000 per step -- and their in-kernel resets are INSIDE it; --spread 0: rounds
+1-5's region straight behind a reset of all envs).  Weak scaling: every rank owns 8192 envs; the only
+cross-GPU traffic is the gather of 8-byte (reward, done, success, times_up) records to rank 0,
+batched every --gather-every steps on a side stream.
 
 Output: one JSON line on rank 0 (see README / the driver contract), with
-  roofline     -- algorithmic HBM bytes per launch / measured average launch duration (HIP events on
-                  the launch stream) against the 8 TB/s HBM3E peak
+  roofline     -- algorithmic HBM bytes per step / ms_per_step against the 8 TB/s HBM3E peak, plus -- as
+                  short numeric fields, measured in the same run behind the timed region -- the same
+                  region under the library's default fences, without episode ends, 400 steps long,
+                  unstaged, with a forced one-rank exchange, and C5 / the observation variants
   cpu_baseline -- the oracle (plain-C restatement, OpenMP over envs) timed on this host on a bounded
-                  sample of the same workload.
+                  sample of the same workload, and the bit-for-bit replay of the timed run on it.
 """
 import argparse
 import json
@@ -340,7 +345,9 @@ def main():
     # N > 1: the window is cut so that at least one closes -- one RCCL exchange is issued -- inside the timed steps
     forced = os.environ.get("SAFELIFE_FORCE_GATHER", "0") == "1"         # one rank, exchange on (RCCL to itself)
     every_used = gather_window(args.gather_every, K) if (world > 1 or forced) else args.gather_every
-    gather = RewardGather(env, every=every_used, world=world, rank=rank)
+    # (the 8-byte record -- reward, done, success, times_up: what a learner on rank 0 needs of every step -- not the whole
+    #  16-byte sl_step_out: half the bytes per window)
+    gather = RewardGather(env, every=every_used, world=world, rank=rank, record="compact")
     gather.prime()
     every = gather.every
     # windows are counted from the END of the timed block: its last step closes one (a learner that consumes K-step
@@ -610,7 +617,7 @@ def main():
                 variants["unstaged_us"] = median_us(stage=False)
             variants["k20_median_us"] = median_us(n=5)
             env.queues_close()
-            g2 = RewardGather(env, every=gather_window(args.gather_every, K), world=1, rank=0, force=True)
+            g2 = RewardGather(env, every=gather_window(args.gather_every, K), world=1, rank=0, force=True, record="compact")
             g2.prime()
             shift2 = (g2.every - (W + K) % g2.every) % g2.every
             if K >= 8 and g2.every >= 8:
@@ -1174,7 +1181,7 @@ def main():
                        "level_pool": len(pool), "parallelism": "envs sharded %d-way, step records gathered "
                                                                "to rank 0 every %d steps (%s); %s" % (
                                                                    world, every_used,
-                                                                   "RCCL send/recv on a side stream" if gather.collective
+                                                                   "8-byte records, RCCL send/recv on a side stream" if gather.collective
                                                                    else "one rank: nothing to exchange",
                                                                    ("%d slice(s) per GPU, one dispatch each on an AQL queue of "
                                                                     "the library's own (barrier bit; fences: see "
@@ -1242,17 +1249,17 @@ def main():
                          "measured_ceiling": ceiling,
                          # the issue side next to the HBM side (C3, four waves per SIMD; counters and timing-only builds
                          # committed under profiles/, not measured in this run)
-                         "issue_side": ({"valu_per_wave": 539, "salu_per_wave": 235, "lds_per_wave": 53, "waves_per_simd": 4,
+                         "issue_side": ({"valu_per_wave": 538, "salu_per_wave": 226, "lds_per_wave": 52, "waves_per_simd": 4,
                                          "valu_cycles_each": [2, 4],
-                                         "valu_issue_us_per_step": [4 * 539 * 2 / 2.4e3, 4 * 539 * 4 / 2.4e3],
+                                         "valu_issue_us_per_step": [4 * 538 * 2 / 2.4e3, 4 * 538 * 4 / 2.4e3],
                                          "hbm_floor_us_per_step": bytes_per_step * B / (HBM_PEAK_GBS * 1e3),
                                          "timing_only_us_per_step": {"full": 6.4, "no_ca": 5.7, "no_scores": 6.2,
                                                                      "no_leader_work": 6.1, "skeleton": 4.8},
                                          "binds": "neither roofline: the step is one launch's latency chain (DMA issue, "
                                                   "memory latency, three workgroup barriers, stores) plus the CP's "
                                                   "boundary between launches; the SIMDs are at most half busy",
-                                         "source": "profiles/round5_m_queues4_none_pmc.txt, round5_a_c3_issue_pmc.txt, "
-                                                   "round5_f_timing_only.txt; DESIGN.md section 6"}
+                                         "source": "profiles/round6_z_pmc.txt (538 / 226 / 52 per wave on this tree), "
+                                                   "round5_a_c3_issue_pmc.txt, round5_f_timing_only.txt; DESIGN.md section 6"}
                                         if args.pool == "prune_still_25" and B == 8192 and not args.obs else None),
                          "note": "frac = bytes_per_env_step x envs / ms_per_step / peak.  rocprofv3 serialises the queues' "
                                  "dispatches (its kernel trace gives per-launch durations only); the four queues' overlap "

@@ -22,6 +22,7 @@ nq = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 B = 8192
 NO_HEAD = os.environ.get("KFIT_NO_HEAD") == "1"
 NO_TORCH_SYNC = os.environ.get("KFIT_NO_TORCH_SYNC") == "1"
+STAGE = os.environ.get("KFIT_STAGE") == "1"         # staged regions + "untouched" first steps, as bench.py times them
 pool = bench.load_pool("prune_still_25", _device_counts)
 env = SafeLifeVectorEnv(pool, B, time_limit=1000, view_shape=(25, 25), output_channels=bench.TRAIN_CHANNELS, auto_reset=True,
                         with_obs=False, slices=2)
@@ -43,8 +44,13 @@ for K in Ks:
         env.queues_sync(); torch.cuda.synchronize()
         if NO_HEAD:
             env._caller_ahead = False           # (experiment: the first step of the region without its system-scope acquire)
-        t0 = time.perf_counter()
-        env.step_queues_many(acts[40:40 + K], assume_ordered=True)
+        if STAGE and K <= 48:                   # (bench.py's region: staged ahead of the clock, released inside it)
+            env.step_queues_many(acts[40:40 + K], assume_ordered="untouched", defer=True)
+            t0 = time.perf_counter()
+            env.queues_go()
+        else:
+            t0 = time.perf_counter()
+            env.step_queues_many(acts[40:40 + K], assume_ordered="untouched" if STAGE else True)
         t1 = time.perf_counter()
         if not NO_TORCH_SYNC:
             torch.cuda.synchronize()
@@ -59,5 +65,5 @@ x = np.array(Ks, float); y = np.array([med[K][0] for K in Ks])
 A = np.stack([np.ones_like(x), x], 1)
 (fixed, per), *_ = np.linalg.lstsq(A, y, rcond=None)
 print("%s spread=%d fences=%s queues=%d%s%s: elapsed = %.1f us + %.3f us x K   (K=20 -> %.2f us/step)" % (
-    os.path.basename(os.environ.get("SAFELIFE_HIP_LIB", "tree")), spread, fences, env.queue_slices, " no-head" if NO_HEAD else "", " no-torch-sync" if NO_TORCH_SYNC else "", fixed, per,
+    os.path.basename(os.environ.get("SAFELIFE_HIP_LIB", "tree")), spread, fences, env.queue_slices, (" no-head" if NO_HEAD else "") + (" staged+untouched" if STAGE else ""), " no-torch-sync" if NO_TORCH_SYNC else "", fixed, per,
     (fixed + 20 * per) / 20))
