@@ -124,3 +124,14 @@ print("  %-24s %6.0f %6.0f %6.0f   (same workgroup, one step earlier: its stores
       % ("successor starts after", succ.mean(), np.percentile(succ, 50), np.percentile(succ, 90)))
 cyc = (tr[3 * SL:, :, 0] - tr[2 * SL:-SL, :, 0]).astype(np.float64).reshape(-1) * 10.0
 print("  %-24s %6.0f %6.0f %6.0f   (start to start of the same workgroup's consecutive steps)" % ("workgroup cycle", cyc.mean(), np.percentile(cyc, 50), np.percentile(cyc, 90)))
+
+# the waves a launch waits for: phase breakdown of the slowest 0.5 % (with --spread 1: the workgroups that reload a level)
+lt = (st[:, :, 10] - st[:, :, 0])
+cut = np.percentile(lt.reshape(-1), 99.5)
+slow = lt >= cut
+print("slowest 0.5 %% of waves (lifetime >= %.0f ns, %d waves): phases, mean ns" % (cut, int(slow.sum())))
+for i, n in enumerate(names):
+    print("  %-24s %6.0f   (all waves %6.0f)" % (n, ph[:, :, i][slow].mean(), ph[:, :, i].mean()))
+print("  %-24s %6.0f   (all waves %6.0f)" % ("wave lifetime", lt[slow].mean(), lt.mean()))
+per_launch_max = lt.max(axis=1)
+print("per launch: slowest wave %.0f ns mean (median wave %.0f)" % (per_launch_max.mean(), np.median(lt, axis=1).mean()))
