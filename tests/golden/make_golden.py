@@ -567,6 +567,126 @@ def gen_env_traces(R, out):
         np.savez_compressed(os.path.join(out, "trace_%s.npz" % name), **blob)
 
 
+# --------------------------------------------------------------- multi-agent traces (single_agent=False)
+
+def run_trace_multi(R, games, actions, env_kw):
+    """The reference SafeLifeEnv with single_agent=False (safelife_env.py:148-218) over `games`, one episode each:
+    per-agent observation, reward, done, episode accumulators; the env is reset when EVERY agent is done
+    (training/base_algo.py:231-236).  actions: int [T, A]."""
+    env = R.env.SafeLifeEnv(iter(games), single_agent=False, **env_kw)
+    rec = {k: [] for k in ("obs", "reward", "done", "board", "goals", "agent_locs", "times_up", "ep_length", "ep_reward",
+                           "success", "reset_obs", "reset_board", "reset_rng", "reset_required", "rng_after", "num_steps")}
+
+    def note_reset(obs):
+        rec["reset_obs"].append(obs.copy())
+        rec["reset_board"].append(env.game.board.copy())
+        rec["reset_rng"].append(words(env.game._rng.bit_generator))
+        rec["reset_required"].append(np.array(env.game.required_points(), np.int64))
+
+    note_reset(env.reset())
+    reset_at = [0]
+    for t, a in enumerate(actions):
+        obs, reward, done, info = env.step(np.array(a, np.int64))
+        assert reward.dtype == np.float32 and obs.shape[0] == len(a)
+        rec["obs"].append(obs.copy())
+        rec["reward"].append(reward.copy())
+        rec["done"].append(np.array(done, bool))
+        rec["board"].append(info["board"].copy())
+        rec["goals"].append(info["goals"].copy())
+        rec["agent_locs"].append(np.array(info["agent_locs"], np.int64).copy())
+        rec["times_up"].append(bool(info["times_up"]))
+        rec["ep_length"].append(np.array(info["episode"]["length"], np.int64).copy())
+        rec["ep_reward"].append(np.array(info["episode"]["reward"], np.float32).copy())
+        rec["success"].append(np.array(info["episode"]["success"], bool))
+        rec["rng_after"].append(words(env.game._rng.bit_generator))
+        rec["num_steps"].append(env.game.num_steps)
+        if np.all(done):
+            try:
+                obs = env.reset()
+            except StopIteration:
+                break
+            note_reset(obs)
+            reset_at.append(t + 1)
+    out = {k: np.array(v) for k, v in rec.items()}
+    out["reset_at"] = np.array(reset_at)
+    out["actions"] = np.array(actions[:len(rec["reward"])], np.int32)
+    return out
+
+
+def gen_multi_agent_traces(R, out):
+    """Two-agent levels of the reference's own multi-agent specs (levels/random/multi-agent/*.yaml: distinct agent
+    colours, flags and points tables) at 26x26, and a hand-made 10x10 level on which one agent walks into the open exit
+    while the other plays on -- the multi-agent half of SafeLifeEnv.step (safelife_env.py:162-170)."""
+    Game = R.game.SafeLifeGame
+    rng = np.random.default_rng(99)
+
+    def blob_of(name, games_fn, actions, env_kw):
+        games = games_fn()
+        tr = run_trace_multi(R, games, actions, env_kw)
+        blob = {}
+        for i, g in enumerate(games_fn()):
+            for k, v in level_record(g).items():
+                blob["level%d_%s" % (i, k)] = v
+            blob["level%d_rng" % i] = words(g._rng.bit_generator)
+        blob["n_levels"] = np.array(len(games))
+        for k, v in tr.items():
+            blob["trace_" + k] = v
+        for k, v in env_kw.items():
+            blob["env_" + k] = np.array(-1 if v is None else v)
+        np.savez_compressed(os.path.join(out, "trace_multi_%s.npz" % name), **blob)
+        print("multi-agent trace %-18s steps=%4d episodes=%d sum_reward=%s exits=%d" % (
+            name, len(tr["reward"]), len(tr["reset_at"]), tr["reward"].sum(0), int(tr["success"].any(1).sum())))
+
+    train15 = (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 25, 26, 27)
+    for spec, seed, n_levels, env_kw in (
+            ("asym1", 5, 3, dict(view_shape=(9, 9), output_channels=None, time_limit=45, should_calculate_side_effects=False)),
+            ("build-coop", 6, 2, dict(view_shape=(15, 15), output_channels=train15, time_limit=60,
+                                      should_calculate_side_effects=False)),
+            ("build-compete", 7, 2, dict(view_shape=(25, 25), output_channels=None, time_limit=50,
+                                         should_calculate_side_effects=False))):
+        def games_fn(spec=spec, seed=seed, n_levels=n_levels):
+            it = R.levels.SafeLifeLevelIterator("random/multi-agent/" + spec, seed=seed, num_workers=0)
+            return [next(it) for _ in range(n_levels)]
+        n_agents = len(games_fn()[0].agent_locs)
+        assert n_agents == 2
+        acts = rng.integers(0, 9, (150, n_agents))
+        blob_of(spec.replace("-", "_"), games_fn, acts, env_kw)
+
+    # hand-made: exits open from the start (min_performance -1); agent 0 walks right into the exit at step 2 and is
+    # done (success) while agent 1 keeps playing until the time limit; then a second episode in which both walk out
+    CT = R.game.CellTypes
+    b = np.zeros((10, 10), np.uint16)
+    b[5, 5] = CT.level_exit
+    b[2, 7] = CT.level_exit
+    b[5, 3] = CT.player | CT.color_r
+    b[2, 2] = CT.player | CT.color_b
+    b[7, 7] = CT.life | CT.color_g
+    b[7, 8] = CT.life | CT.color_g
+    b[8, 7] = CT.life | CT.color_g
+    b[8, 8] = CT.life | CT.color_g
+    goals = np.zeros_like(b)
+    goals[1, 1] = CT.color_g
+
+    def hand_games():
+        gs = []
+        for k in range(2):
+            g = Game(board_size=(10, 10))
+            g.board = b.copy()
+            g.goals = goals.copy()
+            g.agent_locs = np.array([[5, 3], [2, 2]])
+            g.min_performance = -1
+            g.reset_points_table()
+            g.update_exit_locs()
+            data = g.serialize()
+            gs.append(seeded(Game.loaddata(data), 40 + k))
+        return gs
+    # actions: 1 up, 2 right, 3 down, 4 left (safelife_game.py action table); 0 = no-op once an agent has left
+    ep1 = [[2, 0], [2, 5], [0, 2], [0, 2], [0, 6], [0, 3], [0, 0], [0, 1]]
+    ep2 = [[2, 2], [2, 2], [0, 2], [0, 2], [0, 2], [0, 0]]
+    blob_of("hand_exit", hand_games, np.array(ep1 + ep2), dict(view_shape=(7, 7), output_channels=None, time_limit=8,
+                                                              should_calculate_side_effects=False))
+
+
 # --------------------------------------------------------------- level pools
 
 def gen_pool(R, out, spec, shape, n, seed, tag):
@@ -757,6 +877,8 @@ def main():
         gen_pool(R, out, "prune-still", (25, 25), 96, 2024, "prune_still_25")
         gen_pool(R, out, "append-spawn", (25, 25), 64, 2025, "append_spawn_25")
         gen_pool(R, out, "append-still", (26, 26), 32, 2026, "append_still_26")
+    if "multi" in todo:
+        gen_multi_agent_traces(R, out)
     if "bulk" in todo:
         gen_bulk(R, out)
     if args.nav64:

@@ -529,6 +529,45 @@ def test_compat_env_trace(name):
             assert np.array_equal(obs, tr["trace_reset_obs"][episode]), where
 
 
+MULTI_TRACES = ["multi_asym1", "multi_build_coop", "multi_build_compete", "multi_hand_exit"]
+
+
+@pytest.mark.parametrize("name", MULTI_TRACES)
+def test_compat_env_trace_multi_agent(name):
+    """single_agent=False (safelife_env.py:162-170, advance_board.c:217-220): two-agent levels of the reference's own
+    multi-agent specs -- distinct colours, flags and points tables per agent -- and a hand-made level on which the agents
+    leave through the exit one after the other; every agent's observation, reward, done, episode accumulators and the
+    shared board against the reference's SafeLifeEnv, step for step, resets when all agents are done."""
+    from safelife_amd.env import SafeLifeEnv
+    tr = util.load_trace(name)
+    kw = util.env_kwargs_from_trace(tr)
+    env = SafeLifeEnv(iter(_compat_games(tr)), single_agent=False, **kw)
+    obs = env.reset()
+    assert np.array_equal(obs, tr["trace_reset_obs"][0])
+    assert np.array_equal(env.game.required_points(), tr["trace_reset_required"][0])
+    episode = 0
+    for t in range(len(tr["trace_reward"])):
+        obs, reward, done, info = env.step(tr["trace_actions"][t].astype(np.int64))
+        where = "step %d" % t
+        assert reward.dtype == np.float32 and np.array_equal(reward, tr["trace_reward"][t]), where
+        assert np.array_equal(np.asarray(done, bool), tr["trace_done"][t]), where
+        assert np.array_equal(obs, tr["trace_obs"][t]), where
+        assert np.array_equal(info["board"], tr["trace_board"][t]), where
+        assert np.array_equal(info["goals"], tr["trace_goals"][t]), where
+        assert np.array_equal(info["agent_locs"], tr["trace_agent_locs"][t]), where
+        assert bool(info["times_up"]) == bool(tr["trace_times_up"][t]), where
+        assert np.array_equal(info["episode"]["length"], tr["trace_ep_length"][t]), where
+        assert np.array_equal(info["episode"]["reward"], tr["trace_ep_reward"][t]), where
+        assert np.array_equal(np.asarray(info["episode"]["success"], bool), tr["trace_success"][t]), where
+        if np.all(done):
+            episode += 1
+            if episode >= len(tr["trace_reset_at"]):
+                break
+            obs = env.reset()
+            assert np.array_equal(obs, tr["trace_reset_obs"][episode]), where
+            assert np.array_equal(env.game.required_points(), tr["trace_reset_required"][episode]), where
+
+
 @pytest.mark.parametrize("name", ["wrap_train_prune-still", "wrap_train_append-still", "wrap_other_prune-still",
                                   "wrap_se_append-stochastic-1", "wrap_mv_noagent"])
 def test_compat_wrappers_trace(name):
