@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SL_ABI_VERSION 13       /* 13: slhip_queues_stage / slhip_queues_go, sl_env_batch.pool_ready, sl_level_scalars.ready; 12: slhip_pool_write; 11: sl_env_batch.goal_cache, slhip_goal_cache_bytes; 10: slhip_queues_open_on, slhip_queues_stream_shares, slhip_gather_stream_shares, slhip_gather_poke */
+#define SL_ABI_VERSION 13       /* 13: slhip_queues_stage / slhip_queues_go, sl_env_batch.pool_ready / out_compact, sl_level_scalars.ready, slhip_env_step_multi / _reset_multi; 12: slhip_pool_write; 11: sl_env_batch.goal_cache, slhip_goal_cache_bytes; 10: slhip_queues_open_on, slhip_queues_stream_shares, slhip_gather_stream_shares, slhip_gather_poke */
 #define SL_MAX_CELLS 16384        /* H*W limit of one board */
 #define SL_MAX_CHANNELS 32
 
@@ -533,6 +533,44 @@ int slhip_gather_window_queued(void *comm, const void *send, void *recv, size_t 
 
 /* SafeLifeEnv.get_obs() for the current state. */
 int slhip_env_obs(const sl_env_batch *env, void *stream);
+
+/* ---- multi-agent batches (round 6): SafeLifeEnv(single_agent=False), safelife_env.py:148-218 with :162-170 NOT taken --
+ * every board carries n_agents agents (advance_board.c:217-220: their actions in index order), each with its own points
+ * table, exit condition, reward, done flag and episode accumulators (safelife_game.py:505-552,657-719 evaluated per
+ * agent; the exits turn red when ANY agent may leave), and an observation centred on itself.  The fused step is the
+ * size-generic family's (one workgroup per board, any shape).  `env` supplies the boards, goals, generators, exit tables,
+ * the level pool, the points tables and the view; of sl_env_scalars only num_steps, level_idx, episode_idx, spawn_prob,
+ * goals_static and loaded are used (the per-agent words live in `agents`).  env->obs and env->out are ignored: the
+ * per-agent outputs are `multi`'s.  An env whose agents are ALL done reloads its next pool level inside the step when
+ * env->auto_reset is set (training/base_algo.py:231-236 resets on np.all(done)); wrappers, the finished-episode queue
+ * and the policy layout are single-agent features (SL_E_UNSUPPORTED). */
+typedef struct sl_agent_state {   /* per env and agent (48 bytes) */
+    int32_t row, col;             /* where the agent is -- or was when it left the board (GameState.agent_locs) */
+    int32_t old_value;            /* SafeLifeEnv._old_game_value[a] */
+    int32_t required_points;      /* SafeLifeGame.required_points()[a] */
+    int32_t initial_points;       /* sum(points_table[a] * initial_counts) */
+    int32_t table_idx;            /* the agent's table in env->points_table */
+    int32_t episode_length;
+    float episode_reward;
+    int32_t is_active;            /* SafeLifeEnv._is_active[a] */
+    int32_t reserved[3];
+} sl_agent_state;
+typedef struct sl_level_agent {   /* per pool level and agent (32 bytes); row < 0: the level has fewer agents */
+    int32_t row, col, required_reset, required_step, initial_points, table_idx, reserved[2];
+} sl_level_agent;
+typedef struct sl_multi_agent {
+    int32_t n_agents;             /* A, 1 to SL_MAX_AGENTS */
+    int32_t reserved;
+    sl_agent_state *agents;       /* [B, A] */
+    const sl_level_agent *pool_agents;   /* [L, A] */
+    sl_step_out *out;             /* [B, A]: one record per agent and step */
+    uint8_t *obs;                 /* [B, A, view_h, view_w, n_channels] uint8, or uint32 [B, A, view_h, view_w]; NULL = skip */
+} sl_multi_agent;
+#define SL_MAX_AGENTS 8
+/* actions: int32 [B, A] in 0..8 (an agent that is done takes 0, as training/base_algo.py:216-219 feeds it). */
+int slhip_env_step_multi(const sl_env_batch *env, const sl_multi_agent *multi, const int32_t *actions, void *stream);
+/* SafeLifeEnv.reset() for the envs with mask[e] != 0 (NULL: all), as slhip_env_reset. */
+int slhip_env_reset_multi(const sl_env_batch *env, const sl_multi_agent *multi, const uint8_t *mask, void *stream);
 
 /* The raw uint32 view (output_channels=None, safelife_env.py:141) -> the tensor the policy network
  * convolves: channel-first with the spatial axes swapped, out[b][c][x][y] = (view[b][y][x] >> channels[c]) & 1,

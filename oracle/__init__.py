@@ -157,6 +157,8 @@ def lib():
         L.slo_env_reset.argtypes = [C.POINTER(EnvBatch), C.c_void_p]
         L.slo_env_step.argtypes = [C.POINTER(EnvBatch), C.c_void_p, C.c_int]
         L.slo_env_obs.argtypes = [C.POINTER(EnvBatch), C.c_int]
+        L.slo_env_reset_multi.argtypes = [C.POINTER(EnvBatch), C.POINTER(Multi), C.c_void_p]
+        L.slo_env_step_multi.argtypes = [C.POINTER(EnvBatch), C.POINTER(Multi), C.c_void_p, C.c_int]
         L.slo_env_reset_wrapped.argtypes = [C.POINTER(EnvBatch), C.POINTER(Wrappers), C.c_void_p]
         L.slo_env_step_wrapped.argtypes = [C.POINTER(EnvBatch), C.POINTER(Wrappers), C.c_void_p, C.c_int]
         _LIB = L
@@ -420,3 +422,64 @@ class OracleEnv:
         rc = lib().slo_env_step_wrapped(C.byref(self.s), w, _ptr(acts), n_threads)
         assert rc == 0, rc
         return self.obs, self.a["reward"], self.a["done"]
+
+
+# ----------------------------------------------------------- multi-agent env (slo_multi)
+
+_MULTI_ARRAYS = (("agent_loc", np.int32), ("old_value", np.int32), ("required_points", np.int32), ("initial_points", np.int32),
+                 ("table_idx", np.int32), ("is_active", np.uint8), ("episode_reward", np.float32),
+                 ("episode_length", np.int32), ("pool_agent_loc", np.int32), ("pool_required_reset", np.int32),
+                 ("pool_required_step", np.int32), ("pool_initial_points", np.int32), ("pool_table_idx", np.int32),
+                 ("reward", np.float32), ("done", np.uint8), ("success", np.uint8))
+
+
+class Multi(C.Structure):
+    """struct slo_multi"""
+    _fields_ = [("A", C.c_int32), ("reserved", C.c_int32)] + [(k, C.c_void_p) for k, _ in _MULTI_ARRAYS] + [("obs", C.c_void_p)]
+
+
+class OracleMultiEnv(OracleEnv):
+    """Batched SafeLifeEnv(single_agent=False) on the CPU oracle (slo_env_step_multi).  `arrays`: as OracleEnv;
+    `pool`: a safelife_amd.levels.LevelPool(n_agents=A) (its pool_agent_* arrays)."""
+
+    def __init__(self, arrays, pool, **kw):
+        kw = dict(kw)
+        with_obs = kw.pop("with_obs", True)
+        super().__init__(arrays, with_obs=False, **kw)
+        B, A, L = self.s.B, int(pool.n_agents), self.s.L
+        self.A = A
+        ma = self.ma = {
+            "agent_loc": np.zeros((B, A, 2), np.int32), "old_value": np.zeros((B, A), np.int32),
+            "required_points": np.zeros((B, A), np.int32), "initial_points": np.zeros((B, A), np.int32),
+            "table_idx": np.zeros((B, A), np.int32), "is_active": np.zeros((B, A), np.uint8),
+            "episode_reward": np.zeros((B, A), np.float32), "episode_length": np.zeros((B, A), np.int32),
+            "pool_agent_loc": np.ascontiguousarray(pool.pool_agent_locs, np.int32).reshape(L, A, 2),
+            "pool_required_reset": np.ascontiguousarray(pool.pool_agent_required_reset, np.int32),
+            "pool_required_step": np.ascontiguousarray(pool.pool_agent_required_step, np.int32),
+            "pool_initial_points": np.ascontiguousarray(pool.pool_agent_initial_points, np.int32),
+            "pool_table_idx": np.ascontiguousarray(pool.pool_agent_table_idx, np.int32),
+            "reward": np.zeros((B, A), np.float32), "done": np.zeros((B, A), np.uint8), "success": np.zeros((B, A), np.uint8),
+        }
+        vh, vw, nc = self.s.view_h, self.s.view_w, self.s.n_channels
+        self.obs = None
+        if with_obs:
+            self.obs = np.zeros((B, A, vh, vw, nc), np.uint8) if nc else np.zeros((B, A, vh, vw), np.uint32)
+        m = self.m = Multi()
+        m.A = A
+        for k, dt in _MULTI_ARRAYS:
+            assert ma[k].dtype == dt and ma[k].flags.c_contiguous, k
+            setattr(m, k, ma[k].ctypes.data)
+        m.obs = self.obs.ctypes.data if self.obs is not None else None
+
+    def reset(self, mask=None):
+        mk = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        rc = lib().slo_env_reset_multi(C.byref(self.s), C.byref(self.m), None if mk is None else _ptr(mk))
+        assert rc == 0, rc
+        return self.obs
+
+    def step(self, actions, n_threads=1):
+        acts = np.ascontiguousarray(actions, dtype=np.int32)
+        assert acts.shape == (self.s.B, self.A)
+        rc = lib().slo_env_step_multi(C.byref(self.s), C.byref(self.m), _ptr(acts), n_threads)
+        assert rc == 0, rc
+        return self.obs, self.ma["reward"], self.ma["done"]

@@ -395,12 +395,17 @@ static inline int floormod(int a, int n) {
 }
 
 /* SafeLifeEnv.get_obs (safelife_env.py:105-146) + recenter_view (helper_utils.py:42-75) */
+static void make_obs_at(const slo_env_batch *env, int e, int y0, int x0, uint8_t *obs, size_t slot);
 static void make_obs(const slo_env_batch *env, int e) {
     if (!env->obs) return;
+    make_obs_at(env, e, env->agent_loc[2 * e], env->agent_loc[2 * e + 1], env->obs, (size_t)e);
+}
+
+/* the view of env e centred on (y0, x0), written to entry `slot` of `obs` */
+static void make_obs_at(const slo_env_batch *env, int e, int y0, int x0, uint8_t *obs, size_t slot) {
     int H = env->H, W = env->W, vh = env->view_h, vw = env->view_w, C = env->n_channels;
     size_t n = (size_t)H * W;
     const uint16_t *board = env->board + e * n, *goals = env->goals + e * n;
-    int y0 = env->agent_loc[2 * e], x0 = env->agent_loc[2 * e + 1];
     if (y0 < 0) { y0 = 0; x0 = 0; }
     uint32_t *view = (uint32_t *)malloc((size_t)vh * vw * sizeof(uint32_t));
 #define OBS_WORD(idx) \
@@ -425,9 +430,9 @@ static void make_obs(const slo_env_batch *env, int e) {
     }
 #undef OBS_WORD
     if (C == 0) {
-        memcpy((uint32_t *)env->obs + (size_t)e * vh * vw, view, (size_t)vh * vw * 4);
+        memcpy((uint32_t *)obs + slot * vh * vw, view, (size_t)vh * vw * 4);
     } else {
-        uint8_t *o = env->obs + (size_t)e * vh * vw * C;
+        uint8_t *o = obs + slot * vh * vw * C;
         for (int i = 0; i < vh * vw; i++)
             for (int c = 0; c < C; c++) o[(size_t)i * C + c] = (view[i] >> env->channels[c]) & 1;
     }
@@ -667,6 +672,175 @@ int slo_env_step_wrapped(slo_env_batch *env, slo_wrappers *wrap, const int32_t *
                 }
             }
             make_obs(env, e);
+        }
+        free(scratch);
+    }
+    return 0;
+}
+
+
+/* ------------------------------------------------ multi-agent envs: SafeLifeEnv(single_agent=False)
+ * safelife_env.py:148-218 with the unwrapping of :162-170 not taken; per-agent points (safelife_game.py:684-694),
+ * exit condition (:716-719) and exit bit (:537-552: the exits turn red when ANY agent may leave); actions in agent
+ * order (advance_board.c:217-220); the driver resets an env when every agent is done (training/base_algo.py:231-236). */
+
+static void recolor_exits_multi(uint16_t *board, int w, const int32_t *loc, const int32_t *score, int A,
+                                const int32_t *initial, const int32_t *required, const int32_t *exits, int E,
+                                int32_t exit_points) {
+    int can[SLO_MAX_AGENTS], any_can = 0;
+    for (int a = 0; a < A; a++) {                  /* can_exit() for every agent on the board as it stands */
+        uint16_t cell = board[loc[2 * a] * w + loc[2 * a + 1]];
+        int32_t earned = score[a] - initial[a] + exit_points * has_exited(cell);
+        if (earned < 0) earned = 0;
+        can[a] = (cell & C_AGENT) && earned >= required[a];
+        any_can |= can[a];
+    }
+    for (int a = 0; a < A; a++) {
+        uint16_t *cell = board + loc[2 * a] * w + loc[2 * a + 1];
+        *cell = (uint16_t)((*cell & ~C_EXIT) | (can[a] ? C_EXIT : 0));
+    }
+    uint16_t paint = (uint16_t)(C_FROZEN | C_EXIT | (any_can ? C_COLOR_R : 0));
+    for (int k = 0; k < E; k++)
+        if (exits[k] >= 0) board[exits[k]] = paint;
+}
+
+static void reset_one_multi(slo_env_batch *env, slo_multi *m, int e) {
+    int H = env->H, W = env->W, E = env->E, A = m->A;
+    size_t n = (size_t)H * W;
+    int l = env->level_idx[e];
+    uint16_t *board = env->board + e * n, *goals = env->goals + e * n;
+    memcpy(board, env->pool_board + l * n, n * sizeof(uint16_t));
+    memcpy(goals, env->pool_goals + l * n, n * sizeof(uint16_t));
+    memcpy(env->exit_locs + (size_t)e * E, env->pool_exit_locs + (size_t)l * E, E * sizeof(int32_t));
+    env->rng[e] = env->pool_rng[l];
+    if (env->stream_salt) {
+        uint64_t a = mix64(((uint64_t)(uint32_t)(env->stream_salt + e) << 32) | (uint64_t)(uint32_t)env->episode_idx[e]);
+        env->rng[e].state_hi ^= a;
+        env->rng[e].state_lo ^= mix64(a);
+    }
+    env->loaded[e] = 1;
+    env->spawn_prob[e] = env->pool_spawn_prob[l];
+    env->num_steps[e] = 0;
+    env->goals_static[e] = 0;
+    int32_t *loc = m->agent_loc + (size_t)e * A * 2;
+    int32_t score[SLO_MAX_AGENTS];
+    for (int a = 0; a < A; a++) {
+        size_t ea = (size_t)e * A + a, la = (size_t)l * A + a;
+        loc[2 * a] = m->pool_agent_loc[2 * la];
+        loc[2 * a + 1] = m->pool_agent_loc[2 * la + 1];
+        m->table_idx[ea] = m->pool_table_idx[la];
+        m->initial_points[ea] = m->pool_initial_points[la];
+        score[a] = table_score(board, goals, (int)n, env->points_table + 72 * m->table_idx[ea]);
+    }
+    recolor_exits_multi(board, W, loc, score, A, m->initial_points + (size_t)e * A, m->pool_required_reset + (size_t)l * A,
+                        env->exit_locs + (size_t)e * E, E, env->exit_points);
+    for (int a = 0; a < A; a++) {
+        size_t ea = (size_t)e * A + a, la = (size_t)l * A + a;
+        m->old_value[ea] = score[a] + env->exit_points * has_exited(board[loc[2 * a] * W + loc[2 * a + 1]]);
+        m->required_points[ea] = m->pool_required_step[la];
+        m->is_active[ea] = 1;
+        m->episode_reward[ea] = 0.0f;
+        m->episode_length[ea] = 0;
+    }
+    env->agent_loc[2 * e] = loc[0];
+    env->agent_loc[2 * e + 1] = loc[1];
+}
+
+static void obs_multi(const slo_env_batch *env, const slo_multi *m, int e) {
+    if (!m->obs) return;
+    for (int a = 0; a < m->A; a++) {
+        const int32_t *loc = m->agent_loc + ((size_t)e * m->A + a) * 2;
+        make_obs_at(env, e, loc[0], loc[1], m->obs, (size_t)e * m->A + a);
+    }
+}
+
+int slo_env_reset_multi(slo_env_batch *env, slo_multi *m, const uint8_t *mask) {
+    if (m->A < 1 || m->A > SLO_MAX_AGENTS) return -1;
+    for (int e = 0; e < env->B; e++) {
+        if (mask && !mask[e]) continue;
+        if (env->loaded[e]) {
+            env->level_idx[e] = env->pool_next ? env->pool_next[env->level_idx[e]]
+                                               : (env->level_idx[e] + env->level_stride) % env->L;
+            env->episode_idx[e] += 1;
+        }
+        reset_one_multi(env, m, e);
+        obs_multi(env, m, e);
+    }
+    return 0;
+}
+
+static void step_one_multi(slo_env_batch *env, slo_multi *m, int e, const int32_t *actions, uint16_t *scratch) {
+    int H = env->H, W = env->W, E = env->E, A = m->A;
+    size_t n = (size_t)H * W;
+    uint16_t *board = env->board + e * n, *goals = env->goals + e * n;
+    int32_t *loc = m->agent_loc + (size_t)e * A * 2;
+    slo_rng rng = {env->rng + e, slo_pcg64_next_double};
+    double p = (double)env->spawn_prob[e];
+    uint16_t *nxt = scratch, *rows = scratch + n, *acc = scratch + 2 * n;
+    for (int a = 0; a < A; a++) {                  /* safelife_env.py:151, agents in index order */
+        int64_t l64[2] = {loc[2 * a], loc[2 * a + 1]};
+        act_one(board, H, W, l64, actions[a]);
+        loc[2 * a] = (int32_t)l64[0];
+        loc[2 * a + 1] = (int32_t)l64[1];
+    }
+    env->num_steps[e] += 1;                        /* safelife_env.py:152 */
+    ca_step(board, nxt, H, W, p, &rng, rows, acc);
+    memcpy(board, nxt, n * sizeof(uint16_t));
+    if (env->goals_static[e] != 1) {
+        ca_step(goals, nxt, H, W, p, &rng, rows, acc);
+        if (env->goals_static[e] == 0) {
+            int is_static = memcmp(goals, nxt, n * sizeof(uint16_t)) == 0;
+            for (size_t i = 0; i < n && is_static; i++)
+                if (nxt[i] & C_SPAWNING) is_static = 0;
+            env->goals_static[e] = is_static ? 1 : 2;
+        }
+        memcpy(goals, nxt, n * sizeof(uint16_t));
+    }
+    int32_t score[SLO_MAX_AGENTS];                 /* safelife_env.py:153-160, per agent */
+    for (int a = 0; a < A; a++)
+        score[a] = table_score(board, goals, (int)n, env->points_table + 72 * m->table_idx[(size_t)e * A + a]);
+    recolor_exits_multi(board, W, loc, score, A, m->initial_points + (size_t)e * A, m->required_points + (size_t)e * A,
+                        env->exit_locs + (size_t)e * E, E, env->exit_points);
+    int times_up = env->num_steps[e] >= env->time_limit;
+    env->times_up[e] = (uint8_t)times_up;
+    for (int a = 0; a < A; a++) {
+        size_t ea = (size_t)e * A + a;
+        uint16_t cell = board[loc[2 * a] * W + loc[2 * a + 1]];
+        int success = has_exited(cell);
+        int32_t value = score[a] + env->exit_points * success;
+        float reward = (float)((value - m->old_value[ea]) * (m->is_active[ea] ? 1 : 0));
+        int done = !(cell & C_AGENT) || times_up;
+        m->old_value[ea] = value;
+        m->episode_reward[ea] += reward;
+        m->episode_length[ea] += m->is_active[ea] ? 1 : 0;
+        m->is_active[ea] = (uint8_t)(m->is_active[ea] && !done);
+        m->reward[ea] = reward;
+        m->done[ea] = (uint8_t)done;
+        m->success[ea] = (uint8_t)success;
+    }
+    env->agent_loc[2 * e] = loc[0];
+    env->agent_loc[2 * e + 1] = loc[1];
+}
+
+int slo_env_step_multi(slo_env_batch *env, slo_multi *m, const int32_t *actions, int n_threads) {
+    if (env->H < 3 || env->W < 3 || m->A < 1 || m->A > SLO_MAX_AGENTS) return -1;
+    size_t n = (size_t)env->H * env->W;
+    int nt = pick_threads(n_threads);
+#pragma omp parallel num_threads(nt)
+    {
+        uint16_t *scratch = (uint16_t *)malloc(3 * n * sizeof(uint16_t));
+#pragma omp for schedule(static)
+        for (int e = 0; e < env->B; e++) {
+            step_one_multi(env, m, e, actions + (size_t)e * m->A, scratch);
+            int all_done = 1;
+            for (int a = 0; a < m->A; a++) all_done &= m->done[(size_t)e * m->A + a];
+            if (env->auto_reset && all_done) {
+                env->level_idx[e] = env->pool_next ? env->pool_next[env->level_idx[e]]
+                                                   : (env->level_idx[e] + env->level_stride) % env->L;
+                env->episode_idx[e] += 1;
+                reset_one_multi(env, m, e);
+            }
+            obs_multi(env, m, e);
         }
         free(scratch);
     }

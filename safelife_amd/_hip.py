@@ -22,7 +22,7 @@ EXPORTS = (
     "slhip_advance_board", "slhip_advance_board_each", "slhip_life_occupancy", "slhip_alive_counts", "slhip_execute_actions",
     "slhip_env_prepare", "slhip_pool_baseline", "slhip_pool_write", "slhip_goal_cache_bytes", "slhip_env_reset", "slhip_env_step", "slhip_env_step_slices", "slhip_env_step_range", "slhip_env_rollout",
     "slhip_streams_concurrent", "slhip_streams_order",
-    "slhip_env_obs",
+    "slhip_env_obs", "slhip_env_step_multi", "slhip_env_reset_multi",
     "slhip_obs_to_policy", "slhip_sample_actions", "slhip_side_effects",
     "slhip_gather_unique_id", "slhip_gather_init", "slhip_gather_window", "slhip_gather_destroy",
     "slhip_gather_window_async", "slhip_gather_done", "slhip_gather_wait_streams",
@@ -106,6 +106,25 @@ class EpisodeQueue(C.Structure):
     _fields_ = [("capacity", C.c_int32), ("env_base", C.c_int32), ("count", _p), ("records", _p), ("boards", _p)]
 
 
+class AgentState(C.Structure):
+    """struct sl_agent_state (48 bytes = 12 int32 columns)"""
+    _fields_ = [("row", C.c_int32), ("col", C.c_int32), ("old_value", C.c_int32), ("required_points", C.c_int32),
+                ("initial_points", C.c_int32), ("table_idx", C.c_int32), ("episode_length", C.c_int32),
+                ("episode_reward", C.c_float), ("is_active", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
+AGENT_COLS = {"row": 0, "col": 1, "old_value": 2, "required_points": 3, "initial_points": 4, "table_idx": 5,
+              "episode_length": 6, "episode_reward": 7, "is_active": 8}
+LEVEL_AGENT_COLS = {"row": 0, "col": 1, "required_reset": 2, "required_step": 3, "initial_points": 4, "table_idx": 5}
+SL_MAX_AGENTS = 8
+
+
+class MultiAgent(C.Structure):
+    """struct sl_multi_agent"""
+    _fields_ = [("n_agents", C.c_int32), ("reserved", C.c_int32), ("agents", C.c_void_p), ("pool_agents", C.c_void_p),
+                ("out", C.c_void_p), ("obs", C.c_void_p)]
+
+
 class EnvBatch(C.Structure):
     _fields_ = (
         [(n, C.c_int32) for n in ENV_SCALARS_HEAD]
@@ -161,6 +180,9 @@ def lib():
         L.slhip_streams_order.argtypes = [_p, C.c_int, _p, C.c_int]
         L.slhip_env_rollout.argtypes = [C.POINTER(EnvBatch), _p, C.c_int, _p, _p, _p]
         L.slhip_env_obs.argtypes = [C.POINTER(EnvBatch), _p]
+        if hasattr(L, "slhip_env_step_multi"):
+            L.slhip_env_step_multi.argtypes = [C.POINTER(EnvBatch), C.POINTER(MultiAgent), _p, _p]
+            L.slhip_env_reset_multi.argtypes = [C.POINTER(EnvBatch), C.POINTER(MultiAgent), _p, _p]
         if hasattr(L, "slhip_queues_step"):
             L.slhip_queues_open.argtypes = [C.POINTER(EnvBatch), C.c_int, _p, C.c_int, C.POINTER(C.c_void_p)]
             L.slhip_queues_step.argtypes = [C.c_void_p, C.POINTER(EnvBatch), _p, C.c_int]

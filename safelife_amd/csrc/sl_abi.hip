@@ -1443,6 +1443,38 @@ int slhip_side_effects(const sl_env_batch *env, const sl_episode_queue *queue, i
     return err == hipSuccess ? SL_OK : hip_fail(err, "side_effects launch");
 }
 
+static int check_multi(const sl_env_batch *env, const sl_multi_agent *m) {
+    int rc = check_env(env);
+    if (rc) return rc;
+    if (!m) return fail(SL_E_ARG, "null multi-agent description");
+    if (m->n_agents < 1 || m->n_agents > SL_MAX_AGENTS) return fail(SL_E_ARG, "n_agents outside 1..SL_MAX_AGENTS");
+    if (!m->agents || !m->pool_agents || !m->out) return fail(SL_E_ARG, "null pointer in sl_multi_agent");
+    if (env->wrap.flags || env->finished.capacity > 0 || env->policy_obs)
+        return fail(SL_E_UNSUPPORTED, "wrappers, the finished-episode queue and the policy layout are single-agent features");
+    return SL_OK;
+}
+
+int slhip_env_step_multi(const sl_env_batch *env, const sl_multi_agent *multi, const int32_t *actions, void *stream) {
+    int rc = check_multi(env, multi);
+    if (rc) return rc;
+    if (!actions) return fail(SL_E_ARG, "null actions");
+    if (env->B == 0) return SL_OK;
+    const sl::Jump *jump;
+    if ((rc = jump_table(&jump))) return rc;
+    hipError_t err = drop_goal_cache(env, (hipStream_t)stream);
+    if (err == hipSuccess) err = sl::launch_env_step_multi(*env, *multi, actions, jump, (hipStream_t)stream);
+    return err == hipSuccess ? SL_OK : hip_fail(err, "env_step_multi launch");
+}
+
+int slhip_env_reset_multi(const sl_env_batch *env, const sl_multi_agent *multi, const uint8_t *mask, void *stream) {
+    int rc = check_multi(env, multi);
+    if (rc) return rc;
+    if (env->B == 0) return SL_OK;
+    hipError_t err = drop_goal_cache(env, (hipStream_t)stream);
+    if (err == hipSuccess) err = sl::launch_env_reset_multi(*env, *multi, mask, (hipStream_t)stream);
+    return err == hipSuccess ? SL_OK : hip_fail(err, "env_reset_multi launch");
+}
+
 int slhip_env_obs(const sl_env_batch *env, void *stream) {
     int rc = check_env(env);
     if (rc) return rc;

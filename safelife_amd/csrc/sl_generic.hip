@@ -266,8 +266,11 @@ __device__ bool recolor_exits(u16 *board, int W, int ly, int lx, const int32_t *
 
 // SafeLifeEnv.get_obs for env e from the board in LDS; goals through `goals` (LDS or global).
 __device__ void write_obs(const sl_env_batch &env, int e, const u16 *board, const u16 *goals,
-                          int ly, int lx, const int32_t *exits) {
-    if (!env.obs && !env.policy_obs) return;
+                          int ly, int lx, const int32_t *exits, uint8_t *obs_base = nullptr, int slot = -1) {
+    // (obs_base / slot: the multi-agent kernels write agent a of env e to slot e * A + a of their own tensor)
+    uint8_t *const obs_out = obs_base ? obs_base : env.obs;
+    if (slot >= 0) e = slot;
+    if (!obs_out && !env.policy_obs) return;
     const int H = env.H, W = env.W, vh = env.view_h, vw = env.view_w, C = env.n_channels;
     const int y0 = ly >= 0 ? ly : 0, x0 = ly >= 0 ? lx : 0;
     const int nv = vh * vw;
@@ -290,15 +293,15 @@ __device__ void write_obs(const sl_env_batch &env, int e, const u16 *board, cons
             jx = min(max(jx, 0), vw - 1);
             if (jy == vy && jx == vx) word = obs_word(board[ex], goals[ex], env.remove_white_goals);
         }
-        if (env.obs) {
+        if (obs_out) {
             if (C == 0) {
-                ((u32 *)env.obs)[(size_t)e * nv + v] = word;
+                ((u32 *)obs_out)[(size_t)e * nv + v] = word;
             } else {
-                uint8_t *o = env.obs + ((size_t)e * nv + v) * C;
+                uint8_t *o = obs_out + ((size_t)e * nv + v) * C;
                 for (int c = 0; c < C; ++c) o[c] = (word >> env.channels[c]) & 1u;
             }
         }
-        if (env.policy_obs) {        // channel-first, spatial axes swapped: [C, vw, vh] (training/models.py:100-103)
+        if (env.policy_obs && slot < 0) {        // channel-first, spatial axes swapped: [C, vw, vh] (training/models.py:100-103)
             const size_t base = (size_t)e * C * nv + (size_t)vx * vh + vy;
             for (int c = 0; c < C; ++c) {
                 const u32 bit = (word >> env.channels[c]) & 1u;
@@ -539,6 +542,254 @@ __global__ __launch_bounds__(GB_MAX) void k_env_rollout_generic(sl_env_batch env
     write_obs(env, e, cur, ggoals, ivar[0], ivar[1], exits);
 }
 
+// ------------------------------------------------------------------------- multi-agent env step / reset
+// SafeLifeEnv(single_agent=False): include/safelife_hip.h, sl_multi_agent.  One workgroup per board; what concerns a
+// single agent is serial work of thread 0, in agent order (advance_board.c:217-220; safelife_game.py:537-552).
+
+// per-agent words shared by the workgroup, behind the four board buffers of the dynamic LDS
+struct MultiLds {
+    int *loc;       // [2 A]
+    int *score;     // [A]  sum(points_table[a] * alive_counts)
+    int *flag;      // [0] every agent is done
+};
+__device__ __forceinline__ MultiLds carve_multi(unsigned char *smem, int HW) {
+    int *base = (int *)(smem + 128 + (size_t)4 * ((HW + 7) & ~7) * sizeof(u16));        // (= generic_lds_bytes(HW, 4))
+    return MultiLds{base, base + 2 * SL_MAX_AGENTS, base + 3 * SL_MAX_AGENTS};
+}
+static size_t multi_lds_bytes(int HW) { return generic_lds_bytes(HW, 4) + 4 * SL_MAX_AGENTS * sizeof(int); }
+
+// GameState.update_exit_colors for A agents (safelife_game.py:537-552), by thread 0: every agent's cell gets the EXIT bit
+// iff THAT agent may leave (its own points against its own requirement); the exits turn red when any agent may.
+__device__ bool recolor_exits_multi(u16 *board, int W, const int *loc, const int *score, int A, const sl_agent_state *ag,
+                                    const int *required, const int32_t *exits, int E, int exit_points) {
+    bool can[SL_MAX_AGENTS];
+    bool any_can = false;
+    for (int a = 0; a < A; ++a) {           // can_exit() is evaluated on the board as it stands, for all agents, first
+        const u32 cell = board[loc[2 * a] * W + loc[2 * a + 1]];
+        int earned = score[a] - ag[a].initial_points + exit_points * (has_exited(cell) ? 1 : 0);
+        if (earned < 0) earned = 0;
+        can[a] = (cell & AGENT) && earned >= required[a];
+        any_can = any_can || can[a];
+    }
+    for (int a = 0; a < A; ++a) {
+        u16 *cell = board + loc[2 * a] * W + loc[2 * a + 1];
+        *cell = (u16)((*cell & ~EXIT) | (can[a] ? EXIT : 0u));
+    }
+    const u16 paint = (u16)(FROZEN | EXIT | (any_can ? COLOR_R : 0u));
+    for (int k = 0; k < E; ++k) {
+        const int ex = exits[k];
+        if (ex >= 0) board[ex] = paint;
+    }
+    return any_can;
+}
+
+// SafeLifeEnv.reset() body of a multi-agent env: pool level -> LDS board and the per-env / per-agent state.
+__device__ void reset_block_multi(const sl_env_batch &env, const sl_multi_agent &m, int e, u16 *brd, MultiLds ml, int *wave_tot) {
+    const int HW = env.H * env.W, tid = threadIdx.x, E = env.E, A = m.n_agents;
+    sl_env_scalars *sc = env.scalars + e;
+    const int l = sc->level_idx;
+    const sl_level_scalars lv = env.pool_scalars[l];
+    const sl_level_agent *pa = m.pool_agents + (size_t)l * A;
+    sl_agent_state *ag = m.agents + (size_t)e * A;
+    const u16 *pb = env.pool_board + (size_t)l * HW, *pg = env.pool_goals + (size_t)l * HW;
+    u16 *gdst = env.goals + (size_t)e * HW;
+    for (int i = tid; i < HW; i += GB) {
+        brd[i] = pb[i];
+        gdst[i] = pg[i];
+    }
+    for (int k = tid; k < E; k += GB) env.exit_locs[(size_t)e * E + k] = env.pool_exit_locs[(size_t)l * E + k];
+    if (tid < A) {
+        ml.loc[2 * tid] = pa[tid].row;
+        ml.loc[2 * tid + 1] = pa[tid].col;
+    }
+    if (tid == 0) {
+        sl_pcg64 gen = env.pool_rng[l];
+        if (env.stream_salt) sl_episode_stream(gen.state_hi, gen.state_lo, env.stream_salt + e, sc->episode_idx);
+        env.rng[e] = gen;
+    }
+    __syncthreads();
+    for (int a = 0; a < A; ++a) {
+        const int s = board_score(brd, pg, HW, env.points_table + 72 * pa[a].table_idx, wave_tot);
+        if (tid == 0) ml.score[a] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int required[SL_MAX_AGENTS];
+        for (int a = 0; a < A; ++a) {
+            ag[a].initial_points = pa[a].initial_points;
+            required[a] = pa[a].required_reset;
+        }
+        recolor_exits_multi(brd, env.W, ml.loc, ml.score, A, ag, required, env.pool_exit_locs + (size_t)l * E, E, env.exit_points);
+        for (int a = 0; a < A; ++a) {
+            const int exited = has_exited(brd[ml.loc[2 * a] * env.W + ml.loc[2 * a + 1]]) ? 1 : 0;
+            sl_agent_state n;
+            n.row = ml.loc[2 * a];
+            n.col = ml.loc[2 * a + 1];
+            n.old_value = ml.score[a] + env.exit_points * exited;
+            n.required_points = pa[a].required_step;
+            n.initial_points = pa[a].initial_points;
+            n.table_idx = pa[a].table_idx;
+            n.episode_length = 0;
+            n.episode_reward = 0.0f;
+            n.is_active = 1;
+            n.reserved[0] = n.reserved[1] = n.reserved[2] = 0;
+            ag[a] = n;
+        }
+        sl_env_scalars n0 = *sc;
+        n0.agent_row = ml.loc[0];
+        n0.agent_col = ml.loc[1];
+        n0.num_steps = 0;
+        n0.old_value = ag[0].old_value;
+        n0.required_points = ag[0].required_points;
+        n0.initial_points = ag[0].initial_points;
+        n0.table_idx = ag[0].table_idx;
+        n0.episode_length = 0;
+        n0.episode_reward = 0.0f;
+        n0.spawn_prob = lv.spawn_prob;
+        n0.goals_static = 0;
+        n0.is_active = 1;
+        n0.exit_open_at_reset = 0;
+        n0.loaded = 1;
+        *sc = n0;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(GB_MAX) void k_env_step_multi(sl_env_batch env, sl_multi_agent m,
+                                                       const int32_t *__restrict__ actions,
+                                                       const Jump *__restrict__ jump) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int H = env.H, W = env.W, HW = H * W, E = env.E, A = m.n_agents;
+    const int e = blockIdx.x, tid = threadIdx.x;
+    GenericLds l = carve(smem, HW, 4);
+    MultiLds ml = carve_multi(smem, HW);
+    u16 *cur = l.buf[0], *rows = l.buf[1], *nxt = l.buf[2], *aux = l.buf[3];
+    u16 *gboard = env.board + (size_t)e * HW;
+    u16 *ggoals = env.goals + (size_t)e * HW;
+    sl_env_scalars *sc = env.scalars + e;
+    sl_agent_state *ag = m.agents + (size_t)e * A;
+    const int32_t *exits = env.exit_locs + (size_t)e * E;
+    const float inv_w = 1.0f / (float)W;
+
+    for (int i = tid; i < HW; i += GB) cur[i] = gboard[i];
+    if (tid < 4) l.rng[tid] = ((const u64 *)(env.rng + e))[tid];
+    if (tid < A) {
+        ml.loc[2 * tid] = ag[tid].row;
+        ml.loc[2 * tid + 1] = ag[tid].col;
+    }
+    __syncthreads();
+    // safelife_env.py:151  game.execute_actions: every agent's action, in index order (advance_board.c:217-220)
+    if (tid == 0)
+        for (int a = 0; a < A; ++a) act_one<int>(cur, H, W, ml.loc + 2 * a, actions[(size_t)e * A + a]);
+    __syncthreads();
+    // safelife_env.py:152  game.advance_board (board, then goals unless static)
+    const double p = (double)sc->spawn_prob;
+    ca_step_block(cur, rows, nxt, H, W, inv_w, p, l.rng, jump, l.wave_tot);
+    const u16 *goals = ggoals;
+    const int gstatic = sc->goals_static;
+    if (gstatic != 1) {
+        for (int i = tid; i < HW; i += GB) cur[i] = ggoals[i];
+        __syncthreads();
+        ca_step_block(cur, rows, aux, H, W, inv_w, p, l.rng, jump, l.wave_tot);
+        int changed = 0;
+        for (int i = tid; i < HW; i += GB) {
+            u16 g = aux[i];
+            changed |= (g != cur[i]) || (g & SPAWNING);
+            ggoals[i] = g;
+        }
+        changed = __syncthreads_or(changed);
+        if (tid == 0 && gstatic == 0) sc->goals_static = changed ? 2 : 1;
+        goals = aux;
+    }
+    // safelife_env.py:153-160, per agent: its own table against the shared counts (safelife_game.py:684-687)
+    for (int a = 0; a < A; ++a) {
+        const int s = board_score(nxt, goals, HW, env.points_table + 72 * ag[a].table_idx, l.wave_tot);
+        if (tid == 0) ml.score[a] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int required[SL_MAX_AGENTS];
+        for (int a = 0; a < A; ++a) required[a] = ag[a].required_points;
+        recolor_exits_multi(nxt, W, ml.loc, ml.score, A, ag, required, exits, E, env.exit_points);
+        const int steps = sc->num_steps + 1;
+        sc->num_steps = steps;
+        const bool times_up = steps >= env.time_limit;
+        bool all_done = true;
+        for (int a = 0; a < A; ++a) {
+            const u32 cell = nxt[ml.loc[2 * a] * W + ml.loc[2 * a + 1]];
+            const bool success = has_exited(cell);
+            const bool active = ag[a].is_active != 0;
+            const int value = ml.score[a] + env.exit_points * (success ? 1 : 0);
+            const float reward = (float)((value - ag[a].old_value) * (active ? 1 : 0));
+            const bool done = !(cell & AGENT) || times_up;
+            sl_step_out o;
+            o.reward = reward;
+            o.done = done;
+            o.success = success;
+            o.times_up = times_up;
+            o.reserved = 0;
+            o.episode_reward = ag[a].episode_reward + reward;
+            o.episode_length = ag[a].episode_length + (active ? 1 : 0);
+            m.out[(size_t)e * A + a] = o;
+            ag[a].row = ml.loc[2 * a];
+            ag[a].col = ml.loc[2 * a + 1];
+            ag[a].old_value = value;
+            ag[a].episode_reward = o.episode_reward;
+            ag[a].episode_length = o.episode_length;
+            ag[a].is_active = (active && !done) ? 1 : 0;
+            all_done = all_done && done;
+        }
+        sc->agent_row = ml.loc[0];
+        sc->agent_col = ml.loc[1];
+        ml.flag[0] = all_done ? 1 : 0;
+    }
+    __syncthreads();
+    u16 *sw = cur;
+    cur = nxt;
+    nxt = sw;
+    if (env.auto_reset && ml.flag[0]) {     // training/base_algo.py:231-236: a fresh level once every agent is done
+        if (tid == 0) {
+            sc->level_idx = env.pool_next ? env.pool_next[sc->level_idx] : (sc->level_idx + env.level_stride) % env.L;
+            sc->episode_idx += 1;
+        }
+        __syncthreads();
+        reset_block_multi(env, m, e, cur, ml, l.wave_tot);
+        if (tid < 4) l.rng[tid] = ((const u64 *)(env.rng + e))[tid];
+        __syncthreads();
+    }
+    for (int i = tid; i < HW; i += GB) gboard[i] = cur[i];
+    if (tid < 4) ((u64 *)(env.rng + e))[tid] = l.rng[tid];
+    __syncthreads();   // goals written by this workgroup are read back below
+    if (m.obs)
+        for (int a = 0; a < A; ++a)
+            write_obs(env, e, cur, ggoals, ml.loc[2 * a], ml.loc[2 * a + 1], exits, m.obs, e * A + a);
+}
+
+__global__ __launch_bounds__(GB_MAX) void k_env_reset_multi(sl_env_batch env, sl_multi_agent m,
+                                                        const uint8_t *__restrict__ mask) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int HW = env.H * env.W, e = blockIdx.x, tid = threadIdx.x, A = m.n_agents;
+    if (mask && !mask[e]) return;
+    GenericLds l = carve(smem, HW, 4);
+    MultiLds ml = carve_multi(smem, HW);
+    if (tid == 0) {         // a slot that already holds a level moves on to its next one (safelife_env.py:204)
+        sl_env_scalars *sc = env.scalars + e;
+        if (sc->loaded) {
+            sc->level_idx = env.pool_next ? env.pool_next[sc->level_idx] : pos_mod(sc->level_idx + env.level_stride, env.L);
+            sc->episode_idx += 1;
+        }
+    }
+    __syncthreads();
+    reset_block_multi(env, m, e, l.buf[0], ml, l.wave_tot);
+    u16 *gboard = env.board + (size_t)e * HW;
+    for (int i = tid; i < HW; i += GB) gboard[i] = l.buf[0][i];
+    __syncthreads();
+    if (m.obs)
+        for (int a = 0; a < A; ++a)
+            write_obs(env, e, l.buf[0], env.goals + (size_t)e * HW, ml.loc[2 * a], ml.loc[2 * a + 1],
+                      env.exit_locs + (size_t)e * env.E, m.obs, e * A + a);
+}
+
 __global__ __launch_bounds__(GB_MAX) void k_env_reset_generic(sl_env_batch env,
                                                           const uint8_t *__restrict__ mask) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -684,6 +935,23 @@ hipError_t launch_env_reset_generic(const sl_env_batch &env, const uint8_t *mask
     hipError_t err = set_lds((const void *)k_env_reset_generic, lds);
     if (err != hipSuccess) return err;
     hipLaunchKernelGGL(k_env_reset_generic, dim3(env.B), dim3(generic_threads(env.H * env.W)), lds, stream, env, mask);
+    return hipGetLastError();
+}
+
+hipError_t launch_env_step_multi(const sl_env_batch &env, const sl_multi_agent &m, const int32_t *actions, const Jump *jump,
+                                 hipStream_t stream) {
+    const size_t lds = multi_lds_bytes(env.H * env.W);
+    hipError_t err = set_lds((const void *)k_env_step_multi, lds);
+    if (err != hipSuccess) return err;
+    hipLaunchKernelGGL(k_env_step_multi, dim3(env.B), dim3(generic_threads(env.H * env.W)), lds, stream, env, m, actions, jump);
+    return hipGetLastError();
+}
+
+hipError_t launch_env_reset_multi(const sl_env_batch &env, const sl_multi_agent &m, const uint8_t *mask, hipStream_t stream) {
+    const size_t lds = multi_lds_bytes(env.H * env.W);
+    hipError_t err = set_lds((const void *)k_env_reset_multi, lds);
+    if (err != hipSuccess) return err;
+    hipLaunchKernelGGL(k_env_reset_multi, dim3(env.B), dim3(generic_threads(env.H * env.W)), lds, stream, env, m, mask);
     return hipGetLastError();
 }
 

@@ -24,6 +24,10 @@ hipError_t launch_env_reset_generic(const sl_env_batch &env, const uint8_t *mask
 // SimpleSideEffectPenalty's "inaction" baseline, one CA step on (all envs of `env`)
 hipError_t launch_inaction_generic(const sl_env_batch &env, const Jump *jump, hipStream_t stream);
 hipError_t launch_env_obs_generic(const sl_env_batch &env, hipStream_t stream);
+// multi-agent boards (sl_multi_agent): the fused step / reset, one workgroup per board
+hipError_t launch_env_step_multi(const sl_env_batch &env, const sl_multi_agent &m, const int32_t *actions, const Jump *jump,
+                                 hipStream_t stream);
+hipError_t launch_env_reset_multi(const sl_env_batch &env, const sl_multi_agent &m, const uint8_t *mask, hipStream_t stream);
 struct sl_channel_list {
     int32_t c[SL_MAX_CHANNELS];
 };

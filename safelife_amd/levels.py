@@ -190,7 +190,7 @@ class LevelPool(object):
               "pool_initial_points", "pool_table_idx", "points_table")
 
     def __init__(self, levels, *, min_performance_fraction=1.0, seed=None, counts_fn=None,
-                 exit_slots=None, refreshable=False):
+                 exit_slots=None, refreshable=False, n_agents=1):
         """
         levels : list of Level (same shape, at most one agent each)
         min_performance_fraction : the MinPerformanceScheduler factor (env_wrappers.py:142-145):
@@ -199,6 +199,10 @@ class LevelPool(object):
         seed : levels without an RNG of their own get children of this SeedSequence, in order
             (as SafeLifeLevelIterator.fill_queue does, level_iterator.py:218).
         counts_fn : (boards[L,H,W], goals[L,H,W]) -> int64 [L,8,9]; defaults to the HIP kernel.
+        n_agents : > 1 -- a pool of MULTI-agent levels (exactly that many agents each: the reference's
+            levels/random/multi-agent specs) for ``multi_env.SafeLifeMultiAgentVectorEnv``: the per-agent
+            constants (locations, points tables, initial and required points: safelife_game.py:684-714 per agent)
+            are kept in ``pool_agent_*`` arrays [L, A, ...]; the single-agent arrays describe agent 0.
         refreshable : the pool can take NEW levels while envs are stepping (``replace`` here,
             ``SafeLifeVectorEnv.pool_stage`` / ``pool_commit`` on the device) -- the device-resident
             counterpart of the reference's level iterator handing every reset a fresh level
@@ -215,8 +219,14 @@ class LevelPool(object):
         for lv in levels:
             if lv.shape != shape:
                 raise ValueError("all levels of a pool must share one board shape")
-            if len(lv.agent_locs) > 1:
-                raise ValueError("the fused environment is single-agent (use SafeLifeEnv for more)")
+            if int(n_agents) > 1:
+                if len(lv.agent_locs) != int(n_agents) or len(lv.points_table) != int(n_agents):
+                    raise ValueError("a multi-agent pool holds levels with exactly n_agents agents (and one points table each)")
+            elif len(lv.agent_locs) > 1:
+                raise ValueError("a single-agent pool (LevelPool(n_agents=A) + SafeLifeMultiAgentVectorEnv for more)")
+        self.n_agents = int(n_agents)
+        if self.n_agents > 1 and refreshable:
+            raise ValueError("refreshable pools are single-agent")
         self.levels = list(levels)
         self.shape = shape
         H, W = shape
@@ -244,17 +254,19 @@ class LevelPool(object):
             rng.append(lv.initial_rng_words())
         self.pool_rng = np.stack(rng).astype(np.uint64)
 
-        # de-duplicated points tables
+        # de-duplicated points tables (every agent's, agent 0's first)
         tables, idx = [], []
-        for lv in levels:
-            t = (lv.points_table[0] if len(lv.points_table) else DEFAULT_POINTS_TABLE).astype(np.int32)
+
+        def table_index(t):
             for j, u in enumerate(tables):
                 if np.array_equal(t, u):
-                    idx.append(j)
-                    break
-            else:
-                idx.append(len(tables))
-                tables.append(t)
+                    return j
+            tables.append(t)
+            return len(tables) - 1
+        for lv in levels:
+            idx.append(table_index((lv.points_table[0] if len(lv.points_table) else DEFAULT_POINTS_TABLE).astype(np.int32)))
+        agent_idx = [[table_index(lv.points_table[a].astype(np.int32)) for a in range(self.n_agents)] for lv in levels] \
+            if self.n_agents > 1 else None
         self.points_table = np.stack(tables).astype(np.int32)
         self.pool_table_idx = np.array(idx, np.int32)
 
@@ -272,6 +284,22 @@ class LevelPool(object):
             self.pool_required_reset[k] = required_points(lv.min_performance, avail)
             # game.min_performance *= fraction  (float64 product, then the same ceil)
             self.pool_required_step[k] = required_points(np.float64(lv.min_performance) * frac, avail)
+
+        if self.n_agents > 1:       # the same per agent: its own table against the level's counts
+            A = self.n_agents
+            self.pool_agent_locs = np.stack([lv.agent_locs for lv in levels]).astype(np.int32).reshape(L, A, 2)
+            self.pool_agent_table_idx = np.array(agent_idx, np.int32).reshape(L, A)
+            self.pool_agent_initial_points = np.zeros((L, A), np.int32)
+            self.pool_agent_required_reset = np.zeros((L, A), np.int32)
+            self.pool_agent_required_step = np.zeros((L, A), np.int32)
+            for k, lv in enumerate(levels):
+                colors = initial_colors(lv.board)
+                for a in range(A):
+                    table = self.points_table[agent_idx[k][a]].astype(np.int64)
+                    self.pool_agent_initial_points[k, a] = int((table * counts[k]).sum())
+                    avail = available_points(table, counts[k], colors)
+                    self.pool_agent_required_reset[k, a] = required_points(lv.min_performance, avail)
+                    self.pool_agent_required_step[k, a] = required_points(np.float64(lv.min_performance) * frac, avail)
 
         self._frac, self._seq, self._counts_fn = frac, seq, counts_fn
         self.refreshable = bool(refreshable)

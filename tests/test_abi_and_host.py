@@ -39,7 +39,8 @@ def _ctypes_layout(struct, prefix=""):
 def test_env_struct_layout_matches_header(tmp_path):
     """ctypes mirrors vs the C structs as gcc lays them out: offset and size of every field."""
     structs = {"sl_env_batch": _hip.EnvBatch, "sl_wrappers": _hip.Wrappers, "sl_wrap_state": _hip.WrapState,
-               "sl_pcg64": _hip.Pcg64, "sl_episode_record": _hip.EpisodeRecord, "sl_episode_queue": _hip.EpisodeQueue}
+               "sl_pcg64": _hip.Pcg64, "sl_episode_record": _hip.EpisodeRecord, "sl_episode_queue": _hip.EpisodeQueue,
+               "sl_agent_state": _hip.AgentState, "sl_multi_agent": _hip.MultiAgent}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "safelife_hip.h"', 'int main(void) {']
     want = []
     for cname, st in structs.items():

@@ -568,6 +568,45 @@ def test_compat_env_trace_multi_agent(name):
             assert np.array_equal(env.game.required_points(), tr["trace_reset_required"][episode]), where
 
 
+@pytest.mark.parametrize("name", MULTI_TRACES)
+def test_multi_agent_env_trace(name):
+    """slhip_env_step_multi / _reset_multi (SafeLifeMultiAgentVectorEnv): the fused multi-agent step on the device
+    against the reference's SafeLifeEnv(single_agent=False) traces, as the oracle's test does on the CPU."""
+    tr = util.load_trace(name)
+    assert util.replay_trace_multi(tr, util.DeviceMultiBackend, _device_counts) > 0
+
+
+@pytest.mark.parametrize("B,view,chans", [(96, (9, 9), None), (33, (25, 25), tuple(range(12)) + (25, 26, 27))])
+def test_multi_agent_batch_vs_oracle(B, view, chans):
+    """A batch of two-agent envs over the reference's multi-agent levels (asym1 / build-coop / build-compete at 26x26:
+    distinct points tables, colours and flags per agent), random actions for both agents, reloads inside the step when
+    all agents of an env are done, per-episode random streams: device against oracle, every array, every step."""
+    levels = []
+    for name in ("multi_asym1", "multi_build_coop", "multi_build_compete"):
+        levels += util.levels_from_trace(util.load_trace(name))
+    from safelife_amd.levels import LevelPool
+    pool_d = LevelPool(levels, counts_fn=_device_counts, n_agents=2, min_performance_fraction=0.1)
+    pool_c = LevelPool(levels, counts_fn=util.oracle_counts, n_agents=2, min_performance_fraction=0.1)
+    for k in ("pool_agent_initial_points", "pool_agent_required_step", "pool_agent_table_idx"):
+        assert np.array_equal(getattr(pool_d, k), getattr(pool_c, k))
+    kw = dict(first_level=(np.arange(B) * 3) % len(levels), auto_reset=True, level_stride=2, time_limit=17, view_shape=view,
+              output_channels=chans)
+    dev = util.DeviceMultiBackend(pool_d, B, **kw)
+    cpu = util.OracleMultiBackend(pool_c, B, **kw)
+    assert np.array_equal(dev.reset(), cpu.reset())
+    rng = np.random.default_rng(12)
+    for t in range(60):
+        acts = rng.integers(0, 9, (B, 2)).astype(np.int32)
+        acts[cpu.get("is_active") == 0] = 0             # (training/base_algo.py:216-219: a done agent gets no action)
+        od, rd, dd = dev.step(acts)
+        oc, rc, dc = cpu.step(acts)
+        assert np.array_equal(rd, rc) and np.array_equal(dd, dc), t
+        assert np.array_equal(od, oc), t
+        for name in util.MULTI_STATE:
+            assert np.array_equal(dev.get(name), cpu.get(name)), (t, name)
+    assert cpu.get("episode_idx").min() >= 2
+
+
 @pytest.mark.parametrize("name", ["wrap_train_prune-still", "wrap_train_append-still", "wrap_other_prune-still",
                                   "wrap_se_append-stochastic-1", "wrap_mv_noagent"])
 def test_compat_wrappers_trace(name):

@@ -227,3 +227,13 @@ def test_refreshable_pool_on_the_oracle():
         b.replace([1, 1], ready.take([0, 1]))
     with pytest.raises(ValueError):
         b.replace([L], ready.take([0]))
+
+
+@pytest.mark.parametrize("name", ["multi_asym1", "multi_build_coop", "multi_build_compete", "multi_hand_exit"])
+def test_oracle_multi_agent_env_traces(name):
+    """slo_env_step_multi / _reset_multi -- the multi-agent half of SafeLifeEnv.step (single_agent=False,
+    safelife_env.py:148-218) -- against traces of the reference's own env on its own two-agent levels: every agent's
+    observation, reward, done, success, episode accumulators, the shared board, goals and generator, step for step,
+    reloading when all agents are done."""
+    tr = util.load_trace(name)
+    assert util.replay_trace_multi(tr, util.OracleMultiBackend, util.oracle_counts) > 0

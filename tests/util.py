@@ -44,8 +44,9 @@ def random_rng_words(rng, B):
 
 
 def trace_names():
-    return sorted(os.path.basename(p)[len("trace_"):-4]
-                  for p in glob.glob(os.path.join(GOLDEN, "trace_*.npz")))
+    """The single-agent SafeLifeEnv traces (the multi-agent ones, trace_multi_*.npz, have their own replay)."""
+    return sorted(n for n in (os.path.basename(p)[len("trace_"):-4] for p in glob.glob(os.path.join(GOLDEN, "trace_*.npz")))
+                  if not n.startswith("multi_"))
 
 
 def load_trace(name):
@@ -205,6 +206,100 @@ def replay_trace(tr, backend_cls, counts_fn):
             assert np.array_equal(obs[0], tr["trace_obs"][t]), where + " obs"
             assert int(be.get("episode_length")[0]) == int(tr["trace_ep_length"][t]), where
             assert be.get("episode_reward")[0] == tr["trace_ep_reward"][t], where
+            assert int(be.get("num_steps")[0]) == int(tr["trace_num_steps"][t]), where
+    return T
+
+
+# ---------------------------------------------------------------- multi-agent envs (single_agent=False)
+
+class OracleMultiBackend(object):
+    def __init__(self, pool, B, first_level=0, **kw):
+        import oracle
+        from safelife_amd.levels import empty_env_arrays
+        self.arrays = empty_env_arrays(pool, B)
+        self.arrays["level_idx"][:] = first_level
+        kw.setdefault("view_shape", (15, 15))
+        kw["stream_salt"] = 1 + int(kw.pop("env_offset", 0)) if kw.pop("episode_streams", True) else 0
+        self.env = oracle.OracleMultiEnv(self.arrays, pool, **kw)
+
+    def reset(self):
+        return self.env.reset().copy()
+
+    def step(self, actions):
+        obs, r, d = self.env.step(actions)
+        return obs.copy(), r.copy(), d.copy()
+
+    def get(self, name):
+        if name == "agent_locs":
+            return self.env.ma["agent_loc"].copy()
+        if name in self.env.ma:
+            return self.env.ma[name].copy()
+        if name == "times_up":
+            return np.repeat(self.arrays["times_up"][:, None], self.env.A, axis=1)
+        return self.arrays[name].copy()
+
+
+class DeviceMultiBackend(object):
+    def __init__(self, pool, B, first_level=0, **kw):
+        from safelife_amd.multi_env import SafeLifeMultiAgentVectorEnv
+        self.env = SafeLifeMultiAgentVectorEnv(pool, B, first_level=first_level, **kw)
+
+    def reset(self):
+        self.env.reset()
+        return self.env.numpy("obs")
+
+    def step(self, actions):
+        self.env.step(actions)
+        return self.env.numpy("obs"), self.env.numpy("reward"), self.env.numpy("done")
+
+    def get(self, name):
+        return self.env.numpy(name)
+
+
+MULTI_STATE = ("board", "goals", "rng", "num_steps", "level_idx", "episode_idx", "goals_static", "exit_locs", "agent_locs",
+               "old_value", "required_points", "initial_points", "table_idx", "is_active", "episode_reward",
+               "episode_length", "reward", "done", "success")
+
+
+def replay_trace_multi(tr, backend_cls, counts_fn):
+    """Replay a reference SafeLifeEnv(single_agent=False) trace (B = 1; the env reloads once every agent is done)."""
+    from safelife_amd.levels import LevelPool
+    levels = levels_from_trace(tr)
+    A = len(levels[0].agent_locs)
+    pool = LevelPool(levels, counts_fn=counts_fn, n_agents=A)
+    be = backend_cls(pool, 1, first_level=0, auto_reset=True, level_stride=1, episode_streams=False,
+                     **env_kwargs_from_trace(tr))
+    obs = be.reset()
+    n_resets = len(tr["trace_reset_at"])
+    assert np.array_equal(obs[0], tr["trace_reset_obs"][0]), "first reset obs"
+    assert np.array_equal(be.get("board")[0], tr["trace_reset_board"][0])
+    assert np.array_equal(be.get("rng")[0], tr["trace_reset_rng"][0])
+    assert np.array_equal(be.get("required_points")[0], tr["trace_reset_required"][0])
+    episode = 0
+    T = len(tr["trace_reward"])
+    for t in range(T):
+        obs, reward, done = be.step(tr["trace_actions"][t][None].astype(np.int32))
+        where = "step %d" % t
+        assert np.array_equal(reward[0], tr["trace_reward"][t]), where
+        assert np.array_equal(done[0].astype(bool), tr["trace_done"][t]), where
+        assert np.array_equal(be.get("success")[0].astype(bool), tr["trace_success"][t]), where
+        assert bool(be.get("times_up")[0][0]) == bool(tr["trace_times_up"][t]), where
+        if np.all(tr["trace_done"][t]):
+            episode += 1
+            if episode >= n_resets:
+                break
+            assert np.array_equal(obs[0], tr["trace_reset_obs"][episode]), where + " reset obs"
+            assert np.array_equal(be.get("board")[0], tr["trace_reset_board"][episode]), where
+            assert np.array_equal(be.get("rng")[0], tr["trace_reset_rng"][episode]), where
+            assert np.array_equal(be.get("required_points")[0], tr["trace_reset_required"][episode]), where
+        else:
+            assert np.array_equal(be.get("board")[0], tr["trace_board"][t]), where + " board"
+            assert np.array_equal(be.get("goals")[0], tr["trace_goals"][t]), where + " goals"
+            assert np.array_equal(be.get("agent_locs")[0], tr["trace_agent_locs"][t]), where + " locs"
+            assert np.array_equal(be.get("rng")[0], tr["trace_rng_after"][t]), where + " rng"
+            assert np.array_equal(obs[0], tr["trace_obs"][t]), where + " obs"
+            assert np.array_equal(be.get("episode_length")[0], tr["trace_ep_length"][t]), where
+            assert np.array_equal(be.get("episode_reward")[0], tr["trace_ep_reward"][t]), where
             assert int(be.get("num_steps")[0]) == int(tr["trace_num_steps"][t]), where
     return T
 
