@@ -837,6 +837,40 @@ def main():
                     extra[tag + "_queues_us_per_step"] = variants[tag.split("_25x25")[0] + "_queues_us"] = envo.last_queues_us
                 del envo
 
+            # multi-agent envs (SafeLifeEnv(single_agent=False), the reference's levels/random/multi-agent specs at 26x26):
+            # two agents per board, one fused launch per step of the size-generic family (slhip_env_step_multi)
+            try:
+                from safelife_amd.levels import Level, LevelPool
+                from safelife_amd.multi_env import SafeLifeMultiAgentVectorEnv
+                mlv = []
+                for nm in ("multi_asym1", "multi_build_coop", "multi_build_compete"):
+                    with np.load(os.path.join(REPO, "tests", "golden", "trace_%s.npz" % nm)) as d:
+                        for i in range(int(d["n_levels"])):
+                            rec = {k[len("level%d_" % i):]: d[k] for k in d.files if k.startswith("level%d_" % i)}
+                            rw = rec.pop("rng")
+                            lv = Level.from_data(rec)
+                            lv.rng_words = np.array(rw, np.uint64)
+                            mlv.append(lv)
+                envm = SafeLifeMultiAgentVectorEnv(LevelPool(mlv, counts_fn=_device_counts, n_agents=2), B, time_limit=1000,
+                                                   view_shape=(25, 25), output_channels=TRAIN_CHANNELS, auto_reset=True)
+                envm.reset()
+                actm = torch.randint(0, 9, (64, B, 2), generator=gen, device=dev, dtype=torch.int32)
+                for t in range(10):
+                    envm.step(actm[t])
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for t in range(50):
+                    envm.step(actm[10 + t])
+                e1.record()
+                torch.cuda.synchronize()
+                extra["multi_agent_2x26x26_obs15_us_per_step"] = e0.elapsed_time(e1) / 50 * 1e3
+                extra["multi_agent_note"] = ("%d envs x 2 agents, 26x26 levels of the reference's multi-agent specs, uint8 25x25x15 "
+                                             "observation per agent, one launch per step (one workgroup per board)" % B)
+                del envm
+            except Exception as e:          # noqa: BLE001
+                extra["multi_agent_error"] = "%s: %s" % (type(e).__name__, e)
+
             # level-pool refresh while stepping (levels.LevelPool(refreshable=True), pool_stage / pool_commit): C3's batch through
             # the queues in calls of `chunk` steps, with a sixth of the pool's levels replaced every call (staged one call
             # ahead, committed between two calls) against the same calls without any refresh
