@@ -4,7 +4,7 @@
 # (barriers, loads, stores, record write-back and the launch boundary stay).  -DSL_DEV_SHAPES keeps the 25x25 and 64x64
 # shapes only (a quarter of the compile time).
 #   tools/exp/timing_only.sh            -> tools/exp/lib_cur.so, lib_skip1.so, lib_skip2.so, lib_skip3.so, lib_skip4.so, lib_skip7.so
-# then, on the GPU box (what tools/r5/sixth.sh does):
+# then, on the GPU box:
 #   for lib in cur skip1 skip2 skip3 skip4 skip7; do
 #     SAFELIFE_HIP_LIB=$PWD/tools/exp/lib_$lib.so python bench.py --steps 400 --warmup 40 --extras 0 --rollout 0 --cpu-baseline 0
 #   done
