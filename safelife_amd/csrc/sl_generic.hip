@@ -266,8 +266,10 @@ __device__ bool recolor_exits(u16 *board, int W, int ly, int lx, const int32_t *
 
 // SafeLifeEnv.get_obs for env e from the board in LDS; goals through `goals` (LDS or global).
 __device__ void write_obs(const sl_env_batch &env, int e, const u16 *board, const u16 *goals,
-                          int ly, int lx, const int32_t *exits, uint8_t *obs_base = nullptr, int slot = -1) {
-    // (obs_base / slot: the multi-agent kernels write agent a of env e to slot e * A + a of their own tensor)
+                          int ly, int lx, const int32_t *exits, uint8_t *obs_base = nullptr, int slot = -1,
+                          uint8_t *stage = nullptr) {
+    // (obs_base / slot: the multi-agent kernels write agent a of env e to slot e * A + a of their own tensor; stage: room
+    //  in LDS for one observation's view_h x view_w x C bytes -- the channel bytes are parked there and leave as dwords)
     uint8_t *const obs_out = obs_base ? obs_base : env.obs;
     if (slot >= 0) e = slot;
     if (!obs_out && !env.policy_obs) return;
@@ -297,7 +299,7 @@ __device__ void write_obs(const sl_env_batch &env, int e, const u16 *board, cons
             if (C == 0) {
                 ((u32 *)obs_out)[(size_t)e * nv + v] = word;
             } else {
-                uint8_t *o = obs_out + ((size_t)e * nv + v) * C;
+                uint8_t *o = stage ? stage + (size_t)v * C : obs_out + ((size_t)e * nv + v) * C;
                 for (int c = 0; c < C; ++c) o[c] = (word >> env.channels[c]) & 1u;
             }
         }
@@ -309,6 +311,23 @@ __device__ void write_obs(const sl_env_batch &env, int e, const u16 *board, cons
                 else ((float *)env.policy_obs)[base + (size_t)c * nv] = (float)bit;
             }
         }
+    }
+    if (stage && obs_out && C > 0) {
+        // the parked observation -> global memory: the bytes up to the first 4-byte boundary of the destination one by
+        // one, then whole dwords (assembled from four LDS bytes: the stage is not aligned with the destination), then
+        // the tail.  15 byte stores per cell become 15/4 dword stores.
+        __syncthreads();
+        const int total = nv * C;
+        uint8_t *dst = obs_out + (size_t)e * total;
+        const int head = min(total, (int)((4 - ((size_t)dst & 3)) & 3));
+        const int nd = (total - head) >> 2;
+        for (int i = threadIdx.x; i < head; i += GB) dst[i] = stage[i];
+        u32 *d4 = (u32 *)(dst + head);
+        const uint8_t *s1 = stage + head;
+        for (int k = threadIdx.x; k < nd; k += GB)
+            d4[k] = (u32)s1[4 * k] | ((u32)s1[4 * k + 1] << 8) | ((u32)s1[4 * k + 2] << 16) | ((u32)s1[4 * k + 3] << 24);
+        for (int i = head + 4 * nd + threadIdx.x; i < total; i += GB) dst[i] = stage[i];
+        __syncthreads();            // (the next agent's observation reuses the stage)
     }
 }
 
@@ -551,12 +570,19 @@ struct MultiLds {
     int *loc;       // [2 A]
     int *score;     // [A]  sum(points_table[a] * alive_counts)
     int *flag;      // [0] every agent is done
+    uint8_t *stage; // one observation's channel bytes (write_obs), or null
 };
-__device__ __forceinline__ MultiLds carve_multi(unsigned char *smem, int HW) {
+__device__ __forceinline__ MultiLds carve_multi(unsigned char *smem, int HW, bool staged) {
     int *base = (int *)(smem + 128 + (size_t)4 * ((HW + 7) & ~7) * sizeof(u16));        // (= generic_lds_bytes(HW, 4))
-    return MultiLds{base, base + 2 * SL_MAX_AGENTS, base + 3 * SL_MAX_AGENTS};
+    return MultiLds{base, base + 2 * SL_MAX_AGENTS, base + 3 * SL_MAX_AGENTS,
+                    staged ? (uint8_t *)(base + 4 * SL_MAX_AGENTS) : nullptr};
 }
-static size_t multi_lds_bytes(int HW) { return generic_lds_bytes(HW, 4) + 4 * SL_MAX_AGENTS * sizeof(int); }
+static size_t multi_stage_bytes(const sl_env_batch &env, const sl_multi_agent &m) {
+    return (m.obs && env.n_channels > 0) ? (((size_t)env.view_h * env.view_w * env.n_channels + 15) & ~(size_t)15) : 0;
+}
+static size_t multi_lds_bytes(const sl_env_batch &env, const sl_multi_agent &m) {
+    return generic_lds_bytes(env.H * env.W, 4) + 4 * SL_MAX_AGENTS * sizeof(int) + multi_stage_bytes(env, m);
+}
 
 // GameState.update_exit_colors for A agents (safelife_game.py:537-552), by thread 0: every agent's cell gets the EXIT bit
 // iff THAT agent may leave (its own points against its own requirement); the exits turn red when any agent may.
@@ -662,7 +688,7 @@ __global__ __launch_bounds__(GB_MAX) void k_env_step_multi(sl_env_batch env, sl_
     const int H = env.H, W = env.W, HW = H * W, E = env.E, A = m.n_agents;
     const int e = blockIdx.x, tid = threadIdx.x;
     GenericLds l = carve(smem, HW, 4);
-    MultiLds ml = carve_multi(smem, HW);
+    MultiLds ml = carve_multi(smem, HW, m.obs && env.n_channels > 0);
     u16 *cur = l.buf[0], *rows = l.buf[1], *nxt = l.buf[2], *aux = l.buf[3];
     u16 *gboard = env.board + (size_t)e * HW;
     u16 *ggoals = env.goals + (size_t)e * HW;
@@ -762,7 +788,7 @@ __global__ __launch_bounds__(GB_MAX) void k_env_step_multi(sl_env_batch env, sl_
     __syncthreads();   // goals written by this workgroup are read back below
     if (m.obs)
         for (int a = 0; a < A; ++a)
-            write_obs(env, e, cur, ggoals, ml.loc[2 * a], ml.loc[2 * a + 1], exits, m.obs, e * A + a);
+            write_obs(env, e, cur, ggoals, ml.loc[2 * a], ml.loc[2 * a + 1], exits, m.obs, e * A + a, ml.stage);
 }
 
 __global__ __launch_bounds__(GB_MAX) void k_env_reset_multi(sl_env_batch env, sl_multi_agent m,
@@ -771,7 +797,7 @@ __global__ __launch_bounds__(GB_MAX) void k_env_reset_multi(sl_env_batch env, sl
     const int HW = env.H * env.W, e = blockIdx.x, tid = threadIdx.x, A = m.n_agents;
     if (mask && !mask[e]) return;
     GenericLds l = carve(smem, HW, 4);
-    MultiLds ml = carve_multi(smem, HW);
+    MultiLds ml = carve_multi(smem, HW, m.obs && env.n_channels > 0);
     if (tid == 0) {         // a slot that already holds a level moves on to its next one (safelife_env.py:204)
         sl_env_scalars *sc = env.scalars + e;
         if (sc->loaded) {
@@ -787,7 +813,7 @@ __global__ __launch_bounds__(GB_MAX) void k_env_reset_multi(sl_env_batch env, sl
     if (m.obs)
         for (int a = 0; a < A; ++a)
             write_obs(env, e, l.buf[0], env.goals + (size_t)e * HW, ml.loc[2 * a], ml.loc[2 * a + 1],
-                      env.exit_locs + (size_t)e * env.E, m.obs, e * A + a);
+                      env.exit_locs + (size_t)e * env.E, m.obs, e * A + a, ml.stage);
 }
 
 __global__ __launch_bounds__(GB_MAX) void k_env_reset_generic(sl_env_batch env,
@@ -940,7 +966,7 @@ hipError_t launch_env_reset_generic(const sl_env_batch &env, const uint8_t *mask
 
 hipError_t launch_env_step_multi(const sl_env_batch &env, const sl_multi_agent &m, const int32_t *actions, const Jump *jump,
                                  hipStream_t stream) {
-    const size_t lds = multi_lds_bytes(env.H * env.W);
+    const size_t lds = multi_lds_bytes(env, m);
     hipError_t err = set_lds((const void *)k_env_step_multi, lds);
     if (err != hipSuccess) return err;
     hipLaunchKernelGGL(k_env_step_multi, dim3(env.B), dim3(generic_threads(env.H * env.W)), lds, stream, env, m, actions, jump);
@@ -948,7 +974,7 @@ hipError_t launch_env_step_multi(const sl_env_batch &env, const sl_multi_agent &
 }
 
 hipError_t launch_env_reset_multi(const sl_env_batch &env, const sl_multi_agent &m, const uint8_t *mask, hipStream_t stream) {
-    const size_t lds = multi_lds_bytes(env.H * env.W);
+    const size_t lds = multi_lds_bytes(env, m);
     hipError_t err = set_lds((const void *)k_env_reset_multi, lds);
     if (err != hipSuccess) return err;
     hipLaunchKernelGGL(k_env_reset_multi, dim3(env.B), dim3(generic_threads(env.H * env.W)), lds, stream, env, m, mask);
