@@ -10,6 +10,7 @@
 #                    tools/trace_overlap.py 12 --queues 4 --fences none <args>
 #   prof             rocprofv3 --kernel-trace --stats of the bench + the PMC passes (tools/prof_run.sh; agent fences)
 #   soak[:seconds]   tools/soak.py (randomised differential run against the oracle)
+#   soakmulti[:s]    tools/soak_multi.py (the multi-agent step against the oracle)
 #   abcache          the goal-word cache on / off (SAFELIFE_GOAL_CACHE) at K = 20 and K = 400, alternating
 cd ${GRAFT_REPO_ROOT:-$(dirname "$0")/..}
 O=gpurun_out; mkdir -p $O
@@ -33,6 +34,7 @@ for task in "$@"; do
     trace)    SAFELIFE_HIP_LIB=$PWD/tools/lib_trace.so SAFELIFE_HIP_LIB_ANY_ABI=1 timeout 300 python tools/trace_overlap.py 12 --queues 4 --fences none $arg 2>&1 | grep -v amdgpu.ids > $out ;;
     prof)     bash tools/prof_run.sh $TAG > /dev/null 2>&1; head -4 $O/${TAG}_kernel_trace.txt > $out; grep -E "FETCH_SIZE|WRITE_SIZE" $O/${TAG}_pmc.txt >> $out ;;
     soak)     ( timeout 1200 python tools/soak.py ${arg:-120} 2>&1 | tail -5 ) > $out ;;
+    soakmulti) ( timeout 1200 python tools/soak_multi.py ${arg:-120} 2>&1 | tail -3 ) > $out ;;
     abcache)  # the goal-word cache on / off at the driver's K = 20 and at K = 400, alternating, same box
               for rep in 1 2 3; do for gc in 1 0; do for k in 20 400; do
                 w=$([ $k = 400 ] && echo 40 || echo 5)
