@@ -1278,6 +1278,11 @@ def main():
                                                          "k20_median_us", "forced_gather_us", "c5_with_side_effects_us",
                                                          "c5_with_side_effects_streams_us", "life_occupancy_64x64_board_steps_per_s",
                                                          "obs_u8_queues_us", "obs_u32_view_queues_us", "obs_policy_layout_u8_queues_us")},
+                         # (rounds 1-5 timed the region without episode ends: the fraction of THAT regime, for comparison)
+                         "no_reset_frac": (bytes_per_step * B / (variants["no_reset_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+                                           if variants.get("no_reset_us") else None),
+                         "k400_frac": (bytes_per_step * B / (variants["k400_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+                                       if variants.get("k400_us") else None),
                          "scaling_curve": "not measured by this build (no multi-GPU node was available to it): the 1-to-N curve "
                                           "is the driver's",
                          "measured_ceiling": ceiling,
