@@ -555,7 +555,7 @@ typedef struct sl_agent_state {   /* per env and agent (48 bytes) */
     int32_t is_active;            /* SafeLifeEnv._is_active[a] */
     int32_t reserved[3];
 } sl_agent_state;
-typedef struct sl_level_agent {   /* per pool level and agent (32 bytes); row < 0: the level has fewer agents */
+typedef struct sl_level_agent {   /* per pool level and agent (32 bytes); every level of the pool has exactly n_agents agents */
     int32_t row, col, required_reset, required_step, initial_points, table_idx, reserved[2];
 } sl_level_agent;
 typedef struct sl_multi_agent {
