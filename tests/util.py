@@ -359,6 +359,24 @@ def smoke_check():
         assert np.array_equal(r1, r2) and np.array_equal(d1, d2) and np.array_equal(o1, o2), t
         for name in ("board", "goals", "agent_loc", "rng", "num_steps", "level_idx"):
             assert np.array_equal(dev.get(name), cpu.get(name)), (t, name)
+    # ... and the headline's launcher: a staged region on the library's AQL queues (slhip_queues_stage / _go)
+    import torch
+    from safelife_amd._hip import SafeLifeHipError
+    acts = rng.integers(0, 9, (6, B)).astype(np.int32)
+    try:
+        dev.env.queues_open(2)
+    except SafeLifeHipError:
+        return
+    d_acts = torch.from_numpy(acts).to(dev.env.device)
+    torch.cuda.synchronize()
+    dev.env.step_queues_many(d_acts, defer=True)
+    dev.env.queues_go()
+    dev.env.queues_sync()
+    for t in range(len(acts)):
+        cpu.env.step(acts[t])
+    for name in ("board", "goals", "agent_loc", "rng", "num_steps", "level_idx", "reward", "done"):
+        assert np.array_equal(dev.get(name), cpu.get(name)), ("queues", name)
+    dev.env.queues_close()
 
 
 # ---- the shipped benchmark levels in bulk (tests/golden/levels + bulk_levels.npz, make_golden.py gen_bulk) ----------
