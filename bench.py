@@ -1089,7 +1089,10 @@ def main():
                     torch.cuda.synchronize()
                     ms = e0.elapsed_time(e1)
                     n_eps = sum(len(b) for b in batches)
-                    extra["c5_with_side_effects_us_per_step"] = variants["c5_with_side_effects_streams_us"] = ms * 1e3 / n_meas
+                    # (extra only: through HIP streams the figure depends on how the runtime maps the slice and side streams
+                    #  onto hardware queues on the box -- 46.7 us on most, 86-102 where two of them share one; the queues'
+                    #  figure below is the one `roofline` carries)
+                    extra["c5_with_side_effects_us_per_step"] = ms * 1e3 / n_meas
                     extra["c5_with_side_effects_env_steps_per_s_per_gpu"] = n_c5 * n_meas / (ms * 1e-3)
                     extra["c5_with_side_effects_episodes_scored"] = n_eps
                     extra["c5_with_side_effects_note"] = ("%d envs x 64x64 navigation, %d steps, episode-end pass every %d steps "
@@ -1276,7 +1279,7 @@ def main():
                          #   c5_with_side_effects_us  C5's per-GPU share with the episode-end pass in the region (queues)
                          **{k: variants.get(k) for k in ("agent_fences_us", "no_reset_us", "steady_state_us", "k400_us", "unstaged_us",
                                                          "k20_median_us", "forced_gather_us", "c5_with_side_effects_us",
-                                                         "c5_with_side_effects_streams_us", "life_occupancy_64x64_board_steps_per_s",
+                                                         "life_occupancy_64x64_board_steps_per_s",
                                                          "obs_u8_queues_us", "obs_u32_view_queues_us", "obs_policy_layout_u8_queues_us")},
                          # (rounds 1-5 timed the region without episode ends: the fraction of THAT regime, for comparison)
                          "no_reset_frac": (bytes_per_step * B / (variants["no_reset_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
