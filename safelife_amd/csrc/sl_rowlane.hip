@@ -2916,6 +2916,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
             }
         }
         if (!(any & 1)) return;
+        SL_STAMP(13);       // (trace builds: the reload block's own phases -- entered / rows fetched and placed / leaders done)
         // on-device auto-reset (training/base_algo.py:231-236 calls env.reset() after a done step)
         // (the leaders' own fetches -- the level's constants and its first exit -- go out FIRST, beside the rows' below,
         //  not behind them: one memory round trip less on the chain a reloading workgroup holds its launch up with)
@@ -2999,7 +3000,9 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
             if (rlead) box[gb].score0 = s0;
         }
         if (rlead) box[gb].gstat = gstatic;
+        SL_STAMP(14);
         wg_sync();
+        SL_STAMP(15);
         if (lead && box[lq].reset_level >= 0) {
             const int l_level = box[lq].reset_level;
             const int episodes = lrec->episode_idx + 1;

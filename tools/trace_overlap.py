@@ -135,3 +135,13 @@ for i, n in enumerate(names):
 print("  %-24s %6.0f   (all waves %6.0f)" % ("wave lifetime", lt[slow].mean(), lt.mean()))
 per_launch_max = lt.max(axis=1)
 print("per launch: slowest wave %.0f ns mean (median wave %.0f)" % (per_launch_max.mean(), np.median(lt, axis=1).mean()))
+
+# the reload block of those waves (stamps 13-15, written only by workgroups that reload a level in the launch)
+full = tr[2 * SL:, :, :16].astype(np.float64) * 10.0
+has = (tr[2 * SL:, :, 13] != 0) & (tr[2 * SL:, :, 14] != 0) & (tr[2 * SL:, :, 15] != 0)
+if has.any():
+    f = full[has]
+    print("reload block, %d waves: score barrier -> block entered %.0f | rows fetched and placed %.0f | barrier %.0f | "
+          "leaders' new record + last barrier %.0f | (whole 'leaders' phase %.0f) ns"
+          % (int(has.sum()), (f[:, 13] - f[:, 6]).mean(), (f[:, 14] - f[:, 13]).mean(), (f[:, 15] - f[:, 14]).mean(),
+             (f[:, 7] - f[:, 15]).mean(), (f[:, 7] - f[:, 6]).mean()))
