@@ -2920,14 +2920,11 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
         // on-device auto-reset (training/base_algo.py:231-236 calls env.reset() after a done step)
         // (the leaders' own fetches -- the level's constants and its first exit -- go out FIRST, beside the rows' below,
         //  not behind them: one memory round trip less on the chain a reloading workgroup holds its launch up with)
-#ifndef SL_TIMING_RESET
-#define SL_TIMING_RESET 0       /* TIMING-ONLY builds (wrong results): 1 = a reloading workgroup fetches nothing of its new level (what a prefetch under the step could save at most) */
-#endif
         const bool ready_pool = env.pool_ready != nullptr;          // (uniform)
         const bool l_reset = lead && box[lq].reset_level >= 0;
         sl_level_scalars lv_pre = {};
         int exit0_pre = -1;
-        if (l_reset && !(SL_TIMING_RESET & 1)) {
+        if (l_reset) {
             lv_pre = env.pool_scalars[box[lq].reset_level];
             exit0_pre = env.pool_exit_locs[(size_t)box[lq].reset_level * E];
         }
@@ -2954,8 +2951,8 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
             for (int a = 0; a < 2; ++a) {
                 u32 tw[WS];
 #pragma unroll
-                for (int j = 0; j < W / 2; ++j) tw[j] = (SL_TIMING_RESET & 1) ? (u32)(r2 == j ? 9u : 0u) : *(const u32_a2 *)(rows[a] + 2 * j);
-                if (Gm::ODD) tw[WS - 1] = (SL_TIMING_RESET & 1) ? 0u : rows[a][W - 1];
+                for (int j = 0; j < W / 2; ++j) tw[j] = *(const u32_a2 *)(rows[a] + 2 * j);
+                if (Gm::ODD) tw[WS - 1] = rows[a][W - 1];
                 if (NOGOALS && a == 1) {
                     // no goal image: the row goes to the env's goal array as it came, and into the registers the score reads
                     u16 *grow = env.goals + (size_t)e * HW + r2 * W;
@@ -2975,13 +2972,11 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
                 }
                 if (Gm::ODD) imgs[a][Gm::cell(r, W - 1)] = (u16)tw[WS - 1];
             }
-            if (!(SL_TIMING_RESET & 1)) {
             lut_base = (u32)env.pool_scalars[level].table_idx * (u32)SCORE_LUT_BYTES;
             p = (double)env.pool_scalars[level].spawn_prob;
             if (r2 < 4) rng_lds[4 * g + r2] = ((const u64 *)(env.pool_rng + level))[r2];
             for (int k = r2; k < E; k += H)
                 env.exit_locs[(size_t)e * E + k] = env.pool_exit_locs[(size_t)level * E + k];
-            }
             if (!NOGOALS) *dirty_flag = 1;               // (any wave that changes its goals raises the flag)
             if (r2 == 0) box[gb].dirty = 1;              // (and the whole board is new)
         }
