@@ -2527,17 +2527,34 @@ constexpr bool leadx() { return LEAN && Geom<H, W>::LEADX_OK; }
 // the order the lanes read them back (16 bytes per lane and 1 KiB per wave instruction, then single dwords), and raises
 // the workgroup's flag word; a launch that finds the flag raised moves no goal span at all and loads the words straight
 // into registers, under the board's DMA.  A board that resets (or whose goals evolve) lowers the flag in the same
-// launch, and the next launch takes the LDS route again and decides anew.  Same bytes per env-step as the goal span
-// (WS dwords per row lane instead of W cells), no LDS traffic, no vector instructions.
+// launch, and the next launch takes the LDS route again and decides anew.  No LDS traffic; since round 6 a fifth of
+// the goal span's bytes (the words are packed five to a dword, below) for two vector instructions per word.
 //
 // Layout: one block per workgroup of the BATCH (env index / NB: launches start at multiples of NB -- the launcher passes
 // no cache otherwise), whatever slice, queue or stream steps it: a 256-byte header whose first dword is the flag, then
-// WAVES x WS x 64 dwords.  Zeroing the whole cache lowers every flag.
+// WAVES x PW x 64 dwords (PW = ceil(WS / 5): five goal words per dword, below).  Zeroing the whole cache lowers every flag.
 template <int H, int W>
 struct GoalCache {
     using Gm = Geom<H, W>;
-    static constexpr int X4 = Gm::WS / 4, TAIL = Gm::WS % 4;       // 16-byte loads per lane, then single dwords
-    static constexpr int WAVE_DWORDS = Gm::WS * 64;
+    // (round 6) a goal word carries six bits -- the colours of its two cells at bits 5-7 and 21-23 (goal_shift) -- so
+    // the cache keeps FIVE of them per dword (word 5 q + j of the lane at bits 3 j .. 3 j + 2 of either half of dword q):
+    // a fifth of the bytes (25x25: 3 dwords per row lane and step instead of 13 -- 940 of the 3750 bytes an env-step
+    // moves; 64x64: 7 instead of 32), for a shift and a mask per word on the way into the registers
+    static constexpr int PW = (Gm::WS + 4) / 5;                     // packed dwords per lane
+    static constexpr int X4 = PW / 4, TAIL = PW % 4;               // 16-byte loads per lane, then single dwords
+    static constexpr int WAVE_DWORDS = PW * 64;
+    static __device__ __forceinline__ u32 unpack(u32 p, int j) {    // goal word j of the five in p
+        return (j == 0 ? p << 5 : j == 1 ? p << 2 : p >> (3 * j - 5)) & 0x00E000E0u;
+    }
+    static __device__ __forceinline__ void pack(const u32 *gsh, u32 (&pk)[PW]) {
+#pragma unroll
+        for (int q = 0; q < PW; ++q) {
+            pk[q] = 0;
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+                if (5 * q + j < Gm::WS) pk[q] |= (gsh[5 * q + j] >> 5) << (3 * j);
+        }
+    }
     static constexpr int HEAD_DWORDS = 64;
     static constexpr int BLOCK_DWORDS = HEAD_DWORDS + WAVES * WAVE_DWORDS;
     static __host__ __device__ constexpr size_t bytes(int B) { return 4 * (size_t)((B + Gm::NB - 1) / Gm::NB) * BLOCK_DWORDS; }
@@ -2793,16 +2810,19 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     }
     if (GCACHE && goals_free && live) {
         // the lane's goal words, as an earlier launch left them (GoalCache): straight into the registers the score reads
+        u32 pk[Gc::PW];
 #pragma unroll
         for (int c = 0; c < Gc::X4; ++c) {
             const u32x4 v = *Gc::x4(gc_block, wave, lane, c);
-            gsh_reg[4 * c + 0] = v.x;
-            gsh_reg[4 * c + 1] = v.y;
-            gsh_reg[4 * c + 2] = v.z;
-            gsh_reg[4 * c + 3] = v.w;
+            pk[4 * c + 0] = v.x;
+            pk[4 * c + 1] = v.y;
+            pk[4 * c + 2] = v.z;
+            pk[4 * c + 3] = v.w;
         }
 #pragma unroll
-        for (int j = 0; j < Gc::TAIL; ++j) gsh_reg[4 * Gc::X4 + j] = *Gc::tail(gc_block, wave, lane, j);
+        for (int j = 0; j < Gc::TAIL; ++j) pk[4 * Gc::X4 + j] = *Gc::tail(gc_block, wave, lane, j);
+#pragma unroll
+        for (int k = 0; k < WS; ++k) gsh_reg[k] = Gc::unpack(pk[k / 5], k % 5);
     }
 #ifndef SL_MOVE_BOX
 #define SL_MOVE_BOX 1           /* A/B knob: 0 = the round-3 form of the move (leader writes the image, a barrier of its own) */
@@ -3418,11 +3438,13 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
             for (int q = 0; q < Gm::NB; ++q)
                 if (q < nbb && box[q].gstat != 1) all_static = false;
             if (all_static && rwave && live && (nbb == Gm::NB || e0b + nbb >= env.B)) {
+                u32 pk[Gc::PW];
+                Gc::pack(gsh_lane, pk);
 #pragma unroll
                 for (int c = 0; c < Gc::X4; ++c)
-                    *Gc::x4(gc_block, wave2, lane2, c) = u32x4{gsh_lane[4 * c], gsh_lane[4 * c + 1], gsh_lane[4 * c + 2], gsh_lane[4 * c + 3]};
+                    *Gc::x4(gc_block, wave2, lane2, c) = u32x4{pk[4 * c], pk[4 * c + 1], pk[4 * c + 2], pk[4 * c + 3]};
 #pragma unroll
-                for (int j = 0; j < Gc::TAIL; ++j) *Gc::tail(gc_block, wave2, lane2, j) = gsh_lane[4 * Gc::X4 + j];
+                for (int j = 0; j < Gc::TAIL; ++j) *Gc::tail(gc_block, wave2, lane2, j) = pk[4 * Gc::X4 + j];
             }
         }
         // (a workgroup at the ragged end of a SLICE holds fewer boards than the block has words for: it may use and
