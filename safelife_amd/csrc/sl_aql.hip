@@ -502,7 +502,10 @@ hipError_t emit(Device &d, const Hsa &h, int queue, hipFunction_t f, unsigned gr
                 const AqlPatch *patch = nullptr) {
     const KernelInfo *k = kernel_info(d, f);
     if (!k) return hipErrorNotFound;
-    if (arg_bytes > k->kernarg || k->kernarg > KARG_SLOT || k->priv != 0) {
+#ifndef SL_AQL_SCRATCH
+#define SL_AQL_SCRATCH 0        /* experiment: 1 = kernels with a private segment are dispatched too (the queue's scratch is the runtime's to set up) */
+#endif
+    if (arg_bytes > k->kernarg || k->kernarg > KARG_SLOT || (k->priv != 0 && !SL_AQL_SCRATCH)) {
         // (never expected: say which -- a kernel that spills has private memory, which these packets do not set up)
         fprintf(stderr, "libsafelife_hip: AQL dispatch refused: argument block %zu bytes, kernel takes %u (slot %zu), private "
                         "segment %u bytes\n", arg_bytes, (unsigned)k->kernarg, KARG_SLOT, (unsigned)k->priv);
@@ -542,7 +545,7 @@ hipError_t emit(Device &d, const Hsa &h, int queue, hipFunction_t f, unsigned gr
     p->grid_size_x = grid * threads;
     p->grid_size_y = 1;
     p->grid_size_z = 1;
-    p->private_segment_size = 0;
+    p->private_segment_size = SL_AQL_SCRATCH ? k->priv : 0;
     p->group_segment_size = k->group + lds;
     p->kernel_object = k->object;
     p->kernarg_address = slot;

@@ -1150,8 +1150,26 @@ __device__ __forceinline__ int group_total(int v, int g) {
 constexpr u32 SCORE_CELL_MASK = 0x8E1D8E1Du;
 constexpr int SCORE_LUT_BYTES = 4096 + 65536;     // per points table: compact form, then wide form
 __device__ __forceinline__ u32 goal_shift(u32 g) { return (g >> 4) & 0x00E000E0u; }
+// Five goal words to a dword (round 6): a goal word carries six bits -- the colours of its two cells at bits 5-7 and
+// 21-23 -- so word 5 q + j of a row sits at bits 3 j .. 3 j + 2 of either half of packed dword q.  The form the
+// goal-word cache keeps in memory, and the one its kernels keep in registers (64-cell rows: 7 registers instead of 32).
+__device__ __forceinline__ u32 goal_unpack(u32 p, int j) {      // goal_shift() of word j of the five in p
+    return (j == 0 ? p << 5 : j == 1 ? p << 2 : p >> (3 * j - 5)) & 0x00E000E0u;
+}
+template <int H, int W>
+__device__ __forceinline__ void goal_pack_row(const RowWords<H, W> &g, u32 *pk) {       // g: the goal cells of a row
+    constexpr int WS = Geom<H, W>::WS;
+#pragma unroll
+    for (int q = 0; q < (WS + 4) / 5; ++q) {
+        u32 v = 0;
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+            if (5 * q + j < WS) v |= ((g[5 * q + j] >> 9) & 0x00070007u) << (3 * j);
+        pk[q] = v;
+    }
+}
 
-template <int H, int W, bool LDS_LUT>
+template <int H, int W, bool LDS_LUT, bool PACKED = false>       // PACKED: gsh_lane holds the row's words five to a dword
 __device__ __forceinline__ int row_score(const RowWords<H, W> &n, const u32 *gsh_lane,
                                          const int8_t *__restrict__ lut, u32 lut_base, const int8_t *lds_lut,
                                          u32 cell_mask, u32 c100) {
@@ -1159,7 +1177,7 @@ __device__ __forceinline__ int row_score(const RowWords<H, W> &n, const u32 *gsh
     int s = 0;
 #pragma unroll
     for (int k = 0; k < Gm::WS; ++k) {
-        u32 idx = BO3_AND_OR(n[k], cell_mask, gsh_lane[k]);
+        u32 idx = BO3_AND_OR(n[k], cell_mask, PACKED ? goal_unpack(gsh_lane[k / 5], k % 5) : gsh_lane[k]);
         if (LDS_LUT) {
             idx = BO3_AND_OR(n[k] >> 7, c100, idx);       // pullable -> bit 8 (cell_mask leaves bit 15 out in this form)
             s += lds_lut[idx & 0xFFFFu];
@@ -2536,25 +2554,12 @@ constexpr bool leadx() { return LEAN && Geom<H, W>::LEADX_OK; }
 template <int H, int W>
 struct GoalCache {
     using Gm = Geom<H, W>;
-    // (round 6) a goal word carries six bits -- the colours of its two cells at bits 5-7 and 21-23 (goal_shift) -- so
-    // the cache keeps FIVE of them per dword (word 5 q + j of the lane at bits 3 j .. 3 j + 2 of either half of dword q):
-    // a fifth of the bytes (25x25: 3 dwords per row lane and step instead of 13 -- 940 of the 3750 bytes an env-step
-    // moves; 64x64: 7 instead of 32), for a shift and a mask per word on the way into the registers
+    // (round 6) the cache keeps the words FIVE to a dword (goal_unpack above): a fifth of the bytes (25x25: 3 dwords per
+    // row lane and step instead of 13 -- 940 of the 3750 bytes an env-step moves; 64x64: 7 instead of 32), for a shift
+    // and a mask per word where the score reads them
     static constexpr int PW = (Gm::WS + 4) / 5;                     // packed dwords per lane
     static constexpr int X4 = PW / 4, TAIL = PW % 4;               // 16-byte loads per lane, then single dwords
     static constexpr int WAVE_DWORDS = PW * 64;
-    static __device__ __forceinline__ u32 unpack(u32 p, int j) {    // goal word j of the five in p
-        return (j == 0 ? p << 5 : j == 1 ? p << 2 : p >> (3 * j - 5)) & 0x00E000E0u;
-    }
-    static __device__ __forceinline__ void pack(const u32 *gsh, u32 (&pk)[PW]) {
-#pragma unroll
-        for (int q = 0; q < PW; ++q) {
-            pk[q] = 0;
-#pragma unroll
-            for (int j = 0; j < 5; ++j)
-                if (5 * q + j < Gm::WS) pk[q] |= (gsh[5 * q + j] >> 5) << (3 * j);
-        }
-    }
     static constexpr int HEAD_DWORDS = 64;
     static constexpr int BLOCK_DWORDS = HEAD_DWORDS + WAVES * WAVE_DWORDS;
     static __host__ __device__ constexpr size_t bytes(int B) { return 4 * (size_t)((B + Gm::NB - 1) / Gm::NB) * BLOCK_DWORDS; }
@@ -2600,13 +2605,18 @@ constexpr bool nogoals_lds(bool spawn, bool lean, bool one) {
 template <int H, int W>
 constexpr int nogoals_shift() { return Geom<H, W>::REGION - 16; }
 
-template <int H, int W, bool LDS_LUT, bool SPAWN, bool WRAP, bool LEAN, bool ONE>
 #ifndef SL_WIDE_WAVES
-#define SL_WIDE_WAVES 3         /* A/B knob: waves per SIMD the plain single-step kernels of the wide shapes are compiled for (2: rounds 1-4) */
+#define SL_WIDE_WAVES 4         /* A/B knob: waves per SIMD the plain single-step kernels of the wide shapes are compiled for (2: rounds 1-4;
+                                   3: round 5; 4 since the goal words stay packed in registers -- 64x64 without spawners 141 -> 123 registers,
+                                   so that all four workgroups a CU gets of a four-queue step are resident at once; the spawner variants
+                                   of 48- and 64-cell rows do not fit 128 and stay at 3) */
 #endif
+template <int H, int W>
+constexpr int wide_waves(bool spawn) { return spawn && Geom<H, W>::WS > 20 ? (SL_WIDE_WAVES < 3 ? SL_WIDE_WAVES : 3) : SL_WIDE_WAVES; }
+template <int H, int W, bool LDS_LUT, bool SPAWN, bool WRAP, bool LEAN, bool ONE>
 __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
                              (leadx<H, W, LEAN>() ? 5
-                              : (Geom<H, W>::WAVES_PER_SIMD < 4 && nogoals_lds<H, W>(SPAWN, LEAN, ONE)) ? SL_WIDE_WAVES
+                              : (Geom<H, W>::WAVES_PER_SIMD < 4 && nogoals_lds<H, W>(SPAWN, LEAN, ONE)) ? wide_waves<H, W>(SPAWN)
                                                                                                        : Geom<H, W>::WAVES_PER_SIMD)) void k_env_rollout_rowlane(
     // the eight arguments the prologue needs before anything else come first: with
     // -amdgpu-kernarg-preload-count=8 they arrive in SGPRs with the wave instead of behind an s_load
@@ -2698,13 +2708,25 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     constexpr bool GSH_REG = gsh_in_registers<H, W>(SPAWN, LEAN, ONE);
     constexpr bool SHRINK = lean_lds<H, W>(SPAWN, LEAN, ONE);
     constexpr int OFF_LUT_V = SHRINK ? Gm::OFF_GSH : Gm::OFF_LUT, OFF_MOVE_V = SHRINK ? Gm::OFF_GSH + 4096 : Gm::OFF_MOVE;
-    u32 gsh_reg[GSH_REG ? WS : 1];
+    // (round 6) the kernels that keep the goal-word cache hold the words as the cache does, five to a dword (goal_unpack):
+    // what lives from the prologue's loads to the score is 3 registers at 25x25 and 7 at 64x64 instead of 13 and 32
+    constexpr bool GPK = LEAN && GSH_REG && ONE && !LEADX;
+    u32 gsh_reg[GSH_REG ? (GPK ? (WS + 4) / 5 : WS) : 1];
     u32 *gsh_lane = GSH_REG ? gsh_reg : (u32 *)(smem_hi + Gm::OFF_GSH) + (wave * 64 + lane) * WS;
+    auto set_goal_words = [&](const RowWords<H, W> &g) {        // g: the goal cells of the lane's row
+        if constexpr (GPK) {
+            goal_pack_row<H, W>(g, gsh_reg);
+        } else {
+#pragma unroll
+            for (int k = 0; k < WS; ++k) gsh_lane[k] = goal_shift(g[k]);
+        }
+    };
     // the goal-word cache (GoalCache above): LEAN kernels whose goal words live in registers
     // (single-step launches: the T-step instantiations sit at their register limit -- a T-step launch of a batch that
     //  has a cache lowers every flag first, launch_rollout_t)
     constexpr bool GCACHE = LEAN && GSH_REG && ONE && !LEADX;
     static_assert(GCACHE == NOGOALS, "the kernels that keep the cache are the ones without a goal image");
+    static_assert(GCACHE == GPK, "the kernels that keep the cache hold the words in its packed form");
     using Gc = GoalCache<H, W>;
     u32 *const gc_block = GCACHE && hot_gcache ? hot_gcache + (size_t)((unsigned)hot_first / Gm::NB + blockIdx.x) * Gc::BLOCK_DWORDS
                                                : nullptr;
@@ -2810,19 +2832,16 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     }
     if (GCACHE && goals_free && live) {
         // the lane's goal words, as an earlier launch left them (GoalCache): straight into the registers the score reads
-        u32 pk[Gc::PW];
 #pragma unroll
         for (int c = 0; c < Gc::X4; ++c) {
             const u32x4 v = *Gc::x4(gc_block, wave, lane, c);
-            pk[4 * c + 0] = v.x;
-            pk[4 * c + 1] = v.y;
-            pk[4 * c + 2] = v.z;
-            pk[4 * c + 3] = v.w;
+            gsh_reg[4 * c + 0] = v.x;
+            gsh_reg[4 * c + 1] = v.y;
+            gsh_reg[4 * c + 2] = v.z;
+            gsh_reg[4 * c + 3] = v.w;
         }
 #pragma unroll
-        for (int j = 0; j < Gc::TAIL; ++j) pk[4 * Gc::X4 + j] = *Gc::tail(gc_block, wave, lane, j);
-#pragma unroll
-        for (int k = 0; k < WS; ++k) gsh_reg[k] = Gc::unpack(pk[k / 5], k % 5);
+        for (int j = 0; j < Gc::TAIL; ++j) gsh_reg[4 * Gc::X4 + j] = *Gc::tail(gc_block, wave, lane, j);
     }
 #ifndef SL_MOVE_BOX
 #define SL_MOVE_BOX 1           /* A/B knob: 0 = the round-3 form of the move (leader writes the image, a barrier of its own) */
@@ -2897,8 +2916,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     if (live && !goals_free) {
         if constexpr (NOGOALS) read_row_global<H, W>(k_goals + (size_t)e * HW + r * W, b);
         else read_row<H, W>(goals, gb, r, b);
-#pragma unroll
-        for (int k = 0; k < WS; ++k) gsh_lane[k] = goal_shift(b[k]);
+        set_goal_words(b);
     }
     // Goals still undecided (the first step after a reset; the reference finds out by advancing them once,
     // safelife_game.py:753-760): a goal array without a single ALIVE or SPAWNING cell cannot change and draws
@@ -2981,8 +2999,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
                     if (Gm::ODD) grow[W - 1] = (u16)tw[WS - 1];
                     RowWords<H, W> gw;
                     words_from_pairs<H, W>(tw, gw);
-#pragma unroll
-                    for (int k = 0; k < WS; ++k) gsh_lane[k] = goal_shift(gw[k]);
+                    set_goal_words(gw);
                     continue;
                 }
 #pragma unroll
@@ -3011,7 +3028,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
         }
         if (!ready_pool) {
             const int s0 = group_total<H, W>(
-                mine ? row_score<H, W, LDS_LUT>(b, gsh_lane, lut, lut_base, lds_lut, cell_mask, c100) : 0, live ? g : 0);
+                mine ? row_score<H, W, LDS_LUT, GPK>(b, gsh_lane, lut, lut_base, lds_lut, cell_mask, c100) : 0, live ? g : 0);
             if (rlead) box[gb].score0 = s0;
         }
         if (rlead) box[gb].gstat = gstatic;
@@ -3201,8 +3218,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
                 const int moved = group_total<H, W>(mine && diff ? 1 : 0, rowl ? g : 0);
                 if (has && gstatic == 0) gstatic = moved ? 2 : 1;
                 if (mine) {
-#pragma unroll
-                    for (int k = 0; k < WS; ++k) gsh_lane[k] = goal_shift(b[k]);
+                    set_goal_words(b);
                     if (!NOGOALS) *dirty_flag = 1;
                 }
             }
@@ -3218,7 +3234,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
         SL_STAMP(5);
         // safelife_env.py:153-160
         const int score_rows = (SL_TIMING_SKIP & 2) ? (int)(b[0] & 1u) : group_total<H, W>(
-            live ? row_score<H, W, LDS_LUT>(b, gsh_lane, lut, lut_base, lds_lut, cell_mask, c100) : 0, live ? g : 0);
+            live ? row_score<H, W, LDS_LUT, GPK>(b, gsh_lane, lut, lut_base, lds_lut, cell_mask, c100) : 0, live ? g : 0);
         if (rlead) {
             box[gb].score = score_rows;
             box[gb].gstat = gstatic;
@@ -3438,13 +3454,11 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
             for (int q = 0; q < Gm::NB; ++q)
                 if (q < nbb && box[q].gstat != 1) all_static = false;
             if (all_static && rwave && live && (nbb == Gm::NB || e0b + nbb >= env.B)) {
-                u32 pk[Gc::PW];
-                Gc::pack(gsh_lane, pk);
 #pragma unroll
                 for (int c = 0; c < Gc::X4; ++c)
-                    *Gc::x4(gc_block, wave2, lane2, c) = u32x4{pk[4 * c], pk[4 * c + 1], pk[4 * c + 2], pk[4 * c + 3]};
+                    *Gc::x4(gc_block, wave2, lane2, c) = u32x4{gsh_reg[4 * c], gsh_reg[4 * c + 1], gsh_reg[4 * c + 2], gsh_reg[4 * c + 3]};
 #pragma unroll
-                for (int j = 0; j < Gc::TAIL; ++j) *Gc::tail(gc_block, wave2, lane2, j) = pk[4 * Gc::X4 + j];
+                for (int j = 0; j < Gc::TAIL; ++j) *Gc::tail(gc_block, wave2, lane2, j) = gsh_reg[4 * Gc::X4 + j];
             }
         }
         // (a workgroup at the ragged end of a SLICE holds fewer boards than the block has words for: it may use and
