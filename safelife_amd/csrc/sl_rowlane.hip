@@ -2803,6 +2803,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
             pre_c[2] = src[gi[2]];
             pre_c[3] = src[gi[3]];
         }
+        SL_STAMP(14);       // (trace builds: the leaders' first round trip is back, the move's cells are asked for)
         gc_look();
     } else {
         // everything bulky goes through the LDS DMA, issued by the waves that are not the leader
@@ -2894,7 +2895,15 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     // the load barrier: the DMA waves wait for their loads, the leader wave only for its LDS stores (it moved none
     // of the spans, and what it has in flight is its own business)
     if (lwave) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef SL_TRACE
+    else {              // (trace builds: when this wave's own loads have landed, apart from when the barrier lets it go)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        SL_STAMP(13);       // (slots 13 / 14 are the reload block's as well: it overwrites them in the workgroups that reload)
+        __syncthreads();
+    }
+#else
     else __syncthreads();
+#endif
     SL_STAMP(2);
     // Release-free queue stepping: the state this workgroup has just loaded was left in the L2 of the XCD that
     // workgroup i of this slice's queue always runs on.  Scalar code, no memory access unless it fails, and behind the

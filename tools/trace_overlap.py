@@ -117,6 +117,24 @@ for i, n in enumerate(names):
 life = (st[:, :, 10] - st[:, :, 0]).reshape(-1)
 print("  %-24s %6.0f %6.0f %6.0f" % ("wave lifetime", life.mean(), np.percentile(life, 50), np.percentile(life, 90)))
 
+# the load barrier: who it waits for (stamps 13 / 14 of trace builds in workgroups that do not reload a level -- the reload
+# block reuses the two slots; wave 0 of a workgroup is its leader wave)
+allst = tr[2 * SL:, :, :16].astype(np.float64) * 10.0
+lead = (np.arange(allst.shape[1]) % 4) == 0
+if (tr[2 * SL:, :, 13] != 0).any():
+    def pct(v):
+        v = v.reshape(-1)
+        return "%5.0f / %5.0f / %5.0f" % (v.mean(), np.percentile(v, 50), np.percentile(v, 90))
+    t0 = allst[:, :, 0]
+    print("load barrier, ns since the wave's start (mean / p50 / p90):")
+    print("  loading waves: loads issued and flag seen  %s" % pct((allst[:, :, 1] - t0)[:, ~lead]))
+    ok11 = (allst[:, :, 13] != 0) & (allst[:, :, 15] == 0) & ~lead[None, :]
+    ok12 = (allst[:, :, 14] != 0) & (allst[:, :, 15] == 0) & lead[None, :]
+    print("  loading waves: own loads landed            %s   (%d of %d waves stamped)" % (pct((allst[:, :, 13] - t0)[ok11]), int(ok11.sum()), int((~lead).sum()) * allst.shape[0]))
+    print("  leader waves:  first round trip back       %s   (%d of %d)" % (pct((allst[:, :, 14] - t0)[ok12]), int(ok12.sum()), int(lead.sum()) * allst.shape[0]))
+    print("  leader waves:  move decided, at the barrier %s" % pct((allst[:, :, 1] - t0)[:, lead]))
+    print("  all waves:     barrier released            %s" % pct(allst[:, :, 2] - t0))
+
 # what a workgroup's CU slot does between two steps: a wave's start against the end (stores acknowledged) of the same wave
 # of the same slice one step earlier (same workgroup: same XCD, same clock)
 succ = (tr[3 * SL:, :, 0] - tr[2 * SL:-SL, :, 10]).astype(np.float64).reshape(-1) * 10.0
