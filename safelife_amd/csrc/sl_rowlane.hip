@@ -2786,12 +2786,29 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     int pre_i[4] = {0, 0, 0, 0}, pre_y1 = 0, pre_x1 = 0;   // the move of step 0, on cells taken from global memory
     u32 pre_c[4] = {0u, 0u, 0u, 0u};
     bool pre_write = false;
+#ifndef SL_MOVE_BOX
+#define SL_MOVE_BOX 1           /* A/B knob: 0 = the round-3 form of the move (leader writes the image, a barrier of its own) */
+#endif
+#ifndef SL_MOVE_LDS
+#define SL_MOVE_LDS 1           /* A/B knob: 0 = the move's cells come from global memory, in front of the load barrier (round 4) */
+#endif
+    // (round 6) single-step launches: the leaders take the four cells of their move from the IMAGE, right behind the load
+    // barrier, and the rows wait at a second barrier for the move to be in it.  Fetched from global memory ahead of the
+    // barrier (round 4) the cells are a second round trip behind the record's -- 0.80 -> 1.4 us after the wave's start,
+    // while the loading waves have the whole board in LDS at 1.05 (profiles/round6_t4_leader_path_trace.txt).
+    // (not the wrappers' kernels: the "inaction" baseline copies the board as it stands BEFORE the move, inside the step
+    //  loop; not the wide shapes: at 64x64 the second barrier costs more than the round trip, 23.7 against 23.45 us per C5 step)
+    constexpr bool MOVE_LDS = SL_MOVE_LDS && SL_MOVE_BOX && ONE && !WRAP && Gm::WAVES_PER_SIMD == 4 && !(SPAWN && GSH_REG);
     if (lwave) {
         ly = hot_scalars[el].agent_row;
         lx = hot_scalars[el].agent_col;
         action = actions[el];
         exit0 = env.exit_locs[(size_t)el * E];
-        if (T > 0 && lead && ly >= 0) {
+        if (MOVE_LDS && T > 0 && lead && ly >= 0) {
+            int gi[4];
+            act_cells<H, W>(ly, lx, action, pre_i, gi, pre_y1, pre_x1);
+        }
+        if (!MOVE_LDS && T > 0 && lead && ly >= 0) {
             // safelife_env.py:151 for the first step of the launch: the four cells the move can touch are
             // fetched from global memory now (the previous launch's board); they are not waited for here --
             // the leader wave goes through the load barrier and its own goal rows first
@@ -2805,6 +2822,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
         }
         SL_STAMP(14);       // (trace builds: the leaders' first round trip is back, the move's cells are asked for)
         gc_look();
+        SL_STAMP(13);       // (trace builds, leader wave: the goal-word flag is in)
     } else {
         // everything bulky goes through the LDS DMA, issued by the waves that are not the leader
         constexpr int DW = LEADX ? WAVES : WAVES - 1;
@@ -2844,10 +2862,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
 #pragma unroll
         for (int j = 0; j < Gc::TAIL; ++j) gsh_reg[4 * Gc::X4 + j] = *Gc::tail(gc_block, wave, lane, j);
     }
-#ifndef SL_MOVE_BOX
-#define SL_MOVE_BOX 1           /* A/B knob: 0 = the round-3 form of the move (leader writes the image, a barrier of its own) */
-#endif
-    constexpr bool MOVE_BOX = SL_MOVE_BOX && ONE && !(SPAWN && GSH_REG && Gm::WAVES_PER_SIMD == 4);
+    constexpr bool MOVE_BOX = !MOVE_LDS && SL_MOVE_BOX && ONE && !(SPAWN && GSH_REG && Gm::WAVES_PER_SIMD == 4);
     // (Round 4, measured and dropped -- as round 3's variant of it was: every wave sending its OWN boards to global
     //  memory right behind its CA pass, under the score phase and the leaders' work, the leaders storing the agent's
     //  and the exits' cells themselves behind the end barrier.  Same-box A/B, K = 400: 6.47-6.52 us per step without,
@@ -2866,6 +2881,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
         asm volatile("" ::"s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(T), "s"(p0), "s"(p1), "s"(p2), "s"(p3),
                      "s"(p4), "s"(p5), "s"(p6), "s"(reward_t), "s"(done_t), "s"(xcd_base), "s"(xcd_flag));
     }
+    if (lwave) SL_STAMP(15);    // (trace builds, leader wave: goal words asked for, the kernel arguments are in)
     typedef __attribute__((address_space(3))) int *lds_int;       // (a generic volatile pointer would go through FLAT)
     lds_int dirty_flag = (lds_int)(smem + Gm::OFF_GOALS);              // in the region's leading pad
     if (tid == 0) *dirty_flag = 0;
@@ -2914,6 +2930,23 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
         lane == 0)
         __hip_atomic_store(xcd_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 
+    if (MOVE_LDS && T > 0) {
+        if (lwave && lead && ly >= 0) {
+            pre_c[0] = lboard16[pre_i[0]];
+            pre_c[1] = lboard16[pre_i[1]];
+            pre_c[2] = lboard16[pre_i[2]];
+            pre_c[3] = lboard16[pre_i[3]];
+            pre_write = act_rule(pre_c, action, ly, lx, pre_y1, pre_x1);
+            if (pre_write) {
+                lboard16[pre_i[0]] = (u16)pre_c[0];
+                lboard16[pre_i[1]] = (u16)pre_c[1];
+                lboard16[pre_i[2]] = (u16)pre_c[2];
+                lboard16[pre_i[3]] = (u16)pre_c[3];
+            }
+        }
+        // (LDS only: nobody's vector loads -- the goal words are still on their way -- are waited for here)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
     RowWords<H, W> b;
     Elig elig;
     // (lanes without a row compute on whatever their registers hold -- nothing of theirs is ever stored or summed;
@@ -3117,7 +3150,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
                     write_row<H, W>(inb, gb, r, b);
                 }
             }
-            if (!MOVE_BOX) wg_sync();           // (the leaders write the move into the image: behind the rows' reads)
+            if (!MOVE_BOX && !MOVE_LDS) wg_sync();           // (the leaders write the move into the image: behind the rows' reads)
         }
         if (MOVE_BOX && rwave && rlead) {
             // the move the board's leader decided: into the image, by the board's own wave, ahead of its row reads
@@ -3131,7 +3164,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
             }
         }
         // safelife_env.py:151
-        if (!MOVE_BOX) {
+        if (!MOVE_BOX && !MOVE_LDS) {
             if (lwave) {
                 if (t == 0) {
                     if (lead && ly >= 0) pre_write = act_rule(pre_c, action, ly, lx, pre_y1, pre_x1);

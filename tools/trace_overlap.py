@@ -128,10 +128,14 @@ if (tr[2 * SL:, :, 13] != 0).any():
     t0 = allst[:, :, 0]
     print("load barrier, ns since the wave's start (mean / p50 / p90):")
     print("  loading waves: loads issued and flag seen  %s" % pct((allst[:, :, 1] - t0)[:, ~lead]))
-    ok11 = (allst[:, :, 13] != 0) & (allst[:, :, 15] == 0) & ~lead[None, :]
-    ok12 = (allst[:, :, 14] != 0) & (allst[:, :, 15] == 0) & lead[None, :]
+    # (a workgroup that reloads a level stamps 13-15 again, behind its score barrier: left out)
+    late = (allst[:, :, 13] > allst[:, :, 6]) | (allst[:, :, 14] > allst[:, :, 6]) | (allst[:, :, 15] > allst[:, :, 6])
+    ok11 = (allst[:, :, 13] != 0) & ~late & ~lead[None, :]
+    ok12 = (allst[:, :, 14] != 0) & ~late & lead[None, :]
     print("  loading waves: own loads landed            %s   (%d of %d waves stamped)" % (pct((allst[:, :, 13] - t0)[ok11]), int(ok11.sum()), int((~lead).sum()) * allst.shape[0]))
     print("  leader waves:  first round trip back       %s   (%d of %d)" % (pct((allst[:, :, 14] - t0)[ok12]), int(ok12.sum()), int(lead.sum()) * allst.shape[0]))
+    print("  leader waves:  goal-word flag seen         %s" % pct((allst[:, :, 13] - t0)[ok12]))
+    print("  leader waves:  kernel arguments in         %s" % pct((allst[:, :, 15] - t0)[ok12]))
     print("  leader waves:  move decided, at the barrier %s" % pct((allst[:, :, 1] - t0)[:, lead]))
     print("  all waves:     barrier released            %s" % pct(allst[:, :, 2] - t0))
 
