@@ -2736,7 +2736,30 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     // The flag is FETCHED here, first thing, and LOOKED AT where the goal span would be issued (gc_look below) -- behind
     // the record loads and the board's DMA instructions, so that its round trip runs under them.
     u32 gc_word = 0;
-    if (GCACHE && gc_flag && T > 0) gc_word = *(const u32 *)gc_flag;
+#ifndef SL_GOALS_FIRST
+#define SL_GOALS_FIRST 1        /* A/B knob: 0 = the goal words are asked for behind the flag's round trip (round 5) */
+#endif
+    // (both knobs: the narrow shapes only -- at 64x64 either costs C5's step 1 %, 24.2 against 23.9 us)
+    constexpr bool GOALS_FIRST = SL_GOALS_FIRST && Gm::WAVES_PER_SIMD == 4;
+    if (GCACHE && gc_flag && T > 0) {
+        gc_word = *(const u32 *)gc_flag;
+        // (round 6) ... and the lane's goal words with it, BEFORE the flag says whether they are any good (a block has
+        // words for all 64 lanes of its four waves; a launch that finds the flag lowered overwrites them below): with
+        // the leaders' move out of the way (MOVE_LDS) the load barrier waits for the loading waves' youngest loads, and
+        // behind the flag's round trip these were the youngest (own loads landed 1.05 -> 0.85 us after the wave's start)
+        if (GOALS_FIRST) {
+#pragma unroll
+            for (int c = 0; c < Gc::X4; ++c) {
+                const u32x4 v = *Gc::x4(gc_block, wave, lane, c);
+                gsh_reg[4 * c + 0] = v.x;
+                gsh_reg[4 * c + 1] = v.y;
+                gsh_reg[4 * c + 2] = v.z;
+                gsh_reg[4 * c + 3] = v.w;
+            }
+#pragma unroll
+            for (int j = 0; j < Gc::TAIL; ++j) gsh_reg[4 * Gc::X4 + j] = *Gc::tail(gc_block, wave, lane, j);
+        }
+    }
     bool goals_free = false;
     auto gc_look = [&]() {      // (through a VGPR: an SGPR constraint here has tripped "illegal VGPR to SGPR copy" in the backend)
         if constexpr (GCACHE) {
@@ -2786,6 +2809,21 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     int pre_i[4] = {0, 0, 0, 0}, pre_y1 = 0, pre_x1 = 0;   // the move of step 0, on cells taken from global memory
     u32 pre_c[4] = {0u, 0u, 0u, 0u};
     bool pre_write = false;
+#ifndef SL_ARGS_EARLY
+#define SL_ARGS_EARLY 1         /* A/B knob: 0 = the leader wave fetches the kernel arguments where the loading waves do (round 5) */
+#endif
+    // Every kernel argument the rest of the kernel needs that did not arrive preloaded: fetched in ONE batch, in the
+    // shadow of the bulk loads -- by the loading waves behind their DMA instructions, by the leader wave (round 6) behind
+    // the loads of its first round trip: behind the look at the flag it stood, 0.15 us, on the leaders' way to the barrier.
+    constexpr bool ARGS_EARLY = SL_ARGS_EARLY && Gm::WAVES_PER_SIMD == 4;
+    auto fetch_args = [&]() {
+        const int a0 = env.time_limit, a1 = env.exit_points, a2 = env.auto_reset, a3 = env.L, a4 = env.level_stride;
+        const int a5 = env.B, a6 = env.stream_salt, a7 = env.out_compact;
+        const void *p0 = out_rec, *p1 = env.pool_board, *p2 = env.pool_goals, *p3 = env.pool_exit_locs;
+        const void *p4 = env.pool_rng, *p5 = env.pool_scalars, *p6 = env.exit_locs;
+        asm volatile("" ::"s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(T), "s"(p0), "s"(p1), "s"(p2), "s"(p3),
+                     "s"(p4), "s"(p5), "s"(p6), "s"(reward_t), "s"(done_t), "s"(xcd_base), "s"(xcd_flag), "s"(a5), "s"(a6), "s"(a7));
+    };
 #ifndef SL_MOVE_BOX
 #define SL_MOVE_BOX 1           /* A/B knob: 0 = the round-3 form of the move (leader writes the image, a barrier of its own) */
 #endif
@@ -2804,6 +2842,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
         lx = hot_scalars[el].agent_col;
         action = actions[el];
         exit0 = env.exit_locs[(size_t)el * E];
+        if (ARGS_EARLY) fetch_args();
         if (MOVE_LDS && T > 0 && lead && ly >= 0) {
             int gi[4];
             act_cells<H, W>(ly, lx, action, pre_i, gi, pre_y1, pre_x1);
@@ -2849,7 +2888,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
             }
         }
     }
-    if (GCACHE && goals_free && live) {
+    if (!GOALS_FIRST && GCACHE && goals_free && live) {
         // the lane's goal words, as an earlier launch left them (GoalCache): straight into the registers the score reads
 #pragma unroll
         for (int c = 0; c < Gc::X4; ++c) {
@@ -2872,15 +2911,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     //  LDS image, the "goal rows" phase of the trace.  Same-box A/B, K = 400: 6.46 us per step without it, 6.60-6.65
     //  with it through the queues, 8.03 against 8.72 through stream slices: the extra vector-memory instructions in
     //  front of the DMA cost more than the LDS pass they replace.)
-    // Every kernel argument the rest of the kernel needs that did not arrive preloaded: fetched in ONE batch
-    // here, in the shadow of the bulk loads.
-    {
-        const int a0 = env.time_limit, a1 = env.exit_points, a2 = env.auto_reset, a3 = env.L, a4 = env.level_stride;
-        const void *p0 = out_rec, *p1 = env.pool_board, *p2 = env.pool_goals, *p3 = env.pool_exit_locs;
-        const void *p4 = env.pool_rng, *p5 = env.pool_scalars, *p6 = env.exit_locs;
-        asm volatile("" ::"s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(T), "s"(p0), "s"(p1), "s"(p2), "s"(p3),
-                     "s"(p4), "s"(p5), "s"(p6), "s"(reward_t), "s"(done_t), "s"(xcd_base), "s"(xcd_flag));
-    }
+    if (!lwave || !ARGS_EARLY) fetch_args();
     if (lwave) SL_STAMP(15);    // (trace builds, leader wave: goal words asked for, the kernel arguments are in)
     typedef __attribute__((address_space(3))) int *lds_int;       // (a generic volatile pointer would go through FLAT)
     lds_int dirty_flag = (lds_int)(smem + Gm::OFF_GOALS);              // in the region's leading pad
