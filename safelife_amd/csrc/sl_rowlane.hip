@@ -2836,7 +2836,7 @@ __global__ __launch_bounds__(64 * (WAVES + (leadx<H, W, LEAN>() ? 1 : 0)),
     // while the loading waves have the whole board in LDS at 1.05 (profiles/round6_t4_leader_path_trace.txt).
     // (not the wrappers' kernels: the "inaction" baseline copies the board as it stands BEFORE the move, inside the step
     //  loop; not the wide shapes: at 64x64 the second barrier costs more than the round trip, 23.7 against 23.45 us per C5 step)
-    constexpr bool MOVE_LDS = SL_MOVE_LDS && SL_MOVE_BOX && ONE && !WRAP && Gm::WAVES_PER_SIMD == 4 && !(SPAWN && GSH_REG);
+    constexpr bool MOVE_LDS = SL_MOVE_LDS && SL_MOVE_BOX && ONE && !WRAP && Gm::WAVES_PER_SIMD == 4;
     if (lwave) {
         ly = hot_scalars[el].agent_row;
         lx = hot_scalars[el].agent_col;
