@@ -160,7 +160,9 @@ print("per launch: slowest wave %.0f ns mean (median wave %.0f)" % (per_launch_m
 
 # the reload block of those waves (stamps 13-15, written only by workgroups that reload a level in the launch)
 full = tr[2 * SL:, :, :16].astype(np.float64) * 10.0
-has = (tr[2 * SL:, :, 13] != 0) & (tr[2 * SL:, :, 14] != 0) & (tr[2 * SL:, :, 15] != 0)
+# (slots 13-15 also carry the load barrier's stamps of every wave: a reload's are the ones behind the score barrier)
+has = ((tr[2 * SL:, :, 13] > tr[2 * SL:, :, 6]) & (tr[2 * SL:, :, 14] > tr[2 * SL:, :, 13]) &
+       (tr[2 * SL:, :, 15] > tr[2 * SL:, :, 14]))
 if has.any():
     f = full[has]
     print("reload block, %d waves: score barrier -> block entered %.0f | rows fetched and placed %.0f | barrier %.0f | "
